@@ -1,0 +1,97 @@
+"""ctypes binding of libgpqhe_hip.so (the C ABI in include/gpqhe_hip.h).
+
+There is no fallback: if the HIP library is missing or fails to load, importing
+anything that needs it raises.  Nothing here touches oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpqhe_hip.so")
+
+u64 = C.c_uint64
+vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/gpqhe_hip.h one to one
+SIGNATURES = {
+    "gpq_ctx_create": (C.c_int, [C.POINTER(vp), C.c_uint, C.c_uint, C.c_int]),
+    "gpq_ctx_create_from_tables": (C.c_int, [C.POINTER(vp), C.c_uint, C.c_uint, C.POINTER(u64),
+                                             C.POINTER(C.POINTER(u64)), C.POINTER(C.POINTER(u64)), C.c_int]),
+    "gpq_ctx_destroy": (None, [vp]),
+    "gpq_ctx_logn": (C.c_uint, [vp]),
+    "gpq_ctx_nprimes": (C.c_uint, [vp]),
+    "gpq_ctx_device": (C.c_int, [vp]),
+    "gpq_ctx_const": (u64, [vp, C.c_uint, C.c_int]),
+    "gpq_ctx_zetas": (C.POINTER(u64), [vp, C.c_uint, C.c_int]),
+    "gpq_dimub": (C.c_uint, [C.c_uint, C.c_uint]),
+    "gpq_last_error": (C.c_char_p, []),
+    "gpq_malloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
+    "gpq_free": (C.c_int, [vp]),
+    "gpq_upload": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "gpq_download": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "gpq_stream_sync": (C.c_int, [vp]),
+    "gpq_ntt": (C.c_int, [vp, vp, C.c_uint, C.c_uint, vp]),
+    "gpq_invntt": (C.c_int, [vp, vp, C.c_uint, C.c_uint, vp]),
+    "gpq_rns_mul": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, vp]),
+    "gpq_rns_add": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, vp]),
+    "gpq_poly_mul_rns": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, vp]),
+    "gpq_set_chunk": (C.c_int, [vp, C.c_uint]),
+    "gpq_tensor_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
+    "gpq_keyswitch_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
+    "gpq_he_mul_tensor": (C.c_int, [vp] * 8 + [C.c_uint, C.c_uint, vp, vp]),
+    "gpq_keyswitch": (C.c_int, [vp] * 6 + [C.c_uint, C.c_uint, vp, vp]),
+    "gpq_timer_create": (C.c_int, [C.POINTER(vp)]),
+    "gpq_timer_start": (C.c_int, [vp, vp]),
+    "gpq_timer_stop": (C.c_int, [vp, vp]),
+    "gpq_timer_elapsed_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+    "gpq_timer_destroy": (None, [vp]),
+    # reference-named drop-in symbols (include/gpqhe_hip_compat.h)
+    "ntt": (None, [vp, vp]),
+    "invntt": (None, [vp, vp]),
+    "poly_ntt": (None, [vp, vp]),
+    "poly_invntt": (None, [vp, vp]),
+    "poly_rns_add": (None, [vp, vp, vp, vp]),
+    "poly_rns_mul": (None, [vp, vp, vp, vp]),
+    "montgomery_inv": (u64, [u64]),
+    "barrett_inv": (u64, [u64]),
+    "gpq_dropin_set_logn": (None, [C.c_uint]),
+    "gpq_dropin_reset": (None, []),
+}
+# by-value unsigned __int128 arguments cannot be expressed in ctypes; these two are
+# exercised from C (tests/c/dropin_host.c)
+EXPORTED_ONLY = ["montgomery_reduce", "barrett_reduce"]
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (torch first, when present, so that both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "gpqhe_amd: %s is missing -- build it with `make -C gpqhe_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (binds libamdhip64 once for the whole process)
+    except ImportError:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    for name in EXPORTED_ONLY:
+        getattr(lib, name)
+    _lib = lib
+    return lib
+
+
+class GpqError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise GpqError("%s failed (%d): %s" % (what, rc, load().gpq_last_error().decode()))

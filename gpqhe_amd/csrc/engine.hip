@@ -1,0 +1,541 @@
+// engine.hip -- host side of libgpqhe_hip.so: context construction (the RNS
+// part of polyctx_init, src/precomp.c:244-264 and :354-380), kernel launchers
+// and the C ABI declared in include/gpqhe_hip.h.
+#include "../../include/gpqhe_hip.h"
+#include "engine_internal.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+using namespace gpq;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int gpq_fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+extern "C" const char *gpq_last_error(void) { return g_err; }
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return gpq_fail(GPQ_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// host number theory (64-bit), own implementation of what precomp.c needs
+// ---------------------------------------------------------------------------
+namespace {
+
+typedef unsigned __int128 u128h;
+
+inline uint64_t mulm(uint64_t a, uint64_t b, uint64_t m) { return (uint64_t)((u128h)a * b % m); }
+
+uint64_t powm(uint64_t b, uint64_t e, uint64_t m) {
+  uint64_t r = 1 % m;
+  b %= m;
+  while (e) {
+    if (e & 1) r = mulm(r, b, m);
+    b = mulm(b, b, m);
+    e >>= 1;
+  }
+  return r;
+}
+
+// Deterministic Miller-Rabin for 64-bit inputs (7-base set).  The reference
+// draws 50 rand() witnesses (src/precomp.c:153-191); both accept exactly the
+// primes.
+bool is_prime_u64(uint64_t n) {
+  if (n < 2) return false;
+  for (uint64_t sp : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull}) {
+    if (n % sp == 0) return n == sp;
+  }
+  uint64_t d = n - 1;
+  int s = __builtin_ctzll(d);
+  d >>= s;
+  for (uint64_t a : {2ull, 325ull, 9375ull, 28178ull, 450775ull, 9780504ull, 1795265022ull}) {
+    uint64_t x = powm(a, d, n);
+    if (x == 0 || x == 1 || x == n - 1) continue;
+    bool witness = true;
+    for (int r = 1; r < s && witness; ++r) {
+      x = mulm(x, x, n);
+      if (x == n - 1) witness = false;
+    }
+    if (witness) return false;
+  }
+  return true;
+}
+
+// distinct prime factors of m (m = p-1, always has a large power of two)
+std::vector<uint64_t> prime_factors(uint64_t m) {
+  std::vector<uint64_t> f;
+  auto strip = [&](uint64_t d) {
+    if (m % d == 0) {
+      f.push_back(d);
+      while (m % d == 0) m /= d;
+    }
+  };
+  strip(2);
+  strip(3);
+  for (uint64_t d = 5; d * d <= m; d += 6) {
+    strip(d);
+    strip(d + 2);
+  }
+  if (m > 1) f.push_back(m);
+  return f;
+}
+
+// least primitive root, as the loop at src/precomp.c:216-224 finds it
+uint64_t least_generator(uint64_t p) {
+  const std::vector<uint64_t> f = prime_factors(p - 1);
+  for (uint64_t g = 2; g < p; ++g) {
+    bool ok = true;
+    for (uint64_t q : f)
+      if (powm(g, (p - 1) / q, p) == 1) { ok = false; break; }
+    if (ok) return g;
+  }
+  return 0;
+}
+
+inline uint32_t bitrev(uint32_t v, unsigned bits) {
+  return bits ? (__builtin_bitreverse32(v) >> (32 - bits)) : 0;
+}
+
+uint64_t inv_mod_2_64(uint64_t q) {  // Newton; equals the 64-step product of src/reduce.c:36-48 for odd q
+  uint64_t x = q;                    // 3 correct bits
+  for (int i = 0; i < 6; ++i) x *= 2 - q * x;
+  return x;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+static int upload_tables(gpq_ctx *c) {
+  const size_t n = c->n, np = c->nprimes;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMalloc((void **)&c->d_w, np * n * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void **)&c->d_winv, np * n * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void **)&c->d_tabs, np * sizeof(LimbTab)));
+  std::vector<uint64_t> wstd(np * n), wistd(np * n);
+  std::vector<LimbTab> tabs(np);
+  for (size_t d = 0; d < np; ++d) {
+    const uint64_t p = c->p[d];
+    if (p <= (1ull << 59) || p - (1ull << 59) >= GPQ_FOLD_CMAX)
+      return gpq_fail(GPQ_ERR_UNSUPPORTED, "prime %llu is not 2^59 + c with c < %u", (unsigned long long)p, GPQ_FOLD_CMAX);
+    const uint64_t pinv = c->pinv_mont[d];
+    // Montgomery form -> standard form: z * 2^-64 mod p  (montgomery_reduce, src/reduce.c:59-66)
+    auto from_mont = [&](uint64_t z) {
+      const uint64_t u = z * pinv;
+      const uint64_t t = (uint64_t)(((u128h)u * p) >> 64);
+      return t ? p - t : 0;  // hi = 0 here, so hi - t + p
+    };
+    for (size_t i = 0; i < n; ++i) {
+      wstd[d * n + i] = from_mont(c->zetas[d * n + i]);
+      wistd[d * n + i] = from_mont(c->zetas_inv[d * n + i]);
+    }
+    LimbTab &t = tabs[d];
+    t.k.p = p; t.k.p2 = 2 * p; t.k.p4 = 4 * p; t.k.c = (uint32_t)(p - (1ull << 59)); t.k.pad = 0;
+    t.w = c->d_w + d * n;
+    t.winv = c->d_winv + d * n;
+    t.ninv = from_mont(c->ninv_mont[d]);
+    t.winv1_ninv = n >= 2 ? mulm(wistd[d * n + 1], t.ninv, p) : t.ninv;
+  }
+  HIP_TRY(hipMemcpy(c->d_w, wstd.data(), np * n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->d_winv, wistd.data(), np * n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->d_tabs, tabs.data(), np * sizeof(LimbTab), hipMemcpyHostToDevice));
+  return GPQ_OK;
+}
+
+static void fill_scalar_constants(gpq_ctx *c, size_t d) {
+  const uint64_t p = c->p[d];
+  c->pinv_mont[d] = inv_mod_2_64(p);                                                  // src/reduce.c:36-48
+  c->pinv_barr[d] = (uint64_t)(((u128h)1 << (2 * (64 - __builtin_clzll(p)))) / p);   // src/reduce.c:75-78
+  const uint64_t r_mod_p = (uint64_t)(((u128h)1 << 64) % p);
+  c->ninv_mont[d] = mulm(powm(c->n, p - 2, p), r_mod_p, p);                           // src/precomp.c:248
+}
+
+extern "C" int gpq_ctx_create(gpq_ctx **out, unsigned logn, unsigned nprimes, int device) {
+  if (!out || logn < 1 || logn > 17 || nprimes < 1 || nprimes > 4096)
+    return gpq_fail(GPQ_ERR_INVALID, "gpq_ctx_create: logn=%u nprimes=%u out of range", logn, nprimes);
+  gpq_ctx *c = new (std::nothrow) gpq_ctx();
+  if (!c) return gpq_fail(GPQ_ERR_NOMEM, "out of host memory");
+  c->device = device; c->logn = logn; c->n = 1u << logn; c->nprimes = nprimes;
+  const size_t n = c->n;
+  c->p.resize(nprimes); c->pinv_mont.resize(nprimes); c->pinv_barr.resize(nprimes);
+  c->ninv_mont.resize(nprimes); c->psi.resize(nprimes);
+  c->zetas.resize((size_t)nprimes * n); c->zetas_inv.resize((size_t)nprimes * n);
+  uint64_t p = (1ull << 59) + 1;                         // src/precomp.c:358 (GPQHE_LOGP = 59)
+  for (size_t d = 0; d < nprimes; ++d) {
+    do p += 2 * n; while (!is_prime_u64(p));            // src/precomp.c:372-376
+    c->p[d] = p;
+    fill_scalar_constants(c, d);
+    const uint64_t psi = powm(least_generator(p), (p - 1) / (2 * n), p);  // src/precomp.c:235-242, :251
+    const uint64_t psi_inv = powm(psi, p - 2, p);
+    const uint64_t r_mod_p = (uint64_t)(((u128h)1 << 64) % p);
+    c->psi[d] = psi;
+    uint64_t pw = r_mod_p, pwi = r_mod_p;               // psi^i * 2^64 mod p, carried in Montgomery form
+    for (uint32_t i = 0; i < n; ++i) {                  // src/precomp.c:255-263
+      const uint32_t j = bitrev(i, logn);
+      c->zetas[d * n + j] = pw;
+      c->zetas_inv[d * n + j] = pwi;
+      pw = mulm(pw, psi, p);
+      pwi = mulm(pwi, psi_inv, p);
+    }
+  }
+  int rc = upload_tables(c);
+  if (rc != GPQ_OK) { gpq_ctx_destroy(c); return rc; }
+  *out = c;
+  return GPQ_OK;
+}
+
+extern "C" int gpq_ctx_create_from_tables(gpq_ctx **out, unsigned logn, unsigned nprimes, const uint64_t *primes,
+                                          const uint64_t *const *zetas_mont, const uint64_t *const *zetas_inv_mont,
+                                          int device) {
+  if (!out || !primes || !zetas_mont || !zetas_inv_mont || logn < 1 || logn > 17 || nprimes < 1)
+    return gpq_fail(GPQ_ERR_INVALID, "gpq_ctx_create_from_tables: bad arguments");
+  gpq_ctx *c = new (std::nothrow) gpq_ctx();
+  if (!c) return gpq_fail(GPQ_ERR_NOMEM, "out of host memory");
+  c->device = device; c->logn = logn; c->n = 1u << logn; c->nprimes = nprimes;
+  const size_t n = c->n;
+  c->p.assign(primes, primes + nprimes);
+  c->pinv_mont.resize(nprimes); c->pinv_barr.resize(nprimes); c->ninv_mont.resize(nprimes); c->psi.assign(nprimes, 0);
+  c->zetas.resize((size_t)nprimes * n); c->zetas_inv.resize((size_t)nprimes * n);
+  for (size_t d = 0; d < nprimes; ++d) {
+    if (!(c->p[d] & 1)) { delete c; return gpq_fail(GPQ_ERR_INVALID, "even modulus"); }
+    fill_scalar_constants(c, d);
+    memcpy(&c->zetas[d * n], zetas_mont[d], n * 8);
+    memcpy(&c->zetas_inv[d * n], zetas_inv_mont[d], n * 8);
+  }
+  int rc = upload_tables(c);
+  if (rc != GPQ_OK) { gpq_ctx_destroy(c); return rc; }
+  *out = c;
+  return GPQ_OK;
+}
+
+extern "C" void gpq_ctx_destroy(gpq_ctx *c) {
+  if (!c) return;
+  if (c->d_w) (void)hipFree(c->d_w);
+  if (c->d_winv) (void)hipFree(c->d_winv);
+  if (c->d_tabs) (void)hipFree(c->d_tabs);
+  delete c;
+}
+
+extern "C" unsigned gpq_ctx_logn(const gpq_ctx *c) { return c->logn; }
+extern "C" unsigned gpq_ctx_nprimes(const gpq_ctx *c) { return c->nprimes; }
+extern "C" int gpq_ctx_device(const gpq_ctx *c) { return c->device; }
+extern "C" uint64_t gpq_ctx_const(const gpq_ctx *c, unsigned d, int which) {
+  if (d >= c->nprimes) return 0;
+  switch (which) {
+    case 0: return c->p[d];
+    case 1: return c->pinv_mont[d];
+    case 2: return c->pinv_barr[d];
+    case 3: return c->ninv_mont[d];
+    case 4: return c->psi[d];
+  }
+  return 0;
+}
+extern "C" const uint64_t *gpq_ctx_zetas(const gpq_ctx *c, unsigned d, int inverse) {
+  if (d >= c->nprimes) return nullptr;
+  return (inverse ? c->zetas_inv.data() : c->zetas.data()) + (size_t)d * c->n;
+}
+extern "C" unsigned gpq_dimub(unsigned logn, unsigned logq) { return (1 + logn + 4 * logq) / 59 + 1; }
+
+// ---------------------------------------------------------------------------
+// memory / stream helpers
+// ---------------------------------------------------------------------------
+extern "C" int gpq_malloc(void **dptr, size_t bytes) { HIP_TRY(hipMalloc(dptr, bytes)); return GPQ_OK; }
+extern "C" int gpq_free(void *dptr) { HIP_TRY(hipFree(dptr)); return GPQ_OK; }
+extern "C" int gpq_upload(void *dst, const void *src, size_t bytes, void *stream) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return GPQ_OK;
+}
+extern "C" int gpq_download(void *dst, const void *src, size_t bytes, void *stream) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return GPQ_OK;
+}
+extern "C" int gpq_stream_sync(void *stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return GPQ_OK; }
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+namespace {
+
+struct Shape { unsigned dim, batch; };
+
+int check_shape(const gpq_ctx *c, unsigned dim, unsigned batch, const char *who) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "%s: null context", who);
+  if (dim < 1 || dim > c->nprimes) return gpq_fail(GPQ_ERR_INVALID, "%s: dim=%u outside 1..%u", who, dim, c->nprimes);
+  if (batch < 1) return gpq_fail(GPQ_ERR_INVALID, "%s: empty batch", who);
+  return GPQ_OK;
+}
+
+PassArgs make_args(const gpq_ctx *c, unsigned dim, unsigned nslab) {
+  PassArgs a;
+  memset(&a, 0, sizeof a);
+  a.tabs = c->d_tabs;
+  a.poly_stride = (unsigned long long)dim << c->logn;
+  a.logn = c->logn;
+  a.limb0 = 0;
+  a.nslab = nslab;
+  return a;
+}
+
+template <int M1, int EL, bool INV, bool CANON>
+int launch_strided_t(const PassArgs &a, dim3 grid, hipStream_t s) {
+  using G = StridedGeom<M1, EL>;
+  hipLaunchKernelGGL((strided_pass<M1, EL, INV, CANON>), grid, dim3(G::T), 0, s, a);
+  return GPQ_OK;
+}
+
+// strided pass over `polys` polynomials of each of a.nslab slabs, all `dim` limbs
+template <bool INV>
+int launch_strided(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned polys, hipStream_t s) {
+  const dim3 grid(16, polys * a.nslab, dim);
+  switch (c->logn) {
+    case 13: return launch_strided_t<5, 4, INV, false>(a, grid, s);
+    case 14: return launch_strided_t<6, 4, INV, false>(a, grid, s);
+    case 15: return launch_strided_t<7, 4, INV, false>(a, grid, s);
+    case 16: return launch_strided_t<8, 4, INV, false>(a, grid, s);
+    case 17: return launch_strided_t<9, 5, INV, false>(a, grid, s);
+  }
+  return gpq_fail(GPQ_ERR_INVALID, "two-pass NTT needs 13 <= logn <= 17 (got %u)", c->logn);
+}
+
+template <bool INV>
+int launch_contig(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned polys, hipStream_t s) {
+  const dim3 grid(c->n >> 12, polys * a.nslab, dim);
+  hipLaunchKernelGGL((contig_pass<INV>), grid, dim3(CONTIG_WAVES * 64), 0, s, a);
+  return GPQ_OK;
+}
+
+template <bool INV>
+int launch_small(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned polys, hipStream_t s) {
+  const dim3 grid(1, polys * a.nslab, dim);
+  hipLaunchKernelGGL((small_ntt<INV>), grid, dim3(256), 0, s, a);
+  return GPQ_OK;
+}
+
+inline bool two_pass(const gpq_ctx *c) { return c->logn > (unsigned)SMALL_MAX_LOGN; }
+
+int after_launch(const char *who) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return gpq_fail(GPQ_ERR_HIP, "%s: launch failed: %s", who, hipGetErrorString(e));
+  return GPQ_OK;
+}
+
+// in-place forward transform of nslab slabs given in a.src/a.dst
+int forward_slabs(const gpq_ctx *c, PassArgs a, unsigned dim, unsigned polys, hipStream_t s) {
+  int rc;
+  if (!two_pass(c)) return launch_small<false>(c, a, dim, polys, s);
+  if ((rc = launch_strided<false>(c, a, dim, polys, s)) != GPQ_OK) return rc;
+  for (unsigned i = 0; i < a.nslab; ++i) a.src[i] = a.dst[i];
+  return launch_contig<false>(c, a, dim, polys, s);
+}
+
+int inverse_slabs(const gpq_ctx *c, PassArgs a, unsigned dim, unsigned polys, hipStream_t s) {
+  int rc;
+  if (!two_pass(c)) return launch_small<true>(c, a, dim, polys, s);
+  if ((rc = launch_contig<true>(c, a, dim, polys, s)) != GPQ_OK) return rc;
+  for (unsigned i = 0; i < a.nslab; ++i) a.src[i] = a.dst[i];
+  return launch_strided<true>(c, a, dim, polys, s);
+}
+
+}  // namespace
+
+extern "C" int gpq_ntt(gpq_ctx *c, uint64_t *slab, unsigned dim, unsigned batch, void *stream) {
+  int rc = check_shape(c, dim, batch, "gpq_ntt");
+  if (rc) return rc;
+  if (!slab) return gpq_fail(GPQ_ERR_INVALID, "gpq_ntt: null slab");
+  PassArgs a = make_args(c, dim, 1);
+  a.src[0] = slab; a.dst[0] = slab;
+  if ((rc = forward_slabs(c, a, dim, batch, (hipStream_t)stream)) != GPQ_OK) return rc;
+  return after_launch("gpq_ntt");
+}
+
+extern "C" int gpq_invntt(gpq_ctx *c, uint64_t *slab, unsigned dim, unsigned batch, void *stream) {
+  int rc = check_shape(c, dim, batch, "gpq_invntt");
+  if (rc) return rc;
+  if (!slab) return gpq_fail(GPQ_ERR_INVALID, "gpq_invntt: null slab");
+  PassArgs a = make_args(c, dim, 1);
+  a.src[0] = slab; a.dst[0] = slab;
+  if ((rc = inverse_slabs(c, a, dim, batch, (hipStream_t)stream)) != GPQ_OK) return rc;
+  return after_launch("gpq_invntt");
+}
+
+template <bool MUL>
+static int pointwise_api(gpq_ctx *c, uint64_t *r, const uint64_t *x, const uint64_t *y, unsigned dim, unsigned batch,
+                         void *stream, const char *who) {
+  int rc = check_shape(c, dim, batch, who);
+  if (rc) return rc;
+  if (!r || !x || !y) return gpq_fail(GPQ_ERR_INVALID, "%s: null slab", who);
+  PassArgs a = make_args(c, dim, 1);
+  a.src[0] = x; a.src[1] = y; a.dst[0] = r;
+  const unsigned bx = c->n >= 512 ? c->n / 512 : 1;
+  hipLaunchKernelGGL((pointwise<MUL>), dim3(bx, batch, dim), dim3(256), 0, (hipStream_t)stream, a);
+  return after_launch(who);
+}
+
+extern "C" int gpq_rns_mul(gpq_ctx *c, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned dim, unsigned batch, void *stream) {
+  return pointwise_api<true>(c, r, a, b, dim, batch, stream, "gpq_rns_mul");
+}
+extern "C" int gpq_rns_add(gpq_ctx *c, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned dim, unsigned batch, void *stream) {
+  return pointwise_api<false>(c, r, a, b, dim, batch, stream, "gpq_rns_add");
+}
+
+extern "C" int gpq_poly_mul_rns(gpq_ctx *c, uint64_t *r, uint64_t *a, uint64_t *b, unsigned dim, unsigned batch, void *stream) {
+  int rc;
+  if ((rc = gpq_ntt(c, a, dim, batch, stream))) return rc;
+  if ((rc = gpq_ntt(c, b, dim, batch, stream))) return rc;
+  if ((rc = gpq_rns_mul(c, r, a, b, dim, batch, stream))) return rc;
+  return gpq_invntt(c, r, dim, batch, stream);
+}
+
+// ---------------------------------------------------------------------------
+// fused he_mul RNS core
+// ---------------------------------------------------------------------------
+static unsigned tensor_chunk(const gpq_ctx *c, unsigned batch) {
+  return batch < c->chunk ? batch : c->chunk;
+}
+
+extern "C" size_t gpq_tensor_workspace_bytes(const gpq_ctx *c, unsigned dim, unsigned batch) {
+  if (!two_pass(c)) return 4ull * batch * ((size_t)dim << c->logn) * 8;
+  return 4ull * tensor_chunk(c, batch) * ((size_t)dim << c->logn) * 8;
+}
+extern "C" size_t gpq_keyswitch_workspace_bytes(const gpq_ctx *c, unsigned dim, unsigned batch) {
+  if (!two_pass(c)) return 1ull * batch * ((size_t)dim << c->logn) * 8;
+  return 1ull * tensor_chunk(c, batch) * ((size_t)dim << c->logn) * 8;
+}
+
+extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_t *d2,
+                                 const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1,
+                                 unsigned dim, unsigned batch, void *workspace, void *stream) {
+  int rc = check_shape(c, dim, batch, "gpq_he_mul_tensor");
+  if (rc) return rc;
+  if (!d0 || !d1 || !d2 || !a0 || !a1 || !b0 || !b1 || !workspace)
+    return gpq_fail(GPQ_ERR_INVALID, "gpq_he_mul_tensor: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t poly = (size_t)dim << c->logn;
+  uint64_t *ws = (uint64_t *)workspace;
+  const uint64_t *in[4] = {a0, a1, b0, b1};
+
+  if (!two_pass(c)) {
+    // small rings: unfused sequence, same dataflow as src/he-mult.c:121-136
+    uint64_t *t[4];
+    for (int i = 0; i < 4; ++i) {
+      t[i] = ws + (size_t)i * batch * poly;
+      HIP_TRY(hipMemcpyAsync(t[i], in[i], batch * poly * 8, hipMemcpyDeviceToDevice, s));
+      if ((rc = gpq_ntt(c, t[i], dim, batch, stream))) return rc;
+    }
+    if ((rc = gpq_rns_mul(c, d0, t[0], t[2], dim, batch, stream))) return rc;   // c0*c0'
+    if ((rc = gpq_rns_mul(c, d2, t[1], t[3], dim, batch, stream))) return rc;   // c1*c1'
+    if ((rc = gpq_rns_mul(c, t[0], t[0], t[3], dim, batch, stream))) return rc; // c0*c1'
+    if ((rc = gpq_rns_mul(c, t[1], t[1], t[2], dim, batch, stream))) return rc; // c1*c0'
+    if ((rc = gpq_rns_add(c, d1, t[0], t[1], dim, batch, stream))) return rc;
+    if ((rc = gpq_invntt(c, d0, dim, batch, stream))) return rc;
+    if ((rc = gpq_invntt(c, d1, dim, batch, stream))) return rc;
+    return gpq_invntt(c, d2, dim, batch, stream);
+  }
+
+  const unsigned chunk = tensor_chunk(c, batch);
+  for (unsigned k0 = 0; k0 < batch; k0 += chunk) {
+    const unsigned polys = (batch - k0 < chunk) ? batch - k0 : chunk;
+    // 1. strided forward pass, inputs -> workspace
+    PassArgs f = make_args(c, dim, 4);
+    for (int i = 0; i < 4; ++i) { f.src[i] = in[i] + k0 * poly; f.dst[i] = ws + (size_t)i * chunk * poly; }
+    if ((rc = launch_strided<false>(c, f, dim, polys, s))) return rc;
+    // 2. low forward stages, products, low inverse stages -> outputs
+    PassArgs m = make_args(c, dim, 1);
+    for (int i = 0; i < 4; ++i) m.src[i] = f.dst[i];
+    m.dst[0] = d0 + k0 * poly; m.dst[1] = d1 + k0 * poly; m.dst[2] = d2 + k0 * poly;
+    hipLaunchKernelGGL(tensor_mid, dim3(c->n >> 12, polys, dim), dim3(CONTIG_WAVES * 64), 0, s, m);
+    // 3. strided inverse pass in place on the three outputs
+    PassArgs b = make_args(c, dim, 3);
+    for (int i = 0; i < 3; ++i) { b.src[i] = m.dst[i]; b.dst[i] = m.dst[i]; }
+    if ((rc = launch_strided<true>(c, b, dim, polys, s))) return rc;
+  }
+  return after_launch("gpq_he_mul_tensor");
+}
+
+extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint64_t *x,
+                             const uint64_t *evk0, const uint64_t *evk1,
+                             unsigned dim, unsigned batch, void *workspace, void *stream) {
+  int rc = check_shape(c, dim, batch, "gpq_keyswitch");
+  if (rc) return rc;
+  if (!c0 || !c1 || !x || !evk0 || !evk1 || !workspace) return gpq_fail(GPQ_ERR_INVALID, "gpq_keyswitch: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t poly = (size_t)dim << c->logn;
+  uint64_t *ws = (uint64_t *)workspace;
+
+  if (!two_pass(c)) {
+    HIP_TRY(hipMemcpyAsync(ws, x, batch * poly * 8, hipMemcpyDeviceToDevice, s));
+    if ((rc = gpq_ntt(c, ws, dim, batch, stream))) return rc;
+    for (unsigned k = 0; k < batch; ++k) {  // the key is shared by the batch
+      if ((rc = gpq_rns_mul(c, c0 + k * poly, ws + k * poly, evk0, dim, 1, stream))) return rc;
+      if ((rc = gpq_rns_mul(c, c1 + k * poly, ws + k * poly, evk1, dim, 1, stream))) return rc;
+    }
+    if ((rc = gpq_invntt(c, c0, dim, batch, stream))) return rc;
+    return gpq_invntt(c, c1, dim, batch, stream);
+  }
+
+  const unsigned chunk = tensor_chunk(c, batch);
+  for (unsigned k0 = 0; k0 < batch; k0 += chunk) {
+    const unsigned polys = (batch - k0 < chunk) ? batch - k0 : chunk;
+    PassArgs f = make_args(c, dim, 1);
+    f.src[0] = x + k0 * poly; f.dst[0] = ws;
+    if ((rc = launch_strided<false>(c, f, dim, polys, s))) return rc;
+    KeyswitchArgs m;
+    m.p = make_args(c, dim, 1);
+    m.p.src[0] = ws; m.p.dst[0] = c0 + k0 * poly; m.p.dst[1] = c1 + k0 * poly;
+    m.evk0 = evk0; m.evk1 = evk1;
+    hipLaunchKernelGGL(keyswitch_mid, dim3(c->n >> 12, polys, dim), dim3(CONTIG_WAVES * 64), 0, s, m);
+    PassArgs b = make_args(c, dim, 2);
+    for (int i = 0; i < 2; ++i) { b.src[i] = m.p.dst[i]; b.dst[i] = m.p.dst[i]; }
+    if ((rc = launch_strided<true>(c, b, dim, polys, s))) return rc;
+  }
+  return after_launch("gpq_keyswitch");
+}
+
+extern "C" int gpq_set_chunk(gpq_ctx *c, unsigned chunk) {
+  if (!c || chunk < 1) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_chunk: bad arguments");
+  c->chunk = chunk;
+  return GPQ_OK;
+}
+
+// ---------------------------------------------------------------------------
+// timers (HIP events recorded on the caller's stream)
+// ---------------------------------------------------------------------------
+struct gpq_timer { hipEvent_t a, b; };
+
+extern "C" int gpq_timer_create(gpq_timer **t) {
+  gpq_timer *x = new (std::nothrow) gpq_timer();
+  if (!x) return gpq_fail(GPQ_ERR_NOMEM, "out of host memory");
+  HIP_TRY(hipEventCreate(&x->a));
+  HIP_TRY(hipEventCreate(&x->b));
+  *t = x;
+  return GPQ_OK;
+}
+extern "C" int gpq_timer_start(gpq_timer *t, void *stream) { HIP_TRY(hipEventRecord(t->a, (hipStream_t)stream)); return GPQ_OK; }
+extern "C" int gpq_timer_stop(gpq_timer *t, void *stream) { HIP_TRY(hipEventRecord(t->b, (hipStream_t)stream)); return GPQ_OK; }
+extern "C" int gpq_timer_elapsed_ms(gpq_timer *t, float *ms) {
+  HIP_TRY(hipEventSynchronize(t->b));
+  HIP_TRY(hipEventElapsedTime(ms, t->a, t->b));
+  return GPQ_OK;
+}
+extern "C" void gpq_timer_destroy(gpq_timer *t) {
+  if (!t) return;
+  (void)hipEventDestroy(t->a);
+  (void)hipEventDestroy(t->b);
+  delete t;
+}

@@ -1,0 +1,428 @@
+// ntt_kernels.hpp -- device side of the negacyclic NTT / INTT over the RNS
+// prime tower (reference: src/ntt.c:37-73) and of the fused he_mul RNS core
+// (reference limb loops: src/he-mult.c:116-138 and :58-66).
+//
+// Decomposition.  The reference runs logn radix-2 stages over one limb
+// (len = n/2 .. 1 forward, 1 .. n/2 inverse), each stage pairing a[j] with
+// a[j+len] and using zetas[n/(2len) + j/(2len)].  The same butterflies at the
+// same positions are grouped here into two passes so that every coefficient
+// crosses HBM twice per transform instead of logn times:
+//
+//   strided pass     stages with len >= 256: element index i = r*256 + col;
+//                    a workgroup owns 2^M1 rows x 16 columns (M1 = logn-8)
+//   contiguous pass  stages with len <= 128: inside 256-element blocks;
+//                    a wave owns 4 consecutive blocks, no workgroup barrier
+//
+// Inside a pass a thread keeps 2^EL coefficients in registers and runs EL
+// (or fewer) stages on them before exchanging through LDS (padded, conflict
+// free both ways).  Arithmetic is lazy (modarith.hpp); only the last stage of
+// a transform canonicalises, so results are bit-identical with src/ntt.c.
+//
+// Twiddle tables on the device are in standard form (the reference stores
+// zeta*2^64 mod p; converted once at context creation) and keep the
+// reference's bit-reversed indexing, so index formulas below read like
+// src/ntt.c: stage with len uses table[n/(2len) + i/(2len)].
+#pragma once
+#include "modarith.hpp"
+
+namespace gpq {
+
+struct LimbTab {           // one per prime, array resident in HBM
+  PrimeK k;
+  const uint64_t *w;       // forward twiddles, standard form, [n], index as rns->zetas (src/precomp.c:255-263)
+  const uint64_t *winv;    // inverse twiddles, as rns->zetas_inv
+  uint64_t ninv;           // n^-1 mod p, standard form (reference: rns->ninv is n^-1*2^64, src/precomp.c:248)
+  uint64_t winv1_ninv;     // winv[1]*n^-1 mod p : last inverse stage with the scaling folded in
+};
+
+#define GPQ_MAX_SLABS 4
+struct PassArgs {
+  const LimbTab *tabs;               // tabs[limb0 + blockIdx.z]
+  const uint64_t *src[GPQ_MAX_SLABS];
+  uint64_t *dst[GPQ_MAX_SLABS];
+  unsigned long long poly_stride;    // elements between consecutive polynomials of a slab (= limbs_in_slab * n)
+  unsigned logn;
+  unsigned limb0;
+  unsigned nslab;                    // blockIdx.y = poly * nslab + slab
+};
+
+// ---------------------------------------------------------------------------
+// Register groups.  x[] holds E = 2^EL coefficients; register bit b stands for
+// global index bit (rs + b); ibase is the global index of x[0].  A stage on
+// register bit b is the reference stage with len = 2^(rs+b).
+// ---------------------------------------------------------------------------
+template <int EL, int BHI, int BLO, bool UNIFORM>
+__device__ __forceinline__ void ct_group(uint64_t (&x)[1 << EL], unsigned ibase, int rs, unsigned logn,
+                                         const uint64_t *__restrict__ w, const PrimeK &k) {
+#pragma unroll
+  for (int b = BHI; b >= BLO; --b) {
+    const int sh = rs + b + 1;                         // i / (2 len)
+    const uint64_t *wp = w + (1u << (logn - sh)) + (UNIFORM ? 0u : (ibase >> sh));
+#pragma unroll
+    for (int e = 0; e < (1 << EL); ++e)
+      if (!(e & (1 << b))) ct_bfly(x[e], x[e + (1 << b)], wp[e >> (b + 1)], k);
+  }
+}
+
+template <int EL, int BLO, int BHI, bool UNIFORM>
+__device__ __forceinline__ void gs_group(uint64_t (&x)[1 << EL], unsigned ibase, int rs, unsigned logn,
+                                         const uint64_t *__restrict__ winv, const PrimeK &k) {
+#pragma unroll
+  for (int b = BLO; b <= BHI; ++b) {
+    const int sh = rs + b + 1;
+    const uint64_t *wp = winv + (1u << (logn - sh)) + (UNIFORM ? 0u : (ibase >> sh));
+#pragma unroll
+    for (int e = 0; e < (1 << EL); ++e)
+      if (!(e & (1 << b))) gs_bfly(x[e], x[e + (1 << b)], wp[e >> (b + 1)], k);
+  }
+}
+
+// Last inverse stage (len = n/2, twiddle winv[1]) with the n^-1 scaling of
+// src/ntt.c:71-72 folded in, canonical outputs.  in: x,y < 4p.
+__device__ __forceinline__ void gs_last(uint64_t &x, uint64_t &y, const LimbTab &t) {
+  const uint64_t s = x + y;                 // < 8p
+  const uint64_t d = x + t.k.p4 - y;        // (0, 8p)
+  x = canon4(mulmod_lazy(s, t.ninv, t.k), t.k);
+  y = canon4(mulmod_lazy(d, t.winv1_ninv, t.k), t.k);
+}
+
+// ---------------------------------------------------------------------------
+// Strided pass: the M1 = logn-8 stages with len >= 256.
+// Tile = 2^M1 rows x 16 columns, T = 2^(M1+4-EL) threads, tid = col + 16*q.
+//   group A: rows q + 2^(M1-EL)*e      (register bits = top EL row bits)
+//   group B: rows (q << EL) + e        (register bits = low EL row bits, the
+//                                       low M1-EL of them still to be done)
+// Forward runs A then B, inverse B then A.
+// ---------------------------------------------------------------------------
+template <int M1, int EL>
+struct StridedGeom {
+  static constexpr int E = 1 << EL;
+  static constexpr int T = 1 << (M1 + 4 - EL);
+  static constexpr int S2 = M1 - EL;                      // stages left for group B
+  static constexpr int LDS_ELEMS = (1 << (M1 + 4)) + ((S2 > 0) ? (16 << S2) : 0);
+  __device__ static __forceinline__ unsigned pad(unsigned l) { return l + ((l >> (EL + 4)) << 4); }
+};
+
+template <int M1, int EL, bool INV, bool CANON_OUT>
+__global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArgs a) {
+  using G = StridedGeom<M1, EL>;
+  constexpr int E = G::E;
+  constexpr unsigned logn = M1 + 8;
+  __shared__ uint64_t lds[G::S2 > 0 ? G::LDS_ELEMS : 1];
+
+  const LimbTab &tab = a.tabs[a.limb0 + blockIdx.z];
+  const PrimeK k = tab.k;
+  const unsigned slab = blockIdx.y % a.nslab, poly = blockIdx.y / a.nslab;
+  const size_t off = (size_t)poly * a.poly_stride + ((size_t)blockIdx.z << logn);
+  const uint64_t *__restrict__ src = a.src[slab] + off;
+  uint64_t *__restrict__ dst = a.dst[slab] + off;
+
+  const unsigned tid = threadIdx.x;
+  const unsigned col = (blockIdx.x << 4) + (tid & 15);
+  const unsigned q = tid >> 4;
+  // group A: element e at row q + (e << S2); group B: row (q << EL) + e
+  const unsigned iA = (q << 8) + col, iB = (q << (EL + 8)) + col;
+  constexpr unsigned strideA = 1u << (G::S2 + 8), strideB = 1u << 8;
+  uint64_t x[E];
+
+  if (!INV) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] = src[iA + e * strideA];
+    ct_group<EL, EL - 1, 0, true>(x, iA, G::S2 + 8, logn, tab.w, k);
+    if (G::S2 > 0) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) lds[G::pad(tid + e * G::T)] = x[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; ++e) x[e] = lds[G::pad((q << (EL + 4)) + (e << 4) + (tid & 15))];
+      ct_group<EL, (G::S2 > 0 ? G::S2 - 1 : 0), 0, false>(x, iB, 8, logn, tab.w, k);
+#pragma unroll
+      for (int e = 0; e < E; ++e) dst[iB + e * strideB] = CANON_OUT ? canon8(x[e], k) : x[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) dst[iA + e * strideA] = CANON_OUT ? canon8(x[e], k) : x[e];
+    }
+  } else {
+    if (G::S2 > 0) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) x[e] = src[iB + e * strideB];
+      gs_group<EL, 0, (G::S2 > 0 ? G::S2 - 1 : 0), false>(x, iB, 8, logn, tab.winv, k);
+#pragma unroll
+      for (int e = 0; e < E; ++e) lds[G::pad((q << (EL + 4)) + (e << 4) + (tid & 15))] = x[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; ++e) x[e] = lds[G::pad(tid + e * G::T)];
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) x[e] = src[iA + e * strideA];
+    }
+    // top EL row bits, the very last one (len = n/2) carries the n^-1 scaling
+    if (EL > 1) gs_group<EL, 0, (EL > 1 ? EL - 2 : 0), true>(x, iA, G::S2 + 8, logn, tab.winv, k);
+#pragma unroll
+    for (int e = 0; e < E / 2; ++e) gs_last(x[e], x[e + E / 2], tab);
+#pragma unroll
+    for (int e = 0; e < E; ++e) dst[iA + e * strideA] = x[e];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Contiguous pass: the 8 stages with len <= 128, inside 256-element blocks.
+// A wave owns 4 consecutive blocks (1024 coefficients); lane = j + 16*blk.
+//   group H: k = j + 16*e   (register bits = k bits 7..4)
+//   group L: k = 16*j + e   (register bits = k bits 3..0)
+// The H<->L exchange stays inside the wave's own LDS region.
+// ---------------------------------------------------------------------------
+constexpr int CONTIG_WAVES = 4;                       // waves per workgroup
+constexpr int CONTIG_LDS_PER_WAVE = 1024 + 64;        // padded: l + (l >> 4)
+
+// LDS traffic of one wave is ordered by the hardware; this only stops the
+// compiler from moving the wave's LDS reads across its LDS writes.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct ContigLane {
+  unsigned j, blk, hbase, lbase;                      // hbase/lbase: index of x[0] inside the wave's 1024 coefficients
+  uint64_t *lds;
+  __device__ __forceinline__ ContigLane(uint64_t *wave_lds) {
+    const unsigned lane = threadIdx.x & 63;
+    j = lane & 15; blk = lane >> 4;
+    hbase = (blk << 8) + j;
+    lbase = (blk << 8) + (j << 4);
+    lds = wave_lds;
+  }
+  __device__ static __forceinline__ unsigned pad(unsigned l) { return l + (l >> 4); }
+  // registers in H layout -> registers in L layout
+  __device__ __forceinline__ void h_to_l(uint64_t (&x)[16]) const {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lds[pad(hbase + 16 * e)] = x[e];
+    wave_lds_sync();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = lds[pad(lbase + e)];
+    wave_lds_sync();
+  }
+  __device__ __forceinline__ void l_to_h(uint64_t (&x)[16]) const {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lds[pad(lbase + e)] = x[e];
+    wave_lds_sync();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = lds[pad(hbase + 16 * e)];
+    wave_lds_sync();
+  }
+};
+
+// forward: coefficients (H layout, < 8p) -> NTT domain (L layout, < 8p)
+__device__ __forceinline__ void contig_fwd(uint64_t (&x)[16], const ContigLane &ln, unsigned wave0, unsigned logn,
+                                           const LimbTab &tab) {
+  ct_group<4, 3, 0, false>(x, wave0 + ln.hbase, 4, logn, tab.w, tab.k);
+  ln.h_to_l(x);
+  ct_group<4, 3, 0, false>(x, wave0 + ln.lbase, 0, logn, tab.w, tab.k);
+}
+// inverse: NTT domain (L layout, < 4p) -> coefficients after the 8 low stages (H layout, < 4p)
+__device__ __forceinline__ void contig_inv(uint64_t (&x)[16], const ContigLane &ln, unsigned wave0, unsigned logn,
+                                           const LimbTab &tab) {
+  gs_group<4, 0, 3, false>(x, wave0 + ln.lbase, 0, logn, tab.winv, tab.k);
+  ln.l_to_h(x);
+  gs_group<4, 0, 3, false>(x, wave0 + ln.hbase, 4, logn, tab.winv, tab.k);
+}
+
+__device__ __forceinline__ void load_h(uint64_t (&x)[16], const uint64_t *__restrict__ p, const ContigLane &ln) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = p[ln.hbase + 16 * e];
+}
+__device__ __forceinline__ void store_h(uint64_t *__restrict__ p, const uint64_t (&x)[16], const ContigLane &ln) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) p[ln.hbase + 16 * e] = x[e];
+}
+__device__ __forceinline__ void load_l(uint64_t (&x)[16], const uint64_t *__restrict__ p, const ContigLane &ln) {
+  const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(p + ln.lbase);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { ulonglong2 t = v[e]; x[2 * e] = t.x; x[2 * e + 1] = t.y; }
+}
+__device__ __forceinline__ void store_l(uint64_t *__restrict__ p, const uint64_t (&x)[16], const ContigLane &ln) {
+  ulonglong2 *v = reinterpret_cast<ulonglong2 *>(p + ln.lbase);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = make_ulonglong2(x[2 * e], x[2 * e + 1]);
+}
+
+struct ContigBlock {       // per-workgroup addressing shared by the contiguous kernels
+  unsigned wave0;          // limb-relative index of the wave's first coefficient
+  size_t off;              // offset of the limb inside a slab + wave0
+  unsigned slab, poly;
+  __device__ __forceinline__ ContigBlock(const PassArgs &a) {
+    const unsigned wave = threadIdx.x >> 6;
+    wave0 = (blockIdx.x * CONTIG_WAVES + wave) << 10;
+    slab = blockIdx.y % a.nslab; poly = blockIdx.y / a.nslab;
+    off = (size_t)poly * a.poly_stride + ((size_t)blockIdx.z << a.logn) + wave0;
+  }
+};
+
+// MODE 0: forward, output canonical.  MODE 1: inverse low stages (feeds the strided inverse pass).
+// If logn == 8 the contiguous pass is the whole transform: inverse applies the scaling itself.
+template <bool INV>
+__global__ __launch_bounds__(CONTIG_WAVES * 64) void contig_pass(PassArgs a) {
+  __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
+  const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
+  const ContigBlock cb(a);
+  const LimbTab &tab = a.tabs[a.limb0 + blockIdx.z];
+  uint64_t x[16];
+  if (!INV) {
+    load_h(x, a.src[cb.slab] + cb.off, ln);
+    contig_fwd(x, ln, cb.wave0, a.logn, tab);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = canon8(x[e], tab.k);
+    store_l(a.dst[cb.slab] + cb.off, x, ln);
+  } else {
+    load_l(x, a.src[cb.slab] + cb.off, ln);
+    contig_inv(x, ln, cb.wave0, a.logn, tab);
+    store_h(a.dst[cb.slab] + cb.off, x, ln);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fused middle of the he_mul tensor stage (src/he-mult.c:121-136), per limb:
+//   low 8 forward stages of ct1.c0, ct1.c1, ct2.c0, ct2.c1
+//   d0 = c0*c0', d2 = c1*c1', d1 = c0*c1' + c1*c0'   (the add moved in front
+//   of the inverse transform: INTT is linear, canonical results are identical)
+//   low 8 inverse stages of d0, d1, d2
+// src[0..3] = a0,a1,b0,b1 after the strided forward pass; dst[0..2] = d0,d1,d2.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(CONTIG_WAVES * 64) void tensor_mid(PassArgs a) {
+  __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
+  const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
+  const ContigBlock cb(a);           // nslab == 1 here: blockIdx.y = poly
+  const LimbTab &tab = a.tabs[a.limb0 + blockIdx.z];
+  const PrimeK k = tab.k;
+  uint64_t a0[16], a1[16], b0[16], b1[16];
+  load_h(a0, a.src[0] + cb.off, ln);
+  load_h(b0, a.src[2] + cb.off, ln);
+  load_h(a1, a.src[1] + cb.off, ln);
+  load_h(b1, a.src[3] + cb.off, ln);
+  contig_fwd(a0, ln, cb.wave0, a.logn, tab);
+  contig_fwd(b0, ln, cb.wave0, a.logn, tab);
+  contig_fwd(a1, ln, cb.wave0, a.logn, tab);
+  contig_fwd(b1, ln, cb.wave0, a.logn, tab);
+  // products: left operand < 2p, right operand < 4p  =>  a*b < 8p^2, as mulmod_lazy needs
+  uint64_t d1[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const uint64_t u0 = csub(csub(a0[e], k.p4), k.p2), u1 = csub(csub(a1[e], k.p4), k.p2);
+    const uint64_t v0 = csub(b0[e], k.p4), v1 = csub(b1[e], k.p4);
+    a0[e] = mulmod_lazy(u0, v0, k);                                   // d0 < 4p
+    d1[e] = csub(mulmod_lazy(u0, v1, k) + mulmod_lazy(u1, v0, k), k.p4);  // d1 < 4p
+    a1[e] = mulmod_lazy(u1, v1, k);                                   // d2 < 4p
+  }
+  contig_inv(a0, ln, cb.wave0, a.logn, tab);
+  store_h(a.dst[0] + cb.off, a0, ln);
+  contig_inv(d1, ln, cb.wave0, a.logn, tab);
+  store_h(a.dst[1] + cb.off, d1, ln);
+  contig_inv(a1, ln, cb.wave0, a.logn, tab);
+  store_h(a.dst[2] + cb.off, a1, ln);
+}
+
+// ---------------------------------------------------------------------------
+// Fused middle of the key-switch inner product (src/he-mult.c:60-64 ==
+// src/he-automorphism.c:61-65): src[0] = d2 after the strided forward pass,
+// evk0/evk1 = NTT-domain key limbs (shared by the whole batch, no poly
+// stride), dst[0..1] = low inverse stages of d2*evk.p0 and d2*evk.p1.
+// ---------------------------------------------------------------------------
+struct KeyswitchArgs { PassArgs p; const uint64_t *evk0; const uint64_t *evk1; };
+
+__global__ __launch_bounds__(CONTIG_WAVES * 64) void keyswitch_mid(KeyswitchArgs ka) {
+  __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
+  const PassArgs &a = ka.p;
+  const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
+  const ContigBlock cb(a);
+  const LimbTab &tab = a.tabs[a.limb0 + blockIdx.z];
+  const PrimeK k = tab.k;
+  const size_t koff = ((size_t)blockIdx.z << a.logn) + cb.wave0;
+  uint64_t x[16], e0[16], e1[16];
+  load_h(x, a.src[0] + cb.off, ln);
+  load_l(e0, ka.evk0 + koff, ln);
+  load_l(e1, ka.evk1 + koff, ln);
+  contig_fwd(x, ln, cb.wave0, a.logn, tab);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const uint64_t u = csub(x[e], k.p4);           // < 4p ; evk limbs are canonical (< p)
+    e0[e] = mulmod_lazy(u, e0[e], k);
+    e1[e] = mulmod_lazy(u, e1[e], k);
+  }
+  contig_inv(e0, ln, cb.wave0, a.logn, tab);
+  store_h(a.dst[0] + cb.off, e0, ln);
+  contig_inv(e1, ln, cb.wave0, a.logn, tab);
+  store_h(a.dst[1] + cb.off, e1, ln);
+}
+
+// ---------------------------------------------------------------------------
+// Pointwise limb ops on whole slabs: poly_rns_mul / poly_rns_add,
+// src/poly.c:71-82.  16 bytes per lane, grid-stride free (exact grid).
+// ---------------------------------------------------------------------------
+template <bool MUL>
+__global__ __launch_bounds__(256) void pointwise(PassArgs a) {
+  const LimbTab &tab = a.tabs[a.limb0 + blockIdx.z];
+  const PrimeK k = tab.k;
+  const unsigned i2 = 2 * (blockIdx.x * 256 + threadIdx.x);
+  if (i2 >= (1u << a.logn)) return;
+  const size_t off = (size_t)blockIdx.y * a.poly_stride + ((size_t)blockIdx.z << a.logn) + i2;
+  const ulonglong2 u = *reinterpret_cast<const ulonglong2 *>(a.src[0] + off);
+  const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(a.src[1] + off);
+  ulonglong2 r;
+  if (MUL) { r.x = mulmod_canon(u.x, v.x, k); r.y = mulmod_canon(u.y, v.y, k); }
+  else     { r.x = addmod_canon(u.x, v.x, k); r.y = addmod_canon(u.y, v.y, k); }
+  *reinterpret_cast<ulonglong2 *>(a.dst[0] + off) = r;
+}
+
+// ---------------------------------------------------------------------------
+// Small rings (n <= 2^SMALL_MAX_LOGN): one workgroup per limb, the limb lives
+// in LDS, radix-2 stages exactly as src/ntt.c walks them.  Also the in-device
+// cross-check for the two-pass kernels in the tests.
+// ---------------------------------------------------------------------------
+constexpr int SMALL_MAX_LOGN = 12;
+
+template <bool INV>
+__global__ __launch_bounds__(256) void small_ntt(PassArgs a) {
+  __shared__ uint64_t s[1 << SMALL_MAX_LOGN];
+  const LimbTab &tab = a.tabs[a.limb0 + blockIdx.z];
+  const PrimeK k = tab.k;
+  const unsigned n = 1u << a.logn;
+  const unsigned slab = blockIdx.y % a.nslab, poly = blockIdx.y / a.nslab;
+  const size_t off = (size_t)poly * a.poly_stride + ((size_t)blockIdx.z << a.logn);
+  const uint64_t *__restrict__ src = a.src[slab] + off;
+  uint64_t *__restrict__ dst = a.dst[slab] + off;
+  for (unsigned i = threadIdx.x; i < n; i += 256) s[i] = src[i];
+  __syncthreads();
+  if (!INV) {
+    for (unsigned len = n >> 1; len >= 1; len >>= 1) {
+      for (unsigned b = threadIdx.x; b < (n >> 1); b += 256) {
+        const unsigned blk = b / len, j = blk * 2 * len + (b % len);
+        uint64_t x = s[j], y = s[j + len];
+        ct_bfly(x, y, tab.w[n / (2 * len) + blk], k);
+        s[j] = canon8(x, k); s[j + len] = canon8(y, k);
+      }
+      __syncthreads();
+    }
+  } else {
+    for (unsigned len = 1; len < (n >> 1); len <<= 1) {
+      for (unsigned b = threadIdx.x; b < (n >> 1); b += 256) {
+        const unsigned blk = b / len, j = blk * 2 * len + (b % len);
+        uint64_t x = s[j], y = s[j + len];
+        gs_bfly(x, y, tab.winv[n / (2 * len) + blk], k);
+        s[j] = canon4(x, k); s[j + len] = canon4(y, k);
+      }
+      __syncthreads();
+    }
+    if (n >= 2) {
+      for (unsigned b = threadIdx.x; b < (n >> 1); b += 256) {
+        uint64_t x = s[b], y = s[b + (n >> 1)];
+        gs_last(x, y, tab);
+        s[b] = x; s[b + (n >> 1)] = y;
+      }
+      __syncthreads();
+    }
+  }
+  for (unsigned i = threadIdx.x; i < n; i += 256) dst[i] = s[i];
+}
+
+}  // namespace gpq

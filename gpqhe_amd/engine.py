@@ -1,0 +1,164 @@
+"""Host-side mirror of the reference's RNS interface on top of the C ABI.
+
+Names follow the reference: `PolyContext` is the RNS part of `polyctx`
+(src/poly.h:49-65), `poly_ntt` / `poly_invntt` / `poly_rns_mul` / `poly_rns_add`
+are src/ntt.c:37,54 and src/poly.c:71-82 applied to whole limb-major slabs
+`uint64[batch][dim][n]` in HBM, `he_mul_tensor` / `he_keyswitch` are the limb
+loops of src/he-mult.c:116-138 and :58-66.  Slabs are torch int64 CUDA tensors
+carrying the uint64 bit patterns (torch is the allocator/stream provider; the
+arithmetic happens in libgpqhe_hip.so).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_device(a, device=None):
+    """numpy uint64 array -> int64 CUDA tensor with the same bits."""
+    torch = _torch()
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).to(device or "cuda")
+
+
+def to_host(t):
+    """int64 CUDA tensor -> numpy uint64 array."""
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+class PolyContext:
+    """`polyctx_init(logn, q)` restricted to what the hot path reads: ring
+    degree, the prime chain and the per-prime NTT tables (src/precomp.c:244-264,
+    :354-380).  `nprimes` is `polyctx.dimub`; pass `logq` instead to get the
+    reference's own bound (src/precomp.c:357)."""
+
+    def __init__(self, logn, nprimes=None, logq=None, device=None):
+        self.lib = _native.load()
+        if nprimes is None:
+            if logq is None:
+                raise ValueError("PolyContext needs nprimes or logq")
+            nprimes = self.lib.gpq_dimub(logn, logq)
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _native.GpqError("gpqhe_amd needs a HIP device; there is no CPU path")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        h = C.c_void_p()
+        _native.check(self.lib.gpq_ctx_create(C.byref(h), logn, nprimes, self.device), "gpq_ctx_create")
+        self.h = h
+        self.logn, self.n, self.nprimes = logn, 1 << logn, nprimes
+        self.p = [self.lib.gpq_ctx_const(h, d, 0) for d in range(nprimes)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gpq_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def const(self, name, d):
+        which = {"p": 0, "pinv_mont": 1, "pinv_barr": 2, "ninv": 3, "psi": 4}[name]
+        return self.lib.gpq_ctx_const(self.h, d, which)
+
+    def zetas(self, d, inverse=False):
+        ptr = self.lib.gpq_ctx_zetas(self.h, d, 1 if inverse else 0)
+        return np.ctypeslib.as_array(ptr, shape=(self.n,)).copy()
+
+    def set_chunk(self, chunk):
+        _native.check(self.lib.gpq_set_chunk(self.h, chunk), "gpq_set_chunk")
+
+    def _shape(self, slab, dim):
+        per = dim * self.n
+        if slab.numel() % per:
+            raise ValueError("slab of %d words is not a multiple of dim*n = %d" % (slab.numel(), per))
+        return slab.numel() // per
+
+    # --- src/ntt.c:37,54 over slabs, in place ---
+    def poly_ntt(self, slab, dim):
+        _native.check(self.lib.gpq_ntt(self.h, _ptr(slab), dim, self._shape(slab, dim), _stream()), "gpq_ntt")
+        return slab
+
+    def poly_invntt(self, slab, dim):
+        _native.check(self.lib.gpq_invntt(self.h, _ptr(slab), dim, self._shape(slab, dim), _stream()), "gpq_invntt")
+        return slab
+
+    # --- src/poly.c:71-82 over slabs ---
+    def poly_rns_mul(self, r, a, b, dim):
+        _native.check(self.lib.gpq_rns_mul(self.h, _ptr(r), _ptr(a), _ptr(b), dim, self._shape(a, dim), _stream()), "gpq_rns_mul")
+        return r
+
+    def poly_rns_add(self, r, a, b, dim):
+        _native.check(self.lib.gpq_rns_add(self.h, _ptr(r), _ptr(a), _ptr(b), dim, self._shape(a, dim), _stream()), "gpq_rns_add")
+        return r
+
+    # --- limb loop of poly_mul, src/poly.c:96-103 ---
+    def poly_mul_rns(self, r, a, b, dim):
+        _native.check(self.lib.gpq_poly_mul_rns(self.h, _ptr(r), _ptr(a), _ptr(b), dim, self._shape(a, dim), _stream()),
+                      "gpq_poly_mul_rns")
+        return r
+
+    # --- he_mul RNS core ---
+    def tensor_workspace(self, dim, batch):
+        torch = _torch()
+        nbytes = self.lib.gpq_tensor_workspace_bytes(self.h, dim, batch)
+        return torch.empty(nbytes // 8, dtype=torch.int64, device="cuda")
+
+    def keyswitch_workspace(self, dim, batch):
+        torch = _torch()
+        nbytes = self.lib.gpq_keyswitch_workspace_bytes(self.h, dim, batch)
+        return torch.empty(nbytes // 8, dtype=torch.int64, device="cuda")
+
+    def he_mul_tensor(self, d0, d1, d2, a0, a1, b0, b1, dim, workspace=None):
+        """src/he-mult.c:116-138 on decomposed inputs: d0=a0*b0, d1=a0*b1+a1*b0, d2=a1*b1."""
+        batch = self._shape(a0, dim)
+        ws = workspace if workspace is not None else self.tensor_workspace(dim, batch)
+        _native.check(self.lib.gpq_he_mul_tensor(self.h, _ptr(d0), _ptr(d1), _ptr(d2), _ptr(a0), _ptr(a1), _ptr(b0), _ptr(b1),
+                                                 dim, batch, _ptr(ws), _stream()), "gpq_he_mul_tensor")
+        return d0, d1, d2
+
+    def he_keyswitch(self, c0, c1, x, evk0, evk1, dim, workspace=None):
+        """src/he-mult.c:58-66 / src/he-automorphism.c:59-67 on a decomposed input."""
+        batch = self._shape(x, dim)
+        ws = workspace if workspace is not None else self.keyswitch_workspace(dim, batch)
+        _native.check(self.lib.gpq_keyswitch(self.h, _ptr(c0), _ptr(c1), _ptr(x), _ptr(evk0), _ptr(evk1),
+                                             dim, batch, _ptr(ws), _stream()), "gpq_keyswitch")
+        return c0, c1
+
+
+class StreamTimer:
+    """HIP-event timer on the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.lib = _native.load()
+        self.h = C.c_void_p()
+        _native.check(self.lib.gpq_timer_create(C.byref(self.h)), "gpq_timer_create")
+
+    def start(self):
+        _native.check(self.lib.gpq_timer_start(self.h, _stream()), "gpq_timer_start")
+
+    def stop(self):
+        _native.check(self.lib.gpq_timer_stop(self.h, _stream()), "gpq_timer_stop")
+
+    def elapsed_ms(self):
+        ms = C.c_float()
+        _native.check(self.lib.gpq_timer_elapsed_ms(self.h, C.byref(ms)), "gpq_timer_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.gpq_timer_destroy(self.h)
+            self.h = None

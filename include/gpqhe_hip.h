@@ -1,0 +1,141 @@
+/*
+ * gpqhe_hip.h -- C ABI of libgpqhe_hip.so, the MI355X engine behind GPQHE's
+ * RNS/NTT hot path.  Plain C: pointers, sizes, opaque handles; no HIP or
+ * torch types (a hipStream_t travels as void*).
+ *
+ * Two groups of entry points:
+ *
+ *  (1) Reference-named drop-in symbols (gpqhe_hip_compat.h): `ntt`, `invntt`,
+ *      `poly_rns_mul`, `poly_rns_add`, `montgomery_*`, `barrett_*` with the
+ *      reference's exact signatures (host pointers, one limb, synchronous),
+ *      plus the north-star aliases `poly_ntt`, `poly_invntt`.
+ *
+ *  (2) The slab API below: whole limb-major slabs `uint64_t[batch][dim][n]`
+ *      resident in HBM, asynchronous on a caller-supplied stream.  These are
+ *      what the reference's limb loops (src/poly.c:96-103, src/he-mult.c:
+ *      116-138 and :58-66, src/he-automorphism.c:59-67) become once the loop
+ *      body is a kernel launch instead of a per-limb function call.
+ *
+ * Value contract (same as the reference): inputs are
+ * canonical residues < p_d, outputs canonical; forward output order is the
+ * reference's bit-reversed order; slab element (d, i) lives at d*n + i
+ * (src/poly.c:99, src/rns.c:67).
+ *
+ * Errors: the slab API returns GPQ_OK or a negative code and records a
+ * message (gpq_last_error); it never aborts.  The drop-in symbols keep the
+ * reference's convention: void return, errno=EINVAL + message + abort() on
+ * misuse (src/reduce.c:95-100).
+ */
+#ifndef GPQHE_HIP_H
+#define GPQHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPQ_OK 0
+#define GPQ_ERR_INVALID (-1)     /* bad argument / unsupported ring size        */
+#define GPQ_ERR_HIP (-2)         /* HIP runtime error, see gpq_last_error()      */
+#define GPQ_ERR_UNSUPPORTED (-3) /* prime outside the 2^59+c family the kernels fold */
+#define GPQ_ERR_NOMEM (-4)
+
+typedef struct gpq_ctx gpq_ctx;
+
+/* ---- context: replaces polyctx_init's RNS part ------------------------------
+ * Builds the reference's prime chain and per-prime tables for ring degree
+ * n = 2^logn and uploads them to `device`:
+ *   primes      p_0 < p_1 < ..., next prime == 1 (mod 2n) above 2^59+1   src/precomp.c:358, :372-376
+ *   constants   pinv_mont, pinv_barr, ninv                               src/precomp.c:246-248
+ *   twiddles    psi = g^((p-1)/2n), g least primitive root; tables in
+ *               bit-reversed order                                       src/precomp.c:206-242, :251-263
+ * `nprimes` plays polyctx.dimub (src/precomp.c:357).  logn in [1,17].
+ */
+int gpq_ctx_create(gpq_ctx **out, unsigned logn, unsigned nprimes, int device);
+
+/* Same, but adopting tables the caller already has in the reference's format
+ * (struct rns_ctx fields p / zetas / zetas_inv, Montgomery form): what the
+ * drop-in symbols use so that results follow the caller's tables exactly. */
+int gpq_ctx_create_from_tables(gpq_ctx **out, unsigned logn, unsigned nprimes, const uint64_t *primes,
+                               const uint64_t *const *zetas_mont, const uint64_t *const *zetas_inv_mont, int device);
+void gpq_ctx_destroy(gpq_ctx *ctx);
+
+unsigned gpq_ctx_logn(const gpq_ctx *ctx);
+unsigned gpq_ctx_nprimes(const gpq_ctx *ctx);
+int gpq_ctx_device(const gpq_ctx *ctx);
+/* Per-prime constants exactly as the reference's struct rns_ctx holds them
+ * (src/poly.h:28-41): which = 0 p, 1 pinv_mont, 2 pinv_barr, 3 ninv, 4 psi. */
+uint64_t gpq_ctx_const(const gpq_ctx *ctx, unsigned d, int which);
+/* Host copies of rns->zetas / rns->zetas_inv (Montgomery form), n entries. */
+const uint64_t *gpq_ctx_zetas(const gpq_ctx *ctx, unsigned d, int inverse);
+
+/* polyctx.dimub for a modulus of logq bits, src/precomp.c:357 (logqub=logq). */
+unsigned gpq_dimub(unsigned logn, unsigned logq);
+
+const char *gpq_last_error(void);
+
+/* ---- device memory helpers (for hosts without another allocator) ---------- */
+int gpq_malloc(void **dptr, size_t bytes);
+int gpq_free(void *dptr);
+int gpq_upload(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int gpq_download(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int gpq_stream_sync(void *stream);
+
+/* ---- slab operations ------------------------------------------------------
+ * All slabs are device pointers to uint64_t[batch][dim][n] using primes
+ * 0..dim-1 of the context.  `stream` is a hipStream_t (NULL = default).
+ */
+
+/* ntt / invntt over every limb of every polynomial, in place.
+ * Replaces the per-limb calls `ntt(a, rns)` / `invntt(a, rns)`, src/ntt.c:37,54. */
+int gpq_ntt(gpq_ctx *ctx, uint64_t *slab, unsigned dim, unsigned batch, void *stream);
+int gpq_invntt(gpq_ctx *ctx, uint64_t *slab, unsigned dim, unsigned batch, void *stream);
+
+/* r = a (*) b and r = a + b, coefficient-wise mod p_d; r may alias a or b.
+ * Replace poly_rns_mul / poly_rns_add, src/poly.c:71-82 (decl src/poly.h:84-85). */
+int gpq_rns_mul(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned dim, unsigned batch, void *stream);
+int gpq_rns_add(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned dim, unsigned batch, void *stream);
+
+/* Limb loop of poly_mul, src/poly.c:96-103 (without rns_decompose):
+ * r = invntt(ntt(a) (*) ntt(b)).  a and b are overwritten (NTT domain). */
+int gpq_poly_mul_rns(gpq_ctx *ctx, uint64_t *r, uint64_t *a, uint64_t *b, unsigned dim, unsigned batch, void *stream);
+
+/* The fused operations process the batch in groups of `chunk` polynomials so
+ * that pass-to-pass scratch stays cache resident (default 4). */
+int gpq_set_chunk(gpq_ctx *ctx, unsigned chunk);
+
+/* Bytes of scratch the two fused operations below need for this shape. */
+size_t gpq_tensor_workspace_bytes(const gpq_ctx *ctx, unsigned dim, unsigned batch);
+size_t gpq_keyswitch_workspace_bytes(const gpq_ctx *ctx, unsigned dim, unsigned batch);
+
+/* Tensor stage of he_mul, src/he-mult.c:116-138 without the rns_decompose
+ * calls: a0,a1,b0,b1 stand for the decomposed ct1.c0, ct1.c1, ct2.c0, ct2.c1;
+ *   d0 = a0*b0, d2 = a1*b1, d1 = a0*b1 + a1*b0   (negacyclic, per limb).
+ * Inputs are preserved.  Outputs may not alias inputs. */
+int gpq_he_mul_tensor(gpq_ctx *ctx, uint64_t *d0, uint64_t *d1, uint64_t *d2,
+                      const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1,
+                      unsigned dim, unsigned batch, void *workspace, void *stream);
+
+/* Key-switch inner product of he_relin / he_swk, src/he-mult.c:58-66 ==
+ * src/he-automorphism.c:59-67 without rns_decompose: x is the decomposed d2
+ * (or d1); evk0/evk1 are ONE key's NTT-domain slabs uint64_t[dim][n] as built
+ * by he_genswk (src/he-kem.c:103-110), shared by the whole batch.
+ *   c0 = invntt(ntt(x) (*) evk0), c1 = invntt(ntt(x) (*) evk1).  x preserved. */
+int gpq_keyswitch(gpq_ctx *ctx, uint64_t *c0, uint64_t *c1, const uint64_t *x,
+                  const uint64_t *evk0, const uint64_t *evk1,
+                  unsigned dim, unsigned batch, void *workspace, void *stream);
+
+/* ---- timing on the stream the kernels run on (HIP events) ----------------- */
+typedef struct gpq_timer gpq_timer;
+int gpq_timer_create(gpq_timer **t);
+int gpq_timer_start(gpq_timer *t, void *stream);
+int gpq_timer_stop(gpq_timer *t, void *stream);
+int gpq_timer_elapsed_ms(gpq_timer *t, float *ms); /* synchronises on the stop event */
+void gpq_timer_destroy(gpq_timer *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPQHE_HIP_H */

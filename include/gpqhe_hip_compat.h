@@ -1,0 +1,97 @@
+/*
+ * gpqhe_hip_compat.h -- the reference-named symbols libgpqhe_hip.so exports so
+ * that GPQHE's own objects link against it unchanged (SURVEY.md section 8b:
+ * the boundary is plain link-time C symbols of libgpqhe.so, src/Makefile:55-58).
+ *
+ * A GPQHE build that uses this library drops src/ntt.c and src/reduce.c from
+ * SOURCES and the two pointwise functions from src/poly.c;
+ * everything else of GPQHE keeps calling these names.
+ *
+ * The struct declarations restate the reference's memory layout only
+ * (src/poly.h:28-65) with `MPI` spelled as the opaque pointer it is
+ * (`typedef struct gcry_mpi *MPI`, src/types.h:47), so that this header does
+ * not need <gcrypt.h>.  When compiling GPQHE itself include its own poly.h
+ * instead -- the layouts are identical.
+ */
+#ifndef GPQHE_HIP_COMPAT_H
+#define GPQHE_HIP_COMPAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef POLY_H /* GPQHE's own poly.h not seen: declare layout-compatible types */
+typedef unsigned __int128 gpq_u128;
+typedef void *gpq_MPI;
+
+struct rns_ctx {               /* src/poly.h:28-41 */
+  unsigned int dim;
+  uint64_t p;
+  uint64_t pinv_mont;
+  uint64_t pinv_barr;
+  uint64_t ninv;
+  uint64_t *zetas;
+  uint64_t *zetas_inv;
+  gpq_MPI P;
+  gpq_MPI P_2;
+  gpq_MPI *phat;
+  uint64_t *phat_invmp;
+  struct rns_ctx *next;
+};
+
+struct ring_ctx {              /* src/poly.h:43-47 */
+  unsigned int *cyc_group;
+  _Complex double *zetas;
+  double cM;
+};
+
+struct poly_ctx {              /* src/poly.h:49-65 */
+  unsigned int logn;
+  unsigned int n;
+  unsigned int m;
+  unsigned int logqub;
+  unsigned int logq;
+  gpq_MPI q;
+  unsigned int logR;
+  gpq_u128 R;
+  gpq_u128 Rsub1;
+  unsigned int dimub;
+  struct rns_ctx *rns;
+  struct ring_ctx ring;
+};
+#else
+typedef u128 gpq_u128;
+#endif
+
+/* src/ntt.c:37,54 -- in place on one limb of n = polyctx.n coefficients (host
+ * memory); n is read from the global `polyctx` like the reference does
+ * (src/ntt.c:26,42).  Synchronous: the limb goes to the GPU and back. */
+void ntt(uint64_t a[], const struct rns_ctx *rns);
+void invntt(uint64_t a[], const struct rns_ctx *rns);
+/* north-star spellings of the same two functions (BASELINE.json) */
+void poly_ntt(uint64_t a[], const struct rns_ctx *rns);
+void poly_invntt(uint64_t a[], const struct rns_ctx *rns);
+
+/* src/poly.c:71-82, declared src/poly.h:84-85.  rhat may alias ahat/bhat
+ * (src/he-mult.c:130,183). */
+void poly_rns_add(uint64_t rhat[], const uint64_t ahat[], const uint64_t bhat[], const struct rns_ctx *rns);
+void poly_rns_mul(uint64_t rhat[], const uint64_t ahat[], const uint64_t bhat[], const struct rns_ctx *rns);
+
+/* src/reduce.c:36,59,75,88 -- scalar host helpers used by precomp.c at init. */
+uint64_t montgomery_inv(uint64_t q);
+uint64_t montgomery_reduce(gpq_u128 a, uint64_t q, int64_t qinv);
+uint64_t barrett_inv(uint64_t q);
+uint64_t barrett_reduce(gpq_u128 a, uint64_t q, uint64_t qinv);
+
+/* When the host program has no `polyctx` symbol (the library references it
+ * weakly), the ring degree for the drop-in calls is set here instead. */
+void gpq_dropin_set_logn(unsigned int logn);
+/* Releases the device tables the drop-in calls cached (per rns_ctx). */
+void gpq_dropin_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPQHE_HIP_COMPAT_H */

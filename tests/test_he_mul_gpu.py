@@ -1,0 +1,99 @@
+"""Parity of the fused he_mul RNS core (tensor stage + key-switch inner product)
+with the oracle's replay of src/he-mult.c:116-138 / :58-66 and with the golden
+digests the compiled reference produced."""
+import numpy as np
+import pytest
+
+from gpqhe_amd import to_device, to_host
+from oracle.oracle import fnv
+
+pytestmark = pytest.mark.gpu
+
+
+def _empty_like(t):
+    import torch
+    return torch.empty_like(t)
+
+
+def _tensor(g, ins, dim):
+    dev = [to_device(x) for x in ins]
+    outs = [_empty_like(dev[0]) for _ in range(3)]
+    g.he_mul_tensor(outs[0], outs[1], outs[2], dev[0], dev[1], dev[2], dev[3], dim)
+    for d, x in zip(dev, ins):
+        assert np.array_equal(to_host(d), x), "inputs must be preserved"
+    return [to_host(t) for t in outs]
+
+
+def _keyswitch(g, x, e0, e1, dim):
+    dx, d0, d1 = to_device(x), to_device(e0), to_device(e1)
+    c0, c1 = _empty_like(dx), _empty_like(dx)
+    g.he_keyswitch(c0, c1, dx, d0, d1, dim)
+    assert np.array_equal(to_host(dx), x)
+    return to_host(c0), to_host(c1)
+
+
+@pytest.mark.parametrize("logn", ["7", "12", "15", "16"])
+def test_golden_he_mul_core(golden, engine_ctx, oracle_ctx, logn):
+    kat = golden["he_mul_core_kat"][logn]
+    seeds = golden["he_mul_core_kat"]["_seeds"]
+    dA, dB = kat["dA"], kat["dB"]
+    npr = max(dA, dB)
+    o, g = oracle_ctx(int(logn), npr), engine_ctx(int(logn), npr)
+    ins = [o.gen(seeds[k], dA) for k in ("a0", "a1", "b0", "b1")]
+    assert [fnv(x) for x in ins] == kat["inputs"]
+    d0, d1, d2 = _tensor(g, ins, dA)
+    assert (fnv(d0), fnv(d1), fnv(d2)) == (kat["d0"], kat["d1"], kat["d2"])
+    c0, c1 = _keyswitch(g, o.gen(seeds["d2"], dB), o.gen(seeds["evk0"], dB), o.gen(seeds["evk1"], dB), dB)
+    assert (fnv(c0), fnv(c1)) == (kat["c0"], kat["c1"])
+
+
+@pytest.mark.parametrize("logn,dim,batch,chunk", [(7, 5, 3, 4), (12, 2, 2, 4), (13, 2, 5, 2), (14, 3, 2, 4), (16, 2, 3, 2), (17, 2, 1, 4)])
+def test_batched_core_matches_oracle(engine_ctx, oracle_ctx, logn, dim, batch, chunk):
+    """Batches (including a batch that is not a multiple of the launch chunk) against the oracle."""
+    o, g = oracle_ctx(logn, dim), engine_ctx(logn, dim)
+    g.set_chunk(chunk)
+    per = dim * o.n
+    ins = [np.concatenate([o.gen(100 * s + k, dim) for k in range(batch)]) for s in range(4)]
+    d0, d1, d2 = _tensor(g, ins, dim)
+    for k in range(batch):
+        e0, e1, e2 = o.he_mul_tensor(*[x[k * per:(k + 1) * per].copy() for x in ins], dim)
+        assert np.array_equal(d0[k * per:(k + 1) * per], e0)
+        assert np.array_equal(d1[k * per:(k + 1) * per], e1)
+        assert np.array_equal(d2[k * per:(k + 1) * per], e2)
+    x = np.concatenate([o.gen(900 + k, dim) for k in range(batch)])
+    ev0, ev1 = o.gen(7000, dim), o.gen(7001, dim)
+    c0, c1 = _keyswitch(g, x, ev0, ev1, dim)
+    for k in range(batch):
+        f0, f1 = o.keyswitch(x[k * per:(k + 1) * per].copy(), ev0, ev1, dim)
+        assert np.array_equal(c0[k * per:(k + 1) * per], f0)
+        assert np.array_equal(c1[k * per:(k + 1) * per], f1)
+    g.set_chunk(4)
+
+
+@pytest.mark.parametrize("logn,dim", [(7, 5), (13, 2)])
+def test_poly_mul_limb_loop(engine_ctx, oracle_ctx, logn, dim):
+    """src/poly.c:96-103 without rns_decompose."""
+    o, g = oracle_ctx(logn, dim), engine_ctx(logn, dim)
+    a, b = o.gen(41, dim), o.gen(42, dim)
+    da, db = to_device(a), to_device(b)
+    r = _empty_like(da)
+    g.poly_mul_rns(r, da, db, dim)
+    assert np.array_equal(to_host(r), o.poly_mul_rns(a, b, dim))
+
+
+def test_linearity_full_size(engine_ctx, oracle_ctx):
+    """Size-independent property at BASELINE's full shape (n=2^16, 30 limbs):
+    the tensor stage is bilinear, so tensor(a0+x, a1, b0, b1).d0 == d0 + x*b0."""
+    logn, dim = 16, 30
+    o, g = oracle_ctx(logn, 45), engine_ctx(logn, 45)
+    ins = [o.gen(1000 + s, dim) for s in range(4)]
+    x = o.gen(5, dim)
+    p = np.repeat(np.array(o.p[:dim], dtype=np.uint64), o.n)
+    a0x = (ins[0] + x) % p  # both < p < 2^60: no uint64 overflow
+    d0, d1, d2 = _tensor(g, ins, dim)
+    e0, e1, e2 = _tensor(g, [a0x, ins[1], ins[2], ins[3]], dim)
+    z = np.zeros_like(x)
+    f0, f1, f2 = _tensor(g, [x, z, ins[2], ins[3]], dim)
+    assert np.array_equal(e0, (d0 + f0) % p)
+    assert np.array_equal(e1, (d1 + f1) % p)
+    assert np.array_equal(e2, d2) and not f2.any()

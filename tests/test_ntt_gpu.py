@@ -1,0 +1,121 @@
+"""Parity of the HIP NTT / INTT / pointwise kernels (through the C ABI) with the
+CPU oracle and with the reference's golden digests.  Bit-exact: integer work."""
+import numpy as np
+import pytest
+
+import gpqhe_amd
+from gpqhe_amd import to_device, to_host
+from oracle.oracle import fnv
+
+pytestmark = pytest.mark.gpu
+
+# (logn, dim, batch): small rings (LDS kernel), every two-pass geometry, ragged batch
+SHAPES = [(1, 2, 1), (2, 1, 3), (7, 5, 2), (10, 3, 1), (12, 3, 2), (13, 2, 3), (14, 2, 1), (15, 10, 1), (16, 3, 2), (17, 2, 1)]
+
+
+def _rand_slab(o, seed, dim, batch):
+    return np.concatenate([o.gen(seed + 17 * k, dim) for k in range(batch)])
+
+
+@pytest.mark.parametrize("logn,dim,batch", SHAPES)
+def test_ntt_invntt_match_oracle(engine_ctx, oracle_ctx, logn, dim, batch):
+    o, g = oracle_ctx(logn, dim), engine_ctx(logn, dim)
+    assert g.p == o.p
+    a = _rand_slab(o, 11, dim, batch)
+    dev = to_device(a)
+    g.poly_ntt(dev, dim)
+    fwd = to_host(dev)
+    assert np.array_equal(fwd, o.ntt_slab(a, dim)), "forward NTT differs from src/ntt.c:37-52"
+    g.poly_invntt(dev, dim)
+    assert np.array_equal(to_host(dev), a), "invntt(ntt(a)) != a"
+    # inverse alone on arbitrary canonical input
+    dev2 = to_device(a)
+    g.poly_invntt(dev2, dim)
+    assert np.array_equal(to_host(dev2), o.ntt_slab(a, dim, inverse=True)), "inverse NTT differs from src/ntt.c:54-73"
+
+
+@pytest.mark.parametrize("logn", ["7", "12", "15", "16", "17"])
+def test_golden_single_limb_digest(golden, engine_ctx, oracle_ctx, logn):
+    """digest of ntt(gen(seed=1), limb 0) produced by the compiled reference."""
+    kat = golden["ntt_kat_seed1_limb0"][logn]
+    n = int(logn)
+    o, g = oracle_ctx(n, 1), engine_ctx(n, 1)
+    a = o.gen(1, 1)
+    assert fnv(a) == kat["input"]
+    dev = to_device(a)
+    g.poly_ntt(dev, 1)
+    out = to_host(dev)
+    assert fnv(out) == kat["ntt"]
+    assert [str(v) for v in out[:3]] == kat["out012"]
+
+
+@pytest.mark.parametrize("logn", [7, 12, 16])
+def test_context_tables_match_reference_constants(golden, engine_ctx, oracle_ctx, logn):
+    rec = golden["prime_chain"][str(logn)]
+    g = engine_ctx(logn, rec["count"] if logn < 16 else 8)
+    assert [str(p) for p in g.p[: len(rec["first"])]] == rec["first"]
+    k = golden["p0_constants"][str(logn)]
+    assert str(g.const("pinv_mont", 0)) == k["pinv_mont"]
+    assert str(g.const("pinv_barr", 0)) == k["pinv_barr"]
+    assert str(g.const("ninv", 0)) == k["ninv"]
+    z, zi = g.zetas(0), g.zetas(0, inverse=True)
+    assert str(z[g.n // 2]) == k["zetas_n_2"] and str(z[1]) == k["zetas_1"] and str(zi[1]) == k["zetas_inv_1"]
+    o = oracle_ctx(logn, g.nprimes)
+    for d in (0, g.nprimes - 1):
+        assert np.array_equal(g.zetas(d), o.zetas(d)) and np.array_equal(g.zetas(d, True), o.zetas(d, True))
+
+
+@pytest.mark.parametrize("logn,dim,batch", [(7, 5, 2), (12, 2, 1), (16, 2, 2)])
+def test_pointwise_match_oracle_and_alias(engine_ctx, oracle_ctx, logn, dim, batch):
+    o, g = oracle_ctx(logn, dim), engine_ctx(logn, dim)
+    n = o.n
+    a, b = _rand_slab(o, 3, dim, batch), _rand_slab(o, 5, dim, batch)
+    # edge values: 0, 1, p-1 in the first coefficients of every limb
+    for k in range(batch):
+        for d in range(dim):
+            base = (k * dim + d) * n
+            a[base:base + 4] = [0, 1, o.p[d] - 1, o.p[d] - 1]
+            b[base:base + 4] = [o.p[d] - 1, o.p[d] - 1, o.p[d] - 1, 1]
+    exp_mul = np.concatenate([o.rns_mul(a[i * n:(i + 1) * n], b[i * n:(i + 1) * n], i % dim) for i in range(dim * batch)])
+    exp_add = np.concatenate([o.rns_add(a[i * n:(i + 1) * n], b[i * n:(i + 1) * n], i % dim) for i in range(dim * batch)])
+    da, db = to_device(a), to_device(b)
+    r = to_device(np.zeros_like(a))
+    g.poly_rns_mul(r, da, db, dim)
+    assert np.array_equal(to_host(r), exp_mul)
+    g.poly_rns_add(r, da, db, dim)
+    assert np.array_equal(to_host(r), exp_add)
+    g.poly_rns_mul(da, da, db, dim)  # r aliases a, as src/he-mult.c:130 does
+    assert np.array_equal(to_host(da), exp_mul)
+
+
+@pytest.mark.parametrize("logn", [13, 16])
+def test_lazy_arithmetic_extremes(engine_ctx, oracle_ctx, logn):
+    """All-(p-1) and all-zero limbs drive the lazy ranges of modarith.hpp to their bounds."""
+    dim = 2
+    o, g = oracle_ctx(logn, dim), engine_ctx(logn, dim)
+    for fill in ("max", "zero", "alt"):
+        a = np.empty(dim * o.n, dtype=np.uint64)
+        for d in range(dim):
+            v = a[d * o.n:(d + 1) * o.n]
+            if fill == "max":
+                v[:] = o.p[d] - 1
+            elif fill == "zero":
+                v[:] = 0
+            else:
+                v[0::2] = o.p[d] - 1
+                v[1::2] = 0
+        dev = to_device(a)
+        g.poly_ntt(dev, dim)
+        assert np.array_equal(to_host(dev), o.ntt_slab(a, dim))
+        dev = to_device(a)
+        g.poly_invntt(dev, dim)
+        assert np.array_equal(to_host(dev), o.ntt_slab(a, dim, inverse=True))
+
+
+def test_bad_arguments_are_reported_not_fatal(engine_ctx):
+    g = engine_ctx(7, 5)
+    dev = to_device(np.zeros(5 * 128, dtype=np.uint64))
+    with pytest.raises(gpqhe_amd.GpqError):
+        g.poly_ntt(dev, 6)  # dim beyond the context's prime chain
+    with pytest.raises(ValueError):
+        g.poly_ntt(dev[:100], 5)  # ragged slab
