@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- he_mul RNS-core throughput of the MI355X engine.
+
+Workload (BASELINE.json configs[2]): n = 2^16, tensor stage over
+dimA = 30 limbs (src/he-mult.c:116-138) + key-switch inner product over
+dimB = 45 limbs (src/he-mult.c:58-66) for a batch of 64 independent
+ciphertext multiplications per GPU, synthetic uniform residues already in RNS
+form and resident in HBM.  One "step" = the whole batch once.  he_rescale has
+no RNS-domain work in the reference (src/he-rescale.c:33-54 is big-integer
+only), so it is not part of the timed RNS core.
+
+Multi-GPU: independent ciphertexts, one shard per rank, no data-path collective
+(weak scaling); the only collectives are the timing barrier and a MAX.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOGN, DIM_A, DIM_B = 16, 30, 45
+ALGO_BYTES_PER_HE_MUL = (7 * DIM_A + 5 * DIM_B) * (8 << LOGN)  # 228,065,280
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+# own read+write bytes of one (limb, polynomial) unit of each kernel, in limbs of n*8 bytes
+KERNEL_LIMB_PASSES = {"strided_fwd": 2, "strided_inv": 2, "tensor_mid": 7, "keyswitch_mid": 5,
+                      "contig_fwd": 2, "contig_inv": 2, "pointwise": 3}
+
+
+def rand_slab(torch, ctx, dim, batch, gen):
+    """uniform residues in [0, p_d), limb-major [batch][dim][n]"""
+    out = torch.empty((batch, dim, ctx.n), dtype=torch.int64, device="cuda")
+    for d in range(dim):
+        out[:, d, :] = torch.randint(0, ctx.p[d], (batch, ctx.n), dtype=torch.int64, device="cuda", generator=gen)
+    return out.reshape(-1)
+
+
+def cpu_baseline(ctx, host_inputs, gpu_outputs, sample):
+    """The oracle (CPU restatement of the reference loops) timed on this host, one
+    thread like the reference, on `sample` ciphertexts of the same workload; its
+    outputs double as a bit-exact check of the GPU results for those ciphertexts."""
+    from oracle.oracle import OracleCtx, lib
+    lib().orc_set_threads(1)
+    o = OracleCtx(LOGN, DIM_B)
+    assert o.p == ctx.p[:DIM_B]
+    perA, perB = DIM_A * o.n, DIM_B * o.n
+    a0, a1, b0, b1, x, e0, e1 = host_inputs
+    t0 = time.perf_counter()
+    ok = True
+    for k in range(sample):
+        d = o.he_mul_tensor(*[np.ascontiguousarray(v[k * perA:(k + 1) * perA]) for v in (a0, a1, b0, b1)], DIM_A)
+        c = o.keyswitch(np.ascontiguousarray(x[k * perB:(k + 1) * perB]), e0, e1, DIM_B)
+        for got, exp, per in zip(gpu_outputs, list(d) + list(c), (perA, perA, perA, perB, perB)):
+            ok = ok and np.array_equal(got[k * per:(k + 1) * per], exp)
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "he_mul/s", "cores": 1, "kind": "port",
+            "sample": "%d he_mul RNS cores (tensor %d limbs + key-switch %d limbs, n=2^%d) of the same batch, %.1f s" % (sample, DIM_A, DIM_B, LOGN, dt),
+            "bit_exact_vs_gpu": bool(ok)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="ciphertext multiplications per GPU per step")
+    ap.add_argument("--chunk", type=int, default=0, help="polynomials per fused launch group (0 = library default)")
+    ap.add_argument("--cpu-sample", type=int, default=2, help="ciphertexts the CPU baseline replays (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import gpqhe_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world:
+        if rank == 0 and world > 1:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    ctx = gpqhe_amd.PolyContext(LOGN, DIM_B)
+    if args.chunk:
+        ctx.set_chunk(args.chunk)
+    B = args.batch
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1000 + rank)
+    a0, a1, b0, b1 = (rand_slab(torch, ctx, DIM_A, B, gen) for _ in range(4))
+    x = rand_slab(torch, ctx, DIM_B, B, gen)                   # stands for decompose(d2), SURVEY.md 8d
+    gk = torch.Generator(device="cuda")
+    gk.manual_seed(3000)                                       # one relinearisation key shared by every rank
+    e0, e1 = rand_slab(torch, ctx, DIM_B, 1, gk), rand_slab(torch, ctx, DIM_B, 1, gk)
+    d0, d1, d2 = (torch.empty_like(a0) for _ in range(3))
+    c0, c1 = torch.empty_like(x), torch.empty_like(x)
+    wsA, wsB = ctx.tensor_workspace(DIM_A, B), ctx.keyswitch_workspace(DIM_B, B)
+
+    def step():
+        ctx.he_mul_tensor(d0, d1, d2, a0, a1, b0, b1, DIM_A, wsA)
+        ctx.he_keyswitch(c0, c1, x, e0, e1, DIM_B, wsB)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile(False)
+    prof = ctx.profile_collect()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_he_mul = world * B * args.steps
+        value = total_he_mul / dt
+        # dominant kernel by accumulated device time
+        kname, (kms, kcnt) = max(prof.items(), key=lambda kv: kv[1][0])
+        dim_of = {"tensor_mid": DIM_A, "keyswitch_mid": DIM_B}
+        # strided kernels run for both stages: average units per launch from the launch mix
+        chunk = min(B, args.chunk or 4)
+        launches_per_step = -(-B // chunk)
+        units = {"tensor_mid": DIM_A * chunk, "keyswitch_mid": DIM_B * chunk,
+                 "strided_fwd": (4 * DIM_A + 1 * DIM_B) * chunk / 2.0, "strided_inv": (3 * DIM_A + 2 * DIM_B) * chunk / 2.0}
+        kernels = {}
+        for name, (ms, cnt) in prof.items():
+            avg_ms = ms / cnt
+            byts = KERNEL_LIMB_PASSES[name] * units.get(name, 0) * (8 << LOGN)
+            kernels[name] = {"avg_ms": round(avg_ms, 4), "launches": int(cnt), "share": round(ms / sum(v[0] for v in prof.values()), 3),
+                             "algo_GBps": round(byts / (avg_ms * 1e-3) / 1e9, 1)}
+        kavg = kms / kcnt
+        kbytes = KERNEL_LIMB_PASSES[kname] * units[kname] * (8 << LOGN)
+        achieved = kbytes / (kavg * 1e-3) / 1e9
+        out = {
+            "metric": "ciphertext he_mul/sec (RNS core: tensor 30 limbs + key-switch 45 limbs), N=2^16",
+            "value": round(value, 2), "unit": "he_mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "he_mul RNS core, n=2^16, dimA=30, dimB=45, batch=%d ciphertexts per GPU (BASELINE configs[2]); "
+                                   "he_rescale has no RNS-domain work in the reference" % B,
+                       "batch_per_gpu": B, "chunk": chunk, "parallelism": "ciphertext-per-GPU x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "bytes_per_launch": int(kbytes), "avg_launch_ms": round(kavg, 4)},
+            "he_mul_e2e": {"algo_bytes_per_he_mul": ALGO_BYTES_PER_HE_MUL,
+                           "achieved_GBps_per_gpu": round(ALGO_BYTES_PER_HE_MUL * value / world / 1e9, 1),
+                           "hbm_frac_per_gpu": round(ALGO_BYTES_PER_HE_MUL * value / world / 1e9 / HBM_PEAK_GBS, 4)},
+            "kernels": kernels,
+        }
+        if world == 1 and args.cpu_sample > 0:
+            s = args.cpu_sample
+            host_in = [gpqhe_amd.to_host(v[: s * DIM_A * ctx.n]) for v in (a0, a1, b0, b1)] + \
+                      [gpqhe_amd.to_host(x[: s * DIM_B * ctx.n]), gpqhe_amd.to_host(e0), gpqhe_amd.to_host(e1)]
+            gpu_out = [gpqhe_amd.to_host(v[: s * DIM_A * ctx.n]) for v in (d0, d1, d2)] + \
+                      [gpqhe_amd.to_host(v[: s * DIM_B * ctx.n]) for v in (c0, c1)]
+            out["cpu_baseline"] = cpu_baseline(ctx, host_in, gpu_out, s)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

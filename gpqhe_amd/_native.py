@@ -40,6 +40,10 @@ SIGNATURES = {
     "gpq_keyswitch_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
     "gpq_he_mul_tensor": (C.c_int, [vp] * 8 + [C.c_uint, C.c_uint, vp, vp]),
     "gpq_keyswitch": (C.c_int, [vp] * 6 + [C.c_uint, C.c_uint, vp, vp]),
+    "gpq_profile_enable": (C.c_int, [vp, C.c_int]),
+    "gpq_profile_kernels": (C.c_int, []),
+    "gpq_profile_kernel_name": (C.c_char_p, [C.c_int]),
+    "gpq_profile_collect": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),
     "gpq_timer_create": (C.c_int, [C.POINTER(vp)]),
     "gpq_timer_start": (C.c_int, [vp, vp]),
     "gpq_timer_stop": (C.c_int, [vp, vp]),

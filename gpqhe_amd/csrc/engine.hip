@@ -229,6 +229,8 @@ extern "C" void gpq_ctx_destroy(gpq_ctx *c) {
   if (c->d_w) (void)hipFree(c->d_w);
   if (c->d_winv) (void)hipFree(c->d_winv);
   if (c->d_tabs) (void)hipFree(c->d_tabs);
+  for (gpq_prof_rec &r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
   delete c;
 }
 
@@ -272,6 +274,25 @@ extern "C" int gpq_stream_sync(void *stream) { HIP_TRY(hipStreamSynchronize((hip
 // ---------------------------------------------------------------------------
 namespace {
 
+static const char *const kKernelNames[GPQ_K_COUNT] = {"strided_fwd", "strided_inv", "contig_fwd", "contig_inv",
+                                                      "tensor_mid", "keyswitch_mid", "pointwise", "small_ntt"};
+
+// Brackets one kernel launch with two events on its stream when profiling is on.
+struct ProfScope {
+  gpq_ctx *c; hipStream_t s; gpq_prof_rec r; bool on;
+  ProfScope(const gpq_ctx *cc, int kernel, hipStream_t st) : c(const_cast<gpq_ctx *>(cc)), s(st), on(cc->prof_on) {
+    if (!on) return;
+    auto get = [&]() { hipEvent_t e; if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+    r.kernel = kernel; r.a = get(); r.b = get();
+    (void)hipEventRecord(r.a, s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, s);
+    c->prof.push_back(r);
+  }
+};
+
 struct Shape { unsigned dim, batch; };
 
 int check_shape(const gpq_ctx *c, unsigned dim, unsigned batch, const char *who) {
@@ -303,6 +324,7 @@ int launch_strided_t(const PassArgs &a, dim3 grid, hipStream_t s) {
 template <bool INV>
 int launch_strided(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned polys, hipStream_t s) {
   const dim3 grid(16, polys * a.nslab, dim);
+  ProfScope prof(c, INV ? GPQ_K_STRIDED_INV : GPQ_K_STRIDED_FWD, s);
   switch (c->logn) {
     case 13: return launch_strided_t<5, 4, INV, false>(a, grid, s);
     case 14: return launch_strided_t<6, 4, INV, false>(a, grid, s);
@@ -316,6 +338,7 @@ int launch_strided(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned p
 template <bool INV>
 int launch_contig(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned polys, hipStream_t s) {
   const dim3 grid(c->n >> 12, polys * a.nslab, dim);
+  ProfScope prof(c, INV ? GPQ_K_CONTIG_INV : GPQ_K_CONTIG_FWD, s);
   hipLaunchKernelGGL((contig_pass<INV>), grid, dim3(CONTIG_WAVES * 64), 0, s, a);
   return GPQ_OK;
 }
@@ -323,6 +346,7 @@ int launch_contig(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned po
 template <bool INV>
 int launch_small(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned polys, hipStream_t s) {
   const dim3 grid(1, polys * a.nslab, dim);
+  ProfScope prof(c, GPQ_K_SMALL, s);
   hipLaunchKernelGGL((small_ntt<INV>), grid, dim3(256), 0, s, a);
   return GPQ_OK;
 }
@@ -383,6 +407,7 @@ static int pointwise_api(gpq_ctx *c, uint64_t *r, const uint64_t *x, const uint6
   PassArgs a = make_args(c, dim, 1);
   a.src[0] = x; a.src[1] = y; a.dst[0] = r;
   const unsigned bx = c->n >= 512 ? c->n / 512 : 1;
+  ProfScope prof(c, GPQ_K_POINTWISE, (hipStream_t)stream);
   hipLaunchKernelGGL((pointwise<MUL>), dim3(bx, batch, dim), dim3(256), 0, (hipStream_t)stream, a);
   return after_launch(who);
 }
@@ -459,7 +484,10 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
     PassArgs m = make_args(c, dim, 1);
     for (int i = 0; i < 4; ++i) m.src[i] = f.dst[i];
     m.dst[0] = d0 + k0 * poly; m.dst[1] = d1 + k0 * poly; m.dst[2] = d2 + k0 * poly;
-    hipLaunchKernelGGL(tensor_mid, dim3(c->n >> 12, polys, dim), dim3(CONTIG_WAVES * 64), 0, s, m);
+    {
+      ProfScope prof(c, GPQ_K_TENSOR_MID, s);
+      hipLaunchKernelGGL(tensor_mid, dim3(c->n >> 12, polys, dim), dim3(CONTIG_WAVES * 64), 0, s, m);
+    }
     // 3. strided inverse pass in place on the three outputs
     PassArgs b = make_args(c, dim, 3);
     for (int i = 0; i < 3; ++i) { b.src[i] = m.dst[i]; b.dst[i] = m.dst[i]; }
@@ -499,7 +527,10 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
     m.p = make_args(c, dim, 1);
     m.p.src[0] = ws; m.p.dst[0] = c0 + k0 * poly; m.p.dst[1] = c1 + k0 * poly;
     m.evk0 = evk0; m.evk1 = evk1;
-    hipLaunchKernelGGL(keyswitch_mid, dim3(c->n >> 12, polys, dim), dim3(CONTIG_WAVES * 64), 0, s, m);
+    {
+      ProfScope prof(c, GPQ_K_KEYSWITCH_MID, s);
+      hipLaunchKernelGGL(keyswitch_mid, dim3(c->n >> 12, polys, dim), dim3(CONTIG_WAVES * 64), 0, s, m);
+    }
     PassArgs b = make_args(c, dim, 2);
     for (int i = 0; i < 2; ++i) { b.src[i] = m.p.dst[i]; b.dst[i] = m.p.dst[i]; }
     if ((rc = launch_strided<true>(c, b, dim, polys, s))) return rc;
@@ -510,6 +541,35 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
 extern "C" int gpq_set_chunk(gpq_ctx *c, unsigned chunk) {
   if (!c || chunk < 1) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_chunk: bad arguments");
   c->chunk = chunk;
+  return GPQ_OK;
+}
+
+// ---------------------------------------------------------------------------
+// per-kernel profile (HIP events around every launch, on the launch stream)
+// ---------------------------------------------------------------------------
+extern "C" int gpq_profile_enable(gpq_ctx *c, int on) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_profile_enable: null context");
+  c->prof_on = on != 0;
+  return GPQ_OK;
+}
+extern "C" int gpq_profile_kernels(void) { return GPQ_K_COUNT; }
+extern "C" const char *gpq_profile_kernel_name(int k) { return (k >= 0 && k < GPQ_K_COUNT) ? kKernelNames[k] : ""; }
+
+// Waits for the recorded launches, adds their durations per kernel into
+// total_ms[GPQ_K_COUNT] / launches[GPQ_K_COUNT], then forgets them.
+extern "C" int gpq_profile_collect(gpq_ctx *c, double *total_ms, unsigned long long *launches) {
+  if (!c || !total_ms || !launches) return gpq_fail(GPQ_ERR_INVALID, "gpq_profile_collect: bad arguments");
+  for (int k = 0; k < GPQ_K_COUNT; ++k) { total_ms[k] = 0; launches[k] = 0; }
+  for (gpq_prof_rec &r : c->prof) {
+    float ms = 0;
+    HIP_TRY(hipEventSynchronize(r.b));
+    HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+    total_ms[r.kernel] += ms;
+    launches[r.kernel] += 1;
+    c->prof_pool.push_back(r.a);
+    c->prof_pool.push_back(r.b);
+  }
+  c->prof.clear();
   return GPQ_OK;
 }
 

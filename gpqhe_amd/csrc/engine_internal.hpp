@@ -1,7 +1,14 @@
 // engine_internal.hpp -- the context object behind the opaque gpq_ctx handle.
 #pragma once
+#include <string>
 #include <vector>
 #include "ntt_kernels.hpp"
+
+// Optional per-launch timing with HIP events recorded on the launch stream
+// (bench.py's roofline leg).  Off by default: no events are created.
+struct gpq_prof_rec { int kernel; hipEvent_t a, b; };
+enum { GPQ_K_STRIDED_FWD = 0, GPQ_K_STRIDED_INV, GPQ_K_CONTIG_FWD, GPQ_K_CONTIG_INV, GPQ_K_TENSOR_MID,
+       GPQ_K_KEYSWITCH_MID, GPQ_K_POINTWISE, GPQ_K_SMALL, GPQ_K_COUNT };
 
 struct gpq_ctx {
   int device = 0;
@@ -13,6 +20,10 @@ struct gpq_ctx {
   // device tables (standard form)
   uint64_t *d_w = nullptr, *d_winv = nullptr;
   gpq::LimbTab *d_tabs = nullptr;
+  // profiling
+  bool prof_on = false;
+  std::vector<gpq_prof_rec> prof;     // launches recorded since the last reset
+  std::vector<hipEvent_t> prof_pool;  // recycled events
 };
 
 int gpq_fail(int code, const char *fmt, ...);

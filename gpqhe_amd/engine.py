@@ -81,6 +81,17 @@ class PolyContext:
     def set_chunk(self, chunk):
         _native.check(self.lib.gpq_set_chunk(self.h, chunk), "gpq_set_chunk")
 
+    def profile(self, on):
+        _native.check(self.lib.gpq_profile_enable(self.h, 1 if on else 0), "gpq_profile_enable")
+
+    def profile_collect(self):
+        """{kernel name: (total ms, launches)} of the launches recorded since the last call."""
+        k = self.lib.gpq_profile_kernels()
+        ms = (C.c_double * k)()
+        cnt = (C.c_ulonglong * k)()
+        _native.check(self.lib.gpq_profile_collect(self.h, ms, cnt), "gpq_profile_collect")
+        return {self.lib.gpq_profile_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(k) if cnt[i]}
+
     def _shape(self, slab, dim):
         per = dim * self.n
         if slab.numel() % per:

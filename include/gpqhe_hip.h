@@ -127,6 +127,15 @@ int gpq_keyswitch(gpq_ctx *ctx, uint64_t *c0, uint64_t *c1, const uint64_t *x,
                   const uint64_t *evk0, const uint64_t *evk1,
                   unsigned dim, unsigned batch, void *workspace, void *stream);
 
+/* ---- per-kernel profile ----------------------------------------------------
+ * When enabled every kernel launch of this context is bracketed by two HIP
+ * events on its own stream.  gpq_profile_collect waits for them and adds the
+ * durations per kernel (index < gpq_profile_kernels()) into the two arrays. */
+int gpq_profile_enable(gpq_ctx *ctx, int on);
+int gpq_profile_kernels(void);
+const char *gpq_profile_kernel_name(int kernel);
+int gpq_profile_collect(gpq_ctx *ctx, double *total_ms, unsigned long long *launches);
+
 /* ---- timing on the stream the kernels run on (HIP events) ----------------- */
 typedef struct gpq_timer gpq_timer;
 int gpq_timer_create(gpq_timer **t);

@@ -114,7 +114,7 @@ def test_lazy_arithmetic_extremes(engine_ctx, oracle_ctx, logn):
 
 def test_bad_arguments_are_reported_not_fatal(engine_ctx):
     g = engine_ctx(7, 5)
-    dev = to_device(np.zeros(5 * 128, dtype=np.uint64))
+    dev = to_device(np.zeros(6 * 128, dtype=np.uint64))
     with pytest.raises(gpqhe_amd.GpqError):
         g.poly_ntt(dev, 6)  # dim beyond the context's prime chain
     with pytest.raises(ValueError):
