@@ -147,8 +147,6 @@ static int upload_tables(gpq_ctx *c) {
     }
     LimbTab &t = tabs[d];
     t.k.p = p; t.k.p2 = 2 * p; t.k.p4 = 4 * p; t.k.c = (uint32_t)(p - (1ull << 59)); t.k.pad = 0;
-    t.w = c->d_w + d * n;
-    t.winv = c->d_winv + d * n;
     t.ninv = from_mont(c->ninv_mont[d]);
     t.winv1_ninv = n >= 2 ? mulm(wistd[d * n + 1], t.ninv, p) : t.ninv;
   }
@@ -306,6 +304,8 @@ PassArgs make_args(const gpq_ctx *c, unsigned dim, unsigned nslab) {
   PassArgs a;
   memset(&a, 0, sizeof a);
   a.tabs = c->d_tabs;
+  a.w = c->d_w;
+  a.winv = c->d_winv;
   a.poly_stride = (unsigned long long)dim << c->logn;
   a.logn = c->logn;
   a.limb0 = 0;

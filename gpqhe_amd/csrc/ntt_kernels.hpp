@@ -27,10 +27,8 @@
 
 namespace gpq {
 
-struct LimbTab {           // one per prime, array resident in HBM
+struct LimbTab {           // per-prime scalars, array resident in HBM (read with scalar loads)
   PrimeK k;
-  const uint64_t *w;       // forward twiddles, standard form, [n], index as rns->zetas (src/precomp.c:255-263)
-  const uint64_t *winv;    // inverse twiddles, as rns->zetas_inv
   uint64_t ninv;           // n^-1 mod p, standard form (reference: rns->ninv is n^-1*2^64, src/precomp.c:248)
   uint64_t winv1_ninv;     // winv[1]*n^-1 mod p : last inverse stage with the scaling folded in
 };
@@ -38,6 +36,11 @@ struct LimbTab {           // one per prime, array resident in HBM
 #define GPQ_MAX_SLABS 4
 struct PassArgs {
   const LimbTab *tabs;               // tabs[limb0 + blockIdx.z]
+  // Twiddle tables [nprimes][n], standard form, indexed like rns->zetas / rns->zetas_inv
+  // (src/precomp.c:255-263).  Kernel-argument pointers: the compiler knows they are
+  // global memory, so uniform reads become s_load and the rest global_load.
+  const uint64_t *w;
+  const uint64_t *winv;
   const uint64_t *src[GPQ_MAX_SLABS];
   uint64_t *dst[GPQ_MAX_SLABS];
   unsigned long long poly_stride;    // elements between consecutive polynomials of a slab (= limbs_in_slab * n)
@@ -51,29 +54,48 @@ struct PassArgs {
 // global index bit (rs + b); ibase is the global index of x[0].  A stage on
 // register bit b is the reference stage with len = 2^(rs+b).
 // ---------------------------------------------------------------------------
+// Number of distinct twiddles a group over register bits BHI..BLO touches.
+constexpr int tw_count(int EL, int BHI, int BLO) { return (1 << (EL - BLO)) - (1 << (EL - BHI - 1)); }
+
+// Fetch the twiddles of a group into registers ahead of the butterflies: stage on
+// bit b uses table[n/(2 len) + i/(2 len)], i.e. 2^(EL-b-1) consecutive entries per thread.
 template <int EL, int BHI, int BLO, bool UNIFORM>
-__device__ __forceinline__ void ct_group(uint64_t (&x)[1 << EL], unsigned ibase, int rs, unsigned logn,
-                                         const uint64_t *__restrict__ w, const PrimeK &k) {
+__device__ __forceinline__ void load_tw(uint64_t (&tw)[tw_count(EL, BHI, BLO)], unsigned ibase, int rs, unsigned logn,
+                                        const uint64_t *__restrict__ w) {
+  int o = 0;
 #pragma unroll
   for (int b = BHI; b >= BLO; --b) {
     const int sh = rs + b + 1;                         // i / (2 len)
     const uint64_t *wp = w + (1u << (logn - sh)) + (UNIFORM ? 0u : (ibase >> sh));
 #pragma unroll
-    for (int e = 0; e < (1 << EL); ++e)
-      if (!(e & (1 << b))) ct_bfly(x[e], x[e + (1 << b)], wp[e >> (b + 1)], k);
+    for (int j = 0; j < (1 << (EL - b - 1)); ++j) tw[o + j] = wp[j];
+    o += 1 << (EL - b - 1);
   }
 }
 
-template <int EL, int BLO, int BHI, bool UNIFORM>
-__device__ __forceinline__ void gs_group(uint64_t (&x)[1 << EL], unsigned ibase, int rs, unsigned logn,
-                                         const uint64_t *__restrict__ winv, const PrimeK &k) {
+template <int EL, int BHI, int BLO>
+__device__ __forceinline__ void ct_group(uint64_t (&x)[1 << EL], const uint64_t (&tw)[tw_count(EL, BHI, BLO)],
+                                         const PrimeK &k) {
+  int o = 0;
 #pragma unroll
-  for (int b = BLO; b <= BHI; ++b) {
-    const int sh = rs + b + 1;
-    const uint64_t *wp = winv + (1u << (logn - sh)) + (UNIFORM ? 0u : (ibase >> sh));
+  for (int b = BHI; b >= BLO; --b) {
 #pragma unroll
     for (int e = 0; e < (1 << EL); ++e)
-      if (!(e & (1 << b))) gs_bfly(x[e], x[e + (1 << b)], wp[e >> (b + 1)], k);
+      if (!(e & (1 << b))) ct_bfly(x[e], x[e + (1 << b)], tw[o + (e >> (b + 1))], k);
+    o += 1 << (EL - b - 1);
+  }
+}
+
+// Inverse: stages run from bit BLO up to BHI; tw[] is laid out as load_tw fills it (BHI first).
+template <int EL, int BHI, int BLO>
+__device__ __forceinline__ void gs_group(uint64_t (&x)[1 << EL], const uint64_t (&tw)[tw_count(EL, BHI, BLO)],
+                                         const PrimeK &k) {
+#pragma unroll
+  for (int b = BLO; b <= BHI; ++b) {
+    const int o = (1 << (EL - b - 1)) - (1 << (EL - BHI - 1));   // entries of the higher bits come first
+#pragma unroll
+    for (int e = 0; e < (1 << EL); ++e)
+      if (!(e & (1 << b))) gs_bfly(x[e], x[e + (1 << b)], tw[o + (e >> (b + 1))], k);
   }
 }
 
@@ -92,13 +114,15 @@ __device__ __forceinline__ void gs_last(uint64_t &x, uint64_t &y, const LimbTab 
 //   group A: rows q + 2^(M1-EL)*e      (register bits = top EL row bits)
 //   group B: rows (q << EL) + e        (register bits = low EL row bits, the
 //                                       low M1-EL of them still to be done)
-// Forward runs A then B, inverse B then A.
+// Forward runs A then B, inverse B then A.  Group A's twiddles are the same
+// for the whole grid (scalar loads); group B's are fetched at kernel entry.
 // ---------------------------------------------------------------------------
 template <int M1, int EL>
 struct StridedGeom {
   static constexpr int E = 1 << EL;
   static constexpr int T = 1 << (M1 + 4 - EL);
   static constexpr int S2 = M1 - EL;                      // stages left for group B
+  static constexpr int BB = S2 > 0 ? S2 - 1 : 0;          // highest register bit group B works on
   static constexpr int LDS_ELEMS = (1 << (M1 + 4)) + ((S2 > 0) ? (16 << S2) : 0);
   __device__ static __forceinline__ unsigned pad(unsigned l) { return l + ((l >> (EL + 4)) << 4); }
 };
@@ -110,8 +134,10 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
   constexpr unsigned logn = M1 + 8;
   __shared__ uint64_t lds[G::S2 > 0 ? G::LDS_ELEMS : 1];
 
-  const LimbTab &tab = a.tabs[a.limb0 + blockIdx.z];
+  const unsigned limb = a.limb0 + blockIdx.z;
+  const LimbTab &tab = a.tabs[limb];
   const PrimeK k = tab.k;
+  const uint64_t *__restrict__ wt = (INV ? a.winv : a.w) + ((size_t)limb << logn);
   const unsigned slab = blockIdx.y % a.nslab, poly = blockIdx.y / a.nslab;
   const size_t off = (size_t)poly * a.poly_stride + ((size_t)blockIdx.z << logn);
   const uint64_t *__restrict__ src = a.src[slab] + off;
@@ -124,18 +150,22 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
   const unsigned iA = (q << 8) + col, iB = (q << (EL + 8)) + col;
   constexpr unsigned strideA = 1u << (G::S2 + 8), strideB = 1u << 8;
   uint64_t x[E];
+  uint64_t twB[tw_count(EL, G::BB, 0)];
 
   if (!INV) {
+    uint64_t twA[tw_count(EL, EL - 1, 0)];
 #pragma unroll
     for (int e = 0; e < E; ++e) x[e] = src[iA + e * strideA];
-    ct_group<EL, EL - 1, 0, true>(x, iA, G::S2 + 8, logn, tab.w, k);
+    load_tw<EL, EL - 1, 0, true>(twA, iA, G::S2 + 8, logn, wt);
+    if (G::S2 > 0) load_tw<EL, G::BB, 0, false>(twB, iB, 8, logn, wt);
+    ct_group<EL, EL - 1, 0>(x, twA, k);
     if (G::S2 > 0) {
 #pragma unroll
       for (int e = 0; e < E; ++e) lds[G::pad(tid + e * G::T)] = x[e];
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = lds[G::pad((q << (EL + 4)) + (e << 4) + (tid & 15))];
-      ct_group<EL, (G::S2 > 0 ? G::S2 - 1 : 0), 0, false>(x, iB, 8, logn, tab.w, k);
+      ct_group<EL, G::BB, 0>(x, twB, k);
 #pragma unroll
       for (int e = 0; e < E; ++e) dst[iB + e * strideB] = CANON_OUT ? canon8(x[e], k) : x[e];
     } else {
@@ -143,10 +173,14 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
       for (int e = 0; e < E; ++e) dst[iA + e * strideA] = CANON_OUT ? canon8(x[e], k) : x[e];
     }
   } else {
+    // top EL row bits; the very last one (len = n/2) carries the n^-1 scaling and is done by gs_last
+    uint64_t twA[tw_count(EL, (EL > 1 ? EL - 2 : 0), 0)];
     if (G::S2 > 0) {
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = src[iB + e * strideB];
-      gs_group<EL, 0, (G::S2 > 0 ? G::S2 - 1 : 0), false>(x, iB, 8, logn, tab.winv, k);
+      load_tw<EL, G::BB, 0, false>(twB, iB, 8, logn, wt);
+      if (EL > 1) load_tw<EL, (EL > 1 ? EL - 2 : 0), 0, true>(twA, iA, G::S2 + 8, logn, wt);
+      gs_group<EL, G::BB, 0>(x, twB, k);
 #pragma unroll
       for (int e = 0; e < E; ++e) lds[G::pad((q << (EL + 4)) + (e << 4) + (tid & 15))] = x[e];
       __syncthreads();
@@ -155,9 +189,9 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
     } else {
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = src[iA + e * strideA];
+      if (EL > 1) load_tw<EL, (EL > 1 ? EL - 2 : 0), 0, true>(twA, iA, G::S2 + 8, logn, wt);
     }
-    // top EL row bits, the very last one (len = n/2) carries the n^-1 scaling
-    if (EL > 1) gs_group<EL, 0, (EL > 1 ? EL - 2 : 0), true>(x, iA, G::S2 + 8, logn, tab.winv, k);
+    if (EL > 1) gs_group<EL, (EL > 1 ? EL - 2 : 0), 0>(x, twA, k);
 #pragma unroll
     for (int e = 0; e < E / 2; ++e) gs_last(x[e], x[e + E / 2], tab);
 #pragma unroll
@@ -213,19 +247,26 @@ struct ContigLane {
   }
 };
 
+// The 30 twiddles one lane needs for the 8 low stages of one direction.
+struct ContigTw {
+  uint64_t h[15], l[15];
+  __device__ __forceinline__ void load(const ContigLane &ln, unsigned wave0, unsigned logn, const uint64_t *__restrict__ w) {
+    load_tw<4, 3, 0, false>(h, wave0 + ln.hbase, 4, logn, w);
+    load_tw<4, 3, 0, false>(l, wave0 + ln.lbase, 0, logn, w);
+  }
+};
+
 // forward: coefficients (H layout, < 8p) -> NTT domain (L layout, < 8p)
-__device__ __forceinline__ void contig_fwd(uint64_t (&x)[16], const ContigLane &ln, unsigned wave0, unsigned logn,
-                                           const LimbTab &tab) {
-  ct_group<4, 3, 0, false>(x, wave0 + ln.hbase, 4, logn, tab.w, tab.k);
+__device__ __forceinline__ void contig_fwd(uint64_t (&x)[16], const ContigLane &ln, const ContigTw &tw, const PrimeK &k) {
+  ct_group<4, 3, 0>(x, tw.h, k);
   ln.h_to_l(x);
-  ct_group<4, 3, 0, false>(x, wave0 + ln.lbase, 0, logn, tab.w, tab.k);
+  ct_group<4, 3, 0>(x, tw.l, k);
 }
 // inverse: NTT domain (L layout, < 4p) -> coefficients after the 8 low stages (H layout, < 4p)
-__device__ __forceinline__ void contig_inv(uint64_t (&x)[16], const ContigLane &ln, unsigned wave0, unsigned logn,
-                                           const LimbTab &tab) {
-  gs_group<4, 0, 3, false>(x, wave0 + ln.lbase, 0, logn, tab.winv, tab.k);
+__device__ __forceinline__ void contig_inv(uint64_t (&x)[16], const ContigLane &ln, const ContigTw &tw, const PrimeK &k) {
+  gs_group<4, 3, 0>(x, tw.l, k);
   ln.l_to_h(x);
-  gs_group<4, 0, 3, false>(x, wave0 + ln.hbase, 4, logn, tab.winv, tab.k);
+  gs_group<4, 3, 0>(x, tw.h, k);
 }
 
 __device__ __forceinline__ void load_h(uint64_t (&x)[16], const uint64_t *__restrict__ p, const ContigLane &ln) {
@@ -249,34 +290,41 @@ __device__ __forceinline__ void store_l(uint64_t *__restrict__ p, const uint64_t
 
 struct ContigBlock {       // per-workgroup addressing shared by the contiguous kernels
   unsigned wave0;          // limb-relative index of the wave's first coefficient
+  unsigned limb;           // prime index
   size_t off;              // offset of the limb inside a slab + wave0
+  size_t toff;             // offset of the limb inside the twiddle tables
   unsigned slab, poly;
   __device__ __forceinline__ ContigBlock(const PassArgs &a) {
     const unsigned wave = threadIdx.x >> 6;
     wave0 = (blockIdx.x * CONTIG_WAVES + wave) << 10;
+    limb = a.limb0 + blockIdx.z;
     slab = blockIdx.y % a.nslab; poly = blockIdx.y / a.nslab;
     off = (size_t)poly * a.poly_stride + ((size_t)blockIdx.z << a.logn) + wave0;
+    toff = (size_t)limb << a.logn;
   }
 };
 
-// MODE 0: forward, output canonical.  MODE 1: inverse low stages (feeds the strided inverse pass).
-// If logn == 8 the contiguous pass is the whole transform: inverse applies the scaling itself.
+// Forward: low 8 stages, canonical output (end of gpq_ntt).  Inverse: low 8
+// stages of the inverse transform (feeds the strided inverse pass).
 template <bool INV>
 __global__ __launch_bounds__(CONTIG_WAVES * 64) void contig_pass(PassArgs a) {
   __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
   const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
   const ContigBlock cb(a);
-  const LimbTab &tab = a.tabs[a.limb0 + blockIdx.z];
+  const LimbTab &tab = a.tabs[cb.limb];
   uint64_t x[16];
+  ContigTw tw;
   if (!INV) {
     load_h(x, a.src[cb.slab] + cb.off, ln);
-    contig_fwd(x, ln, cb.wave0, a.logn, tab);
+    tw.load(ln, cb.wave0, a.logn, a.w + cb.toff);
+    contig_fwd(x, ln, tw, tab.k);
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = canon8(x[e], tab.k);
     store_l(a.dst[cb.slab] + cb.off, x, ln);
   } else {
     load_l(x, a.src[cb.slab] + cb.off, ln);
-    contig_inv(x, ln, cb.wave0, a.logn, tab);
+    tw.load(ln, cb.wave0, a.logn, a.winv + cb.toff);
+    contig_inv(x, ln, tw, tab.k);
     store_h(a.dst[cb.slab] + cb.off, x, ln);
   }
 }
@@ -289,21 +337,24 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64) void contig_pass(PassArgs a) {
 //   low 8 inverse stages of d0, d1, d2
 // src[0..3] = a0,a1,b0,b1 after the strided forward pass; dst[0..2] = d0,d1,d2.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(CONTIG_WAVES * 64) void tensor_mid(PassArgs a) {
+__global__ __launch_bounds__(CONTIG_WAVES * 64, 2) void tensor_mid(PassArgs a) {
   __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
   const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
   const ContigBlock cb(a);           // nslab == 1 here: blockIdx.y = poly
-  const LimbTab &tab = a.tabs[a.limb0 + blockIdx.z];
+  const LimbTab &tab = a.tabs[cb.limb];
   const PrimeK k = tab.k;
   uint64_t a0[16], a1[16], b0[16], b1[16];
+  ContigTw tw;
   load_h(a0, a.src[0] + cb.off, ln);
+  tw.load(ln, cb.wave0, a.logn, a.w + cb.toff);
   load_h(b0, a.src[2] + cb.off, ln);
   load_h(a1, a.src[1] + cb.off, ln);
   load_h(b1, a.src[3] + cb.off, ln);
-  contig_fwd(a0, ln, cb.wave0, a.logn, tab);
-  contig_fwd(b0, ln, cb.wave0, a.logn, tab);
-  contig_fwd(a1, ln, cb.wave0, a.logn, tab);
-  contig_fwd(b1, ln, cb.wave0, a.logn, tab);
+  contig_fwd(a0, ln, tw, k);
+  contig_fwd(b0, ln, tw, k);
+  contig_fwd(a1, ln, tw, k);
+  contig_fwd(b1, ln, tw, k);
+  tw.load(ln, cb.wave0, a.logn, a.winv + cb.toff);   // inverse twiddles arrive under the products
   // products: left operand < 2p, right operand < 4p  =>  a*b < 8p^2, as mulmod_lazy needs
   uint64_t d1[16];
 #pragma unroll
@@ -314,11 +365,11 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64) void tensor_mid(PassArgs a) {
     d1[e] = csub(mulmod_lazy(u0, v1, k) + mulmod_lazy(u1, v0, k), k.p4);  // d1 < 4p
     a1[e] = mulmod_lazy(u1, v1, k);                                   // d2 < 4p
   }
-  contig_inv(a0, ln, cb.wave0, a.logn, tab);
+  contig_inv(a0, ln, tw, k);
   store_h(a.dst[0] + cb.off, a0, ln);
-  contig_inv(d1, ln, cb.wave0, a.logn, tab);
+  contig_inv(d1, ln, tw, k);
   store_h(a.dst[1] + cb.off, d1, ln);
-  contig_inv(a1, ln, cb.wave0, a.logn, tab);
+  contig_inv(a1, ln, tw, k);
   store_h(a.dst[2] + cb.off, a1, ln);
 }
 
@@ -330,28 +381,31 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64) void tensor_mid(PassArgs a) {
 // ---------------------------------------------------------------------------
 struct KeyswitchArgs { PassArgs p; const uint64_t *evk0; const uint64_t *evk1; };
 
-__global__ __launch_bounds__(CONTIG_WAVES * 64) void keyswitch_mid(KeyswitchArgs ka) {
+__global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid(KeyswitchArgs ka) {
   __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
   const PassArgs &a = ka.p;
   const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
   const ContigBlock cb(a);
-  const LimbTab &tab = a.tabs[a.limb0 + blockIdx.z];
+  const LimbTab &tab = a.tabs[cb.limb];
   const PrimeK k = tab.k;
   const size_t koff = ((size_t)blockIdx.z << a.logn) + cb.wave0;
   uint64_t x[16], e0[16], e1[16];
+  ContigTw tw;
   load_h(x, a.src[0] + cb.off, ln);
+  tw.load(ln, cb.wave0, a.logn, a.w + cb.toff);
+  contig_fwd(x, ln, tw, k);
   load_l(e0, ka.evk0 + koff, ln);
   load_l(e1, ka.evk1 + koff, ln);
-  contig_fwd(x, ln, cb.wave0, a.logn, tab);
+  tw.load(ln, cb.wave0, a.logn, a.winv + cb.toff);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const uint64_t u = csub(x[e], k.p4);           // < 4p ; evk limbs are canonical (< p)
     e0[e] = mulmod_lazy(u, e0[e], k);
     e1[e] = mulmod_lazy(u, e1[e], k);
   }
-  contig_inv(e0, ln, cb.wave0, a.logn, tab);
+  contig_inv(e0, ln, tw, k);
   store_h(a.dst[0] + cb.off, e0, ln);
-  contig_inv(e1, ln, cb.wave0, a.logn, tab);
+  contig_inv(e1, ln, tw, k);
   store_h(a.dst[1] + cb.off, e1, ln);
 }
 
@@ -387,6 +441,7 @@ __global__ __launch_bounds__(256) void small_ntt(PassArgs a) {
   const LimbTab &tab = a.tabs[a.limb0 + blockIdx.z];
   const PrimeK k = tab.k;
   const unsigned n = 1u << a.logn;
+  const uint64_t *__restrict__ wt = (INV ? a.winv : a.w) + ((size_t)(a.limb0 + blockIdx.z) << a.logn);
   const unsigned slab = blockIdx.y % a.nslab, poly = blockIdx.y / a.nslab;
   const size_t off = (size_t)poly * a.poly_stride + ((size_t)blockIdx.z << a.logn);
   const uint64_t *__restrict__ src = a.src[slab] + off;
@@ -398,7 +453,7 @@ __global__ __launch_bounds__(256) void small_ntt(PassArgs a) {
       for (unsigned b = threadIdx.x; b < (n >> 1); b += 256) {
         const unsigned blk = b / len, j = blk * 2 * len + (b % len);
         uint64_t x = s[j], y = s[j + len];
-        ct_bfly(x, y, tab.w[n / (2 * len) + blk], k);
+        ct_bfly(x, y, wt[n / (2 * len) + blk], k);
         s[j] = canon8(x, k); s[j + len] = canon8(y, k);
       }
       __syncthreads();
@@ -408,7 +463,7 @@ __global__ __launch_bounds__(256) void small_ntt(PassArgs a) {
       for (unsigned b = threadIdx.x; b < (n >> 1); b += 256) {
         const unsigned blk = b / len, j = blk * 2 * len + (b % len);
         uint64_t x = s[j], y = s[j + len];
-        gs_bfly(x, y, tab.winv[n / (2 * len) + blk], k);
+        gs_bfly(x, y, wt[n / (2 * len) + blk], k);
         s[j] = canon4(x, k); s[j + len] = canon4(y, k);
       }
       __syncthreads();
