@@ -146,7 +146,8 @@ static int upload_tables(gpq_ctx *c) {
       wistd[d * n + i] = from_mont(c->zetas_inv[d * n + i]);
     }
     LimbTab &t = tabs[d];
-    t.k.p = p; t.k.p2 = 2 * p; t.k.p4 = 4 * p; t.k.c = (uint32_t)(p - (1ull << 59)); t.k.pad = 0;
+    t.k.p = p; t.k.p2 = 2 * p; t.k.p4 = 4 * p; t.k.c = (uint32_t)(p - (1ull << 59)); t.k.c1 = t.k.c + 1;
+    t.k.kx0 = t.k.c1; t.k.kx1 = (uint64_t)t.k.c1 - 4 * p; t.k.ky = 4 * p - 2 * (uint64_t)t.k.c1;
     t.ninv = from_mont(c->ninv_mont[d]);
     t.winv1_ninv = n >= 2 ? mulm(wistd[d * n + 1], t.ninv, p) : t.ninv;
   }

@@ -30,25 +30,44 @@ typedef unsigned __int128 u128;
 struct PrimeK {        // per-limb constants handed to kernels (uniform per block)
   uint64_t p;          // modulus
   uint64_t p2, p4;     // 2p, 4p
+  uint64_t kx0, kx1;   // c+1 and c+1-4p (mod 2^64): the two addends of the CT x-leg select
+  uint64_t ky;         // 4p - 2(c+1)
   uint32_t c;          // p - 2^59
-  uint32_t pad;
+  uint32_t c1;         // c + 1
 };
 
 __device__ __forceinline__ uint64_t mad_u64(uint32_t a, uint32_t b, uint64_t acc) {
   return (uint64_t)a * b + acc;  // v_mad_u64_u32
 }
+__device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
-// a*w mod p, lazily reduced; see header for ranges.
+// Core of the modular multiply: returns T' with  a*w == T' + (c+1)  (mod p).
+//   x = a*w by 32-bit pieces (a < 2^62.1, w < 2^60: the middle column cannot overflow),
+//   xh = x >> 59, xl = x mod 2^59, t = c*xh, th = t >> 59, tl = t mod 2^59,
+//   x == xl - t == xl + c*th - tl == xl + c*th + (2^59-1-tl) + (c+1) - p.
+// The complement 2^59-1-tl is two bit operations where -tl would be a 64-bit subtract.
+// T' < 2^59 + 2^59 + 2^59.5 < 3.42p - (c+1).
+__device__ __forceinline__ uint64_t mulmod_raw(uint64_t a, uint64_t w, const PrimeK &k) {
+  const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+  const uint64_t m00 = mad_u64(a0, w0, 0);
+  uint64_t mid = mad_u64(a0, w1, (uint32_t)(m00 >> 32));
+  mid = mad_u64(a1, w0, mid);                                   // < 2^60 + 2^62.1 : fits
+  const uint64_t hi = mad_u64(a1, w1, (uint32_t)(mid >> 32));   // x >> 64
+  const uint32_t midlo = (uint32_t)mid, hilo = (uint32_t)hi, hihi = (uint32_t)(hi >> 32);
+  const uint32_t xh0 = __builtin_amdgcn_alignbit(hilo, midlo, 27);
+  const uint32_t xh1 = __builtin_amdgcn_alignbit(hihi, hilo, 27);
+  const uint64_t xl = pack64((uint32_t)m00, midlo & 0x7ffffffu);
+  const uint64_t t0 = mad_u64(k.c, xh0, 0);
+  const uint64_t t1 = mad_u64(k.c, xh1, (uint32_t)(t0 >> 32)); // t = t1 : lo32(t0)
+  const uint32_t t1lo = (uint32_t)t1, t1hi = (uint32_t)(t1 >> 32);
+  const uint32_t th = __builtin_amdgcn_alignbit(t1hi, t1lo, 27);
+  const uint64_t ntl = pack64(~(uint32_t)t0, ~t1lo & 0x7ffffffu);  // 2^59 - 1 - tl
+  return mad_u64(k.c, th, xl) + ntl;
+}
+
+// a*w mod p, lazily reduced: a < 8p, w < p -> (0, 4p)
 __device__ __forceinline__ uint64_t mulmod_lazy(uint64_t a, uint64_t w, const PrimeK &k) {
-  const u128 x = (u128)a * w;
-  const uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
-  const uint64_t xh = (hi << 5) | (lo >> 59);
-  const uint64_t xl = lo & ((1ull << 59) - 1);
-  const uint64_t t0 = mad_u64(k.c, (uint32_t)xh, 0);
-  const uint64_t t1 = mad_u64(k.c, (uint32_t)(xh >> 32), t0 >> 32);  // t = t1 : lo32(t0)
-  const uint64_t tl = ((t1 & ((1u << 27) - 1)) << 32) | (uint32_t)t0; // t mod 2^59
-  const uint32_t th = (uint32_t)(t1 >> 27);                           // t >> 59
-  return mad_u64(k.c, th, xl) + (k.p - tl);
+  return mulmod_raw(a, w, k) + k.c1;
 }
 
 // x - m if x >= m else x
@@ -67,21 +86,23 @@ __device__ __forceinline__ uint64_t canon4(uint64_t x, const PrimeK &k) {
 }
 
 // Cooley-Tukey butterfly of src/ntt.c:45-49 in lazy form.
-// in: x,y < 8p ; out: x,y < 8p
+// in: x,y < 8p ; out: x,y < 8p.  With t = T' + (c+1) and xr = csub(x, 4p):
+//   x' = xr + t = xs + T',  y' = xr + 4p - t = xs + (4p - 2(c+1)) - T',  xs = xr + (c+1)
+// so the (c+1) rides on the constant the conditional subtract selects anyway.
 __device__ __forceinline__ void ct_bfly(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k) {
-  const uint64_t t = mulmod_lazy(y, w, k);  // < 4p
-  const uint64_t xr = csub(x, k.p4);        // < 4p
-  x = xr + t;
-  y = xr + k.p4 - t;
+  const uint64_t t = mulmod_raw(y, w, k);
+  const uint64_t xs = x + (x >= k.p4 ? k.kx1 : k.kx0);
+  x = xs + t;
+  y = xs + k.ky - t;
 }
 
 // Gentleman-Sande butterfly of src/ntt.c:63-68 in lazy form.
 // in: x,y < 4p ; out: x,y < 4p
 __device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k) {
-  const uint64_t s = csub(x + y, k.p4);
+  const uint64_t v = x + y;
   const uint64_t d = x + k.p4 - y;  // (0, 8p)
-  x = s;
-  y = mulmod_lazy(d, w, k);
+  x = v + (v >= k.p4 ? (uint64_t)0 - k.p4 : (uint64_t)0);
+  y = mulmod_raw(d, w, k) + k.c1;
 }
 
 // Exact a*b mod p for canonical a,b (poly_rns_mul, src/poly.c:77-82).

@@ -1,0 +1,108 @@
+// bfly_lab.hip -- A/B of butterfly formulations in one binary (dev tool).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "modarith.hpp"
+using namespace gpq;
+typedef unsigned __int128 u128;
+#define CHECK(x) do { hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1;} } while(0)
+constexpr int ITER = 4096;
+
+// v0: first formulation (128-bit product by the compiler, 64-bit subtracts)
+__device__ __forceinline__ uint64_t mulmod_v0(uint64_t a, uint64_t w, const PrimeK &k) {
+  const u128 x = (u128)a * w;
+  const uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+  const uint64_t xh = (hi << 5) | (lo >> 59);
+  const uint64_t xl = lo & ((1ull << 59) - 1);
+  const uint64_t t0 = mad_u64(k.c, (uint32_t)xh, 0);
+  const uint64_t t1 = mad_u64(k.c, (uint32_t)(xh >> 32), t0 >> 32);
+  const uint64_t tl = ((t1 & ((1u << 27) - 1)) << 32) | (uint32_t)t0;
+  const uint32_t th = (uint32_t)(t1 >> 27);
+  return mad_u64(k.c, th, xl) + (k.p - tl);
+}
+__device__ __forceinline__ void ct_v0(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k) {
+  const uint64_t t = mulmod_v0(y, w, k);
+  const uint64_t xr = csub(x, k.p4);
+  x = xr + t; y = xr + k.p4 - t;
+}
+// v2: v1 + approximate conditional subtract (compare high words only)
+__device__ __forceinline__ void ct_v2(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k) {
+  const uint64_t t = mulmod_raw(y, w, k);
+  const bool ge = (uint32_t)(x >> 32) > (uint32_t)(k.p4 >> 32);
+  const uint64_t xs = x + (ge ? k.kx1 : k.kx0);
+  x = xs + t; y = xs + k.ky - t;
+}
+// v3: no conditional subtract at all (bounds not kept; timing only)
+__device__ __forceinline__ void ct_v3(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k) {
+  const uint64_t t = mulmod_raw(y, w, k);
+  const uint64_t xs = x;
+  x = xs + t; y = xs + k.ky - t;
+}
+// v4: multiply only
+__device__ __forceinline__ void ct_v4(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k) {
+  y = mulmod_raw(y, w, k); x ^= y;
+}
+// v5: only the 4-mad product
+__device__ __forceinline__ void ct_v5(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k) {
+  const uint32_t a0 = (uint32_t)y, a1 = (uint32_t)(y >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+  const uint64_t m00 = mad_u64(a0, w0, 0);
+  uint64_t mid = mad_u64(a0, w1, (uint32_t)(m00 >> 32));
+  mid = mad_u64(a1, w0, mid);
+  const uint64_t hi = mad_u64(a1, w1, (uint32_t)(mid >> 32));
+  y = hi ^ mid; x ^= m00;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void probe(uint64_t *out, uint64_t seed, PrimeK k) {
+  uint64_t v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = seed * (threadIdx.x + 1 + 64 * i) + blockIdx.x;
+  for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] &= 0x3fffffffffffffffull; v[i + 4] &= 0x3fffffffffffffffull;
+      const uint64_t w = k.p - 3 - i;
+      if (V == 0) ct_v0(v[i], v[i + 4], w, k);
+      if (V == 1) ct_bfly(v[i], v[i + 4], w, k);
+      if (V == 2) ct_v2(v[i], v[i + 4], w, k);
+      if (V == 3) ct_v3(v[i], v[i + 4], w, k);
+      if (V == 4) ct_v4(v[i], v[i + 4], w, k);
+      if (V == 5) ct_v5(v[i], v[i + 4], w, k);
+      if (V == 6) gs_bfly(v[i], v[i + 4], w, k);
+    }
+  }
+  uint64_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc ^= v[i];
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+template <int V>
+int run(const char *name, uint64_t *d_out, PrimeK k, int blocks_per_cu) {
+  const int blocks = 256 * blocks_per_cu;
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  hipLaunchKernelGGL(probe<V>, dim3(blocks), dim3(256), 0, 0, d_out, 0x9e3779b97f4a7c15ull, k);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a));
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(probe<V>, dim3(blocks), dim3(256), 0, 0, d_out, 0x9e3779b97f4a7c15ull + r, k);
+  CHECK(hipEventRecord(b));
+  CHECK(hipEventSynchronize(b));
+  float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+  double total = 5.0 * blocks * 256.0 * ITER * 4;
+  printf("%-34s waves/SIMD=%d %8.3f ms  %8.1f Gbfly/s\n", name, blocks_per_cu, ms / 5, total / (ms * 1e-3) / 1e9);
+  return 0;
+}
+
+int main() {
+  uint64_t *d_out; CHECK(hipMalloc(&d_out, 256 * 8 * 256 * 8));
+  PrimeK k; k.p = 576460752308273153ull; k.p2 = 2 * k.p; k.p4 = 4 * k.p; k.c = (uint32_t)(k.p - (1ull << 59)); k.c1 = k.c + 1;
+  k.kx0 = k.c1; k.kx1 = (uint64_t)k.c1 - k.p4; k.ky = k.p4 - 2 * (uint64_t)k.c1;
+  for (int w : {8, 4, 2}) {
+    if (w == 8) { run<0>("ct v0 (first formulation)", d_out, k, 8); run<1>("ct v1 (current)", d_out, k, 8); run<2>("ct v2 (approx csub)", d_out, k, 8);
+                  run<3>("ct v3 (no csub)", d_out, k, 8); run<4>("mulmod only", d_out, k, 8); run<5>("4-mad product only", d_out, k, 8); run<6>("gs (current)", d_out, k, 8); }
+    if (w == 4) { run<0>("ct v0", d_out, k, 4); run<1>("ct v1", d_out, k, 4); }
+    if (w == 2) { run<0>("ct v0", d_out, k, 2); run<1>("ct v1", d_out, k, 2); }
+  }
+  return 0;
+}

@@ -62,7 +62,8 @@ int run(const char *name, double ops_per_iter, uint64_t *d_out, PrimeK k) {
 
 int main() {
   uint64_t *d_out; CHECK(hipMalloc(&d_out, 256 * 8 * 256 * 8));
-  PrimeK k; k.p = 576460752308273153ull; k.p2 = 2 * k.p; k.p4 = 4 * k.p; k.c = (uint32_t)(k.p - (1ull << 59)); k.pad = 0;
+  PrimeK k; k.p = 576460752308273153ull; k.p2 = 2 * k.p; k.p4 = 4 * k.p; k.c = (uint32_t)(k.p - (1ull << 59)); k.c1 = k.c + 1;
+  k.kx0 = k.c1; k.kx1 = (uint64_t)k.c1 - k.p4; k.ky = k.p4 - 2 * (uint64_t)k.c1;
   run<0>("v_add_u32", 8, d_out, k);
   run<1>("v_mul_lo_u32", 8, d_out, k);
   run<2>("v_mad_u64_u32", 8, d_out, k);
