@@ -42,6 +42,24 @@ def rand_slab(torch, ctx, dim, batch, gen):
     return out.reshape(-1)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/, separate
+    rocprofv3 --pmc runs of this same command at chunk 4): 2*FETCH_SIZE + WRITE_SIZE in KiB,
+    the factor 2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        data = json.load(open(files[-1]))
+        for name, v in data.items():
+            if kernel in name.replace("strided_pass<8, 4, false, false>", "strided_fwd").replace("strided_pass<8, 4, true, false>", "strided_inv"):
+                return int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+    except Exception:
+        return None
+    return None
+
+
 def cpu_baseline(ctx, host_inputs, gpu_outputs, sample):
     """The oracle (CPU restatement of the reference loops) timed on this host, one
     thread like the reference, on `sample` ciphertexts of the same workload; its
@@ -129,9 +147,8 @@ def main():
     ctx.profile(False)
     prof = ctx.profile_collect()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        from gpqhe_amd.dist import max_over_ranks
+        dt = max_over_ranks(dt)
 
     if rank == 0:
         total_he_mul = world * B * args.steps
@@ -153,6 +170,7 @@ def main():
         kavg = kms / kcnt
         kbytes = KERNEL_LIMB_PASSES[kname] * units[kname] * (8 << LOGN)
         achieved = kbytes / (kavg * 1e-3) / 1e9
+        traffic = pmc_traffic(kname) if chunk == 4 else None
         out = {
             "metric": "ciphertext he_mul/sec (RNS core: tensor 30 limbs + key-switch 45 limbs), N=2^16",
             "value": round(value, 2), "unit": "he_mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -162,7 +180,7 @@ def main():
                                    "he_rescale has no RNS-domain work in the reference" % B,
                        "batch_per_gpu": B, "chunk": chunk, "parallelism": "ciphertext-per-GPU x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": int(kbytes), "avg_launch_ms": round(kavg, 4)},
             "he_mul_e2e": {"algo_bytes_per_he_mul": ALGO_BYTES_PER_HE_MUL,
                            "achieved_GBps_per_gpu": round(ALGO_BYTES_PER_HE_MUL * value / world / 1e9, 1),

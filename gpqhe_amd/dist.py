@@ -1,0 +1,82 @@
+"""One-ciphertext-per-GPU sharding of a batch of independent he_mul's.
+
+The reference has no communication layer at all: ciphertext
+multiplications are independent, so the only multi-GPU structure is a partition
+of the batch.  Nothing is exchanged inside an NTT; the collectives here are the
+optional scatter of input slabs from rank 0, the gather of output slabs back,
+and the MAX-reduce of the timing.  Backend "nccl" (= RCCL over xGMI) on GPUs,
+"gloo" in the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(batch, world, rank):
+    """Contiguous block partition of `batch` ciphertexts: [lo, hi) of this rank.
+    The first batch % world ranks take one extra ciphertext."""
+    base, extra = divmod(batch, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def scatter_slab(full, per_ct, batch, src=0):
+    """Rank `src` holds `full` = int64[batch*per_ct] (others pass None); every rank
+    gets its own shard int64[(hi-lo)*per_ct].  Ragged shards are allowed."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(batch, world, rank)
+    device = full.device if full is not None else _default_device()
+    mine = torch.empty((hi - lo) * per_ct, dtype=torch.int64, device=device)
+    if world == 1:
+        mine.copy_(full)
+        return mine
+    ops = []
+    if rank == src:
+        for r in range(world):
+            rlo, rhi = shard_range(batch, world, r)
+            piece = full[rlo * per_ct: rhi * per_ct]
+            if r == src:
+                mine.copy_(piece)
+            elif rhi > rlo:
+                ops.append(dist.P2POp(dist.isend, piece.contiguous(), r))
+    elif hi > lo:
+        ops.append(dist.P2POp(dist.irecv, mine, src))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):  # grouped send/recv: one RCCL group on GPUs
+            w.wait()
+    return mine
+
+
+def gather_slab(mine, per_ct, batch, dst=0):
+    """Inverse of scatter_slab: rank `dst` returns int64[batch*per_ct], others None."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world == 1:
+        return mine.clone()
+    ops = []
+    full = None
+    if rank == dst:
+        full = torch.empty(batch * per_ct, dtype=torch.int64, device=mine.device)
+        for r in range(world):
+            rlo, rhi = shard_range(batch, world, r)
+            if r == dst:
+                full[rlo * per_ct: rhi * per_ct].copy_(mine)
+            elif rhi > rlo:
+                ops.append(dist.P2POp(dist.irecv, full[rlo * per_ct: rhi * per_ct], r))
+    elif mine.numel():
+        ops.append(dist.P2POp(dist.isend, mine.contiguous(), dst))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return full
+
+
+def max_over_ranks(seconds, device=None):
+    """Wall time of the slowest rank (the number bench.py reports)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device or _default_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _default_device():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")

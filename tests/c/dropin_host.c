@@ -1,0 +1,99 @@
+/*
+ * dropin_host.c -- a C host that uses libgpqhe_hip.so the way GPQHE itself
+ * would after the swap described in INTEGRATION.md: it owns the global
+ * `polyctx` (as src/precomp.c:41 does), walks a linked list of struct rns_ctx
+ * and runs the limb loop of poly_mul (src/poly.c:96-103, minus rns_decompose)
+ * through the reference-named symbols ntt / invntt / poly_rns_mul, then the
+ * d1 = x + y step of he_mul (src/he-mult.c:136) through poly_rns_add.
+ *
+ * usage: dropin_host <logn> <dim> <seed>   -> prints FNV-1a-64 digests
+ * The pytest wrapper compares them with the oracle's.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gpqhe_hip.h"
+#include "gpqhe_hip_compat.h"
+
+struct poly_ctx polyctx; /* the reference's global, src/precomp.c:41 */
+
+static uint64_t splitmix64(uint64_t *s)
+{
+  uint64_t z = (*s += 0x9e3779b97f4a7c15ull);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+static uint64_t fnv(const uint64_t *a, size_t n)
+{
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (size_t i = 0; i < n; i++)
+    for (int b = 0; b < 8; b++) { h ^= (a[i] >> (8 * b)) & 0xff; h *= 0x100000001b3ull; }
+  return h;
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 4) return 2;
+  unsigned logn = (unsigned)atoi(argv[1]), dim = (unsigned)atoi(argv[2]);
+  uint64_t seed = strtoull(argv[3], NULL, 10);
+  size_t n = (size_t)1 << logn;
+
+  /* what polyctx_init would have filled in (src/precomp.c:333-356) */
+  memset(&polyctx, 0, sizeof polyctx);
+  polyctx.logn = logn; polyctx.n = (unsigned)n; polyctx.m = 2 * (unsigned)n;
+  polyctx.logR = 64; polyctx.R = (gpq_u128)1 << 64; polyctx.Rsub1 = polyctx.R - 1;
+  polyctx.dimub = dim;
+
+  /* per-prime tables in the reference's own format, taken from the engine's context */
+  gpq_ctx *ctx = NULL;
+  if (gpq_ctx_create(&ctx, logn, dim, 0) != GPQ_OK) { fprintf(stderr, "%s\n", gpq_last_error()); return 1; }
+  struct rns_ctx *nodes = calloc(dim, sizeof *nodes);
+  for (unsigned d = 0; d < dim; d++) {
+    nodes[d].dim = d + 1;
+    nodes[d].p = gpq_ctx_const(ctx, d, 0);
+    nodes[d].pinv_mont = gpq_ctx_const(ctx, d, 1);
+    nodes[d].pinv_barr = gpq_ctx_const(ctx, d, 2);
+    nodes[d].ninv = gpq_ctx_const(ctx, d, 3);
+    nodes[d].zetas = (uint64_t *)gpq_ctx_zetas(ctx, d, 0);
+    nodes[d].zetas_inv = (uint64_t *)gpq_ctx_zetas(ctx, d, 1);
+    nodes[d].next = d + 1 < dim ? &nodes[d + 1] : NULL;
+  }
+  polyctx.rns = nodes;
+
+  /* scalar helpers of src/reduce.c on the first prime */
+  uint64_t p0 = nodes[0].p;
+  if (montgomery_inv(p0) != nodes[0].pinv_mont || barrett_inv(p0) != nodes[0].pinv_barr) { fprintf(stderr, "inv mismatch\n"); return 1; }
+  gpq_u128 prod = (gpq_u128)(p0 - 1) * (p0 - 2);
+  uint64_t br = barrett_reduce(prod, p0, nodes[0].pinv_barr);
+  uint64_t mr = montgomery_reduce(prod, p0, (int64_t)nodes[0].pinv_mont);
+  printf("barrett %llu montgomery %llu\n", (unsigned long long)br, (unsigned long long)mr);
+
+  uint64_t *a = malloc(dim * n * 8), *b = malloc(dim * n * 8), *r = malloc(dim * n * 8), *s = malloc(dim * n * 8);
+  uint64_t st = seed;
+  for (unsigned d = 0; d < dim; d++) for (size_t i = 0; i < n; i++) a[d * n + i] = splitmix64(&st) % nodes[d].p;
+  st = seed + 1;
+  for (unsigned d = 0; d < dim; d++) for (size_t i = 0; i < n; i++) b[d * n + i] = splitmix64(&st) % nodes[d].p;
+
+  /* src/poly.c:96-103 */
+  struct rns_ctx *rns = polyctx.rns;
+  for (unsigned d = 0; d < dim; d++) {
+    uint64_t *ahat = a + d * n, *bhat = b + d * n;
+    ntt(ahat, rns);
+    poly_ntt(bhat, rns);                        /* north-star alias of the same symbol */
+    poly_rns_mul(&r[d * n], ahat, bhat, rns);
+    invntt(&r[d * n], rns);
+    poly_rns_add(&s[d * n], ahat, bhat, rns);   /* src/he-mult.c:136 shape */
+    poly_rns_mul(ahat, ahat, bhat, rns);        /* aliased output, src/he-mult.c:130 */
+    poly_invntt(ahat, rns);
+    rns = (d < dim - 1) ? rns->next : rns;
+  }
+  printf("ntt_b %016llx\nmul %016llx\nadd %016llx\nalias %016llx\n", (unsigned long long)fnv(b, dim * n),
+         (unsigned long long)fnv(r, dim * n), (unsigned long long)fnv(s, dim * n), (unsigned long long)fnv(a, dim * n));
+  gpq_dropin_reset();
+  gpq_ctx_destroy(ctx);
+  free(nodes); free(a); free(b); free(r); free(s);
+  return 0;
+}

@@ -1,0 +1,89 @@
+"""The N>1 path on CPU: world_size 2 over gloo.  Independent ciphertexts are
+block-partitioned over ranks, each rank runs the RNS core on its shard (here the
+oracle stands in for the device op -- this is a test), outputs are gathered and
+must equal the single-process result; timing is MAX-reduced as bench.py does."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gpqhe_amd.dist import gather_slab, max_over_ranks, scatter_slab, shard_range
+
+LOGN, DIM, BATCH = 7, 3, 5  # ragged on purpose: 5 ciphertexts over 2 ranks
+
+
+def test_shard_range_partitions_every_batch():
+    for batch in (0, 1, 5, 64, 511, 512):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = shard_range(batch, world, r)
+                assert 0 <= lo <= hi <= batch and hi - lo in (batch // world, batch // world + 1)
+                cover += list(range(lo, hi))
+            assert cover == list(range(batch))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.oracle import OracleCtx
+        o = OracleCtx(LOGN, DIM)
+        per = DIM * o.n
+        full = None
+        if rank == 0:
+            full = [torch.from_numpy(np.concatenate([o.gen(10 * s + k, DIM) for k in range(BATCH)]).view(np.int64)) for s in range(4)]
+        mine = [scatter_slab(full[s] if rank == 0 else None, per, BATCH) for s in range(4)]
+        lo, hi = shard_range(BATCH, world, rank)
+        outs = [np.empty((hi - lo) * per, dtype=np.uint64) for _ in range(3)]
+        for k in range(hi - lo):
+            d = o.he_mul_tensor(*[np.ascontiguousarray(m.numpy().view(np.uint64)[k * per:(k + 1) * per]) for m in mine], DIM)
+            for out, v in zip(outs, d):
+                out[k * per:(k + 1) * per] = v
+        gathered = [gather_slab(torch.from_numpy(v.view(np.int64)), per, BATCH) for v in outs]
+        slowest = max_over_ranks(1.0 + rank)
+        if rank == 0:
+            ok = True
+            for k in range(BATCH):
+                d = o.he_mul_tensor(*[np.ascontiguousarray(f.numpy().view(np.uint64)[k * per:(k + 1) * per]) for f in full], DIM)
+                for g, v in zip(gathered, d):
+                    ok = ok and np.array_equal(g.numpy().view(np.uint64)[k * per:(k + 1) * per], v)
+            q.put((ok, slowest))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_scatter_compute_gather():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, _free_port_once(), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok, slowest = q.get(timeout=150)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert ok, "gathered multi-rank result differs from the single-process result"
+    assert slowest == 2.0  # MAX over ranks of (1.0, 2.0)
+
+
+_PORT = None
+
+
+def _free_port_once():
+    global _PORT
+    if _PORT is None:
+        _PORT = _free_port()
+    return _PORT
