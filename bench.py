@@ -42,10 +42,11 @@ def rand_slab(torch, ctx, dim, batch, gen):
     return out.reshape(-1)
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, chunk):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/, separate
-    rocprofv3 --pmc runs of this same command at chunk 4): 2*FETCH_SIZE + WRITE_SIZE in KiB,
-    the factor 2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section)."""
+    rocprofv3 --pmc runs of this same command): 2*FETCH_SIZE + WRITE_SIZE in KiB, the factor 2
+    being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section).  The PMC run
+    used launch groups of `pmc_chunk` polynomials; traffic scales with the group size."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json")))
     if not files:
@@ -54,10 +55,35 @@ def pmc_traffic(kernel):
         data = json.load(open(files[-1]))
         for name, v in data.items():
             if kernel in name.replace("strided_pass<8, 4, false, false>", "strided_fwd").replace("strided_pass<8, 4, true, false>", "strided_inv"):
-                return int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+                return int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 * chunk / data.get("_chunk", 4))
     except Exception:
         return None
     return None
+
+
+def ntt_rate(torch, gpqhe_amd, logn, dim, batch, iters=5):
+    """Second half of BASELINE's metric: NTT GB/s = 16*n bytes per limb per direction
+    (read + write once) over a forward+inverse pair, HIP-event timed."""
+    ctx = gpqhe_amd.PolyContext(logn, dim)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(7)
+    slab = rand_slab(torch, ctx, dim, batch, gen)
+    ref = slab.clone()
+    ctx.poly_ntt(slab, dim)
+    ctx.poly_invntt(slab, dim)          # warm-up, and the round trip must be the identity
+    ok = bool(torch.equal(slab, ref))
+    t = gpqhe_amd.StreamTimer()
+    t.start()
+    for _ in range(iters):
+        ctx.poly_ntt(slab, dim)
+        ctx.poly_invntt(slab, dim)
+    t.stop()
+    ms = t.elapsed_ms() / iters
+    byts = 2 * 16 * (1 << logn) * dim * batch
+    ctx.close()
+    return {"shape": "n=2^%d, %d limbs, batch %d, forward+inverse" % (logn, dim, batch), "ms_per_pair": round(ms, 4),
+            "GBps": round(byts / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "roundtrip_identity": ok}
 
 
 def cpu_baseline(ctx, host_inputs, gpu_outputs, sample):
@@ -91,6 +117,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="ciphertext multiplications per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="polynomials per fused launch group (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=2, help="ciphertexts the CPU baseline replays (0 = skip)")
+    ap.add_argument("--no-ntt", action="store_true", help="skip the NTT GB/s legs (run after the timed region)")
     args = ap.parse_args()
 
     import torch
@@ -157,7 +184,7 @@ def main():
         kname, (kms, kcnt) = max(prof.items(), key=lambda kv: kv[1][0])
         dim_of = {"tensor_mid": DIM_A, "keyswitch_mid": DIM_B}
         # strided kernels run for both stages: average units per launch from the launch mix
-        chunk = min(B, args.chunk or 4)
+        chunk = min(B, args.chunk or 16)
         launches_per_step = -(-B // chunk)
         units = {"tensor_mid": DIM_A * chunk, "keyswitch_mid": DIM_B * chunk,
                  "strided_fwd": (4 * DIM_A + 1 * DIM_B) * chunk / 2.0, "strided_inv": (3 * DIM_A + 2 * DIM_B) * chunk / 2.0}
@@ -170,7 +197,7 @@ def main():
         kavg = kms / kcnt
         kbytes = KERNEL_LIMB_PASSES[kname] * units[kname] * (8 << LOGN)
         achieved = kbytes / (kavg * 1e-3) / 1e9
-        traffic = pmc_traffic(kname) if chunk == 4 else None
+        traffic = pmc_traffic(kname, chunk)
         out = {
             "metric": "ciphertext he_mul/sec (RNS core: tensor 30 limbs + key-switch 45 limbs), N=2^16",
             "value": round(value, 2), "unit": "he_mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -194,6 +221,9 @@ def main():
             gpu_out = [gpqhe_amd.to_host(v[: s * DIM_A * ctx.n]) for v in (d0, d1, d2)] + \
                       [gpqhe_amd.to_host(v[: s * DIM_B * ctx.n]) for v in (c0, c1)]
             out["cpu_baseline"] = cpu_baseline(ctx, host_in, gpu_out, s)
+        if world == 1 and not args.no_ntt:
+            # NTT GB/s at the headline ring (n=2^16, 30 limbs) and at BASELINE configs[1] (n=2^15, 10 limbs)
+            out["ntt"] = [ntt_rate(torch, gpqhe_amd, 16, DIM_A, B), ntt_rate(torch, gpqhe_amd, 15, 10, 64)]
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

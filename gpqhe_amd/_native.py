@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpqhe_hip.so")
+# GPQHE_HIP_LIB selects another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("GPQHE_HIP_LIB") or os.path.join(_HERE, "libgpqhe_hip.so")
 
 u64 = C.c_uint64
 vp = C.c_void_p

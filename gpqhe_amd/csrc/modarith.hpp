@@ -47,10 +47,14 @@ __device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((
 //   x == xl - t == xl + c*th - tl == xl + c*th + (2^59-1-tl) + (c+1) - p.
 // The complement 2^59-1-tl is two bit operations where -tl would be a 64-bit subtract.
 // T' < 2^59 + 2^59 + 2^59.5 < 3.42p - (c+1).
-__device__ __forceinline__ uint64_t mulmod_raw(uint64_t a, uint64_t w, const PrimeK &k) {
+template <bool PIN>
+__device__ __forceinline__ uint64_t mulmod_raw_t(uint64_t a, uint64_t w, const PrimeK &k) {
   const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
   const uint64_t m00 = mad_u64(a0, w0, 0);
   uint64_t mid = mad_u64(a0, w1, (uint32_t)(m00 >> 32));
+  // PIN keeps the carry inside the mad: stops hipcc re-associating it into a mad + 64-bit add.
+  // Measured (profiles/r01): +5 % on forward butterflies, a loss on the inverse ones, hence per call site.
+  if (PIN) asm volatile("" : "+v"(mid));
   mid = mad_u64(a1, w0, mid);                                   // < 2^60 + 2^62.1 : fits
   const uint64_t hi = mad_u64(a1, w1, (uint32_t)(mid >> 32));   // x >> 64
   const uint32_t midlo = (uint32_t)mid, hilo = (uint32_t)hi, hihi = (uint32_t)(hi >> 32);
@@ -64,6 +68,14 @@ __device__ __forceinline__ uint64_t mulmod_raw(uint64_t a, uint64_t w, const Pri
   const uint64_t ntl = pack64(~(uint32_t)t0, ~t1lo & 0x7ffffffu);  // 2^59 - 1 - tl
   return mad_u64(k.c, th, xl) + ntl;
 }
+
+#ifndef GPQ_PIN_CT
+#define GPQ_PIN_CT true
+#endif
+#ifndef GPQ_PIN_GS
+#define GPQ_PIN_GS true
+#endif
+__device__ __forceinline__ uint64_t mulmod_raw(uint64_t a, uint64_t w, const PrimeK &k) { return mulmod_raw_t<false>(a, w, k); }
 
 // a*w mod p, lazily reduced: a < 8p, w < p -> (0, 4p)
 __device__ __forceinline__ uint64_t mulmod_lazy(uint64_t a, uint64_t w, const PrimeK &k) {
@@ -90,7 +102,7 @@ __device__ __forceinline__ uint64_t canon4(uint64_t x, const PrimeK &k) {
 //   x' = xr + t = xs + T',  y' = xr + 4p - t = xs + (4p - 2(c+1)) - T',  xs = xr + (c+1)
 // so the (c+1) rides on the constant the conditional subtract selects anyway.
 __device__ __forceinline__ void ct_bfly(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k) {
-  const uint64_t t = mulmod_raw(y, w, k);
+  const uint64_t t = mulmod_raw_t<GPQ_PIN_CT>(y, w, k);
   const uint64_t xs = x + (x >= k.p4 ? k.kx1 : k.kx0);
   x = xs + t;
   y = xs + k.ky - t;
@@ -102,7 +114,7 @@ __device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, uint64_t w, co
   const uint64_t v = x + y;
   const uint64_t d = x + k.p4 - y;  // (0, 8p)
   x = v + (v >= k.p4 ? (uint64_t)0 - k.p4 : (uint64_t)0);
-  y = mulmod_raw(d, w, k) + k.c1;
+  y = mulmod_raw_t<GPQ_PIN_GS>(d, w, k) + k.c1;
 }
 
 // Exact a*b mod p for canonical a,b (poly_rns_mul, src/poly.c:77-82).

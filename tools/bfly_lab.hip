@@ -32,6 +32,43 @@ __device__ __forceinline__ void ct_v2(uint64_t &x, uint64_t &y, uint64_t w, cons
   const uint64_t xs = x + (ge ? k.kx1 : k.kx0);
   x = xs + t; y = xs + k.ky - t;
 }
+// v6: v1 with the middle column pinned (no re-association) ; v7: v6 + approx csub
+__device__ __forceinline__ uint64_t mulmod_pin(uint64_t a, uint64_t w, const PrimeK &k) {
+  const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+  const uint64_t m00 = mad_u64(a0, w0, 0);
+  uint64_t mid = mad_u64(a0, w1, (uint32_t)(m00 >> 32));
+  asm volatile("" : "+v"(mid));
+  mid = mad_u64(a1, w0, mid);
+  const uint64_t hi = mad_u64(a1, w1, (uint32_t)(mid >> 32));
+  const uint32_t midlo = (uint32_t)mid, hilo = (uint32_t)hi, hihi = (uint32_t)(hi >> 32);
+  const uint32_t xh0 = __builtin_amdgcn_alignbit(hilo, midlo, 27);
+  const uint32_t xh1 = __builtin_amdgcn_alignbit(hihi, hilo, 27);
+  const uint64_t xl = pack64((uint32_t)m00, midlo & 0x7ffffffu);
+  const uint64_t t0 = mad_u64(k.c, xh0, 0);
+  const uint64_t t1 = mad_u64(k.c, xh1, (uint32_t)(t0 >> 32));
+  const uint32_t t1lo = (uint32_t)t1, t1hi = (uint32_t)(t1 >> 32);
+  const uint32_t th = __builtin_amdgcn_alignbit(t1hi, t1lo, 27);
+  const uint64_t ntl = pack64(~(uint32_t)t0, ~t1lo & 0x7ffffffu);
+  return mad_u64(k.c, th, xl) + ntl;
+}
+__device__ __forceinline__ void ct_v6(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k) {
+  const uint64_t t = mulmod_pin(y, w, k);
+  const uint64_t xs = x + (x >= k.p4 ? k.kx1 : k.kx0);
+  x = xs + t; y = xs + k.ky - t;
+}
+__device__ __forceinline__ void ct_v7(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k) {
+  const uint64_t t = mulmod_pin(y, w, k);
+  const bool ge = (uint32_t)(x >> 32) > (uint32_t)(k.p4 >> 32);
+  const uint64_t xs = x + (ge ? k.kx1 : k.kx0);
+  x = xs + t; y = xs + k.ky - t;
+}
+// v8: v7 with y' = (xs + ky + 1) + ~t
+__device__ __forceinline__ void ct_v8(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k) {
+  const uint64_t t = mulmod_pin(y, w, k);
+  const bool ge = (uint32_t)(x >> 32) > (uint32_t)(k.p4 >> 32);
+  const uint64_t xs = x + (ge ? k.kx1 : k.kx0);
+  x = xs + t; y = (xs + (k.ky + 1)) + ~t;
+}
 // v3: no conditional subtract at all (bounds not kept; timing only)
 __device__ __forceinline__ void ct_v3(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k) {
   const uint64_t t = mulmod_raw(y, w, k);
@@ -69,6 +106,9 @@ __global__ __launch_bounds__(256) void probe(uint64_t *out, uint64_t seed, Prime
       if (V == 4) ct_v4(v[i], v[i + 4], w, k);
       if (V == 5) ct_v5(v[i], v[i + 4], w, k);
       if (V == 6) gs_bfly(v[i], v[i + 4], w, k);
+      if (V == 7) ct_v6(v[i], v[i + 4], w, k);
+      if (V == 8) ct_v7(v[i], v[i + 4], w, k);
+      if (V == 9) ct_v8(v[i], v[i + 4], w, k);
     }
   }
   uint64_t acc = 0;
@@ -100,7 +140,8 @@ int main() {
   k.kx0 = k.c1; k.kx1 = (uint64_t)k.c1 - k.p4; k.ky = k.p4 - 2 * (uint64_t)k.c1;
   for (int w : {8, 4, 2}) {
     if (w == 8) { run<0>("ct v0 (first formulation)", d_out, k, 8); run<1>("ct v1 (current)", d_out, k, 8); run<2>("ct v2 (approx csub)", d_out, k, 8);
-                  run<3>("ct v3 (no csub)", d_out, k, 8); run<4>("mulmod only", d_out, k, 8); run<5>("4-mad product only", d_out, k, 8); run<6>("gs (current)", d_out, k, 8); }
+                  run<3>("ct v3 (no csub)", d_out, k, 8); run<4>("mulmod only", d_out, k, 8); run<5>("4-mad product only", d_out, k, 8); run<6>("gs (current)", d_out, k, 8);
+                  run<7>("ct v6 (pinned mid)", d_out, k, 8); run<8>("ct v7 (pinned + approx csub)", d_out, k, 8); run<9>("ct v8 (v7, y via ~t)", d_out, k, 8); }
     if (w == 4) { run<0>("ct v0", d_out, k, 4); run<1>("ct v1", d_out, k, 4); }
     if (w == 2) { run<0>("ct v0", d_out, k, 2); run<1>("ct v1", d_out, k, 2); }
   }
