@@ -338,9 +338,10 @@ int launch_strided(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned p
 
 template <bool INV>
 int launch_contig(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned polys, hipStream_t s) {
-  const dim3 grid(c->n >> 12, polys * a.nslab, dim);
+  if (a.nslab != 1) return gpq_fail(GPQ_ERR_INVALID, "contig_pass walks one slab");
+  const dim3 grid(c->n >> 12, (polys + CONTIG_POLYS - 1) / CONTIG_POLYS, dim);
   ProfScope prof(c, INV ? GPQ_K_CONTIG_INV : GPQ_K_CONTIG_FWD, s);
-  hipLaunchKernelGGL((contig_pass<INV>), grid, dim3(CONTIG_WAVES * 64), 0, s, a);
+  hipLaunchKernelGGL((contig_pass<INV>), grid, dim3(CONTIG_WAVES * 64), 0, s, a, polys);
   return GPQ_OK;
 }
 

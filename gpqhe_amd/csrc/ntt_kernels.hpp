@@ -59,44 +59,56 @@ constexpr int tw_count(int EL, int BHI, int BLO) { return (1 << (EL - BLO)) - (1
 
 // Fetch the twiddles of a group into registers ahead of the butterflies: stage on
 // bit b uses table[n/(2 len) + i/(2 len)], i.e. 2^(EL-b-1) consecutive entries per thread.
+// Offset of bit b's twiddles inside a group's tw[] (bits above b come first).
+constexpr int tw_off(int EL, int BHI, int b) { return (1 << (EL - b - 1)) - (1 << (EL - BHI - 1)); }
+
+// The stages of a group are unrolled by template recursion so that every
+// register index is a compile-time constant (a plain nested loop over 32
+// registers is not always unrolled completely, and a runtime-indexed register
+// array goes to scratch: measured 8x slower on the n=2^17 forward pass).
+template <int EL, int BHI, int B, int BLO, bool UNIFORM, int NTW>
+__device__ __forceinline__ void load_tw_bits(uint64_t (&tw)[NTW], unsigned ibase, int rs, unsigned logn,
+                                             const uint64_t *__restrict__ w) {
+  const int sh = rs + B + 1;                                          // i / (2 len)
+  const uint64_t *wp = w + (1u << (logn - sh)) + (UNIFORM ? 0u : (ibase >> sh));
+#pragma unroll
+  for (int j = 0; j < (1 << (EL - B - 1)); ++j) tw[tw_off(EL, BHI, B) + j] = wp[j];
+  if constexpr (B > BLO) load_tw_bits<EL, BHI, B - 1, BLO, UNIFORM>(tw, ibase, rs, logn, w);
+}
+
+// Fetch the twiddles of a group into registers ahead of the butterflies: stage on
+// bit b uses table[n/(2 len) + i/(2 len)], i.e. 2^(EL-b-1) consecutive entries per thread.
 template <int EL, int BHI, int BLO, bool UNIFORM>
 __device__ __forceinline__ void load_tw(uint64_t (&tw)[tw_count(EL, BHI, BLO)], unsigned ibase, int rs, unsigned logn,
                                         const uint64_t *__restrict__ w) {
-  int o = 0;
-#pragma unroll
-  for (int b = BHI; b >= BLO; --b) {
-    const int sh = rs + b + 1;                         // i / (2 len)
-    const uint64_t *wp = w + (1u << (logn - sh)) + (UNIFORM ? 0u : (ibase >> sh));
-#pragma unroll
-    for (int j = 0; j < (1 << (EL - b - 1)); ++j) tw[o + j] = wp[j];
-    o += 1 << (EL - b - 1);
-  }
+  load_tw_bits<EL, BHI, BHI, BLO, UNIFORM>(tw, ibase, rs, logn, w);
 }
 
+template <int EL, int BHI, int B, int BLO, int NTW>
+__device__ __forceinline__ void ct_bits(uint64_t (&x)[1 << EL], const uint64_t (&tw)[NTW], const PrimeK &k) {
+#pragma unroll
+  for (int e = 0; e < (1 << EL); ++e)
+    if (!(e & (1 << B))) ct_bfly(x[e], x[e + (1 << B)], tw[tw_off(EL, BHI, B) + (e >> (B + 1))], k);
+  if constexpr (B > BLO) ct_bits<EL, BHI, B - 1, BLO>(x, tw, k);
+}
 template <int EL, int BHI, int BLO>
 __device__ __forceinline__ void ct_group(uint64_t (&x)[1 << EL], const uint64_t (&tw)[tw_count(EL, BHI, BLO)],
                                          const PrimeK &k) {
-  int o = 0;
-#pragma unroll
-  for (int b = BHI; b >= BLO; --b) {
-#pragma unroll
-    for (int e = 0; e < (1 << EL); ++e)
-      if (!(e & (1 << b))) ct_bfly(x[e], x[e + (1 << b)], tw[o + (e >> (b + 1))], k);
-    o += 1 << (EL - b - 1);
-  }
+  ct_bits<EL, BHI, BHI, BLO>(x, tw, k);
 }
 
 // Inverse: stages run from bit BLO up to BHI; tw[] is laid out as load_tw fills it (BHI first).
+template <int EL, int BHI, int B, int NTW>
+__device__ __forceinline__ void gs_bits(uint64_t (&x)[1 << EL], const uint64_t (&tw)[NTW], const PrimeK &k) {
+#pragma unroll
+  for (int e = 0; e < (1 << EL); ++e)
+    if (!(e & (1 << B))) gs_bfly(x[e], x[e + (1 << B)], tw[tw_off(EL, BHI, B) + (e >> (B + 1))], k);
+  if constexpr (B < BHI) gs_bits<EL, BHI, B + 1>(x, tw, k);
+}
 template <int EL, int BHI, int BLO>
 __device__ __forceinline__ void gs_group(uint64_t (&x)[1 << EL], const uint64_t (&tw)[tw_count(EL, BHI, BLO)],
                                          const PrimeK &k) {
-#pragma unroll
-  for (int b = BLO; b <= BHI; ++b) {
-    const int o = (1 << (EL - b - 1)) - (1 << (EL - BHI - 1));   // entries of the higher bits come first
-#pragma unroll
-    for (int e = 0; e < (1 << EL); ++e)
-      if (!(e & (1 << b))) gs_bfly(x[e], x[e + (1 << b)], tw[o + (e >> (b + 1))], k);
-  }
+  gs_bits<EL, BHI, BLO>(x, tw, k);
 }
 
 // Last inverse stage (len = n/2, twiddle winv[1]) with the n^-1 scaling of
@@ -306,26 +318,45 @@ struct ContigBlock {       // per-workgroup addressing shared by the contiguous 
 
 // Forward: low 8 stages, canonical output (end of gpq_ntt).  Inverse: low 8
 // stages of the inverse transform (feeds the strided inverse pass).
+// A pass reads as many twiddle bytes as data bytes (every table entry is used
+// exactly once per limb), so one workgroup walks CONTIG_POLYS polynomials of
+// the same limb and tile with the 30 twiddles of a lane held in registers, and
+// fetches the next polynomial's coefficients while it works on the current one.
+constexpr int CONTIG_POLYS = 4;
+
 template <bool INV>
-__global__ __launch_bounds__(CONTIG_WAVES * 64) void contig_pass(PassArgs a) {
+__global__ __launch_bounds__(CONTIG_WAVES * 64) void contig_pass(PassArgs a, unsigned polys) {
   __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
   const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
-  const ContigBlock cb(a);
-  const LimbTab &tab = a.tabs[cb.limb];
-  uint64_t x[16];
+  const unsigned wave0 = (blockIdx.x * CONTIG_WAVES + (threadIdx.x >> 6)) << 10;
+  const unsigned limb = a.limb0 + blockIdx.z;
+  const LimbTab &tab = a.tabs[limb];
+  const PrimeK k = tab.k;
+  const unsigned p0 = blockIdx.y * CONTIG_POLYS;
+  const unsigned cnt = polys - p0 < CONTIG_POLYS ? polys - p0 : CONTIG_POLYS;
+  const size_t off = (size_t)p0 * a.poly_stride + ((size_t)blockIdx.z << a.logn) + wave0;
+  const uint64_t *__restrict__ src = a.src[0] + off;
+  uint64_t *__restrict__ dst = a.dst[0] + off;
+  uint64_t x[16], nx[16];
   ContigTw tw;
-  if (!INV) {
-    load_h(x, a.src[cb.slab] + cb.off, ln);
-    tw.load(ln, cb.wave0, a.logn, a.w + cb.toff);
-    contig_fwd(x, ln, tw, tab.k);
+  // Global accesses use the H layout only (16 lanes = 128 contiguous bytes); the L layout
+  // (each lane on its own 128-byte line) is reached through one more LDS exchange instead.
+  load_h(x, src, ln);
+  tw.load(ln, wave0, a.logn, (INV ? a.winv : a.w) + ((size_t)limb << a.logn));
+  for (unsigned i = 0; i < cnt; ++i) {
+    if (i + 1 < cnt) load_h(nx, src + (size_t)(i + 1) * a.poly_stride, ln);
+    if (!INV) {
+      contig_fwd(x, ln, tw, k);
+      ln.l_to_h(x);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = canon8(x[e], tab.k);
-    store_l(a.dst[cb.slab] + cb.off, x, ln);
-  } else {
-    load_l(x, a.src[cb.slab] + cb.off, ln);
-    tw.load(ln, cb.wave0, a.logn, a.winv + cb.toff);
-    contig_inv(x, ln, tw, tab.k);
-    store_h(a.dst[cb.slab] + cb.off, x, ln);
+      for (int e = 0; e < 16; ++e) x[e] = canon8(x[e], k);
+    } else {
+      ln.h_to_l(x);
+      contig_inv(x, ln, tw, k);
+    }
+    store_h(dst + (size_t)i * a.poly_stride, x, ln);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = nx[e];
   }
 }
 
@@ -394,9 +425,11 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid(KeyswitchA
   load_h(x, a.src[0] + cb.off, ln);
   tw.load(ln, cb.wave0, a.logn, a.w + cb.toff);
   contig_fwd(x, ln, tw, k);
-  load_l(e0, ka.evk0 + koff, ln);
-  load_l(e1, ka.evk1 + koff, ln);
+  load_h(e0, ka.evk0 + koff, ln);
+  load_h(e1, ka.evk1 + koff, ln);
   tw.load(ln, cb.wave0, a.logn, a.winv + cb.toff);
+  ln.h_to_l(e0);
+  ln.h_to_l(e1);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const uint64_t u = csub(x[e], k.p4);           // < 4p ; evk limbs are canonical (< p)
