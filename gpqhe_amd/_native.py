@@ -41,6 +41,15 @@ SIGNATURES = {
     "gpq_keyswitch_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
     "gpq_he_mul_tensor": (C.c_int, [vp] * 8 + [C.c_uint, C.c_uint, vp, vp]),
     "gpq_keyswitch": (C.c_int, [vp] * 6 + [C.c_uint, C.c_uint, vp, vp]),
+    "gpq_big_words": (C.c_uint, [C.c_uint]),
+    "gpq_ctx_phat_invmp": (u64, [vp, C.c_uint, C.c_uint]),
+    "gpq_ctx_pbits": (C.c_uint, [vp, C.c_uint]),
+    "gpq_rns_decompose": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, vp]),
+    "gpq_rns_reconstruct": (C.c_int, [vp, vp, C.c_uint, vp, C.c_uint, C.c_uint, C.c_uint, vp]),
+    "gpq_poly_mul_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
+    "gpq_poly_mul": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
+    "gpq_he_rs": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp]),
+    "gpq_he_rescale": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp]),
     "gpq_profile_enable": (C.c_int, [vp, C.c_int]),
     "gpq_profile_kernels": (C.c_int, []),
     "gpq_profile_kernel_name": (C.c_char_p, [C.c_int]),

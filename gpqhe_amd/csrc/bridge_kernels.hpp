@@ -1,0 +1,236 @@
+// bridge_kernels.hpp -- the MPI <-> RNS bridge on the device.
+//
+// The reference keeps ciphertext coefficients as libgcrypt big integers and
+// crosses into RNS form around every multiplication:
+//   rns_decompose    src/rns.c:37-48     ahat[i] = a[i] mod p        (floor mod)
+//   rns_reconstruct  src/rns.c:60-75     a = sum_d ahat_d * (phat_d * phat_invmp_d mod P) mod P
+//   poly_rns2mpi     src/poly.c:109-120  reconstruct, mpi_smod(P, P/2), mpi_smod(q, q/2)
+//   mpi_smod         src/types.c:108-113 r mod q, minus q when r >= floor(q/2)
+//   mpi_rdiv         src/types.c:115-128 floor(a/m), plus one when the remainder > floor(m/2)
+//   he_rs            src/he-rescale.c:33-54
+// Here a polynomial of big integers is a "big slab": uint64_t[W][n], word j of
+// coefficient i at j*n + i (word-major, so a wave reads 64 consecutive words),
+// little-endian words, two's complement over 64*W bits.
+#pragma once
+#include "modarith.hpp"
+#include "tables.hpp"
+
+namespace gpq {
+
+constexpr uint64_t M59 = (1ull << 59) - 1;
+
+// r*2^59 + d (mod p), lazily: r < 4p, d < 2^59 -> (0, 4p).
+//   2^59 == -c:  r*2^59 + d == d - c*r ; t = c*r < 2^89.3, t = th*2^59 + tl == tl - c*th
+//   => d - tl + c*th == d + (2^59-1-tl) + c*th + (c+1)  (mod p), every term non-negative.
+__device__ __forceinline__ uint64_t horner59(uint64_t r, uint64_t d, const PrimeK &k) {
+  const uint64_t t0 = mad_u64(k.c, (uint32_t)r, 0);
+  const uint64_t t1 = mad_u64(k.c, (uint32_t)(r >> 32), (uint32_t)(t0 >> 32));  // t = t1 : lo32(t0)
+  const uint32_t t1lo = (uint32_t)t1, t1hi = (uint32_t)(t1 >> 32);
+  const uint32_t th = __builtin_amdgcn_alignbit(t1hi, t1lo, 27);
+  const uint64_t ntl = pack64(~(uint32_t)t0, ~t1lo & 0x7ffffffu);
+  return mad_u64(k.c, th, d + k.c1) + ntl;
+}
+
+// ---------------------------------------------------------------------------
+// rns_decompose: big slab -> limb-major slab, every limb of one coefficient by
+// the same thread (the words are read once, the limb loop is uniform).
+// MAXW = words kept in registers (the value is sign-extended to 64*MAXW bits).
+// ---------------------------------------------------------------------------
+struct DecomposeArgs {
+  const LimbTab *tabs;
+  const uint64_t *big;      // [polys][W][n]
+  uint64_t *slab;           // [polys][dim][n]
+  unsigned W, dim, logn;
+};
+
+template <int MAXW>
+__global__ __launch_bounds__(256) void bridge_decompose(DecomposeArgs a) {
+  constexpr int ND = (64 * MAXW + 58) / 59;             // 59-bit digits, the top one signed
+  constexpr int TOPBITS = 64 * MAXW - 59 * (ND - 1);
+  const unsigned n = 1u << a.logn;
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t *__restrict__ src = a.big + ((size_t)blockIdx.y * a.W << a.logn) + i;
+  uint64_t w[MAXW + 1];
+#pragma unroll
+  for (int j = 0; j < MAXW; ++j) w[j] = j < (int)a.W ? src[(size_t)j << a.logn] : 0;
+  // sign of the value = top bit of its last real word; found without a runtime register index
+  uint64_t sx = 0;
+#pragma unroll
+  for (int j = 0; j < MAXW; ++j) if (j == (int)a.W - 1) sx = (uint64_t)((int64_t)w[j] >> 63);
+#pragma unroll
+  for (int j = 0; j < MAXW; ++j) if (j >= (int)a.W) w[j] = sx;
+  w[MAXW] = sx;
+  uint64_t dg[ND];
+#pragma unroll
+  for (int t = 0; t < ND; ++t) {
+    const int bit = 59 * t, wi = bit >> 6, sh = bit & 63;
+    const uint64_t lo = w[wi] >> sh;
+    const uint64_t hi = sh ? (w[wi + 1] << (64 - sh)) : 0;
+    dg[t] = (lo | hi) & M59;
+  }
+  // top digit as a signed number of TOPBITS bits
+  const int64_t top = ((int64_t)(dg[ND - 1] << (64 - TOPBITS))) >> (64 - TOPBITS);
+  uint64_t *__restrict__ dst = a.slab + ((size_t)blockIdx.y * a.dim << a.logn) + i;
+  for (unsigned d = 0; d < a.dim; ++d) {
+    const PrimeK k = a.tabs[d].k;
+    uint64_t r = top < 0 ? (uint64_t)top + k.p : (uint64_t)top;     // [0, p + 2^58)
+#pragma unroll
+    for (int t = ND - 2; t >= 0; --t) r = horner59(r, dg[t], k);
+    dst[(size_t)d << a.logn] = canon4(r, k);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// poly_rns2mpi: limb-major slab -> big slab.
+//   y_d = ahat_d * phat_invmp_d mod p_d          (one modular multiply per limb)
+//   S   = sum_d y_d * phat_d      < dim * P      (multiword, WP+1 words in registers)
+//   S mod P by conditional subtraction of 32P, 16P, ..., P (dim <= 63)
+//   centre mod P (>= floor(P/2) -> minus P), then centre mod q = 2^logq.
+// Equal to the reference's sum of (ahat_d * C_d mod P) mod P with C_d = phat_d*phat_invmp_d mod P.
+// ---------------------------------------------------------------------------
+struct ReconstructArgs {
+  const LimbTab *tabs;
+  const uint64_t *slab;        // [polys][dim][n]
+  uint64_t *big;               // [polys][Wout][n]
+  const uint64_t *phat;        // [dim][WP]       P / p_d
+  const uint64_t *phat_inv;    // [dim]           (P/p_d)^-1 mod p_d
+  const uint64_t *pmult;       // [6][WP+1]       32P, 16P, 8P, 4P, 2P, P
+  const uint64_t *phalf;       // [WP+1]          floor(P/2)
+  unsigned dim, logn, Wout, logq;   // logq = 0: no reduction mod q (Wout >= WP+1 then)
+};
+
+template <int WP>
+__global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
+  const unsigned n = 1u << a.logn;
+  const unsigned i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t *__restrict__ src = a.slab + ((size_t)blockIdx.y * a.dim << a.logn) + i;
+  uint64_t S[WP + 1];
+#pragma unroll
+  for (int j = 0; j <= WP; ++j) S[j] = 0;
+  for (unsigned d = 0; d < a.dim; ++d) {
+    const PrimeK k = a.tabs[d].k;
+    const uint64_t y = mulmod_canon(src[(size_t)d << a.logn], a.phat_inv[d], k);
+    const uint64_t *__restrict__ ph = a.phat + (size_t)d * WP;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      const u128 t = (u128)y * ph[j] + S[j] + carry;
+      S[j] = (uint64_t)t;
+      carry = (uint64_t)(t >> 64);
+    }
+    S[WP] += carry;
+  }
+  // S mod P
+#pragma unroll 1
+  for (int m = 0; m < 6; ++m) {
+    const uint64_t *__restrict__ mp = a.pmult + (size_t)m * (WP + 1);
+    uint64_t T[WP + 1];
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int j = 0; j <= WP; ++j) {
+      const u128 t = (u128)S[j] - mp[j] - borrow;
+      T[j] = (uint64_t)t;
+      borrow = (uint64_t)(t >> 64) & 1;
+    }
+    if (!borrow) {
+#pragma unroll
+      for (int j = 0; j <= WP; ++j) S[j] = T[j];
+    }
+  }
+  // mpi_smod(., P, P/2): r >= floor(P/2) -> r - P
+  {
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int j = 0; j <= WP; ++j) {
+      const u128 t = (u128)S[j] - a.phalf[j] - borrow;
+      borrow = (uint64_t)(t >> 64) & 1;
+    }
+    if (!borrow) {
+      const uint64_t *__restrict__ mp = a.pmult + (size_t)5 * (WP + 1);
+      uint64_t b2 = 0;
+#pragma unroll
+      for (int j = 0; j <= WP; ++j) {
+        const u128 t = (u128)S[j] - mp[j] - b2;
+        S[j] = (uint64_t)t;
+        b2 = (uint64_t)(t >> 64) & 1;
+      }
+    }
+  }
+  // mpi_smod(., 2^logq, 2^(logq-1)): keep logq bits, sign-extend from bit logq-1
+  uint64_t *__restrict__ dst = a.big + ((size_t)blockIdx.y * a.Wout << a.logn) + i;
+  const uint64_t sext = (uint64_t)((int64_t)S[WP] >> 63);
+  uint64_t qsign = 0;
+  if (a.logq) {
+    const unsigned sb = a.logq - 1;
+#pragma unroll
+    for (int j = 0; j <= WP; ++j) if (j == (int)(sb >> 6)) qsign = 0 - ((S[j] >> (sb & 63)) & 1);
+  }
+#pragma unroll
+  for (int j = 0; j <= WP; ++j) {
+    if (j < (int)a.Wout) {
+      uint64_t v = S[j];
+      if (a.logq) {
+        const int lo = 64 * j;
+        if (lo >= (int)a.logq) v = qsign;
+        else if (lo + 64 > (int)a.logq) {
+          const uint64_t mask = (1ull << (a.logq - lo)) - 1;
+          v = (v & mask) | (qsign & ~mask);
+        }
+      }
+      dst[(size_t)j << a.logn] = v;
+    }
+  }
+  const uint64_t fill = a.logq ? qsign : sext;
+  for (unsigned j = WP + 1; j < a.Wout; ++j) dst[(size_t)j << a.logn] = fill;
+}
+
+// ---------------------------------------------------------------------------
+// he_rs on one big slab, Delta = 2^s and q_l = 2^logql (the reference's test
+// parameters, tests/gpqhe.c:1349-1352): c <- smod(rdiv(c, Delta), q_l), in place.
+//   rdiv: floor(c / 2^s) = arithmetic shift; plus one when (c mod 2^s) > 2^(s-1)
+//   smod: keep logql bits, sign-extend from bit logql-1
+// One thread per coefficient, words walked in ascending order (reads run ahead
+// of writes, so in place is safe).
+// ---------------------------------------------------------------------------
+struct RescaleArgs { uint64_t *big; unsigned W, logn, s, logql; };
+
+__global__ __launch_bounds__(256) void bridge_rescale(RescaleArgs a) {
+  const unsigned n = 1u << a.logn;
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t *__restrict__ c = a.big + ((size_t)blockIdx.y * a.W << a.logn) + i;
+  const unsigned ws = a.s >> 6, bs = a.s & 63;
+  auto word = [&](unsigned j) -> uint64_t {               // sign-extended read
+    return j < a.W ? c[(size_t)j << a.logn] : (uint64_t)((int64_t)c[(size_t)(a.W - 1) << a.logn] >> 63);
+  };
+  // remainder r = c mod 2^s  >  2^(s-1)  <=>  bit s-1 set and some lower bit set
+  uint64_t carry = 0;
+  if (a.s) {
+    const unsigned hb = a.s - 1, hw = hb >> 6, hbit = hb & 63;
+    const uint64_t wh = word(hw);
+    uint64_t lower = wh & ((1ull << hbit) - 1);
+    for (unsigned j = 0; j < hw; ++j) lower |= word(j);
+    carry = ((wh >> hbit) & 1) && lower;
+  }
+  const unsigned sb = a.logql - 1;
+  uint64_t qsign = 0;
+  for (unsigned j = 0; j < a.W; ++j) {
+    const uint64_t lo = word(j + ws), hi = word(j + ws + 1);
+    uint64_t v = bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
+    const uint64_t v1 = v + carry;
+    carry = v1 < v;
+    v = v1;
+    const unsigned base = 64 * j;
+    if (base + 64 > sb && base <= sb) qsign = 0 - ((v >> (sb - base)) & 1);
+    if (base >= a.logql) v = qsign;
+    else if (base + 64 > a.logql) {
+      const uint64_t mask = (1ull << (a.logql - base)) - 1;
+      v = (v & mask) | (qsign & ~mask);
+    }
+    c[(size_t)j << a.logn] = v;
+  }
+}
+
+}  // namespace gpq

@@ -3,6 +3,7 @@
 // and the C ABI declared in include/gpqhe_hip.h.
 #include "../../include/gpqhe_hip.h"
 #include "engine_internal.hpp"
+#include "ntt_kernels.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -228,6 +229,7 @@ extern "C" void gpq_ctx_destroy(gpq_ctx *c) {
   if (c->d_w) (void)hipFree(c->d_w);
   if (c->d_winv) (void)hipFree(c->d_winv);
   if (c->d_tabs) (void)hipFree(c->d_tabs);
+  gpq_bridge_release(c);
   for (gpq_prof_rec &r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
   delete c;

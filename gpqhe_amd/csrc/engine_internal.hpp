@@ -1,14 +1,23 @@
 // engine_internal.hpp -- the context object behind the opaque gpq_ctx handle.
 #pragma once
+#include <map>
 #include <string>
 #include <vector>
-#include "ntt_kernels.hpp"
+#include "tables.hpp"
 
 // Optional per-launch timing with HIP events recorded on the launch stream
 // (bench.py's roofline leg).  Off by default: no events are created.
 struct gpq_prof_rec { int kernel; hipEvent_t a, b; };
 enum { GPQ_K_STRIDED_FWD = 0, GPQ_K_STRIDED_INV, GPQ_K_CONTIG_FWD, GPQ_K_CONTIG_INV, GPQ_K_TENSOR_MID,
        GPQ_K_KEYSWITCH_MID, GPQ_K_POINTWISE, GPQ_K_SMALL, GPQ_K_COUNT };
+
+// CRT constants of one prefix of the prime chain (bridge.hip)
+struct gpq_bridge_basis {
+  unsigned dim = 0, pbits = 0;
+  int WP = 0;
+  uint64_t *d_phat = nullptr, *d_phat_inv = nullptr, *d_pmult = nullptr, *d_phalf = nullptr;
+  std::vector<uint64_t> h_phat_inv;
+};
 
 struct gpq_ctx {
   int device = 0;
@@ -20,6 +29,7 @@ struct gpq_ctx {
   // device tables (standard form)
   uint64_t *d_w = nullptr, *d_winv = nullptr;
   gpq::LimbTab *d_tabs = nullptr;
+  std::map<unsigned, gpq_bridge_basis> bases;  // by prefix length, built on first use
   // profiling
   bool prof_on = false;
   std::vector<gpq_prof_rec> prof;     // launches recorded since the last reset
@@ -27,3 +37,4 @@ struct gpq_ctx {
 };
 
 int gpq_fail(int code, const char *fmt, ...);
+void gpq_bridge_release(gpq_ctx *c);

@@ -1,0 +1,29 @@
+// tables.hpp -- per-prime device tables and the argument block shared by the kernels.
+#pragma once
+#include "modarith.hpp"
+
+namespace gpq {
+
+struct LimbTab {           // per-prime scalars, array resident in HBM (read with scalar loads)
+  PrimeK k;
+  uint64_t ninv;           // n^-1 mod p, standard form (reference: rns->ninv is n^-1*2^64, src/precomp.c:248)
+  uint64_t winv1_ninv;     // winv[1]*n^-1 mod p : last inverse stage with the scaling folded in
+};
+
+#define GPQ_MAX_SLABS 4
+struct PassArgs {
+  const LimbTab *tabs;               // tabs[limb0 + blockIdx.z]
+  // Twiddle tables [nprimes][n], standard form, indexed like rns->zetas / rns->zetas_inv
+  // (src/precomp.c:255-263).  Kernel-argument pointers: the compiler knows they are
+  // global memory, so uniform reads become s_load and the rest global_load.
+  const uint64_t *w;
+  const uint64_t *winv;
+  const uint64_t *src[GPQ_MAX_SLABS];
+  uint64_t *dst[GPQ_MAX_SLABS];
+  unsigned long long poly_stride;    // elements between consecutive polynomials of a slab (= limbs_in_slab * n)
+  unsigned logn;
+  unsigned limb0;
+  unsigned nslab;                    // blockIdx.y = poly * nslab + slab
+};
+
+}  // namespace gpq

@@ -81,6 +81,35 @@ class PolyContext:
     def set_chunk(self, chunk):
         _native.check(self.lib.gpq_set_chunk(self.h, chunk), "gpq_set_chunk")
 
+    # --- MPI <-> RNS bridge on big slabs uint64[batch][W][n] ---
+    def rns_decompose(self, slab, big, W, dim):
+        """src/rns.c:37-48 for all limbs."""
+        batch = big.numel() // (W * self.n)
+        _native.check(self.lib.gpq_rns_decompose(self.h, _ptr(slab), _ptr(big), W, dim, batch, _stream()), "gpq_rns_decompose")
+        return slab
+
+    def rns_reconstruct(self, big, Wout, slab, dim, logq):
+        """src/poly.c:109-120 with q = 2^logq (0: centre mod P only)."""
+        batch = self._shape(slab, dim)
+        _native.check(self.lib.gpq_rns_reconstruct(self.h, _ptr(big), Wout, _ptr(slab), dim, batch, logq, _stream()), "gpq_rns_reconstruct")
+        return big
+
+    def poly_mul(self, r, a, b, W, dim, logq):
+        """src/poly.c:84-107 on big slabs, q = 2^logq."""
+        torch = _torch()
+        batch = a.numel() // (W * self.n)
+        ws = torch.empty(self.lib.gpq_poly_mul_workspace_bytes(self.h, dim, batch) // 8, dtype=torch.int64, device="cuda")
+        _native.check(self.lib.gpq_poly_mul(self.h, _ptr(r), _ptr(a), _ptr(b), W, dim, logq, batch, _ptr(ws), _stream()), "gpq_poly_mul")
+        return r
+
+    def he_rs(self, c0, c1, W, logDelta, logql):
+        """src/he-rescale.c:33-54 with Delta = 2^logDelta, q_l = 2^logql, in place."""
+        batch = c0.numel() // (W * self.n)
+        _native.check(self.lib.gpq_he_rs(self.h, _ptr(c0), _ptr(c1), W, logDelta, logql, batch, _stream()), "gpq_he_rs")
+
+    def phat_invmp(self, dim):
+        return [self.lib.gpq_ctx_phat_invmp(self.h, dim, d) for d in range(dim)]
+
     def profile(self, on):
         _native.check(self.lib.gpq_profile_enable(self.h, 1 if on else 0), "gpq_profile_enable")
 
@@ -148,6 +177,35 @@ class PolyContext:
         _native.check(self.lib.gpq_keyswitch(self.h, _ptr(c0), _ptr(c1), _ptr(x), _ptr(evk0), _ptr(evk1),
                                              dim, batch, _ptr(ws), _stream()), "gpq_keyswitch")
         return c0, c1
+
+
+def ints_to_big(values, W):
+    """Python ints (signed) -> numpy uint64 big slab [W][n], two's complement."""
+    n = len(values)
+    out = np.empty((W, n), dtype=np.uint64)
+    mod = 1 << (64 * W)
+    for i, v in enumerate(values):
+        v = int(v) % mod
+        for j in range(W):
+            out[j, i] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    return out.reshape(-1)
+
+
+def big_to_ints(big, W, n):
+    """numpy uint64 big slab(s) [..][W][n] -> list of signed Python ints per polynomial."""
+    arr = np.asarray(big, dtype=np.uint64).reshape(-1, W, n)
+    res = []
+    for poly in arr:
+        vals = []
+        for i in range(n):
+            v = 0
+            for j in range(W):
+                v |= int(poly[j, i]) << (64 * j)
+            if v >> (64 * W - 1):
+                v -= 1 << (64 * W)
+            vals.append(v)
+        res.append(vals)
+    return res
 
 
 class StreamTimer:

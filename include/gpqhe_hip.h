@@ -127,6 +127,35 @@ int gpq_keyswitch(gpq_ctx *ctx, uint64_t *c0, uint64_t *c1, const uint64_t *x,
                   const uint64_t *evk0, const uint64_t *evk1,
                   unsigned dim, unsigned batch, void *workspace, void *stream);
 
+/* ---- MPI <-> RNS bridge ---------------------------------
+ * The reference keeps coefficients as libgcrypt MPIs.  On the device a polynomial of
+ * big integers is a "big slab": uint64_t[batch][W][n], word j of coefficient i at
+ * j*n + i, little-endian words, two's complement over 64*W bits (centred
+ * coefficients are signed).  Moduli q, Delta are powers of two here, as in every
+ * parameter set of the reference's tests (tests/gpqhe.c:1349-1352, tests/polymul.c:84-87);
+ * other moduli return GPQ_ERR_UNSUPPORTED / are not offered.
+ */
+unsigned gpq_big_words(unsigned bits);
+/* rns->phat_invmp[d] of the node with `dim` limbs (src/precomp.c:288-289); bit length of its P. */
+uint64_t gpq_ctx_phat_invmp(gpq_ctx *ctx, unsigned dim, unsigned d);
+unsigned gpq_ctx_pbits(gpq_ctx *ctx, unsigned dim);
+
+/* rns_decompose for every limb at once, src/rns.c:37-48: slab[k][d][i] = big[k][.][i] mod p_d (>= 0). */
+int gpq_rns_decompose(gpq_ctx *ctx, uint64_t *slab, const uint64_t *big, unsigned W, unsigned dim, unsigned batch, void *stream);
+/* poly_rns2mpi, src/poly.c:109-120, with q = 2^logq: rns_reconstruct (src/rns.c:60-75), centre
+ * mod P, centre mod q.  logq = 0 stops after centring mod P (Wout must then hold P's bits + 1). */
+int gpq_rns_reconstruct(gpq_ctx *ctx, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned dim, unsigned batch,
+                        unsigned logq, void *stream);
+/* poly_mul, src/poly.c:84-107 (decl src/poly.h:86-87), q = 2^logq, on big slabs of W words. */
+size_t gpq_poly_mul_workspace_bytes(const gpq_ctx *ctx, unsigned dim, unsigned batch);
+int gpq_poly_mul(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned W, unsigned dim, unsigned logq,
+                 unsigned batch, void *workspace, void *stream);
+/* he_rs, src/he-rescale.c:33-54 (decl src/gpqhe.h:136), Delta = 2^logDelta, q_l = 2^logql: c0, c1 of
+ * `batch` ciphertexts in place: mpi_rdiv by Delta then mpi_smod q_l.  The l / nu / B bookkeeping
+ * (:36-38) stays with the caller.  gpq_he_rescale is the north-star spelling of the same call. */
+int gpq_he_rs(gpq_ctx *ctx, uint64_t *c0, uint64_t *c1, unsigned W, unsigned logDelta, unsigned logql, unsigned batch, void *stream);
+int gpq_he_rescale(gpq_ctx *ctx, uint64_t *c0, uint64_t *c1, unsigned W, unsigned logDelta, unsigned logql, unsigned batch, void *stream);
+
 /* ---- per-kernel profile ----------------------------------------------------
  * When enabled every kernel launch of this context is bracketed by two HIP
  * events on its own stream.  gpq_profile_collect waits for them and adds the

@@ -1,0 +1,126 @@
+"""Device MPI<->RNS bridge against the Python-integer restatement of the reference's
+libgcrypt code (oracle/bigint_ref.py): rns_decompose, poly_rns2mpi, poly_mul at the
+MPI level (the tests/polymul.c KAT entirely on the device) and he_rs."""
+import random
+
+import numpy as np
+import pytest
+
+from gpqhe_amd import big_to_ints, ints_to_big, to_device, to_host
+from oracle.bigint_ref import (RnsBasis, centred_mod, mpi_rdiv, mpi_smod, negacyclic_mul, poly_rns2mpi,
+                               rns_decompose)
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _edge_values(bits, rng, count):
+    """signed values of at most `bits` bits (two's complement), edges first"""
+    lim = 1 << (bits - 1)
+    vals = [0, 1, -1, lim - 1, -lim, lim // 2, -(lim // 2), (1 << 59) - 1, -(1 << 59), (1 << 64), -(1 << 64) + 1]
+    vals = [v for v in vals if -lim <= v < lim]
+    while len(vals) < count:
+        vals.append(rng.randrange(-lim, lim))
+    return vals[:count]
+
+
+@pytest.mark.parametrize("logn,dim,W,bits", [(7, 5, 1, 62), (7, 5, 2, 128), (7, 3, 4, 200), (8, 6, 14, 851), (7, 4, 16, 1024), (7, 2, 28, 1737)])
+def test_rns_decompose_matches_floor_mod(engine_ctx, logn, dim, W, bits):
+    g = engine_ctx(logn, max(dim, 6))
+    rng = random.Random(1234 + W)
+    polys = [_edge_values(bits, rng, g.n) for _ in range(2)]
+    big = np.concatenate([ints_to_big(v, W) for v in polys])
+    slab = _torch().empty(2 * dim * g.n, dtype=_torch().int64, device="cuda")
+    g.rns_decompose(slab, to_device(big), W, dim)
+    got = to_host(slab).reshape(2, dim, g.n)
+    for k in range(2):
+        for d in range(dim):
+            assert [int(x) for x in got[k, d]] == rns_decompose(polys[k], g.p[d]), (k, d)  # src/rns.c:44-45
+
+
+def test_phat_invmp_matches_reference_printout(golden, engine_ctx):
+    g = engine_ctx(7, 5)
+    for dim, exp in enumerate(golden["phat_invmp_logn7"], start=1):  # tests/polymul.c:106-112 output
+        assert [str(v) for v in g.phat_invmp(dim)] == exp
+
+
+@pytest.mark.parametrize("logn,dim,logq", [(7, 1, 30), (7, 2, 61), (7, 5, 61), (7, 5, 64), (7, 5, 0), (8, 9, 200), (7, 30, 850), (7, 45, 850), (7, 45, 0)])
+def test_poly_rns2mpi_matches_bigint(engine_ctx, oracle_ctx, logn, dim, logq):
+    g, o = engine_ctx(logn, dim), oracle_ctx(logn, dim)
+    basis = RnsBasis(g.p[:dim])
+    rng = random.Random(99 + dim)
+    n = g.n
+    slab = o.gen(5 + dim, dim).reshape(dim, n).copy()
+    # edge residues: 0, p-1, and a centred value just around P/2
+    half = basis.P_2
+    for col, v in enumerate((0, basis.P - 1, half - 1, half, half + 1, 1, (1 << logq) // 2 if logq else 7)):
+        for d in range(dim):
+            slab[d, col] = v % g.p[d]
+    exp = poly_rns2mpi([slab[d] for d in range(dim)], basis, 1 << logq) if logq else \
+        [mpi_smod(sum(int(slab[d][i]) * ((basis.phat[d] * basis.phat_invmp[d]) % basis.P) for d in range(dim)) % basis.P, basis.P)
+         for i in range(n)]
+    Wout = (logq + 63) // 64 if logq else (basis.P.bit_length() + 1 + 63) // 64
+    big = _torch().empty(Wout * n, dtype=_torch().int64, device="cuda")
+    g.rns_reconstruct(big, Wout, to_device(slab.reshape(-1)), dim, logq)
+    assert big_to_ints(to_host(big), Wout, n)[0] == exp
+    assert rng is not None
+
+
+def test_polymul_kat_entirely_on_device(engine_ctx):
+    """tests/polymul.c + tests/polymul.gp: n = 128, dimub = 5 limbs, q = 2^61."""
+    g = engine_ctx(7, 5)
+    N, Q = 128, 1 << 61
+    cases = [([i + 2 for i in range(N)], [i + 3 for i in range(N)]),
+             ([g.p[0] - i - 1 for i in range(N)], [g.p[1] - i - 1 for i in range(N)])]
+    leading = [[382784, 357372, 332350], [18559595904, 18272672062, 17985699960]]
+    W = 1
+    a = to_device(np.concatenate([ints_to_big(c[0], W) for c in cases]))
+    b = to_device(np.concatenate([ints_to_big(c[1], W) for c in cases]))
+    r = _torch().empty_like(a)
+    g.poly_mul(r, a, b, W, 5, 61)  # src/poly.c:84-107 with dim = polyctx.dimub
+    got = big_to_ints(to_host(r), W, N)
+    for (ca, cb), res, lead in zip(cases, got, leading):
+        assert res == [centred_mod(v, Q) for v in negacyclic_mul(ca, cb)]
+        assert [res[127], res[126], res[125]] == lead
+
+
+@pytest.mark.parametrize("logn,W,s,logql", [(7, 1, 10, 40), (7, 2, 50, 70), (7, 14, 50, 800), (7, 14, 64, 700), (7, 3, 128, 60), (7, 14, 30, 820)])
+def test_he_rs_matches_rdiv_smod(engine_ctx, logn, W, s, logql):
+    g = engine_ctx(logn, 5)
+    rng = random.Random(7 * W + s)
+    bits = min(64 * W, logql + s)
+    vals = _edge_values(bits, rng, g.n)
+    half = 1 << (s - 1)
+    # ties and near-ties of the rounding rule: remainder == Delta/2 does NOT round up (src/types.c:124)
+    vals[11:17] = [half, half + 1, half - 1, -half, -half + 1, 3 * half]
+    c0 = to_device(ints_to_big(vals, W))
+    c1 = to_device(ints_to_big([-v for v in vals], W))
+    g.he_rs(c0, c1, W, s, logql)
+    exp0 = [mpi_smod(mpi_rdiv(v, 1 << s), 1 << logql) for v in vals]      # src/he-rescale.c:45-48
+    exp1 = [mpi_smod(mpi_rdiv(-v, 1 << s), 1 << logql) for v in vals]
+    assert big_to_ints(to_host(c0), W, g.n)[0] == exp0
+    assert big_to_ints(to_host(c1), W, g.n)[0] == exp1
+
+
+def test_roundtrip_full_size(engine_ctx):
+    """Size-independent property at the headline shape (n = 2^16, 30 limbs, 851-bit coefficients):
+    poly_rns2mpi(rns_decompose(a)) == a for every centred a, including negatives."""
+    torch = _torch()
+    logn, dim, W, logq = 16, 30, 14, 850
+    g = engine_ctx(logn, 45)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    big = torch.randint(-(1 << 62), 1 << 62, (W, g.n), dtype=torch.int64, device="cuda", generator=gen)
+    top = torch.randint(-(1 << 16), 1 << 16, (g.n,), dtype=torch.int64, device="cuda", generator=gen)  # 850 - 13*64 = 18 bits
+    big[W - 1] = top
+    big = big.reshape(-1).contiguous()
+    slab = torch.empty(dim * g.n, dtype=torch.int64, device="cuda")
+    g.rns_decompose(slab, big, W, dim)
+    back = torch.empty_like(big)
+    g.rns_reconstruct(back, W, slab, dim, logq)
+    assert torch.equal(back, big)
+    assert bool((slab >= 0).all())
