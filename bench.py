@@ -86,6 +86,34 @@ def ntt_rate(torch, gpqhe_amd, logn, dim, batch, iters=5):
             "roundtrip_identity": ok}
 
 
+def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=3):
+    """Whole he_mul of src/he-mult.c:88-156 on device big slabs (q = 2^850: decompose, tensor, CRT, relinearise
+    with exact division by P, centre) -- SURVEY.md 8f rank 1-2, reported beside the RNS-core headline."""
+    logq, W = 850, 14
+    dimP, dimA, dimB, _ = ctx.he_dims(logq, logq)
+    n = ctx.n
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(21)
+
+    def centred():
+        big = torch.randint(-(1 << 62), 1 << 62, (batch, W, n), dtype=torch.int64, device="cuda", generator=gen)
+        big[:, W - 1] = torch.randint(-(1 << 16), 1 << 16, (batch, n), dtype=torch.int64, device="cuda", generator=gen)
+        return big.reshape(-1).contiguous()
+
+    cts = [centred() for _ in range(4)]
+    rlk0, rlk1 = rand_slab(torch, ctx, dimB, 1, gen), rand_slab(torch, ctx, dimB, 1, gen)
+    o0, o1 = torch.empty_like(cts[0]), torch.empty_like(cts[0])
+    ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
+    t = gpqhe_amd.StreamTimer()
+    t.start()
+    for _ in range(iters):
+        ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
+    t.stop()
+    ms = t.elapsed_ms() / iters
+    return {"shape": "n=2^16, q=2^850 (W=14 words), dimA/dimB/dimP=%d/%d/%d, batch %d" % (dimA, dimB, dimP, batch),
+            "ms_per_batch": round(ms, 3), "he_mul_per_s": round(batch / (ms * 1e-3), 1)}
+
+
 def cpu_baseline(ctx, host_inputs, gpu_outputs, sample):
     """The oracle (CPU restatement of the reference loops) timed on this host, one
     thread like the reference, on `sample` ciphertexts of the same workload; its
@@ -224,6 +252,9 @@ def main():
         if world == 1 and not args.no_ntt:
             # NTT GB/s at the headline ring (n=2^16, 30 limbs) and at BASELINE configs[1] (n=2^15, 10 limbs)
             out["ntt"] = [ntt_rate(torch, gpqhe_amd, 16, DIM_A, B), ntt_rate(torch, gpqhe_amd, 15, 10, 64)]
+            del a0, a1, b0, b1, x, d0, d1, d2, c0, c1, wsA, wsB
+            torch.cuda.empty_cache()
+            out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, 16)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

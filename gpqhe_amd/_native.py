@@ -50,6 +50,13 @@ SIGNATURES = {
     "gpq_poly_mul": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
     "gpq_he_rs": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp]),
     "gpq_he_rescale": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp]),
+    "gpq_he_dims": (C.c_int, [vp, C.c_uint, C.c_uint] + [C.POINTER(C.c_uint)] * 4),
+    "gpq_he_mul_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
+    "gpq_he_mul": (C.c_int, [vp] * 9 + [C.c_uint] * 6 + [vp, vp]),
+    "gpq_relin_tail_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
+    "gpq_relin_tail": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
+    "gpq_he_swk_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
+    "gpq_he_swk": (C.c_int, [vp] * 7 + [C.c_uint] * 5 + [vp, vp]),
     "gpq_profile_enable": (C.c_int, [vp, C.c_int]),
     "gpq_profile_kernels": (C.c_int, []),
     "gpq_profile_kernel_name": (C.c_char_p, [C.c_int]),

@@ -46,24 +46,28 @@ void put(std::vector<uint64_t> &dst, size_t off, const Big &v, size_t words) {
 
 const int kWP[] = {8, 16, 32, 48, 56};
 
-// CRT constants of the first `dim` primes: what struct rns_ctx node dim-1 holds (src/poly.h:35-38).
-int get_basis(gpq_ctx *c, unsigned dim, gpq_bridge_basis **out) {
-  auto it = c->bases.find(dim);
+// CRT constants of primes first .. first+dim-1: what struct rns_ctx node dim-1 holds for first = 0
+// (src/poly.h:35-38); sub-ranges serve the exact division of he_relin.
+int get_basis(gpq_ctx *c, unsigned first, unsigned dim, gpq_bridge_basis **out) {
+  const auto key = std::make_pair(first, dim);
+  auto it = c->bases.find(key);
   if (it != c->bases.end()) { *out = &it->second; return GPQ_OK; }
-  if (dim < 1 || dim > c->nprimes || dim > 63) return gpq_fail(GPQ_ERR_INVALID, "bridge: dim=%u outside 1..min(%u,63)", dim, c->nprimes);
+  if (dim < 1 || first + dim > c->nprimes || dim > 63)
+    return gpq_fail(GPQ_ERR_INVALID, "bridge: limbs %u..%u outside the chain of %u (at most 63 per basis)", first, first + dim, c->nprimes);
   Big P{1};
-  for (unsigned d = 0; d < dim; ++d) mul_small(P, c->p[d]);          // src/precomp.c:274-277
+  for (unsigned d = 0; d < dim; ++d) mul_small(P, c->p[first + d]);  // src/precomp.c:274-277
   int WP = 0;
   for (int w : kWP) if ((size_t)w >= P.size()) { WP = w; break; }
   if (!WP) return gpq_fail(GPQ_ERR_UNSUPPORTED, "bridge: P of %u limbs needs %zu words", dim, P.size());
   gpq_bridge_basis b;
-  b.dim = dim; b.WP = WP; b.pbits = 64 * (unsigned)(P.size() - 1) + (64 - __builtin_clzll(P.back()));
+  b.first = first; b.dim = dim; b.WP = WP; b.pbits = 64 * (unsigned)(P.size() - 1) + (64 - __builtin_clzll(P.back()));
   std::vector<uint64_t> phat((size_t)dim * WP), pinv(dim), pmult((size_t)6 * (WP + 1)), phalf(WP + 1);
   for (unsigned d = 0; d < dim; ++d) {
+    const uint64_t pd = c->p[first + d];
     Big q = P;
-    divmod_small(q, c->p[d]);                                        // phat_d = P / p_d   :287
+    divmod_small(q, pd);                                             // phat_d = P / p_d   :287
     put(phat, (size_t)d * WP, q, WP);
-    pinv[d] = powm(mod_small(q, c->p[d]), c->p[d] - 2, c->p[d]);     // :288-289
+    pinv[d] = powm(mod_small(q, pd), pd - 2, pd);                    // :288-289
   }
   Big h = P; shr1(h);                                                // P_2 = floor(P/2)   :278
   put(phalf, 0, h, WP + 1);
@@ -79,7 +83,50 @@ int get_basis(gpq_ctx *c, unsigned dim, gpq_bridge_basis **out) {
   HIP_TRY(hipMemcpy(b.d_pmult, pmult.data(), pmult.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b.d_phalf, phalf.data(), phalf.size() * 8, hipMemcpyHostToDevice));
   b.h_phat_inv = pinv;
-  *out = &(c->bases[dim] = b);
+  b.h_P = P;
+  *out = &(c->bases[key] = b);
+  return GPQ_OK;
+}
+
+int get_relin(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables **out) {
+  const auto key = std::make_pair(dimP, dimB);
+  auto it = c->relins.find(key);
+  if (it != c->relins.end()) { *out = &it->second; return GPQ_OK; }
+  gpq_bridge_basis *bp;
+  int rc = get_basis(c, 0, dimP, &bp);
+  if (rc) return rc;
+  std::vector<uint64_t> pinv(dimB - dimP);
+  for (unsigned d = dimP; d < dimB; ++d) pinv[d - dimP] = powm(mod_small(bp->h_P, c->p[d]), c->p[d] - 2, c->p[d]);
+  gpq_relin_tables t;
+  HIP_TRY(hipMalloc((void **)&t.d_pinv, pinv.size() * 8));
+  HIP_TRY(hipMemcpy(t.d_pinv, pinv.data(), pinv.size() * 8, hipMemcpyHostToDevice));
+  *out = &(c->relins[key] = t);
+  return GPQ_OK;
+}
+
+int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned slab_dim,
+                       unsigned slab_first, unsigned batch, unsigned logq, bool centre, unsigned char *tie, hipStream_t s) {
+  ReconstructArgs a{c->d_tabs, slab, big, b->d_phat, b->d_phat_inv, b->d_pmult, b->d_phalf, tie, b->dim, c->logn, Wout, logq,
+                    b->first, slab_dim, slab_first, centre ? 1u : 0u};
+  const dim3 grid((c->n + 127) / 128, batch), block(128);
+  switch (b->WP) {
+    case 8: hipLaunchKernelGGL((bridge_reconstruct<8>), grid, block, 0, s, a); break;
+    case 16: hipLaunchKernelGGL((bridge_reconstruct<16>), grid, block, 0, s, a); break;
+    case 32: hipLaunchKernelGGL((bridge_reconstruct<32>), grid, block, 0, s, a); break;
+    case 48: hipLaunchKernelGGL((bridge_reconstruct<48>), grid, block, 0, s, a); break;
+    case 56: hipLaunchKernelGGL((bridge_reconstruct<56>), grid, block, 0, s, a); break;
+    default: return gpq_fail(GPQ_ERR_UNSUPPORTED, "reconstruct: WP=%d", b->WP);
+  }
+  return GPQ_OK;
+}
+
+int launch_decompose(gpq_ctx *c, uint64_t *slab, const uint64_t *big, unsigned W, unsigned limb0, unsigned dim, unsigned batch, hipStream_t s) {
+  DecomposeArgs a{c->d_tabs, big, slab, W, dim, c->logn, limb0};
+  const dim3 grid((c->n + 255) / 256, batch), block(256);
+  if (W <= 4) hipLaunchKernelGGL((bridge_decompose<4>), grid, block, 0, s, a);
+  else if (W <= 16) hipLaunchKernelGGL((bridge_decompose<16>), grid, block, 0, s, a);
+  else if (W <= 32) hipLaunchKernelGGL((bridge_decompose<32>), grid, block, 0, s, a);
+  else return gpq_fail(GPQ_ERR_UNSUPPORTED, "decompose: W=%u words (max 32)", W);
   return GPQ_OK;
 }
 
@@ -102,31 +149,27 @@ void gpq_bridge_release(gpq_ctx *c) {
     (void)hipFree(kv.second.d_pmult); (void)hipFree(kv.second.d_phalf);
   }
   c->bases.clear();
+  for (auto &kv : c->relins) (void)hipFree(kv.second.d_pinv);
+  c->relins.clear();
 }
 
 extern "C" unsigned gpq_big_words(unsigned bits) { return (bits + 63) / 64; }
 
 extern "C" uint64_t gpq_ctx_phat_invmp(gpq_ctx *c, unsigned dim, unsigned d) {
   gpq_bridge_basis *b;
-  if (get_basis(c, dim, &b) != GPQ_OK || d >= dim) return 0;
+  if (get_basis(c, 0, dim, &b) != GPQ_OK || d >= dim) return 0;
   return b->h_phat_inv[d];
 }
 extern "C" unsigned gpq_ctx_pbits(gpq_ctx *c, unsigned dim) {
   gpq_bridge_basis *b;
-  return get_basis(c, dim, &b) == GPQ_OK ? b->pbits : 0;
+  return get_basis(c, 0, dim, &b) == GPQ_OK ? b->pbits : 0;
 }
 
 extern "C" int gpq_rns_decompose(gpq_ctx *c, uint64_t *slab, const uint64_t *big, unsigned W, unsigned dim, unsigned batch, void *stream) {
   int rc = check(c, dim, batch, "gpq_rns_decompose");
   if (rc) return rc;
   if (!slab || !big || W < 1) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_decompose: bad arguments");
-  DecomposeArgs a{c->d_tabs, big, slab, W, dim, c->logn};
-  const dim3 grid((c->n + 255) / 256, batch), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  if (W <= 4) hipLaunchKernelGGL((bridge_decompose<4>), grid, block, 0, s, a);
-  else if (W <= 16) hipLaunchKernelGGL((bridge_decompose<16>), grid, block, 0, s, a);
-  else if (W <= 32) hipLaunchKernelGGL((bridge_decompose<32>), grid, block, 0, s, a);
-  else return gpq_fail(GPQ_ERR_UNSUPPORTED, "gpq_rns_decompose: W=%u words (max 32)", W);
+  if ((rc = launch_decompose(c, slab, big, W, 0, dim, batch, (hipStream_t)stream))) return rc;
   return launched("gpq_rns_decompose");
 }
 
@@ -136,20 +179,10 @@ extern "C" int gpq_rns_reconstruct(gpq_ctx *c, uint64_t *big, unsigned Wout, con
   if (rc) return rc;
   if (!slab || !big || Wout < 1) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct: bad arguments");
   gpq_bridge_basis *b;
-  if ((rc = get_basis(c, dim, &b))) return rc;
+  if ((rc = get_basis(c, 0, dim, &b))) return rc;
   if (logq && Wout < (logq + 63) / 64) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct: %u words cannot hold a value mod 2^%u", Wout, logq);
   if (!logq && Wout * 64 < b->pbits + 1) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct: %u words cannot hold a value mod P (%u bits)", Wout, b->pbits);
-  ReconstructArgs a{c->d_tabs, slab, big, b->d_phat, b->d_phat_inv, b->d_pmult, b->d_phalf, dim, c->logn, Wout, logq};
-  const dim3 grid((c->n + 127) / 128, batch), block(128);
-  hipStream_t s = (hipStream_t)stream;
-  switch (b->WP) {
-    case 8: hipLaunchKernelGGL((bridge_reconstruct<8>), grid, block, 0, s, a); break;
-    case 16: hipLaunchKernelGGL((bridge_reconstruct<16>), grid, block, 0, s, a); break;
-    case 32: hipLaunchKernelGGL((bridge_reconstruct<32>), grid, block, 0, s, a); break;
-    case 48: hipLaunchKernelGGL((bridge_reconstruct<48>), grid, block, 0, s, a); break;
-    case 56: hipLaunchKernelGGL((bridge_reconstruct<56>), grid, block, 0, s, a); break;
-    default: return gpq_fail(GPQ_ERR_UNSUPPORTED, "gpq_rns_reconstruct: WP=%d", b->WP);
-  }
+  if ((rc = launch_reconstruct(c, b, big, Wout, slab, dim, 0, batch, logq, true, nullptr, (hipStream_t)stream))) return rc;
   return launched("gpq_rns_reconstruct");
 }
 
@@ -186,4 +219,182 @@ extern "C" int gpq_he_rs(gpq_ctx *c, uint64_t *c0, uint64_t *c1, unsigned W, uns
 }
 extern "C" int gpq_he_rescale(gpq_ctx *c, uint64_t *c0, uint64_t *c1, unsigned W, unsigned logDelta, unsigned logql, unsigned batch, void *stream) {
   return gpq_he_rs(c, c0, c1, W, logDelta, logql, batch, stream);
+}
+
+// ---------------------------------------------------------------------------
+// he_mul / he_swk at the big-slab level (q_l = 2^logql)
+// ---------------------------------------------------------------------------
+namespace {
+
+struct TailPlan { unsigned Wr, cnt; size_t words, bytes; };
+
+int tail_plan(gpq_ctx *c, unsigned W, unsigned dimP, unsigned dimB, unsigned polys, TailPlan *p) {
+  gpq_bridge_basis *bp;
+  int rc = get_basis(c, 0, dimP, &bp);
+  if (rc) return rc;
+  if (dimB <= dimP) return gpq_fail(GPQ_ERR_INVALID, "relin: dimB=%u must exceed dimP=%u", dimB, dimP);
+  p->Wr = bp->pbits / 64 + 1;
+  p->cnt = dimB - dimP;
+  p->words = (size_t)polys * ((size_t)(p->Wr + 2 * p->cnt + W) << c->logn);
+  p->bytes = p->words * 8 + ((size_t)polys << c->logn);
+  return GPQ_OK;
+}
+
+// src/he-mult.c:67-77 (d != null: c = rdiv(c,P) + d) and src/he-automorphism.c:68-76, for q_l = 2^logql.
+int relin_tail(gpq_ctx *c, uint64_t *out, const uint64_t *chat, const uint64_t *dbig, unsigned W, unsigned dimP, unsigned dimB,
+               unsigned logql, unsigned polys, void *ws, hipStream_t s) {
+  TailPlan tp;
+  int rc = tail_plan(c, W, dimP, dimB, polys, &tp);
+  if (rc) return rc;
+  gpq_bridge_basis *bp, *bq;
+  gpq_relin_tables *rt;
+  if ((rc = get_basis(c, 0, dimP, &bp)) || (rc = get_basis(c, dimP, tp.cnt, &bq)) || (rc = get_relin(c, dimP, dimB, &rt))) return rc;
+  if (W > (unsigned)bq->WP + 1) return gpq_fail(GPQ_ERR_UNSUPPORTED, "relin: W=%u words exceed the quotient basis", W);
+  const size_t n = c->n;
+  uint64_t *r = (uint64_t *)ws, *rhat = r + (size_t)polys * tp.Wr * n, *qhat = rhat + (size_t)polys * tp.cnt * n,
+           *qc = qhat + (size_t)polys * tp.cnt * n;
+  unsigned char *tie = (unsigned char *)(qc + (size_t)polys * W * n);
+  // r = x mod P from the first dimP limbs, unsigned
+  if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s))) return rc;
+  if ((rc = launch_decompose(c, rhat, r, tp.Wr, dimP, tp.cnt, polys, s))) return rc;
+  ExactDivArgs e{c->d_tabs, chat, rhat, qhat, rt->d_pinv, dimB, dimP, tp.cnt, c->logn};
+  hipLaunchKernelGGL(bridge_exactdiv, dim3((c->n + 255) / 256, polys, tp.cnt), dim3(256), 0, s, e);
+  // Q = (x - r)/P over the remaining limbs, centred, already reduced smod 2^logql
+  if ((rc = launch_reconstruct(c, bq, qc, W, qhat, tp.cnt, 0, polys, logql, true, tie, s))) return rc;
+  AddRoundArgs ar{out, qc, r, dbig, bp->d_phalf, bq->d_pmult + (size_t)5 * (bq->WP + 1), tie, W, tp.Wr, c->logn, logql};
+  hipLaunchKernelGGL(bridge_addround, dim3((c->n + 255) / 256, polys), dim3(256), 0, s, ar);
+  return launched("relin_tail");
+}
+
+inline size_t align64(size_t b) { return (b + 63) & ~(size_t)63; }
+
+}  // namespace
+
+// dims the reference derives from the modulus chain: hectx.dim src/precomp.c:401, he_mul's
+// tensor dim src/he-mult.c:99, he_relin/he_swk's dim src/he-mult.c:51, dimevk src/precomp.c:407.
+extern "C" int gpq_he_dims(gpq_ctx *c, unsigned logqL, unsigned logql, unsigned *dimP, unsigned *dimA, unsigned *dimB, unsigned *dimevk) {
+  if (!c || !logqL || !logql || logql > logqL) return gpq_fail(GPQ_ERR_INVALID, "gpq_he_dims: bad arguments");
+  const unsigned logn = c->logn;
+  const unsigned dp = (logqL + 1 + logn) / 59 + 1;
+  gpq_bridge_basis *bp;
+  int rc = get_basis(c, 0, dp, &bp);
+  if (rc) return rc;
+  const unsigned nbPqL = bp->pbits + logqL;
+  if (dimP) *dimP = dp;
+  if (dimA) *dimA = (2 * (logql + 1) + logn) / 59 + 1;
+  if (dimB) *dimB = ((logql + 1) + nbPqL + logn) / 59 + 1;
+  if (dimevk) *dimevk = ((logqL + 1) + nbPqL + logn) / 59 + 1;
+  return GPQ_OK;
+}
+
+extern "C" size_t gpq_he_mul_workspace_bytes(gpq_ctx *c, unsigned W, unsigned dimA, unsigned dimB, unsigned dimP, unsigned batch) {
+  const unsigned m = batch < c->chunk ? batch : c->chunk;
+  TailPlan tp;
+  if (tail_plan(c, W, dimP, dimB, m, &tp) != GPQ_OK) return 0;
+  const size_t n = c->n;
+  size_t b = 0;
+  b += align64((size_t)m * 7 * dimA * n * 8);                       // 4 decomposed inputs + d0hat,d1hat,d2hat
+  b += align64(gpq_tensor_workspace_bytes(c, dimA, m));
+  b += align64((size_t)m * 3 * dimB * n * 8);                       // decomposed d2 (or d1), c0hat, c1hat
+  b += align64(gpq_keyswitch_workspace_bytes(c, dimB, m));
+  b += align64((size_t)m * 3 * W * n * 8);                          // d0, d1, d2
+  b += align64(tp.bytes);
+  return b;
+}
+
+// he_mul, src/he-mult.c:88-156 (decl src/gpqhe.h:147), on big slabs of W words, q_l = 2^logql.
+// ct = ct1 * ct2 relinearised with rlk (NTT-domain slabs of at least dimB limbs).  The l / nu / B
+// bookkeeping of :92-95 stays with the caller.
+extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *ct1c0, const uint64_t *ct1c1,
+                          const uint64_t *ct2c0, const uint64_t *ct2c1, const uint64_t *rlk0, const uint64_t *rlk1, unsigned W,
+                          unsigned logql, unsigned dimA, unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream) {
+  int rc = check(c, dimA, batch, "gpq_he_mul");
+  if (rc || (rc = check(c, dimB, batch, "gpq_he_mul"))) return rc;
+  if (!out_c0 || !out_c1 || !ct1c0 || !ct1c1 || !ct2c0 || !ct2c1 || !rlk0 || !rlk1 || !workspace || !logql || W < (logql + 63) / 64)
+    return gpq_fail(GPQ_ERR_INVALID, "gpq_he_mul: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = c->n, bigpoly = (size_t)W * n;
+  const unsigned m = batch < c->chunk ? batch : c->chunk;
+  TailPlan tp;
+  if ((rc = tail_plan(c, W, dimP, dimB, m, &tp))) return rc;
+  char *w = (char *)workspace;
+  uint64_t *sA = (uint64_t *)w; w += align64((size_t)m * 7 * dimA * n * 8);
+  void *wsT = w; w += align64(gpq_tensor_workspace_bytes(c, dimA, m));
+  uint64_t *sB = (uint64_t *)w; w += align64((size_t)m * 3 * dimB * n * 8);
+  void *wsK = w; w += align64(gpq_keyswitch_workspace_bytes(c, dimB, m));
+  uint64_t *dbig = (uint64_t *)w; w += align64((size_t)m * 3 * W * n * 8);
+  void *wsTail = w;
+  gpq_bridge_basis *bA;
+  if ((rc = get_basis(c, 0, dimA, &bA))) return rc;
+  for (unsigned k0 = 0; k0 < batch; k0 += m) {
+    const unsigned polys = batch - k0 < m ? batch - k0 : m;
+    const size_t pa = (size_t)polys * dimA * n, pb = (size_t)polys * dimB * n;
+    uint64_t *h[4] = {sA, sA + pa, sA + 2 * pa, sA + 3 * pa};
+    uint64_t *d0h = sA + 4 * pa, *d1h = sA + 5 * pa, *d2h = sA + 6 * pa;
+    const uint64_t *in[4] = {ct1c0, ct1c1, ct2c0, ct2c1};
+    for (int i = 0; i < 4; ++i)                                                             // :117-120
+      if ((rc = launch_decompose(c, h[i], in[i] + k0 * bigpoly, W, 0, dimA, polys, s))) return rc;
+    if ((rc = gpq_he_mul_tensor(c, d0h, d1h, d2h, h[0], h[1], h[2], h[3], dimA, polys, wsT, stream))) return rc;  // :121-136
+    uint64_t *d0 = dbig, *d1 = dbig + polys * bigpoly, *d2 = dbig + 2 * polys * bigpoly;
+    if ((rc = launch_reconstruct(c, bA, d0, W, d0h, dimA, 0, polys, logql, true, nullptr, s))) return rc;          // :139
+    if ((rc = launch_reconstruct(c, bA, d2, W, d2h, dimA, 0, polys, logql, true, nullptr, s))) return rc;          // :140
+    if ((rc = launch_reconstruct(c, bA, d1, W, d1h, dimA, 0, polys, logql, true, nullptr, s))) return rc;          // :141
+    // he_relin, :40-85
+    uint64_t *d2hat = sB, *c0hat = sB + pb, *c1hat = sB + 2 * pb;
+    if ((rc = launch_decompose(c, d2hat, d2, W, 0, dimB, polys, s))) return rc;                                    // :59
+    if ((rc = gpq_keyswitch(c, c0hat, c1hat, d2hat, rlk0, rlk1, dimB, polys, wsK, stream))) return rc;             // :60-64
+    if ((rc = relin_tail(c, out_c0 + k0 * bigpoly, c0hat, d0, W, dimP, dimB, logql, polys, wsTail, s))) return rc; // :67-77
+    if ((rc = relin_tail(c, out_c1 + k0 * bigpoly, c1hat, d1, W, dimP, dimB, logql, polys, wsTail, s))) return rc;
+  }
+  return launched("gpq_he_mul");
+}
+
+// he_swk, src/he-automorphism.c:40-85: key-switch d1 with swk, c0 += d0, on big slabs, q_l = 2^logql.
+// (poly_rot / poly_conj, src/poly.c:263-283, are coefficient permutations done by the caller.)
+extern "C" int gpq_he_swk(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *d0, const uint64_t *d1,
+                          const uint64_t *swk0, const uint64_t *swk1, unsigned W, unsigned logql, unsigned dimB, unsigned dimP,
+                          unsigned batch, void *workspace, void *stream) {
+  int rc = check(c, dimB, batch, "gpq_he_swk");
+  if (rc) return rc;
+  if (!out_c0 || !out_c1 || !d0 || !d1 || !swk0 || !swk1 || !workspace || !logql || W < (logql + 63) / 64)
+    return gpq_fail(GPQ_ERR_INVALID, "gpq_he_swk: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = c->n, bigpoly = (size_t)W * n;
+  const unsigned m = batch < c->chunk ? batch : c->chunk;
+  TailPlan tp;
+  if ((rc = tail_plan(c, W, dimP, dimB, m, &tp))) return rc;
+  char *w = (char *)workspace;
+  w += align64((size_t)m * 7 * 1 * n * 8) * 0;  // same carving as gpq_he_mul with dimA unused
+  uint64_t *sB = (uint64_t *)w; w += align64((size_t)m * 3 * dimB * n * 8);
+  void *wsK = w; w += align64(gpq_keyswitch_workspace_bytes(c, dimB, m));
+  void *wsTail = w;
+  for (unsigned k0 = 0; k0 < batch; k0 += m) {
+    const unsigned polys = batch - k0 < m ? batch - k0 : m;
+    const size_t pb = (size_t)polys * dimB * n;
+    uint64_t *d1hat = sB, *c0hat = sB + pb, *c1hat = sB + 2 * pb;
+    if ((rc = launch_decompose(c, d1hat, d1 + k0 * bigpoly, W, 0, dimB, polys, s))) return rc;                     // :60
+    if ((rc = gpq_keyswitch(c, c0hat, c1hat, d1hat, swk0, swk1, dimB, polys, wsK, stream))) return rc;             // :61-65
+    if ((rc = relin_tail(c, out_c0 + k0 * bigpoly, c0hat, d0 + k0 * bigpoly, W, dimP, dimB, logql, polys, wsTail, s))) return rc;  // :68-75
+    if ((rc = relin_tail(c, out_c1 + k0 * bigpoly, c1hat, nullptr, W, dimP, dimB, logql, polys, wsTail, s))) return rc;
+  }
+  return launched("gpq_he_swk");
+}
+extern "C" size_t gpq_he_swk_workspace_bytes(gpq_ctx *c, unsigned W, unsigned dimB, unsigned dimP, unsigned batch) {
+  const unsigned m = batch < c->chunk ? batch : c->chunk;
+  TailPlan tp;
+  if (tail_plan(c, W, dimP, dimB, m, &tp) != GPQ_OK) return 0;
+  return align64((size_t)m * 3 * dimB * c->n * 8) + align64(gpq_keyswitch_workspace_bytes(c, dimB, m)) + align64(tp.bytes);
+}
+
+// Tail of he_relin / he_swk alone (src/he-mult.c:67-77): out = smod(rdiv(poly_rns2mpi(chat, P*q_l), P) + d, q_l).
+extern "C" size_t gpq_relin_tail_workspace_bytes(gpq_ctx *c, unsigned W, unsigned dimB, unsigned dimP, unsigned batch) {
+  TailPlan tp;
+  return tail_plan(c, W, dimP, dimB, batch, &tp) == GPQ_OK ? tp.bytes + 64 : 0;
+}
+extern "C" int gpq_relin_tail(gpq_ctx *c, uint64_t *out, const uint64_t *chat, const uint64_t *d, unsigned W, unsigned logql,
+                              unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream) {
+  int rc = check(c, dimB, batch, "gpq_relin_tail");
+  if (rc) return rc;
+  if (!out || !chat || !workspace || !logql || W < (logql + 63) / 64) return gpq_fail(GPQ_ERR_INVALID, "gpq_relin_tail: bad arguments");
+  return relin_tail(c, out, chat, d, W, dimP, dimB, logql, batch, workspace, (hipStream_t)stream);
 }

@@ -39,8 +39,8 @@ __device__ __forceinline__ uint64_t horner59(uint64_t r, uint64_t d, const Prime
 struct DecomposeArgs {
   const LimbTab *tabs;
   const uint64_t *big;      // [polys][W][n]
-  uint64_t *slab;           // [polys][dim][n]
-  unsigned W, dim, logn;
+  uint64_t *slab;           // [polys][dim][n]: limb d of the output is prime limb0 + d
+  unsigned W, dim, logn, limb0;
 };
 
 template <int MAXW>
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void bridge_decompose(DecomposeArgs a) {
   const int64_t top = ((int64_t)(dg[ND - 1] << (64 - TOPBITS))) >> (64 - TOPBITS);
   uint64_t *__restrict__ dst = a.slab + ((size_t)blockIdx.y * a.dim << a.logn) + i;
   for (unsigned d = 0; d < a.dim; ++d) {
-    const PrimeK k = a.tabs[d].k;
+    const PrimeK k = a.tabs[a.limb0 + d].k;
     uint64_t r = top < 0 ? (uint64_t)top + k.p : (uint64_t)top;     // [0, p + 2^58)
 #pragma unroll
     for (int t = ND - 2; t >= 0; --t) r = horner59(r, dg[t], k);
@@ -97,7 +97,11 @@ struct ReconstructArgs {
   const uint64_t *phat_inv;    // [dim]           (P/p_d)^-1 mod p_d
   const uint64_t *pmult;       // [6][WP+1]       32P, 16P, 8P, 4P, 2P, P
   const uint64_t *phalf;       // [WP+1]          floor(P/2)
+  unsigned char *tie;          // optional [polys][n]: 1 where (S mod P) == floor(P/2) exactly
   unsigned dim, logn, Wout, logq;   // logq = 0: no reduction mod q (Wout >= WP+1 then)
+  unsigned limb0;              // the basis is primes limb0 .. limb0+dim-1
+  unsigned slab_dim, slab_first;    // the slab has slab_dim limbs per polynomial; read limbs slab_first ..
+  unsigned centre;             // 0: leave the result in [0, P)
 };
 
 template <int WP>
@@ -105,12 +109,12 @@ __global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
   const unsigned n = 1u << a.logn;
   const unsigned i = blockIdx.x * 128 + threadIdx.x;
   if (i >= n) return;
-  const uint64_t *__restrict__ src = a.slab + ((size_t)blockIdx.y * a.dim << a.logn) + i;
+  const uint64_t *__restrict__ src = a.slab + (((size_t)blockIdx.y * a.slab_dim + a.slab_first) << a.logn) + i;
   uint64_t S[WP + 1];
 #pragma unroll
   for (int j = 0; j <= WP; ++j) S[j] = 0;
   for (unsigned d = 0; d < a.dim; ++d) {
-    const PrimeK k = a.tabs[d].k;
+    const PrimeK k = a.tabs[a.limb0 + d].k;
     const uint64_t y = mulmod_canon(src[(size_t)d << a.logn], a.phat_inv[d], k);
     const uint64_t *__restrict__ ph = a.phat + (size_t)d * WP;
     uint64_t carry = 0;
@@ -140,13 +144,15 @@ __global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
     }
   }
   // mpi_smod(., P, P/2): r >= floor(P/2) -> r - P
-  {
-    uint64_t borrow = 0;
+  if (a.centre) {
+    uint64_t borrow = 0, any = 0;
 #pragma unroll
     for (int j = 0; j <= WP; ++j) {
       const u128 t = (u128)S[j] - a.phalf[j] - borrow;
+      any |= (uint64_t)t;
       borrow = (uint64_t)(t >> 64) & 1;
     }
+    if (a.tie) a.tie[((size_t)blockIdx.y << a.logn) + i] = !borrow && !any;
     if (!borrow) {
       const uint64_t *__restrict__ mp = a.pmult + (size_t)5 * (WP + 1);
       uint64_t b2 = 0;
@@ -184,6 +190,79 @@ __global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
   }
   const uint64_t fill = a.logq ? qsign : sext;
   for (unsigned j = WP + 1; j < a.Wout; ++j) dst[(size_t)j << a.logn] = fill;
+}
+
+// ---------------------------------------------------------------------------
+// Tail of he_relin / he_swk (src/he-mult.c:67-77, src/he-automorphism.c:68-76) for q_l = 2^k:
+//   c  = poly_rns2mpi(chat, P*q_l)         x = CRT(chat) centred mod Pi_B, c == x (mod P*2^k)
+//   c  = mpi_rdiv(c, P)                    floor(c/P) + [c mod P > floor(P/2)]
+//   c  = mpi_smod(mpi_addm(c, d, q_l))     only c mod 2^k matters
+// c mod P == x mod P and floor(c/P) == floor(x/P) (mod 2^k), so with r = x mod P (CRT over
+// the first dimP limbs, where P = p_0..p_{dimP-1}) the quotient Q = (x - r)/P is an exact
+// division, done limb-wise on the remaining limbs:  Qhat_d = (chat_d - r) * P^-1 mod p_d.
+// ---------------------------------------------------------------------------
+struct ExactDivArgs {
+  const LimbTab *tabs;
+  const uint64_t *chat;        // [polys][dimB][n]
+  const uint64_t *rhat;        // [polys][cnt][n]   r mod p_d, d = dimP ..
+  uint64_t *qhat;              // [polys][cnt][n]
+  const uint64_t *pinv;        // [cnt]             P^-1 mod p_d
+  unsigned dimB, dimP, cnt, logn;
+};
+
+__global__ __launch_bounds__(256) void bridge_exactdiv(ExactDivArgs a) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (1u << a.logn)) return;
+  const unsigned d = blockIdx.z;
+  const PrimeK k = a.tabs[a.dimP + d].k;
+  const uint64_t x = a.chat[(((size_t)blockIdx.y * a.dimB + a.dimP + d) << a.logn) + i];
+  const size_t o = (((size_t)blockIdx.y * a.cnt + d) << a.logn) + i;
+  a.qhat[o] = mulmod_canon(x + k.p - a.rhat[o], a.pinv[d], k);   // (x - r) in (0, 2p)
+}
+
+// out = smod(Qc + [r > floor(P/2)] + d, 2^k), W words.  Qc = centred CRT of Qhat already reduced
+// smod 2^k; `tie` marks the coefficients whose quotient sat exactly on floor(Pi'/2), where the
+// centring of x (not of Q) decides the wrap: add Pi' back when r < floor(P/2)  (see DESIGN.md).
+struct AddRoundArgs {
+  uint64_t *out;               // [polys][W][n]
+  const uint64_t *qc;          // [polys][W][n]
+  const uint64_t *r;           // [polys][Wr][n]   in [0, P)
+  const uint64_t *d;           // [polys][W][n] or null
+  const uint64_t *phalf;       // [Wr]  floor(P/2)
+  const uint64_t *piq;         // [>= W words of Pi' (low words)]
+  const unsigned char *tie;    // [polys][n]
+  unsigned W, Wr, logn, logql;
+};
+
+__global__ __launch_bounds__(256) void bridge_addround(AddRoundArgs a) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (1u << a.logn)) return;
+  const uint64_t *__restrict__ r = a.r + ((size_t)blockIdx.y * a.Wr << a.logn) + i;
+  // compare r with floor(P/2), most significant word first
+  int cmp = 0;
+  for (int j = (int)a.Wr - 1; j >= 0 && cmp == 0; --j) {
+    const uint64_t rv = r[(size_t)j << a.logn], hv = a.phalf[j];
+    cmp = rv > hv ? 1 : (rv < hv ? -1 : 0);
+  }
+  uint64_t carry = cmp > 0;                               // mpi_rdiv: round up when r > floor(P/2)
+  const bool fix = a.tie[((size_t)blockIdx.y << a.logn) + i] && cmp < 0;
+  const size_t base = ((size_t)blockIdx.y * a.W << a.logn) + i;
+  const unsigned sb = a.logql - 1;
+  uint64_t qsign = 0;
+  for (unsigned j = 0; j < a.W; ++j) {
+    const size_t o = base + ((size_t)j << a.logn);
+    const u128 t = (u128)a.qc[o] + carry + (a.d ? a.d[o] : 0) + (fix ? a.piq[j] : 0);
+    uint64_t v = (uint64_t)t;
+    carry = (uint64_t)(t >> 64);                          // 0..2
+    const unsigned lo = 64 * j;
+    if (lo + 64 > sb && lo <= sb) qsign = 0 - ((v >> (sb - lo)) & 1);
+    if (lo >= a.logql) v = qsign;
+    else if (lo + 64 > a.logql) {
+      const uint64_t mask = (1ull << (a.logql - lo)) - 1;
+      v = (v & mask) | (qsign & ~mask);
+    }
+    a.out[o] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -13,10 +13,16 @@ enum { GPQ_K_STRIDED_FWD = 0, GPQ_K_STRIDED_INV, GPQ_K_CONTIG_FWD, GPQ_K_CONTIG_
 
 // CRT constants of one prefix of the prime chain (bridge.hip)
 struct gpq_bridge_basis {
-  unsigned dim = 0, pbits = 0;
+  unsigned first = 0, dim = 0, pbits = 0;
   int WP = 0;
   uint64_t *d_phat = nullptr, *d_phat_inv = nullptr, *d_pmult = nullptr, *d_phalf = nullptr;
   std::vector<uint64_t> h_phat_inv;
+  std::vector<uint64_t> h_P;          // the product itself, little-endian words
+};
+
+// P^-1 mod p_d for the limbs above a P of dimP limbs (exact division in he_relin / he_swk)
+struct gpq_relin_tables {
+  uint64_t *d_pinv = nullptr;
 };
 
 struct gpq_ctx {
@@ -29,7 +35,8 @@ struct gpq_ctx {
   // device tables (standard form)
   uint64_t *d_w = nullptr, *d_winv = nullptr;
   gpq::LimbTab *d_tabs = nullptr;
-  std::map<unsigned, gpq_bridge_basis> bases;  // by prefix length, built on first use
+  std::map<std::pair<unsigned, unsigned>, gpq_bridge_basis> bases;   // by (first limb, count), built on first use
+  std::map<std::pair<unsigned, unsigned>, gpq_relin_tables> relins;  // by (dimP, dimB)
   // profiling
   bool prof_on = false;
   std::vector<gpq_prof_rec> prof;     // launches recorded since the last reset

@@ -107,6 +107,41 @@ class PolyContext:
         batch = c0.numel() // (W * self.n)
         _native.check(self.lib.gpq_he_rs(self.h, _ptr(c0), _ptr(c1), W, logDelta, logql, batch, _stream()), "gpq_he_rs")
 
+    def he_dims(self, logqL, logql):
+        """(dimP, dimA, dimB, dimevk) as src/precomp.c:401,407 and src/he-mult.c:99,51 compute them."""
+        v = [C.c_uint() for _ in range(4)]
+        _native.check(self.lib.gpq_he_dims(self.h, logqL, logql, *[C.byref(x) for x in v]), "gpq_he_dims")
+        return tuple(x.value for x in v)
+
+    def he_mul(self, out_c0, out_c1, ct1c0, ct1c1, ct2c0, ct2c1, rlk0, rlk1, W, logql, dimA, dimB, dimP):
+        """src/he-mult.c:88-156 on big slabs, q_l = 2^logql."""
+        torch = _torch()
+        batch = ct1c0.numel() // (W * self.n)
+        nbytes = self.lib.gpq_he_mul_workspace_bytes(self.h, W, dimA, dimB, dimP, batch)
+        ws = torch.empty(nbytes // 8 + 8, dtype=torch.int64, device="cuda")
+        _native.check(self.lib.gpq_he_mul(self.h, _ptr(out_c0), _ptr(out_c1), _ptr(ct1c0), _ptr(ct1c1), _ptr(ct2c0), _ptr(ct2c1),
+                                          _ptr(rlk0), _ptr(rlk1), W, logql, dimA, dimB, dimP, batch, _ptr(ws), _stream()), "gpq_he_mul")
+        return ws
+
+    def relin_tail(self, out, chat, d, W, logql, dimB, dimP):
+        """src/he-mult.c:67-77 alone (d = None: nothing added)."""
+        torch = _torch()
+        batch = self._shape(chat, dimB)
+        ws = torch.empty(self.lib.gpq_relin_tail_workspace_bytes(self.h, W, dimB, dimP, batch) // 8 + 8, dtype=torch.int64, device="cuda")
+        _native.check(self.lib.gpq_relin_tail(self.h, _ptr(out), _ptr(chat), _ptr(d) if d is not None else None, W, logql, dimB, dimP,
+                                              batch, _ptr(ws), _stream()), "gpq_relin_tail")
+        return out
+
+    def he_swk(self, out_c0, out_c1, d0, d1, swk0, swk1, W, logql, dimB, dimP):
+        """src/he-automorphism.c:40-85 on big slabs, q_l = 2^logql."""
+        torch = _torch()
+        batch = d0.numel() // (W * self.n)
+        nbytes = self.lib.gpq_he_swk_workspace_bytes(self.h, W, dimB, dimP, batch)
+        ws = torch.empty(nbytes // 8 + 8, dtype=torch.int64, device="cuda")
+        _native.check(self.lib.gpq_he_swk(self.h, _ptr(out_c0), _ptr(out_c1), _ptr(d0), _ptr(d1), _ptr(swk0), _ptr(swk1),
+                                          W, logql, dimB, dimP, batch, _ptr(ws), _stream()), "gpq_he_swk")
+        return ws
+
     def phat_invmp(self, dim):
         return [self.lib.gpq_ctx_phat_invmp(self.h, dim, d) for d in range(dim)]
 

@@ -156,6 +156,36 @@ int gpq_poly_mul(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, const uint64_t *b
 int gpq_he_rs(gpq_ctx *ctx, uint64_t *c0, uint64_t *c1, unsigned W, unsigned logDelta, unsigned logql, unsigned batch, void *stream);
 int gpq_he_rescale(gpq_ctx *ctx, uint64_t *c0, uint64_t *c1, unsigned W, unsigned logDelta, unsigned logql, unsigned batch, void *stream);
 
+/* Limb counts the reference derives from the modulus chain for q_L = 2^logqL, q_l = 2^logql:
+ * dimP = hectx.dim (src/precomp.c:401; hectx.P is the product of the first dimP primes),
+ * dimA = tensor stage of he_mul (src/he-mult.c:99), dimB = he_relin / he_swk (src/he-mult.c:51,
+ * src/he-automorphism.c:52), dimevk (src/precomp.c:407).  Any output pointer may be NULL. */
+int gpq_he_dims(gpq_ctx *ctx, unsigned logqL, unsigned logql, unsigned *dimP, unsigned *dimA, unsigned *dimB, unsigned *dimevk);
+
+/* he_mul, src/he-mult.c:88-156 (decl src/gpqhe.h:147), on big slabs of W words with q_l = 2^logql:
+ * decompose the four polynomials to dimA limbs, tensor stage, poly_rns2mpi of d0,d1,d2, then he_relin
+ * (:40-85): decompose d2 to dimB limbs, key-switch with rlk (NTT-domain slabs of >= dimB limbs,
+ * src/he-kem.c:103-110), c = rdiv(poly_rns2mpi(.), P) + d, centred mod q_l.  The l/nu/B bookkeeping
+ * (:92-95) stays with the caller.  Outputs may not alias inputs. */
+size_t gpq_he_mul_workspace_bytes(gpq_ctx *ctx, unsigned W, unsigned dimA, unsigned dimB, unsigned dimP, unsigned batch);
+int gpq_he_mul(gpq_ctx *ctx, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *ct1c0, const uint64_t *ct1c1,
+               const uint64_t *ct2c0, const uint64_t *ct2c1, const uint64_t *rlk0, const uint64_t *rlk1, unsigned W,
+               unsigned logql, unsigned dimA, unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream);
+
+/* The tail of he_relin / he_swk on its own, src/he-mult.c:67-77: chat = key-switch output slab of dimB
+ * limbs, d = big slab added afterwards (NULL: none, as for c1 in he_swk):
+ *   out = mpi_smod(mpi_addm(mpi_rdiv(poly_rns2mpi(chat, P*q_l), P), d, q_l), q_l),  q_l = 2^logql. */
+size_t gpq_relin_tail_workspace_bytes(gpq_ctx *ctx, unsigned W, unsigned dimB, unsigned dimP, unsigned batch);
+int gpq_relin_tail(gpq_ctx *ctx, uint64_t *out, const uint64_t *chat, const uint64_t *d, unsigned W, unsigned logql,
+                   unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream);
+
+/* he_swk, src/he-automorphism.c:40-85: key-switch d1 with swk and add d0 into c0, big slabs, q_l = 2^logql
+ * (the rotation / conjugation permutations of src/poly.c:263-283 are the caller's). */
+size_t gpq_he_swk_workspace_bytes(gpq_ctx *ctx, unsigned W, unsigned dimB, unsigned dimP, unsigned batch);
+int gpq_he_swk(gpq_ctx *ctx, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *d0, const uint64_t *d1,
+               const uint64_t *swk0, const uint64_t *swk1, unsigned W, unsigned logql, unsigned dimB, unsigned dimP,
+               unsigned batch, void *workspace, void *stream);
+
 /* ---- per-kernel profile ----------------------------------------------------
  * When enabled every kernel launch of this context is bracketed by two HIP
  * events on its own stream.  gpq_profile_collect waits for them and adds the

@@ -78,3 +78,69 @@ def centred_mod(v, q):
     """liftall(Mod(v, q)) then minus q where >= q/2, as tests/polymul.gp:7-10."""
     v %= q
     return v - q if v >= q // 2 else v
+
+
+# ---------------------------------------------------------------------------
+# he_mul / he_relin / he_swk with Python integers around the C oracle's RNS core
+# ---------------------------------------------------------------------------
+import numpy as _np
+
+
+def he_dims(logn, primes, logqL, logql):
+    """hectx.dim (src/precomp.c:401), he_mul dim (src/he-mult.c:99), he_relin dim (:51), dimevk (src/precomp.c:407)
+    for q_L = 2^logqL, q_l = 2^logql; nbits(2^k) = k+1."""
+    dimP = (logqL + 1 + logn) // 59 + 1
+    P = 1
+    for x in primes[:dimP]:
+        P *= int(x)
+    nb_PqL = (P << logqL).bit_length()
+    dimA = (2 * (logql + 1) + logn) // 59 + 1
+    dimB = ((logql + 1) + nb_PqL + logn) // 59 + 1
+    dimevk = ((logqL + 1) + nb_PqL + logn) // 59 + 1
+    return dimP, dimA, dimB, dimevk
+
+
+def _slab(o, coeffs, dim):
+    return _np.array([v for d in range(dim) for v in rns_decompose(coeffs, o.p[d])], dtype=_np.uint64)
+
+
+def _limbs(slab, dim, n):
+    return [slab[d * n:(d + 1) * n] for d in range(dim)]
+
+
+def he_relin_tail(o, c0hat, c1hat, d0, d1, dimP, dimB, ql):
+    """src/he-mult.c:67-77 (d1 may be None: he_swk, src/he-automorphism.c:68-76)."""
+    n = o.n
+    P = RnsBasis(o.p[:dimP]).P
+    basisB = RnsBasis(o.p[:dimB])
+    out = []
+    for chat, dd in ((c0hat, d0), (c1hat, d1)):
+        c = poly_rns2mpi(_limbs(chat, dimB, n), basisB, P * ql)          # :67-68
+        res = []
+        for i in range(n):
+            v = mpi_rdiv(c[i], P)                                        # :71-72
+            if dd is not None:
+                v = (v + dd[i]) % ql                                     # :73-74  mpi_addm
+            res.append(mpi_smod(v, ql))                                  # :75-76
+        out.append(res)
+    return out
+
+
+def he_mul(o, ct1, ct2, rlk0, rlk1, dimP, dimA, dimB, logql):
+    """src/he-mult.c:88-156 for q_l = 2^logql; ct = (c0, c1) lists of centred ints; o = oracle.OracleCtx."""
+    n, ql = o.n, 1 << logql
+    ins = [_slab(o, c, dimA) for c in (ct1[0], ct1[1], ct2[0], ct2[1])]  # :117-120
+    d0h, d1h, d2h = o.he_mul_tensor(*ins, dimA)                          # :121-136
+    basisA = RnsBasis(o.p[:dimA])
+    d0 = poly_rns2mpi(_limbs(d0h, dimA, n), basisA, ql)                  # :139
+    d2 = poly_rns2mpi(_limbs(d2h, dimA, n), basisA, ql)
+    d1 = poly_rns2mpi(_limbs(d1h, dimA, n), basisA, ql)
+    c0h, c1h = o.keyswitch(_slab(o, d2, dimB), rlk0, rlk1, dimB)         # :59-64
+    return he_relin_tail(o, c0h, c1h, d0, d1, dimP, dimB, ql)
+
+
+def he_swk(o, d0, d1, swk0, swk1, dimP, dimB, logql):
+    """src/he-automorphism.c:40-85 for q_l = 2^logql."""
+    ql = 1 << logql
+    c0h, c1h = o.keyswitch(_slab(o, d1, dimB), swk0, swk1, dimB)
+    return he_relin_tail(o, c0h, c1h, d0, None, dimP, dimB, ql)

@@ -1,0 +1,144 @@
+"""he_mul / he_swk at the MPI level (big slabs) against the restatement of
+src/he-mult.c:40-156 / src/he-automorphism.c:40-85 built from the C oracle's RNS core and
+Python integers for the libgcrypt parts (oracle/bigint_ref.py)."""
+import random
+
+import numpy as np
+import pytest
+
+from gpqhe_amd import big_to_ints, ints_to_big, to_device, to_host
+from oracle import bigint_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def test_he_dims_match_reference_contexts(golden, engine_ctx):
+    """hectx_init(14, 2^438, ., 2^50) and hectx_init(16, 2^850, ., 2^50), SURVEY.md 8c."""
+    for key, logn, logq in (("14_438_50", 14, 438), ("16_850_50", 16, 850)):
+        rec = golden["context_dims"][key]
+        g = engine_ctx(logn, rec["dimevk"])
+        dimP, dimA, dimB, dimevk = g.he_dims(logq, logq)
+        assert (dimP, dimA, dimB, dimevk) == (rec["dim"], rec["dimA"], rec["dimB"], rec["dimevk"])
+        assert ref.he_dims(logn, g.p, logq, logq) == (dimP, dimA, dimB, dimevk)
+        if "nbits_P" in rec:
+            assert g.lib.gpq_ctx_pbits(g.h, dimP) == rec["nbits_P"]
+
+
+def _centred(rng, logq, n):
+    h = 1 << (logq - 1)
+    vals = [rng.randrange(-h, h) for _ in range(n)]
+    vals[:6] = [0, 1, -1, h - 1, -h, h // 2]
+    return vals
+
+
+@pytest.mark.parametrize("logn,logqL,logql,batch", [(7, 120, 120, 2), (7, 120, 90, 1), (8, 200, 150, 1), (7, 61, 61, 3)])
+def test_he_mul_matches_reference_semantics(engine_ctx, oracle_ctx, logn, logqL, logql, batch):
+    torch = _torch()
+    probe = engine_ctx(logn, 12)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logqL, logql)
+    g, o = engine_ctx(logn, dimevk), oracle_ctx(logn, dimevk)
+    assert ref.he_dims(logn, o.p, logqL, logql) == (dimP, dimA, dimB, dimevk)
+    n, W = g.n, (logql + 63) // 64
+    rng = random.Random(logqL * 7 + logql)
+    rlk0, rlk1 = o.gen(3000, dimevk), o.gen(3001, dimevk)     # NTT-domain key slabs (synthetic)
+    cts = [[_centred(rng, logql, n) for _ in range(4)] for _ in range(batch)]
+    dev = [to_device(np.concatenate([ints_to_big(cts[k][j], W) for k in range(batch)])) for j in range(4)]
+    out0, out1 = torch.empty_like(dev[0]), torch.empty_like(dev[0])
+    g.he_mul(out0, out1, dev[0], dev[1], dev[2], dev[3], to_device(rlk0), to_device(rlk1), W, logql, dimA, dimB, dimP)
+    got0, got1 = big_to_ints(to_host(out0), W, n), big_to_ints(to_host(out1), W, n)
+    for k in range(batch):
+        e0, e1 = ref.he_mul(o, (cts[k][0], cts[k][1]), (cts[k][2], cts[k][3]), rlk0[: dimB * n], rlk1[: dimB * n], dimP, dimA, dimB, logql)
+        assert got0[k] == e0, "c0 of ciphertext %d" % k
+        assert got1[k] == e1, "c1 of ciphertext %d" % k
+
+
+@pytest.mark.parametrize("logn,logqL,logql", [(7, 120, 120), (7, 200, 100)])
+def test_he_swk_matches_reference_semantics(engine_ctx, oracle_ctx, logn, logqL, logql):
+    torch = _torch()
+    probe = engine_ctx(logn, 12)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logqL, logql)
+    g, o = engine_ctx(logn, dimevk), oracle_ctx(logn, dimevk)
+    n, W = g.n, (logql + 63) // 64
+    rng = random.Random(5)
+    swk0, swk1 = o.gen(4000, dimevk), o.gen(4001, dimevk)
+    d0, d1 = _centred(rng, logql, n), _centred(rng, logql, n)
+    a0, a1 = to_device(ints_to_big(d0, W)), to_device(ints_to_big(d1, W))
+    out0, out1 = torch.empty_like(a0), torch.empty_like(a0)
+    g.he_swk(out0, out1, a0, a1, to_device(swk0), to_device(swk1), W, logql, dimB, dimP)
+    e0, e1 = ref.he_swk(o, d0, d1, swk0[: dimB * n], swk1[: dimB * n], dimP, dimB, logql)
+    assert big_to_ints(to_host(out0), W, n)[0] == e0
+    assert big_to_ints(to_host(out1), W, n)[0] == e1
+
+
+def test_relin_tail_rounding_ties_and_wrap_corner(engine_ctx, oracle_ctx):
+    """mpi_rdiv rounds up only when the remainder is strictly above floor(P/2) (src/types.c:124): key-switch
+    outputs are built so that x mod P is floor(P/2)-1, floor(P/2), floor(P/2)+1, 0, P-1, and so that the quotient
+    sits exactly on floor(Pi'/2), where the centring of x -- not of the quotient -- decides the sign."""
+    torch = _torch()
+    logn, logqL = 7, 120
+    probe = engine_ctx(logn, 12)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logqL, logqL)
+    g, o = engine_ctx(logn, dimevk), oracle_ctx(logn, dimevk)
+    n, W, ql = g.n, 2, 1 << logqL
+    P = ref.RnsBasis(o.p[:dimP]).P
+    PiB = ref.RnsBasis(o.p[:dimB]).P
+    Piq = PiB // P
+    half, hq = P // 2, Piq // 2
+    rng = random.Random(3)
+    xs = []
+    for i in range(n):
+        r = [half - 1, half, half + 1, 0, P - 1][i % 5] if i < 60 else rng.randrange(P)
+        if i < 20:
+            q = hq                      # quotient on floor(Pi'/2): x wraps (or not) depending on r
+        elif i < 40:
+            q = hq - 1
+        elif i < 50:
+            q = -hq - 1 if r else -hq   # most negative representable x
+        else:
+            q = rng.randrange(-hq + 2, hq - 2)
+        xs.append((q * P + r) % PiB)    # the residues only know x mod Pi_B
+    chat = np.array([v % o.p[d] for d in range(dimB) for v in xs], dtype=np.uint64)
+    dvals = [rng.randrange(-(ql // 2), ql // 2) for _ in range(n)]
+    exp = ref.he_relin_tail(o, chat, chat, dvals, None, dimP, dimB, ql)
+    out = torch.empty(W * n, dtype=torch.int64, device="cuda")
+    g.relin_tail(out, to_device(chat), to_device(ints_to_big(dvals, W)), W, logqL, dimB, dimP)
+    assert big_to_ints(to_host(out), W, n)[0] == exp[0]
+    g.relin_tail(out, to_device(chat), None, W, logqL, dimB, dimP)
+    assert big_to_ints(to_host(out), W, n)[0] == exp[1]
+
+
+def test_he_mul_by_one_is_identity_full_size(engine_ctx):
+    """Size-independent property at the headline shape (n = 2^16, q = 2^850, dimA/dimB = 30/45):
+    multiplying by the trivial ciphertext (c0 = 1, c1 = 0) gives d0 = ct.c0, d1 = ct.c1, d2 = 0, so the
+    relinearisation adds rdiv(0) = 0 and he_mul must return ct itself, whatever the key."""
+    torch = _torch()
+    logn, logq = 16, 850
+    g = engine_ctx(logn, 45)
+    dimP, dimA, dimB, dimevk = g.he_dims(logq, logq)
+    assert (dimP, dimA, dimB) == (15, 30, 45)
+    n, W = g.n, 14
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+
+    def centred():
+        big = torch.randint(-(1 << 62), 1 << 62, (W, n), dtype=torch.int64, device="cuda", generator=gen)
+        big[W - 1] = torch.randint(-(1 << 16), 1 << 16, (n,), dtype=torch.int64, device="cuda", generator=gen)
+        return big.reshape(-1).contiguous()
+
+    c0, c1 = centred(), centred()
+    one = torch.zeros(W * n, dtype=torch.int64, device="cuda")
+    one[0] = 1
+    zero = torch.zeros_like(one)
+    rlk = [torch.randint(0, g.p[d], (n,), dtype=torch.int64, device="cuda", generator=gen) for d in range(dimB)]
+    rlk0 = torch.cat(rlk)
+    rlk1 = torch.cat(rlk[::-1])
+    o0, o1 = torch.empty_like(c0), torch.empty_like(c0)
+    g.he_mul(o0, o1, c0, c1, one, zero, rlk0, rlk1, W, logq, dimA, dimB, dimP)
+    assert torch.equal(o0, c0) and torch.equal(o1, c1)
+    g.he_mul(o0, o1, one, zero, c0, c1, rlk0, rlk1, W, logq, dimA, dimB, dimP)
+    assert torch.equal(o0, c0) and torch.equal(o1, c1)
