@@ -46,6 +46,7 @@ SIGNATURES = {
     "gpq_ctx_pbits": (C.c_uint, [vp, C.c_uint]),
     "gpq_rns_decompose": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, vp]),
     "gpq_rns_reconstruct": (C.c_int, [vp, vp, C.c_uint, vp, C.c_uint, C.c_uint, C.c_uint, vp]),
+    "gpq_set_exact_crt": (C.c_int, [vp, C.c_int]),
     "gpq_poly_mul_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
     "gpq_poly_mul": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
     "gpq_he_rs": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp]),

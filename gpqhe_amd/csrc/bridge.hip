@@ -82,6 +82,13 @@ int get_basis(gpq_ctx *c, unsigned first, unsigned dim, gpq_bridge_basis **out) 
   HIP_TRY(hipMemcpy(b.d_phat_inv, pinv.data(), pinv.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b.d_pmult, pmult.data(), pmult.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b.d_phalf, phalf.data(), phalf.size() * 8, hipMemcpyHostToDevice));
+  std::vector<uint64_t> inv128(2 * (size_t)dim);
+  for (unsigned d = 0; d < dim; ++d) {
+    const u128h q = ~(u128h)0 / c->p[first + d];                     // floor(2^128 / p_d): p_d does not divide 2^128
+    inv128[2 * d] = (uint64_t)q; inv128[2 * d + 1] = (uint64_t)(q >> 64);
+  }
+  HIP_TRY(hipMalloc((void **)&b.d_inv128, inv128.size() * 8));
+  HIP_TRY(hipMemcpy(b.d_inv128, inv128.data(), inv128.size() * 8, hipMemcpyHostToDevice));
   b.h_phat_inv = pinv;
   b.h_P = P;
   *out = &(c->bases[key] = b);
@@ -104,17 +111,43 @@ int get_relin(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables **out) 
   return GPQ_OK;
 }
 
+template <int WP>
+void launch_exact(const ReconstructArgs &a, unsigned n, unsigned batch, hipStream_t s) {
+  hipLaunchKernelGGL((bridge_reconstruct<WP>), dim3((n + 127) / 128, batch), dim3(128), 0, s, a);
+}
+template <int WL>
+void launch_low(const ReconstructArgs &a, unsigned WPstride, unsigned char *redo, unsigned n, unsigned batch, hipStream_t s) {
+  hipLaunchKernelGGL((bridge_reconstruct_low<WL>), dim3((n + 255) / 256, batch), dim3(256), 0, s, a, WPstride, redo);
+}
+
 int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned slab_dim,
                        unsigned slab_first, unsigned batch, unsigned logq, bool centre, unsigned char *tie, hipStream_t s) {
-  ReconstructArgs a{c->d_tabs, slab, big, b->d_phat, b->d_phat_inv, b->d_pmult, b->d_phalf, tie, b->dim, c->logn, Wout, logq,
-                    b->first, slab_dim, slab_first, centre ? 1u : 0u};
-  const dim3 grid((c->n + 127) / 128, batch), block(128);
+  ReconstructArgs a{c->d_tabs, slab, big, b->d_phat, b->d_phat_inv, b->d_pmult, b->d_phalf, tie, nullptr, b->d_inv128,
+                    b->dim, c->logn, Wout, logq, b->first, slab_dim, slab_first, centre ? 1u : 0u};
+  // fast path: centred result modulo a power of two that needs fewer words than P has
+  const unsigned need = (logq + 63) / 64;
+  // (the centring threshold floor(P/2)/P differs from 1/2 by 1/(2P): negligible against the 2^-61 slack only for large P)
+  const bool fast = logq && centre && !c->exact_crt && need + 1 < (unsigned)b->WP && need <= 16 && b->pbits >= 160;
+  if (fast) {
+    const size_t flags = (size_t)batch << c->logn;
+    if (flags > c->redo_cap) {
+      if (c->d_redo) HIP_TRY(hipFree(c->d_redo));
+      HIP_TRY(hipMalloc((void **)&c->d_redo, flags));
+      c->redo_cap = flags;
+    }
+    if (need <= 1) launch_low<1>(a, b->WP, c->d_redo, c->n, batch, s);
+    else if (need <= 2) launch_low<2>(a, b->WP, c->d_redo, c->n, batch, s);
+    else if (need <= 4) launch_low<4>(a, b->WP, c->d_redo, c->n, batch, s);
+    else if (need <= 8) launch_low<8>(a, b->WP, c->d_redo, c->n, batch, s);
+    else launch_low<16>(a, b->WP, c->d_redo, c->n, batch, s);
+    a.only = c->d_redo;   // exact kernel below redoes only the flagged coefficients
+  }
   switch (b->WP) {
-    case 8: hipLaunchKernelGGL((bridge_reconstruct<8>), grid, block, 0, s, a); break;
-    case 16: hipLaunchKernelGGL((bridge_reconstruct<16>), grid, block, 0, s, a); break;
-    case 32: hipLaunchKernelGGL((bridge_reconstruct<32>), grid, block, 0, s, a); break;
-    case 48: hipLaunchKernelGGL((bridge_reconstruct<48>), grid, block, 0, s, a); break;
-    case 56: hipLaunchKernelGGL((bridge_reconstruct<56>), grid, block, 0, s, a); break;
+    case 8: launch_exact<8>(a, c->n, batch, s); break;
+    case 16: launch_exact<16>(a, c->n, batch, s); break;
+    case 32: launch_exact<32>(a, c->n, batch, s); break;
+    case 48: launch_exact<48>(a, c->n, batch, s); break;
+    case 56: launch_exact<56>(a, c->n, batch, s); break;
     default: return gpq_fail(GPQ_ERR_UNSUPPORTED, "reconstruct: WP=%d", b->WP);
   }
   return GPQ_OK;
@@ -146,8 +179,10 @@ int launched(const char *who) {
 void gpq_bridge_release(gpq_ctx *c) {
   for (auto &kv : c->bases) {
     (void)hipFree(kv.second.d_phat); (void)hipFree(kv.second.d_phat_inv);
-    (void)hipFree(kv.second.d_pmult); (void)hipFree(kv.second.d_phalf);
+    (void)hipFree(kv.second.d_pmult); (void)hipFree(kv.second.d_phalf); (void)hipFree(kv.second.d_inv128);
   }
+  if (c->d_redo) (void)hipFree(c->d_redo);
+  c->d_redo = nullptr; c->redo_cap = 0;
   c->bases.clear();
   for (auto &kv : c->relins) (void)hipFree(kv.second.d_pinv);
   c->relins.clear();
@@ -397,4 +432,21 @@ extern "C" int gpq_relin_tail(gpq_ctx *c, uint64_t *out, const uint64_t *chat, c
   if (rc) return rc;
   if (!out || !chat || !workspace || !logql || W < (logql + 63) / 64) return gpq_fail(GPQ_ERR_INVALID, "gpq_relin_tail: bad arguments");
   return relin_tail(c, out, chat, d, W, dimP, dimB, logql, batch, workspace, (hipStream_t)stream);
+}
+
+// Tests: force the exact (full-width) CRT kernel instead of the low-word fast path.
+extern "C" int gpq_set_exact_crt(gpq_ctx *c, int on) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_exact_crt: null context");
+  c->exact_crt = on != 0;
+  return GPQ_OK;
+}
+
+// Diagnostics: how many of the first `count` coefficients the last fast CRT pass flagged for the exact kernel.
+extern "C" long gpq_debug_redo_count(gpq_ctx *c, size_t count) {
+  if (!c || !c->d_redo || count > c->redo_cap) return -1;
+  std::vector<unsigned char> h(count);
+  if (hipMemcpy(h.data(), c->d_redo, count, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  long k = 0;
+  for (unsigned char v : h) k += v != 0;
+  return k;
 }

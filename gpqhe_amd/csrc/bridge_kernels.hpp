@@ -98,6 +98,8 @@ struct ReconstructArgs {
   const uint64_t *pmult;       // [6][WP+1]       32P, 16P, 8P, 4P, 2P, P
   const uint64_t *phalf;       // [WP+1]          floor(P/2)
   unsigned char *tie;          // optional [polys][n]: 1 where (S mod P) == floor(P/2) exactly
+  const unsigned char *only;   // optional [polys][n]: when given, coefficients with 0 are skipped
+  const uint64_t *inv128;      // [dim][2]  floor(2^128 / p_d)        (fast path only)
   unsigned dim, logn, Wout, logq;   // logq = 0: no reduction mod q (Wout >= WP+1 then)
   unsigned limb0;              // the basis is primes limb0 .. limb0+dim-1
   unsigned slab_dim, slab_first;    // the slab has slab_dim limbs per polynomial; read limbs slab_first ..
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
   const unsigned n = 1u << a.logn;
   const unsigned i = blockIdx.x * 128 + threadIdx.x;
   if (i >= n) return;
+  if (a.only && !a.only[((size_t)blockIdx.y << a.logn) + i]) return;
   const uint64_t *__restrict__ src = a.slab + (((size_t)blockIdx.y * a.slab_dim + a.slab_first) << a.logn) + i;
   uint64_t S[WP + 1];
 #pragma unroll
@@ -190,6 +193,80 @@ __global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
   }
   const uint64_t fill = a.logq ? qsign : sext;
   for (unsigned j = WP + 1; j < a.Wout; ++j) dst[(size_t)j << a.logn] = fill;
+}
+
+// ---------------------------------------------------------------------------
+// poly_rns2mpi, fast path for q = 2^logq: the result only needs its low WL >= ceil(logq/64)
+// words, so the CRT sum is accumulated modulo 2^(64 WL); the multiple of P to take off and the
+// centring decision come from a fixed-point estimate of S/P = sum_d y_d / p_d:
+//   F = sum_d y_d * floor(2^128/p_d)   underestimates 2^128 * S/P by less than dim * 2^60 <= 2^66
+//   k = F >> 128,  centred  <=>  frac >= 1/2,  multiple of P to take off = k + centred.
+// If the true fraction crosses 1 while F still reads 1 - eps, the multiple is k+1 either way (centred
+// from below, or not centred with the next k), so only the 1/2 boundary is a real discontinuity:
+// coefficients with frac(F) in [1/2 - 2^-61, 1/2) are flagged and redone by the exact kernel above,
+// which also handles the exact tie S mod P == floor(P/2).  (he_mul's products sit far from +-P/2.)
+// ---------------------------------------------------------------------------
+template <int WL>
+__global__ __launch_bounds__(256) void bridge_reconstruct_low(ReconstructArgs a, unsigned WPstride, unsigned char *redo) {
+  const unsigned n = 1u << a.logn;
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t *__restrict__ src = a.slab + (((size_t)blockIdx.y * a.slab_dim + a.slab_first) << a.logn) + i;
+  uint64_t S[WL];
+#pragma unroll
+  for (int j = 0; j < WL; ++j) S[j] = 0;
+  uint64_t f0 = 0, f1 = 0, f2 = 0;
+  for (unsigned d = 0; d < a.dim; ++d) {
+    const PrimeK k = a.tabs[a.limb0 + d].k;
+    const uint64_t y = mulmod_canon(src[(size_t)d << a.logn], a.phat_inv[d], k);
+    const uint64_t *__restrict__ ph = a.phat + (size_t)d * WPstride;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < WL; ++j) {
+      const u128 t = (u128)y * ph[j] + S[j] + carry;
+      S[j] = (uint64_t)t;
+      carry = (uint64_t)(t >> 64);
+    }
+    const u128 g0 = (u128)y * a.inv128[2 * d] + f0;
+    const u128 g1 = (u128)y * a.inv128[2 * d + 1] + f1 + (uint64_t)(g0 >> 64);
+    f0 = (uint64_t)g0; f1 = (uint64_t)g1; f2 += (uint64_t)(g1 >> 64);
+  }
+  const size_t flag_at = ((size_t)blockIdx.y << a.logn) + i;
+  // frac = f1:f0 / 2^128 ; slack 2^67 on both decisions
+  const bool ambiguous = (f1 >> 3) == ((1ull << 60) - 1);               // frac in [1/2 - 2^-61, 1/2)
+  redo[flag_at] = ambiguous;
+  if (a.tie) a.tie[flag_at] = 0;
+  if (ambiguous) return;                                                // the exact kernel writes this coefficient
+  const uint64_t mult = f2 + (f1 >> 63);                                // k, plus one when centring takes P off once more
+  const uint64_t *__restrict__ P = a.pmult + (size_t)5 * (WPstride + 1);
+  uint64_t borrow = 0, mcarry = 0;
+#pragma unroll
+  for (int j = 0; j < WL; ++j) {
+    const u128 kp = (u128)mult * P[j] + mcarry;
+    mcarry = (uint64_t)(kp >> 64);
+    const u128 t = (u128)S[j] - (uint64_t)kp - borrow;
+    S[j] = (uint64_t)t;
+    borrow = (uint64_t)(t >> 64) & 1;
+  }
+  uint64_t *__restrict__ dst = a.big + ((size_t)blockIdx.y * a.Wout << a.logn) + i;
+  const unsigned sb = a.logq - 1;
+  uint64_t qsign = 0;
+#pragma unroll
+  for (int j = 0; j < WL; ++j) if (j == (int)(sb >> 6)) qsign = 0 - ((S[j] >> (sb & 63)) & 1);
+#pragma unroll
+  for (int j = 0; j < WL; ++j) {
+    if (j < (int)a.Wout) {
+      uint64_t v = S[j];
+      const int lo = 64 * j;
+      if (lo >= (int)a.logq) v = qsign;
+      else if (lo + 64 > (int)a.logq) {
+        const uint64_t mask = (1ull << (a.logq - lo)) - 1;
+        v = (v & mask) | (qsign & ~mask);
+      }
+      dst[(size_t)j << a.logn] = v;
+    }
+  }
+  for (unsigned j = WL; j < a.Wout; ++j) dst[(size_t)j << a.logn] = qsign;
 }
 
 // ---------------------------------------------------------------------------

@@ -15,7 +15,7 @@ enum { GPQ_K_STRIDED_FWD = 0, GPQ_K_STRIDED_INV, GPQ_K_CONTIG_FWD, GPQ_K_CONTIG_
 struct gpq_bridge_basis {
   unsigned first = 0, dim = 0, pbits = 0;
   int WP = 0;
-  uint64_t *d_phat = nullptr, *d_phat_inv = nullptr, *d_pmult = nullptr, *d_phalf = nullptr;
+  uint64_t *d_phat = nullptr, *d_phat_inv = nullptr, *d_pmult = nullptr, *d_phalf = nullptr, *d_inv128 = nullptr;
   std::vector<uint64_t> h_phat_inv;
   std::vector<uint64_t> h_P;          // the product itself, little-endian words
 };
@@ -37,6 +37,9 @@ struct gpq_ctx {
   gpq::LimbTab *d_tabs = nullptr;
   std::map<std::pair<unsigned, unsigned>, gpq_bridge_basis> bases;   // by (first limb, count), built on first use
   std::map<std::pair<unsigned, unsigned>, gpq_relin_tables> relins;  // by (dimP, dimB)
+  unsigned char *d_redo = nullptr;    // per-coefficient "redo exactly" flags of the fast CRT path
+  size_t redo_cap = 0;
+  bool exact_crt = false;             // force the exact CRT kernel (tests)
   // profiling
   bool prof_on = false;
   std::vector<gpq_prof_rec> prof;     // launches recorded since the last reset

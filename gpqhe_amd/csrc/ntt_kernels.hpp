@@ -404,11 +404,9 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid(KeyswitchA
   load_h(x, a.src[0] + cb.off, ln);
   tw.load(ln, cb.wave0, a.logn, a.w + cb.toff);
   contig_fwd(x, ln, tw, k);
-  load_h(e0, ka.evk0 + koff, ln);
-  load_h(e1, ka.evk1 + koff, ln);
+  load_l(e0, ka.evk0 + koff, ln);   // measured faster than H-layout loads + two more LDS exchanges here
+  load_l(e1, ka.evk1 + koff, ln);
   tw.load(ln, cb.wave0, a.logn, a.winv + cb.toff);
-  ln.h_to_l(e0);
-  ln.h_to_l(e1);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const uint64_t u = csub(x[e], k.p4);           // < 4p ; evk limbs are canonical (< p)

@@ -94,6 +94,9 @@ class PolyContext:
         _native.check(self.lib.gpq_rns_reconstruct(self.h, _ptr(big), Wout, _ptr(slab), dim, batch, logq, _stream()), "gpq_rns_reconstruct")
         return big
 
+    def set_exact_crt(self, on):
+        _native.check(self.lib.gpq_set_exact_crt(self.h, 1 if on else 0), "gpq_set_exact_crt")
+
     def poly_mul(self, r, a, b, W, dim, logq):
         """src/poly.c:84-107 on big slabs, q = 2^logq."""
         torch = _torch()

@@ -146,6 +146,11 @@ int gpq_rns_decompose(gpq_ctx *ctx, uint64_t *slab, const uint64_t *big, unsigne
  * mod P, centre mod q.  logq = 0 stops after centring mod P (Wout must then hold P's bits + 1). */
 int gpq_rns_reconstruct(gpq_ctx *ctx, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned dim, unsigned batch,
                         unsigned logq, void *stream);
+/* gpq_rns_reconstruct takes a low-word fast path when q is a power of two shorter than P and redoes the
+ * (rare) coefficients whose rounding it cannot decide with the exact full-width kernel; this forces the
+ * exact kernel for everything (used by the tests to cross-check the two). */
+int gpq_set_exact_crt(gpq_ctx *ctx, int on);
+
 /* poly_mul, src/poly.c:84-107 (decl src/poly.h:86-87), q = 2^logq, on big slabs of W words. */
 size_t gpq_poly_mul_workspace_bytes(const gpq_ctx *ctx, unsigned dim, unsigned batch);
 int gpq_poly_mul(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned W, unsigned dim, unsigned logq,

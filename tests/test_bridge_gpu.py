@@ -124,3 +124,32 @@ def test_roundtrip_full_size(engine_ctx):
     g.rns_reconstruct(back, W, slab, dim, logq)
     assert torch.equal(back, big)
     assert bool((slab >= 0).all())
+
+
+@pytest.mark.parametrize("dim,logq", [(30, 850), (30, 61), (45, 850), (9, 200)])
+def test_fast_crt_path_equals_exact_kernel(engine_ctx, oracle_ctx, dim, logq):
+    """gpq_rns_reconstruct's low-word fast path (fixed-point quotient, flagged coefficients redone exactly)
+    against the full-width kernel on the same slabs, including residues of values that sit on the
+    rounding boundaries (x = k*P/2 +- small), where the fast path must hand over to the exact one."""
+    torch = _torch()
+    logn = 8
+    g, o = engine_ctx(logn, 45), oracle_ctx(logn, 45)
+    basis = RnsBasis(g.p[:dim])
+    n = g.n
+    slab = o.gen(77, dim).reshape(dim, n).copy()
+    half = basis.P_2
+    edge = [half, half - 1, half + 1, 0, basis.P - 1, 1, half + (1 << 40), half - (1 << 40), half - (1 << 900) if dim > 20 else half - 5]
+    for col, v in enumerate(edge):
+        for d in range(dim):
+            slab[d, col] = v % g.p[d]
+    W = (logq + 63) // 64
+    dev = to_device(slab.reshape(-1))
+    fast = torch.empty(W * n, dtype=torch.int64, device="cuda")
+    exact = torch.empty_like(fast)
+    g.rns_reconstruct(fast, W, dev, dim, logq)
+    g.set_exact_crt(True)
+    g.rns_reconstruct(exact, W, dev, dim, logq)
+    g.set_exact_crt(False)
+    assert torch.equal(fast, exact)
+    exp = poly_rns2mpi([slab[d][:16] for d in range(dim)], basis, 1 << logq)
+    assert big_to_ints(to_host(fast), W, n)[0][:16] == exp
