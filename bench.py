@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="polynomials per fused launch group (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=2, help="ciphertexts the CPU baseline replays (0 = skip)")
     ap.add_argument("--no-ntt", action="store_true", help="skip the NTT GB/s legs (run after the timed region)")
+    ap.add_argument("--streams", type=int, default=1, help="2: tensor stage and key-switch stage on separate HIP streams")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank path with several ranks on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -158,8 +161,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        ndev = torch.cuda.device_count()
+        if args.backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.cuda.set_device(local % ndev)
+            dist.init_process_group(backend=args.backend)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world:
@@ -181,9 +189,17 @@ def main():
     c0, c1 = torch.empty_like(x), torch.empty_like(x)
     wsA, wsB = ctx.tensor_workspace(DIM_A, B), ctx.keyswitch_workspace(DIM_B, B)
 
+    streams = [torch.cuda.Stream() for _ in range(2)] if args.streams == 2 else None
+
     def step():
-        ctx.he_mul_tensor(d0, d1, d2, a0, a1, b0, b1, DIM_A, wsA)
-        ctx.he_keyswitch(c0, c1, x, e0, e1, DIM_B, wsB)
+        if streams is None:
+            ctx.he_mul_tensor(d0, d1, d2, a0, a1, b0, b1, DIM_A, wsA)
+            ctx.he_keyswitch(c0, c1, x, e0, e1, DIM_B, wsB)
+        else:  # the two stages of different ciphertexts are independent: let their launch tails overlap
+            with torch.cuda.stream(streams[0]):
+                ctx.he_mul_tensor(d0, d1, d2, a0, a1, b0, b1, DIM_A, wsA)
+            with torch.cuda.stream(streams[1]):
+                ctx.he_keyswitch(c0, c1, x, e0, e1, DIM_B, wsB)
 
     def barrier():
         torch.cuda.synchronize()

@@ -303,8 +303,11 @@ struct ContigBlock {       // per-workgroup addressing shared by the contiguous 
 // fetches the next polynomial's coefficients while it works on the current one.
 constexpr int CONTIG_POLYS = 4;
 
+#ifndef GPQ_CONTIG_MINWAVES
+#define GPQ_CONTIG_MINWAVES 2
+#endif
 template <bool INV>
-__global__ __launch_bounds__(CONTIG_WAVES * 64) void contig_pass(PassArgs a, unsigned polys) {
+__global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_CONTIG_MINWAVES) void contig_pass(PassArgs a, unsigned polys) {
   __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
   const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
   const unsigned wave0 = (blockIdx.x * CONTIG_WAVES + (threadIdx.x >> 6)) << 10;

@@ -2,7 +2,7 @@
 # PMC passes over a short bench run (kernel-trace + counters only; one counter group per pass).
 set -o pipefail
 mkdir -p gpurun_out; export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 1 --warmup 1 --batch 16 --cpu-sample 0"
+BENCH="python3 bench.py --steps 1 --warmup 1 --batch 16 --cpu-sample 0 --no-ntt"
 pass() { # name, counters...
   local name=$1; shift
   rm -rf gpurun_out/pmc_$name
@@ -24,7 +24,9 @@ res={}
 for k,v in out.items():
     res[k]={c:(v[c]/v['_n_'+c]) for c in v if not c.startswith('_n_')}
     res[k]['launches']=max(v[c] for c in v if c.startswith('_n_'))
+res["_chunk"]=16
 json.dump(res, open('gpurun_out/pmc_summary.json','w'), indent=1)
 for k,v in res.items():
+    if k.startswith('_'): continue
     print(k); print('   ', {a:(round(b,1) if b<1e6 else int(b)) for a,b in sorted(v.items())})
 PY
