@@ -81,7 +81,9 @@ SIGNATURES = {
 }
 # by-value unsigned __int128 arguments cannot be expressed in ctypes; these two are
 # exercised from C (tests/c/dropin_host.c)
-EXPORTED_ONLY = ["montgomery_reduce", "barrett_reduce"]
+EXPORTED_ONLY = ["montgomery_reduce", "barrett_reduce",
+                 # MPI-typed surface: driven from C with real libgcrypt MPIs (tests/c/mpi_host.c)
+                 "poly_mul", "he_mul", "he_rs", "he_rescale", "he_moddown"]
 
 _lib = None
 

@@ -1,0 +1,244 @@
+// mpi_shim.hip -- poly_mul / he_mul / he_rs / he_rescale / he_moddown with the reference's own
+// MPI-typed signatures (src/poly.h:86-87, src/gpqhe.h:136-137,147), so that GPQHE objects which
+// call them link against libgpqhe_hip.so unchanged.  The work itself is the device code behind
+// gpq_poly_mul / gpq_he_mul / gpq_he_rs; this file only moves coefficients between libgcrypt MPIs
+// and big slabs and mirrors the host-side bookkeeping (ct->l, nu, B).
+//
+// libgcrypt is reached through its runtime ABI only (dlsym on the library the host program has
+// loaded, or libgcrypt.so.20): this image ships no <gcrypt.h>, and none is needed.
+#include "../../include/gpqhe_hip.h"
+#include "../../include/gpqhe_hip_compat.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+extern "C" struct poly_ctx polyctx __attribute__((weak));   // src/precomp.c:41
+extern "C" struct he_ctx hectx __attribute__((weak));       // src/precomp.c:47
+
+namespace {
+
+typedef void *MPI;
+struct Gcry {
+  MPI (*mpi_new)(unsigned);
+  void (*mpi_release)(MPI);
+  MPI (*mpi_set)(MPI, MPI);
+  MPI (*mpi_set_ui)(MPI, unsigned long);
+  void (*mpi_neg)(MPI, MPI);
+  int (*mpi_is_neg)(MPI);
+  unsigned (*mpi_get_nbits)(MPI);
+  int (*mpi_test_bit)(MPI, unsigned);
+  unsigned (*mpi_print)(int, unsigned char *, size_t, size_t *, MPI);
+  unsigned (*mpi_scan)(MPI *, int, const void *, size_t, size_t *);
+  bool ok = false;
+} G;
+const int FMT_USG = 5;  // GCRYMPI_FMT_USG: unsigned big-endian magnitude
+
+[[noreturn]] void die(const char *what) {
+  errno = EINVAL;  // the reference's error convention (src/reduce.c:95-100, src/precomp.c:344-350)
+  fprintf(stderr, "\033[1m\033[31merror:\033[0m \033[1m%s\033[0m. %s (%s)\n", strerror(errno), what, gpq_last_error());
+  abort();
+}
+
+void need_gcrypt() {
+  if (G.ok) return;
+  void *h = RTLD_DEFAULT;
+  if (!dlsym(h, "gcry_mpi_print")) {
+    h = dlopen("libgcrypt.so.20", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) die("libgcrypt is not loaded and libgcrypt.so.20 cannot be opened");
+  }
+  auto get = [&](const char *n) { void *p = dlsym(h, n); if (!p) die(n); return p; };
+  G.mpi_new = (MPI(*)(unsigned))get("gcry_mpi_new");
+  G.mpi_release = (void (*)(MPI))get("gcry_mpi_release");
+  G.mpi_set = (MPI(*)(MPI, MPI))get("gcry_mpi_set");
+  G.mpi_set_ui = (MPI(*)(MPI, unsigned long))get("gcry_mpi_set_ui");
+  G.mpi_neg = (void (*)(MPI, MPI))get("gcry_mpi_neg");
+  G.mpi_is_neg = (int (*)(MPI))get("gcry_mpi_is_neg");
+  G.mpi_get_nbits = (unsigned (*)(MPI))get("gcry_mpi_get_nbits");
+  G.mpi_test_bit = (int (*)(MPI, unsigned))get("gcry_mpi_test_bit");
+  G.mpi_print = (unsigned (*)(int, unsigned char *, size_t, size_t *, MPI))get("gcry_mpi_print");
+  G.mpi_scan = (unsigned (*)(MPI *, int, const void *, size_t, size_t *))get("gcry_mpi_scan");
+  G.ok = true;
+}
+
+// log2 of a power-of-two MPI; dies otherwise (general moduli have no device path yet)
+unsigned log2_exact(MPI q, const char *what) {
+  const unsigned nb = G.mpi_get_nbits(q);
+  if (!nb || G.mpi_is_neg(q)) die(what);
+  std::vector<unsigned char> buf((nb + 7) / 8);
+  size_t nw = 0;
+  if (G.mpi_print(FMT_USG, buf.data(), buf.size(), &nw, q)) die("gcry_mpi_print failed");
+  unsigned ones = 0;
+  for (size_t i = 0; i < nw; ++i) ones += __builtin_popcount(buf[i]);
+  if (ones != 1) die(what);
+  return nb - 1;
+}
+
+unsigned max_bits(const poly_mpi_t *a, unsigned n) {
+  unsigned m = 0;
+  for (unsigned i = 0; i < n; ++i) { const unsigned b = G.mpi_get_nbits(a->coeffs[i]); if (b > m) m = b; }
+  return m;
+}
+
+// MPI coefficients -> host big slab [W][n], two's complement
+void to_slab(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W) {
+  std::vector<unsigned char> buf(8 * W);
+  for (unsigned i = 0; i < n; ++i) {
+    MPI v = a->coeffs[i];
+    if (G.mpi_get_nbits(v) > 64 * W - 1) die("coefficient does not fit the big slab");
+    size_t nw = 0;
+    if (G.mpi_print(FMT_USG, buf.data(), buf.size(), &nw, v)) die("gcry_mpi_print failed");
+    uint64_t w[64] = {0};
+    for (size_t b = 0; b < nw; ++b) w[(nw - 1 - b) >> 3] |= (uint64_t)buf[b] << (8 * ((nw - 1 - b) & 7));
+    if (G.mpi_is_neg(v)) {
+      uint64_t carry = 1;
+      for (unsigned j = 0; j < W; ++j) { w[j] = ~w[j] + carry; carry = carry && w[j] == 0; }
+    }
+    for (unsigned j = 0; j < W; ++j) dst[(size_t)j * n + i] = w[j];
+  }
+}
+
+// host big slab -> existing MPIs (the caller allocated them, src/poly.c:46-51)
+void from_slab(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W) {
+  std::vector<unsigned char> buf(8 * W);
+  for (unsigned i = 0; i < n; ++i) {
+    uint64_t w[64];
+    for (unsigned j = 0; j < W; ++j) w[j] = src[(size_t)j * n + i];
+    const bool neg = w[W - 1] >> 63;
+    if (neg) {
+      uint64_t carry = 1;
+      for (unsigned j = 0; j < W; ++j) { w[j] = ~w[j] + carry; carry = carry && w[j] == 0; }
+    }
+    size_t len = 8 * W;
+    for (size_t b = 0; b < len; ++b) buf[b] = (unsigned char)(w[(len - 1 - b) >> 3] >> (8 * ((len - 1 - b) & 7)));
+    size_t skip = 0;
+    while (skip < len && buf[skip] == 0) ++skip;
+    if (skip == len) { G.mpi_set_ui(r->coeffs[i], 0); continue; }
+    MPI t = nullptr;
+    if (G.mpi_scan(&t, FMT_USG, buf.data() + skip, len - skip, nullptr)) die("gcry_mpi_scan failed");
+    G.mpi_set(r->coeffs[i], t);
+    G.mpi_release(t);
+    if (neg) G.mpi_neg(r->coeffs[i], r->coeffs[i]);
+  }
+}
+
+// one engine context per (logn, chain length), checked against the caller's prime list
+gpq_ctx *g_engine = nullptr;
+
+gpq_ctx *engine() {
+  if (&polyctx == nullptr || !polyctx.n) die("`polyctx` is not initialised (polyctx_init / hectx_init first)");
+  if (g_engine && gpq_ctx_logn(g_engine) == polyctx.logn && gpq_ctx_nprimes(g_engine) >= polyctx.dimub) return g_engine;
+  if (g_engine) gpq_ctx_destroy(g_engine);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) die("no HIP device");
+  if (gpq_ctx_create(&g_engine, polyctx.logn, polyctx.dimub, dev) != GPQ_OK) die("cannot build the engine context");
+  unsigned d = 0;
+  for (const struct rns_ctx *r = polyctx.rns; r && d < polyctx.dimub; r = r->next, ++d)
+    if (r->p != gpq_ctx_const(g_engine, d, 0)) die("the caller's prime chain differs from src/precomp.c:358-376");
+  return g_engine;
+}
+
+struct DevBuf {
+  void *p = nullptr;
+  explicit DevBuf(size_t bytes) { if (gpq_malloc(&p, bytes ? bytes : 8) != GPQ_OK) die("device allocation failed"); }
+  ~DevBuf() { (void)gpq_free(p); }
+  uint64_t *u64() const { return (uint64_t *)p; }
+};
+
+void up(const DevBuf &d, const std::vector<uint64_t> &h) { if (gpq_upload(d.p, h.data(), h.size() * 8, nullptr) != GPQ_OK) die("upload failed"); }
+void down(std::vector<uint64_t> &h, const DevBuf &d) {
+  if (gpq_download(h.data(), d.p, h.size() * 8, nullptr) != GPQ_OK || gpq_stream_sync(nullptr) != GPQ_OK) die("download failed");
+}
+
+}  // namespace
+
+extern "C" {
+
+// src/poly.c:84-107
+void poly_mul(poly_mpi_t *r, const poly_mpi_t *a, const poly_mpi_t *b, const unsigned int dim, const gpq_MPI q) {
+  need_gcrypt();
+  gpq_ctx *c = engine();
+  const unsigned n = polyctx.n, logq = log2_exact(q, "poly_mul: the modulus must be a power of two");
+  unsigned bits = max_bits(a, n), bb = max_bits(b, n);
+  if (bb > bits) bits = bb;
+  if (logq > bits) bits = logq;
+  const unsigned W = bits / 64 + 1;
+  if (W > 32) die("poly_mul: coefficients wider than 2047 bits");
+  std::vector<uint64_t> ha((size_t)W * n), hb((size_t)W * n), hr((size_t)W * n);
+  to_slab(ha.data(), a, n, W);
+  to_slab(hb.data(), b, n, W);
+  DevBuf da(ha.size() * 8), db(hb.size() * 8), dr(hr.size() * 8), ws(gpq_poly_mul_workspace_bytes(c, dim, 1));
+  up(da, ha); up(db, hb);
+  if (gpq_poly_mul(c, dr.u64(), da.u64(), db.u64(), W, dim, logq, 1, ws.p, nullptr) != GPQ_OK) die("poly_mul failed");
+  down(hr, dr);
+  from_slab(r, hr.data(), n, W);
+}
+
+// src/he-mult.c:88-156
+void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t *rlk) {
+  need_gcrypt();
+  if (&hectx == nullptr || !hectx.q) die("`hectx` is not initialised (hectx_init first)");
+  if (ct1->l != ct2->l) die("he_mul: operands at different levels");   // assert at src/he-mult.c:90
+  gpq_ctx *c = engine();
+  const unsigned n = polyctx.n, l = ct1->l;
+  const double nu = ct1->nu * ct2->nu;                                                        // :93
+  const double B = ct1->nu * ct2->B + ct2->nu * ct1->B + ct1->B * ct2->B + hectx.bnd.Bmult[l];  // :94-95
+  const unsigned logql = log2_exact(hectx.q[l], "he_mul: q_l must be a power of two");
+  const unsigned nbq = logql + 1, nbPqL = G.mpi_get_nbits(hectx.PqL);
+  const unsigned dimA = (nbq * 2 + polyctx.logn) / 59 + 1;                                     // :99
+  const unsigned dimB = (nbq + nbPqL + polyctx.logn) / 59 + 1;                                 // :51
+  const unsigned dimP = hectx.dim;                                                             // hectx.P, src/precomp.c:401-404
+  if (gpq_ctx_pbits(c, dimP) != G.mpi_get_nbits(hectx.P)) die("he_mul: hectx.P is not the product of the first hectx.dim primes");
+  const unsigned W = logql / 64 + 1;
+  const size_t big = (size_t)W * n, evk = (size_t)dimB * n;
+  std::vector<uint64_t> h[4] = {std::vector<uint64_t>(big), std::vector<uint64_t>(big), std::vector<uint64_t>(big), std::vector<uint64_t>(big)};
+  const poly_mpi_t *in[4] = {&ct1->c0, &ct1->c1, &ct2->c0, &ct2->c1};
+  for (int i = 0; i < 4; ++i) to_slab(h[i].data(), in[i], n, W);
+  DevBuf d0(big * 8), d1(big * 8), d2(big * 8), d3(big * 8), o0(big * 8), o1(big * 8), k0(evk * 8), k1(evk * 8),
+      ws(gpq_he_mul_workspace_bytes(c, W, dimA, dimB, dimP, 1));
+  up(d0, h[0]); up(d1, h[1]); up(d2, h[2]); up(d3, h[3]);
+  if (gpq_upload(k0.p, rlk->p0.coeffs, evk * 8, nullptr) != GPQ_OK || gpq_upload(k1.p, rlk->p1.coeffs, evk * 8, nullptr) != GPQ_OK) die("upload failed");
+  if (gpq_he_mul(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), d2.u64(), d3.u64(), k0.u64(), k1.u64(), W, logql, dimA, dimB, dimP, 1, ws.p,
+                 nullptr) != GPQ_OK) die("he_mul failed");
+  down(h[0], o0); down(h[1], o1);
+  from_slab(&ct->c0, h[0].data(), n, W);
+  from_slab(&ct->c1, h[1].data(), n, W);
+  ct->l = l; ct->nu = nu; ct->B = B;                                                           // :92-95
+}
+
+static void rescale_common(he_ct_t *ct, bool divide) {
+  need_gcrypt();
+  if (&hectx == nullptr || !hectx.q) die("`hectx` is not initialised (hectx_init first)");
+  gpq_ctx *c = engine();
+  const unsigned n = polyctx.n;
+  if (ct->l == 0) die("he_rs / he_moddown: already at level 0");
+  const unsigned lnew = ct->l - 1;                                                             // src/he-rescale.c:36, :59
+  const unsigned logql = log2_exact(hectx.q[lnew], "he_rs: q_l must be a power of two");
+  const unsigned s = divide ? log2_exact(hectx.p, "he_rs: Delta must be a power of two") : 0;
+  unsigned bits = max_bits(&ct->c0, n), b1 = max_bits(&ct->c1, n);
+  if (b1 > bits) bits = b1;
+  if (logql > bits) bits = logql;
+  const unsigned W = bits / 64 + 1;
+  std::vector<uint64_t> h0((size_t)W * n), h1((size_t)W * n);
+  to_slab(h0.data(), &ct->c0, n, W);
+  to_slab(h1.data(), &ct->c1, n, W);
+  DevBuf d0(h0.size() * 8), d1(h1.size() * 8);
+  up(d0, h0); up(d1, h1);
+  if (gpq_he_rs(c, d0.u64(), d1.u64(), W, s, logql, 1, nullptr) != GPQ_OK) die("he_rs failed");    // :45-48 / :64-65
+  down(h0, d0); down(h1, d1);
+  from_slab(&ct->c0, h0.data(), n, W);
+  from_slab(&ct->c1, h1.data(), n, W);
+  ct->l = lnew;
+  if (divide) { ct->nu /= hectx.Delta; ct->B = ct->B / hectx.Delta + hectx.bnd.Brs; }             // :37-38
+}
+
+void he_rs(struct he_ct *ct) { rescale_common(ct, true); }        // src/he-rescale.c:33-54
+void he_rescale(struct he_ct *ct) { rescale_common(ct, true); }
+void he_moddown(he_ct_t *ct) { rescale_common(ct, false); }       // src/he-rescale.c:56-70
+
+}  // extern "C"

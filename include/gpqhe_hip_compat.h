@@ -65,6 +65,26 @@ struct poly_ctx {              /* src/poly.h:49-65 */
 typedef u128 gpq_u128;
 #endif
 
+#ifndef GPQHE_H /* GPQHE's own gpqhe.h not seen: layout-compatible ciphertext / key / context types */
+#ifndef POLY_H
+typedef struct poly_mpi { gpq_MPI *coeffs; } poly_mpi_t;          /* src/poly.h:69-72 */
+typedef struct poly_rns { uint64_t *coeffs; } poly_rns_t;         /* src/poly.h:74-77 */
+#endif
+struct bnd_ctx { double Bclean, Brs, Bks; double *Bmult; };       /* src/gpqhe.h:29-34 */
+struct he_ctx {                                                   /* src/gpqhe.h:36-50 */
+  gpq_MPI P, PqL;
+  gpq_MPI *q, *qh;
+  gpq_MPI p;
+  unsigned int slots;
+  double Delta;
+  unsigned int L, dim, dimevk;
+  struct bnd_ctx bnd;
+  double Bmult;
+};
+typedef struct he_evk { poly_rns_t p0, p1; } he_evk_t;            /* src/gpqhe.h:78-82 */
+typedef struct he_ct { unsigned int l; double nu, B; poly_mpi_t c0, c1; } he_ct_t;   /* src/gpqhe.h:84-91 */
+#endif
+
 /* src/ntt.c:37,54 -- in place on one limb of n = polyctx.n coefficients (host
  * memory); n is read from the global `polyctx` like the reference does
  * (src/ntt.c:26,42).  Synchronous: the limb goes to the GPU and back. */
@@ -84,6 +104,20 @@ uint64_t montgomery_inv(uint64_t q);
 uint64_t montgomery_reduce(gpq_u128 a, uint64_t q, int64_t qinv);
 uint64_t barrett_inv(uint64_t q);
 uint64_t barrett_reduce(gpq_u128 a, uint64_t q, uint64_t qinv);
+
+/* ---- MPI-typed surface (mpi_shim.hip) ---------------------------------------------------
+ * The five names BASELINE.json's north_star lists, with the reference's own signatures and its
+ * libgcrypt types.  Coefficients travel MPI -> device big slab -> MPI through libgcrypt's runtime
+ * ABI (gcry_mpi_print / gcry_mpi_scan, resolved with dlsym from the libgcrypt the host program
+ * already links).  `polyctx` and `hectx` are read like the reference reads them.  Moduli must be
+ * powers of two (every parameter set of the reference's tests); otherwise these abort with the
+ * reference's error convention -- there is no CPU path behind them. */
+void poly_mul(poly_mpi_t *r, const poly_mpi_t *a, const poly_mpi_t *b,
+              const unsigned int dim, const gpq_MPI q);                                 /* src/poly.h:86-87 */
+void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t *rlk);  /* src/gpqhe.h:147  */
+void he_rs(struct he_ct *ct);                                                           /* src/gpqhe.h:136  */
+void he_rescale(struct he_ct *ct);                                                      /* north-star name of he_rs */
+void he_moddown(he_ct_t *ct);                                                           /* src/gpqhe.h:137  */
 
 /* When the host program has no `polyctx` symbol (the library references it
  * weakly), the ring degree for the drop-in calls is set here instead. */

@@ -1,0 +1,190 @@
+/*
+ * mpi_host.c -- a C host with REAL libgcrypt MPIs driving the reference-named, MPI-typed
+ * entry points of libgpqhe_hip.so (poly_mul, he_mul, he_rs, he_rescale, he_moddown), the way
+ * GPQHE's own tests/polymul.c and tests/gpqhe.c drive the reference's.
+ *
+ *   mpi_host polymul                     the two products of tests/polymul.c:59-76 (n = 128, 5 limbs, q = 2^61)
+ *   mpi_host hemul  <in.txt>             he_mul on ciphertexts read as hex, then he_rs, then he_moddown
+ *
+ * It owns `polyctx` and `hectx` (as src/precomp.c:41,47 do) and fills the fields the hot path reads,
+ * following polyctx_init / qtable_init (src/precomp.c:328-409) with libgcrypt arithmetic.
+ * libgcrypt's public functions are declared here by hand: the image has the runtime library only.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gpqhe_hip.h"
+#include "gpqhe_hip_compat.h"
+
+typedef void *MPI;
+MPI gcry_mpi_new(unsigned int nbits);
+void gcry_mpi_release(MPI a);
+MPI gcry_mpi_set_ui(MPI w, unsigned long u);
+MPI gcry_mpi_copy(const MPI a);
+void gcry_mpi_mul(MPI w, MPI u, MPI v);
+void gcry_mpi_mul_ui(MPI w, MPI u, unsigned long v);
+void gcry_mpi_lshift(MPI x, MPI a, unsigned int n);
+void gcry_mpi_rshift(MPI x, MPI a, unsigned int n);
+void gcry_mpi_neg(MPI w, MPI u);
+int gcry_mpi_is_neg(MPI a);
+unsigned int gcry_mpi_get_nbits(MPI a);
+unsigned int gcry_mpi_scan(MPI *ret, int format, const void *buffer, size_t buflen, size_t *nscanned);
+unsigned int gcry_mpi_aprint(int format, unsigned char **buffer, size_t *nwritten, const MPI a);
+void gcry_free(void *p);
+#define FMT_HEX 4
+
+struct poly_ctx polyctx; /* src/precomp.c:41 */
+struct he_ctx hectx;     /* src/precomp.c:47 */
+
+static void print_mpi(MPI a)
+{
+  unsigned char *s = NULL;
+  gcry_mpi_aprint(FMT_HEX, &s, NULL, a);
+  printf("%s\n", (char *)s);
+  gcry_free(s);
+}
+
+static void poly_alloc(poly_mpi_t *a)                      /* poly_mpi_alloc, src/poly.c:46-51 */
+{
+  a->coeffs = malloc(polyctx.n * sizeof(MPI));
+  for (unsigned i = 0; i < polyctx.n; i++) a->coeffs[i] = gcry_mpi_new(0);
+}
+
+static gpq_ctx *tables;
+
+static void ctx_init(unsigned logn, unsigned logq)         /* the RNS part of polyctx_init, src/precomp.c:328-383 */
+{
+  memset(&polyctx, 0, sizeof polyctx);
+  polyctx.logn = logn; polyctx.n = 1u << logn; polyctx.m = 2 * polyctx.n;
+  polyctx.logq = logq; polyctx.logqub = logq;
+  polyctx.logR = 64; polyctx.R = (gpq_u128)1 << 64; polyctx.Rsub1 = polyctx.R - 1;
+  polyctx.dimub = gpq_dimub(logn, logq);
+  if (gpq_ctx_create(&tables, logn, polyctx.dimub, 0) != GPQ_OK) { fprintf(stderr, "%s\n", gpq_last_error()); exit(1); }
+  struct rns_ctx *nodes = calloc(polyctx.dimub, sizeof *nodes);
+  for (unsigned d = 0; d < polyctx.dimub; d++) {
+    nodes[d].dim = d + 1;
+    nodes[d].p = gpq_ctx_const(tables, d, 0);
+    nodes[d].pinv_mont = gpq_ctx_const(tables, d, 1);
+    nodes[d].pinv_barr = gpq_ctx_const(tables, d, 2);
+    nodes[d].ninv = gpq_ctx_const(tables, d, 3);
+    nodes[d].zetas = (uint64_t *)gpq_ctx_zetas(tables, d, 0);
+    nodes[d].zetas_inv = (uint64_t *)gpq_ctx_zetas(tables, d, 1);
+    nodes[d].next = d + 1 < polyctx.dimub ? &nodes[d + 1] : NULL;
+  }
+  polyctx.rns = nodes;
+}
+
+static int polymul(void)
+{
+  ctx_init(7, 61);                                          /* tests/polymul.c:84-93 */
+  MPI q = gcry_mpi_new(0);
+  gcry_mpi_set_ui(q, 1);
+  gcry_mpi_lshift(q, q, 61);
+  polyctx.q = q;
+  poly_mpi_t a, b, r;
+  poly_alloc(&a); poly_alloc(&b); poly_alloc(&r);
+  for (int t = 0; t < 2; t++) {
+    for (unsigned i = 0; i < polyctx.n; i++) {
+      if (t == 0) { gcry_mpi_set_ui(a.coeffs[i], i + 2); gcry_mpi_set_ui(b.coeffs[i], i + 3); }             /* :60-63 */
+      else { gcry_mpi_set_ui(a.coeffs[i], polyctx.rns->p - i - 1); gcry_mpi_set_ui(b.coeffs[i], polyctx.rns->next->p - i - 1); } /* :69-74 */
+    }
+    poly_mul(&r, &a, &b, polyctx.dimub, polyctx.q);         /* :64, :75 */
+    for (unsigned i = 0; i < polyctx.n; i++) print_mpi(r.coeffs[i]);
+  }
+  return 0;
+}
+
+static uint64_t splitmix64(uint64_t *s)
+{
+  uint64_t z = (*s += 0x9e3779b97f4a7c15ull);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+static void read_poly(FILE *f, poly_mpi_t *a)
+{
+  char *line = malloc(4096);
+  for (unsigned i = 0; i < polyctx.n; i++) {
+    if (!fgets(line, 4096, f)) exit(3);
+    line[strcspn(line, "\n")] = 0;
+    MPI t = NULL;
+    const int neg = line[0] == '-';
+    gcry_mpi_scan(&t, FMT_HEX, line + neg, 0, NULL);
+    if (neg) gcry_mpi_neg(t, t);
+    gcry_mpi_release(a->coeffs[i]);
+    a->coeffs[i] = t;
+  }
+  free(line);
+}
+
+static int hemul(const char *path)
+{
+  FILE *f = fopen(path, "r");
+  unsigned logn, logq, logDelta, level;
+  if (!f || fscanf(f, "%u %u %u %u\n", &logn, &logq, &logDelta, &level) != 4) return 3;
+  ctx_init(logn, logq);
+  /* qtable_init, src/precomp.c:386-409 */
+  MPI q = gcry_mpi_new(0);
+  gcry_mpi_set_ui(q, 1); gcry_mpi_lshift(q, q, logq);
+  polyctx.q = q;
+  hectx.p = gcry_mpi_new(0);
+  gcry_mpi_set_ui(hectx.p, 1); gcry_mpi_lshift(hectx.p, hectx.p, logDelta);
+  hectx.Delta = (double)(1ull << logDelta);
+  hectx.L = logq / logDelta;
+  hectx.q = malloc((hectx.L + 1) * sizeof(MPI)); hectx.qh = malloc((hectx.L + 1) * sizeof(MPI));
+  MPI cur = gcry_mpi_copy(q);
+  for (int l = (int)hectx.L; l >= 0; l--) {
+    hectx.q[l] = gcry_mpi_copy(cur);
+    hectx.qh[l] = gcry_mpi_new(0); gcry_mpi_rshift(hectx.qh[l], cur, 1);
+    gcry_mpi_rshift(cur, cur, logDelta);
+  }
+  hectx.dim = (gcry_mpi_get_nbits(hectx.q[hectx.L]) + logn) / 59 + 1;
+  hectx.P = gcry_mpi_new(0); gcry_mpi_set_ui(hectx.P, 1);
+  struct rns_ctx *r = polyctx.rns;
+  for (unsigned d = 0; d < hectx.dim; d++, r = r->next) gcry_mpi_mul_ui(hectx.P, hectx.P, r->p);
+  hectx.PqL = gcry_mpi_new(0); gcry_mpi_mul(hectx.PqL, hectx.P, q);
+  hectx.dimevk = (gcry_mpi_get_nbits(hectx.q[hectx.L]) + gcry_mpi_get_nbits(hectx.PqL) + logn) / 59 + 1;
+  hectx.bnd.Brs = 11.5; hectx.bnd.Bmult = malloc((hectx.L + 1) * sizeof(double));
+  for (unsigned l = 0; l <= hectx.L; l++) hectx.bnd.Bmult[l] = 100.0 + l;
+  printf("dims %u %u %u\n", hectx.dim, hectx.dimevk, hectx.L);
+
+  he_ct_t ct1, ct2, ct;
+  poly_alloc(&ct1.c0); poly_alloc(&ct1.c1); poly_alloc(&ct2.c0); poly_alloc(&ct2.c1); poly_alloc(&ct.c0); poly_alloc(&ct.c1);
+  read_poly(f, &ct1.c0); read_poly(f, &ct1.c1); read_poly(f, &ct2.c0); read_poly(f, &ct2.c1);
+  ct1.l = ct2.l = level; ct1.nu = 3.0; ct1.B = 5.0; ct2.nu = 7.0; ct2.B = 11.0;
+  he_evk_t rlk;                                              /* he_alloc_evk, src/he-mem.c:42-46; synthetic NTT-domain key */
+  rlk.p0.coeffs = malloc((size_t)hectx.dimevk * polyctx.n * 8); rlk.p1.coeffs = malloc((size_t)hectx.dimevk * polyctx.n * 8);
+  uint64_t s0 = 3000, s1 = 3001;
+  r = polyctx.rns;
+  for (unsigned d = 0; d < hectx.dimevk; d++, r = r->next)
+    for (unsigned i = 0; i < polyctx.n; i++) {
+      rlk.p0.coeffs[(size_t)d * polyctx.n + i] = splitmix64(&s0) % r->p;
+      rlk.p1.coeffs[(size_t)d * polyctx.n + i] = splitmix64(&s1) % r->p;
+    }
+  he_mul(&ct, &ct1, &ct2, &rlk);                             /* tests/gpqhe.c:458 */
+  printf("he_mul %u %.17g %.17g\n", ct.l, ct.nu, ct.B);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(ct.c0.coeffs[i]);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(ct.c1.coeffs[i]);
+  he_rescale(&ct);                                           /* he_rs, tests/gpqhe.c:480 */
+  printf("he_rs %u %.17g %.17g\n", ct.l, ct.nu, ct.B);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(ct.c0.coeffs[i]);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(ct.c1.coeffs[i]);
+  he_moddown(&ct);                                           /* tests/gpqhe.c:498 */
+  printf("he_moddown %u\n", ct.l);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(ct.c0.coeffs[i]);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(ct.c1.coeffs[i]);
+  he_mul(&ct, &ct, &ct, &rlk);                               /* aliased operands, as src/he-algo.c:151 */
+  printf("he_sq %u\n", ct.l);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(ct.c0.coeffs[i]);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(ct.c1.coeffs[i]);
+  return 0;
+}
+
+int main(int argc, char **argv)
+{
+  if (argc >= 2 && !strcmp(argv[1], "polymul")) return polymul();
+  if (argc >= 3 && !strcmp(argv[1], "hemul")) return hemul(argv[2]);
+  return 2;
+}

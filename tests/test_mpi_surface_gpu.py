@@ -1,0 +1,100 @@
+"""The MPI-typed reference surface (poly_mul, he_mul, he_rs / he_rescale, he_moddown with the signatures of
+src/poly.h:86-87 and src/gpqhe.h:136-137,147) driven from C with real libgcrypt MPIs (tests/c/mpi_host.c),
+checked against the Python-integer restatement of the reference.  `mpi_host polymul` is tests/polymul.c."""
+import os
+import random
+import subprocess
+
+import pytest
+
+from oracle import bigint_ref as ref
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def mpi_host(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("mpi") / "mpi_host")
+    lib_dir = os.path.join(ROOT, "gpqhe_amd")
+    subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "mpi_host.c"),
+                           "-L", lib_dir, "-lgpqhe_hip", "-l:libgcrypt.so.20", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+    return out
+
+
+def _ints(lines):
+    return [int(s, 16) for s in lines]
+
+
+def test_polymul_c_kat_through_reference_signature(mpi_host, oracle_ctx):
+    res = subprocess.run([mpi_host, "polymul"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    vals = _ints(res.stdout.split())
+    assert len(vals) == 256
+    o = oracle_ctx(7, 5)
+    N, Q = 128, 1 << 61
+    cases = [([i + 2 for i in range(N)], [i + 3 for i in range(N)]),
+             ([o.p[0] - i - 1 for i in range(N)], [o.p[1] - i - 1 for i in range(N)])]
+    leading = [[382784, 357372, 332350], [18559595904, 18272672062, 17985699960]]   # the reference's own printout
+    for t, ((a, b), lead) in enumerate(zip(cases, leading)):
+        got = vals[t * N:(t + 1) * N]
+        assert got == [ref.centred_mod(v, Q) for v in ref.negacyclic_mul(a, b)]     # tests/polymul.gp
+        assert [got[127], got[126], got[125]] == lead
+
+
+def test_he_mul_he_rs_he_moddown_with_real_mpis(mpi_host, oracle_ctx, tmp_path):
+    logn, logq, logDelta = 7, 120, 30
+    n, L = 1 << logn, logq // logDelta
+    level = L
+    rng = random.Random(42)
+    h = 1 << (logq - 1)
+    polys = [[rng.randrange(-h, h) for _ in range(n)] for _ in range(4)]
+    for p in polys:
+        p[:4] = [0, -1, h - 1, -h]
+    path = tmp_path / "in.txt"
+    with open(path, "w") as f:
+        f.write("%d %d %d %d\n" % (logn, logq, logDelta, level))
+        for p in polys:
+            for v in p:
+                f.write(("-%X\n" % -v) if v < 0 else ("%X\n" % v))
+    res = subprocess.run([mpi_host, "hemul", str(path)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    lines = res.stdout.split("\n")
+    dimub = (1 + logn + 4 * logq) // 59 + 1
+    o = oracle_ctx(logn, dimub)
+    dimP, dimA, dimB, dimevk = ref.he_dims(logn, o.p, logq, logq)
+    assert lines[0].split() == ["dims", str(dimP), str(dimevk), str(L)]
+    rlk0, rlk1 = o.gen(3000, dimevk), o.gen(3001, dimevk)
+
+    # he_mul at level L (src/he-mult.c:88-156); nu and B as :93-95
+    hdr = lines[1].split()
+    assert hdr[0] == "he_mul" and int(hdr[1]) == level
+    assert float(hdr[2]) == 3.0 * 7.0 and float(hdr[3]) == 3.0 * 11.0 + 7.0 * 5.0 + 5.0 * 11.0 + (100.0 + level)
+    c0, c1 = _ints(lines[2:2 + n]), _ints(lines[2 + n:2 + 2 * n])
+    e0, e1 = ref.he_mul(o, (polys[0], polys[1]), (polys[2], polys[3]), rlk0[: dimB * n], rlk1[: dimB * n], dimP, dimA, dimB, logq)
+    assert c0 == e0 and c1 == e1
+
+    # he_rescale = he_rs (src/he-rescale.c:33-54)
+    base = 2 + 2 * n
+    hdr = lines[base].split()
+    assert hdr[0] == "he_rs" and int(hdr[1]) == level - 1
+    assert float(hdr[2]) == 21.0 / 2.0**logDelta
+    ql1 = 1 << (logq - logDelta)
+    r0 = [ref.mpi_smod(ref.mpi_rdiv(v, 1 << logDelta), ql1) for v in e0]
+    r1 = [ref.mpi_smod(ref.mpi_rdiv(v, 1 << logDelta), ql1) for v in e1]
+    assert _ints(lines[base + 1:base + 1 + n]) == r0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == r1
+
+    # he_moddown (src/he-rescale.c:56-70)
+    base += 1 + 2 * n
+    assert lines[base].split() == ["he_moddown", str(level - 2)]
+    ql2 = 1 << (logq - 2 * logDelta)
+    m0, m1 = [ref.mpi_smod(v, ql2) for v in r0], [ref.mpi_smod(v, ql2) for v in r1]
+    assert _ints(lines[base + 1:base + 1 + n]) == m0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == m1
+
+    # he_mul(&ct, &ct, &ct, rlk): output aliases both operands (src/he-algo.c:151), level L-2
+    base += 1 + 2 * n
+    assert lines[base].split() == ["he_sq", str(level - 2)]
+    logql = logq - 2 * logDelta
+    dP2, dA2, dB2, _ = ref.he_dims(logn, o.p, logq, logql)
+    s0, s1 = ref.he_mul(o, (m0, m1), (m0, m1), rlk0[: dB2 * n], rlk1[: dB2 * n], dP2, dA2, dB2, logql)
+    assert _ints(lines[base + 1:base + 1 + n]) == s0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == s1

@@ -69,6 +69,17 @@ __device__ __forceinline__ void ct_v8(uint64_t &x, uint64_t &y, uint64_t w, cons
   const uint64_t xs = x + (ge ? k.kx1 : k.kx0);
   x = xs + t; y = (xs + (k.ky + 1)) + ~t;
 }
+// v10/v11: two consecutive stages on 4 values (radix-4 shape) -- per-stage csub(4p) vs one csub(6p) per two stages
+__device__ __forceinline__ void ct_nocsub(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k, uint64_t kc1, uint64_t ky3) {
+  const uint64_t t = mulmod_pin(y, w, k);       // x' = x + t + (c+1), y' = x + 3p - t - (c+1)
+  const uint64_t xs = x + kc1;
+  x = xs + t; y = xs + ky3 - t;
+}
+__device__ __forceinline__ void ct_csub6(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k, uint64_t p6, uint64_t k61, uint64_t k60, uint64_t ky3) {
+  const uint64_t t = mulmod_pin(y, w, k);
+  const uint64_t xs = x + (x >= p6 ? k61 : k60);
+  x = xs + t; y = xs + ky3 - t;
+}
 // v3: no conditional subtract at all (bounds not kept; timing only)
 __device__ __forceinline__ void ct_v3(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k) {
   const uint64_t t = mulmod_raw(y, w, k);
@@ -94,6 +105,26 @@ __global__ __launch_bounds__(256) void probe(uint64_t *out, uint64_t seed, Prime
   uint64_t v[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = seed * (threadIdx.x + 1 + 64 * i) + blockIdx.x;
+  const uint64_t p6 = 6 * k.p, ky3 = 3 * k.p - 2 * (uint64_t)k.c1, k60 = k.c1, k61 = (uint64_t)k.c1 - p6;
+  if (V == 10 || V == 11) {
+    for (int it = 0; it < ITER / 2; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] &= 0x3fffffffffffffffull;
+      // stage 1: pairs (0,2),(1,3),(4,6),(5,7); stage 2: pairs (0,1),(2,3),(4,5),(6,7)
+#pragma unroll
+      for (int g = 0; g < 8; g += 4) {
+        const uint64_t w = k.p - 3 - g;
+        if (V == 10) { ct_v6(v[g], v[g + 2], w, k); ct_v6(v[g + 1], v[g + 3], w, k); ct_v6(v[g], v[g + 1], w - 1, k); ct_v6(v[g + 2], v[g + 3], w - 2, k); }
+        else { ct_nocsub(v[g], v[g + 2], w, k, k60, ky3); ct_nocsub(v[g + 1], v[g + 3], w, k, k60, ky3);
+               ct_csub6(v[g], v[g + 1], w - 1, k, p6, k61, k60, ky3); ct_csub6(v[g + 2], v[g + 3], w - 2, k, p6, k61, k60, ky3); }
+      }
+    }
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc ^= v[i];
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+    return;
+  }
   for (int it = 0; it < ITER; ++it) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -141,7 +172,8 @@ int main() {
   for (int w : {8, 4, 2}) {
     if (w == 8) { run<0>("ct v0 (first formulation)", d_out, k, 8); run<1>("ct v1 (current)", d_out, k, 8); run<2>("ct v2 (approx csub)", d_out, k, 8);
                   run<3>("ct v3 (no csub)", d_out, k, 8); run<4>("mulmod only", d_out, k, 8); run<5>("4-mad product only", d_out, k, 8); run<6>("gs (current)", d_out, k, 8);
-                  run<7>("ct v6 (pinned mid)", d_out, k, 8); run<8>("ct v7 (pinned + approx csub)", d_out, k, 8); run<9>("ct v8 (v7, y via ~t)", d_out, k, 8); }
+                  run<7>("ct v6 (pinned mid)", d_out, k, 8); run<8>("ct v7 (pinned + approx csub)", d_out, k, 8); run<9>("ct v8 (v7, y via ~t)", d_out, k, 8);
+                  run<10>("2 stages, csub(4p) each", d_out, k, 8); run<11>("2 stages, one csub(6p)", d_out, k, 8); }
     if (w == 4) { run<0>("ct v0", d_out, k, 4); run<1>("ct v1", d_out, k, 4); }
     if (w == 2) { run<0>("ct v0", d_out, k, 2); run<1>("ct v1", d_out, k, 2); }
   }
