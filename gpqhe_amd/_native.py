@@ -49,6 +49,9 @@ SIGNATURES = {
     "gpq_set_exact_crt": (C.c_int, [vp, C.c_int]),
     "gpq_poly_mul_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
     "gpq_poly_mul": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
+    "gpq_poly_mul_general_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
+    "gpq_rns_reconstruct_general": (C.c_int, [vp, vp, C.c_uint, vp, C.c_uint, C.c_uint, C.POINTER(u64), C.c_uint, vp, vp]),
+    "gpq_poly_mul_general": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.POINTER(u64), C.c_uint, C.c_uint, vp, vp]),
     "gpq_he_rs": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp]),
     "gpq_he_rescale": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp]),
     "gpq_he_dims": (C.c_int, [vp, C.c_uint, C.c_uint] + [C.POINTER(C.c_uint)] * 4),

@@ -46,6 +46,32 @@ void put(std::vector<uint64_t> &dst, size_t off, const Big &v, size_t words) {
 
 const int kWP[] = {8, 16, 32, 48, 56};
 
+// ---- host big integers for the general-modulus path (sizes of a few thousand bits) ----
+int cmp_big(const Big &a, const Big &b) {
+  size_t na = a.size(), nb = b.size();
+  while (na > 1 && a[na - 1] == 0) --na;
+  while (nb > 1 && b[nb - 1] == 0) --nb;
+  if (na != nb) return na < nb ? -1 : 1;
+  for (size_t i = na; i-- > 0;) if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+  return 0;
+}
+void sub_big(Big &a, const Big &b) {  // a -= b, a >= b
+  uint64_t bor = 0;
+  for (size_t i = 0; i < a.size(); ++i) {
+    const u128h d = (u128h)a[i] - (i < b.size() ? b[i] : 0) - bor;
+    a[i] = (uint64_t)d; bor = (uint64_t)(d >> 64) & 1;
+  }
+}
+Big floor_pow2_div(unsigned bits, const Big &m) {  // floor(2^bits / m), restoring division bit by bit
+  Big q((bits + 64) / 64, 0), rem(m.size() + 1, 0);
+  for (int b = (int)bits; b >= 0; --b) {
+    uint64_t c = b == (int)bits ? 1 : 0;           // shift rem left by one, bring in the next dividend bit
+    for (size_t i = 0; i < rem.size(); ++i) { const uint64_t n = rem[i] >> 63; rem[i] = (rem[i] << 1) | c; c = n; }
+    if (cmp_big(rem, m) >= 0) { sub_big(rem, m); q[b >> 6] |= 1ull << (b & 63); }
+  }
+  return q;
+}
+
 // CRT constants of primes first .. first+dim-1: what struct rns_ctx node dim-1 holds for first = 0
 // (src/poly.h:35-38); sub-ranges serve the exact division of he_relin.
 int get_basis(gpq_ctx *c, unsigned first, unsigned dim, gpq_bridge_basis **out) {
@@ -449,4 +475,59 @@ extern "C" long gpq_debug_redo_count(gpq_ctx *c, size_t count) {
   long k = 0;
   for (unsigned char v : h) k += v != 0;
   return k;
+}
+
+// ---------------------------------------------------------------------------
+// general modulus: poly_rns2mpi / poly_mul for any q given as little-endian words
+// ---------------------------------------------------------------------------
+extern "C" size_t gpq_poly_mul_general_workspace_bytes(gpq_ctx *c, unsigned dim, unsigned batch) {
+  gpq_bridge_basis *b;
+  if (get_basis(c, 0, dim, &b) != GPQ_OK) return 0;
+  return gpq_poly_mul_workspace_bytes(c, dim, batch) + (size_t)batch * ((size_t)(b->WP + 1) << c->logn) * 8 + 3 * 8 * 64 + 64;
+}
+
+// poly_rns2mpi (src/poly.c:109-120) for an arbitrary q: centred CRT value, then mpi_smod(., q, floor(q/2)).
+// q = q_words[0..Lq) little-endian; `scratch` holds batch*(WP+1)*n words + 3*64 words.
+extern "C" int gpq_rns_reconstruct_general(gpq_ctx *c, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned dim, unsigned batch,
+                                           const uint64_t *q_words, unsigned Lq, void *scratch, void *stream) {
+  int rc = check(c, dim, batch, "gpq_rns_reconstruct_general");
+  if (rc) return rc;
+  if (!big || !slab || !q_words || !scratch || Lq < 1 || Lq > (unsigned)SMOD_MAXW / 2) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct_general: bad arguments");
+  gpq_bridge_basis *b;
+  if ((rc = get_basis(c, 0, dim, &b))) return rc;
+  Big M(q_words, q_words + Lq);
+  while (M.size() > 1 && M.back() == 0) M.pop_back();
+  const unsigned L = (unsigned)M.size();
+  if (L == 1 && M[0] == 0) return gpq_fail(GPQ_ERR_INVALID, "zero modulus");
+  const unsigned Wx = b->WP + 1;
+  if (Wx > (unsigned)SMOD_MAXW) return gpq_fail(GPQ_ERR_UNSUPPORTED, "general modulus: CRT value of %u words", Wx);
+  if (Wout < L) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct_general: %u words cannot hold a value mod q (%u words)", Wout, L);
+  Big mu = floor_pow2_div(128 * L, M), half = M;
+  shr1(half);
+  std::vector<uint64_t> consts(3 * 64, 0);
+  put(consts, 0, M, L); put(consts, 64, mu, L + 1); put(consts, 128, half, L);
+  hipStream_t s = (hipStream_t)stream;
+  uint64_t *xfull = (uint64_t *)scratch, *dconst = xfull + (size_t)batch * ((size_t)Wx << c->logn);
+  HIP_TRY(hipMemcpyAsync(dconst, consts.data(), consts.size() * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));   // consts is a local
+  const bool was = c->exact_crt;
+  if ((rc = launch_reconstruct(c, b, xfull, Wx, slab, dim, 0, batch, 0, true, nullptr, s))) return rc;   // centred mod P, full width
+  (void)was;
+  SmodArgs a{xfull, big, dconst, dconst + 64, dconst + 128, Wx, Wout, L, c->logn};
+  hipLaunchKernelGGL(bridge_smod_general, dim3((c->n + 63) / 64, batch), dim3(64), 0, s, a);
+  return launched("gpq_rns_reconstruct_general");
+}
+
+// poly_mul (src/poly.c:84-107) for an arbitrary modulus q.
+extern "C" int gpq_poly_mul_general(gpq_ctx *c, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned W, unsigned dim,
+                                    const uint64_t *q_words, unsigned Lq, unsigned batch, void *workspace, void *stream) {
+  int rc = check(c, dim, batch, "gpq_poly_mul_general");
+  if (rc) return rc;
+  if (!r || !a || !b || !workspace) return gpq_fail(GPQ_ERR_INVALID, "gpq_poly_mul_general: bad arguments");
+  const size_t poly = (size_t)dim << c->logn;
+  uint64_t *sa = (uint64_t *)workspace, *sb = sa + batch * poly, *sr = sb + batch * poly, *scratch = sr + batch * poly;
+  if ((rc = gpq_rns_decompose(c, sa, a, W, dim, batch, stream))) return rc;
+  if ((rc = gpq_rns_decompose(c, sb, b, W, dim, batch, stream))) return rc;
+  if ((rc = gpq_poly_mul_rns(c, sr, sa, sb, dim, batch, stream))) return rc;
+  return gpq_rns_reconstruct_general(c, r, W, sr, dim, batch, q_words, Lq, scratch, stream);
 }

@@ -343,6 +343,116 @@ __global__ __launch_bounds__(256) void bridge_addround(AddRoundArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// mpi_smod(x, M, floor(M/2)) for an arbitrary modulus M of L words (src/types.c:108-113): the general
+// form of the second centring of poly_rns2mpi, needed when q is not a power of two (he_genswk calls
+// poly_mul with q = P*q_L, src/he-kem.c:95).  Multiword Barrett (HAC 14.42, base 2^64) on |x| with
+// mu = floor(2^(128 L) / M), then the sign and the centring.  Key-generation path: written for
+// generality, not speed (runtime word loops, per-thread arrays in scratch).
+// ---------------------------------------------------------------------------
+constexpr int SMOD_MAXW = 96;     // x of at most 96 words, modulus of at most 48
+
+struct SmodArgs {
+  const uint64_t *x;       // [polys][Wx][n]  two's complement
+  uint64_t *out;           // [polys][Wout][n]
+  const uint64_t *M;       // [L]
+  const uint64_t *mu;      // [L+1]
+  const uint64_t *Mhalf;   // [L]  floor(M/2)
+  unsigned Wx, Wout, L, logn;
+};
+
+__global__ __launch_bounds__(64) void bridge_smod_general(SmodArgs a) {
+  const unsigned i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= (1u << a.logn)) return;
+  const unsigned L = a.L, Wx = a.Wx;
+  const uint64_t *__restrict__ xs = a.x + ((size_t)blockIdx.y * Wx << a.logn) + i;
+  uint64_t ax[SMOD_MAXW + 2], v[SMOD_MAXW + 2], q2[SMOD_MAXW + 4], r[SMOD_MAXW / 2 + 3];
+  // |x|
+  const bool neg = xs[(size_t)(Wx - 1) << a.logn] >> 63;
+  uint64_t carry = neg;
+  for (unsigned j = 0; j < Wx; ++j) {
+    uint64_t w = xs[(size_t)j << a.logn];
+    if (neg) { w = ~w + carry; carry = carry && w == 0; }
+    ax[j] = w;
+  }
+  // Horner in base b^L from the top block down: r <- (r * b^L + block) mod M, each step one Barrett
+  // reduction of a 2L-word value (r < M < b^L, so the value is below b^(2L) as HAC 14.42 needs)
+  for (unsigned j = 0; j <= L; ++j) r[j] = 0;
+  const unsigned nblk = (Wx + L - 1) / L;
+  for (int blk = (int)nblk - 1; blk >= 0; --blk) {
+    for (unsigned j = 0; j < L; ++j) { const unsigned w = blk * L + j; v[j] = w < Wx ? ax[w] : 0; v[L + j] = r[j]; }
+    v[2 * L] = 0;
+    // q3 = floor( floor(v / b^(L-1)) * mu / b^(L+1) ),  q1 has L+1 words, mu has L+1 words
+    for (unsigned j = 0; j < 2 * L + 3; ++j) q2[j] = 0;
+    for (unsigned s = 0; s <= L; ++s) {
+      const uint64_t q1 = v[L - 1 + s];
+      uint64_t c = 0;
+      for (unsigned t = 0; t <= L; ++t) {
+        const u128 p = (u128)q1 * a.mu[t] + q2[s + t] + c;
+        q2[s + t] = (uint64_t)p;
+        c = (uint64_t)(p >> 64);
+      }
+      q2[s + L + 1] += c;
+    }
+    // r = (v - q3*M) mod b^(L+1);  q3 = q2[L+1 ..]
+    for (unsigned j = 0; j <= L; ++j) r[j] = v[j];
+    for (unsigned s = 0; s <= L; ++s) {
+      const uint64_t q3 = q2[L + 1 + s];
+      uint64_t c = 0, bor = 0;
+      for (unsigned t = 0; s + t <= L; ++t) {
+        const u128 p = (u128)q3 * (t < L ? a.M[t] : 0) + c;
+        c = (uint64_t)(p >> 64);
+        const u128 d = (u128)r[s + t] - (uint64_t)p - bor;
+        r[s + t] = (uint64_t)d;
+        bor = (uint64_t)(d >> 64) & 1;
+      }
+    }
+    // at most two corrective subtractions (HAC 14.42 step 4)
+    for (int rep = 0; rep < 3; ++rep) {
+      uint64_t bor = 0;
+      uint64_t t_[SMOD_MAXW / 2 + 3];
+      for (unsigned j = 0; j <= L; ++j) {
+        const u128 d = (u128)r[j] - (j < L ? a.M[j] : 0) - bor;
+        t_[j] = (uint64_t)d;
+        bor = (uint64_t)(d >> 64) & 1;
+      }
+      if (!bor) for (unsigned j = 0; j <= L; ++j) r[j] = t_[j];
+    }
+  }
+  // sign: (-|x|) mod M = M - r unless r == 0
+  if (neg) {
+    uint64_t any = 0;
+    for (unsigned j = 0; j <= L; ++j) any |= r[j];
+    if (any) {
+      uint64_t bor = 0;
+      for (unsigned j = 0; j <= L; ++j) {
+        const u128 d = (u128)(j < L ? a.M[j] : 0) - r[j] - bor;
+        r[j] = (uint64_t)d;
+        bor = (uint64_t)(d >> 64) & 1;
+      }
+    }
+  }
+  // centre: r >= floor(M/2) -> r - M
+  {
+    uint64_t bor = 0;
+    for (unsigned j = 0; j <= L; ++j) {
+      const u128 d = (u128)r[j] - (j < L ? a.Mhalf[j] : 0) - bor;
+      bor = (uint64_t)(d >> 64) & 1;
+    }
+    if (!bor) {
+      uint64_t b2 = 0;
+      for (unsigned j = 0; j <= L; ++j) {
+        const u128 d = (u128)r[j] - (j < L ? a.M[j] : 0) - b2;
+        r[j] = (uint64_t)d;
+        b2 = (uint64_t)(d >> 64) & 1;
+      }
+    }
+  }
+  uint64_t *__restrict__ dst = a.out + ((size_t)blockIdx.y * a.Wout << a.logn) + i;
+  const uint64_t fill = (uint64_t)((int64_t)r[L] >> 63);
+  for (unsigned j = 0; j < a.Wout; ++j) dst[(size_t)j << a.logn] = j <= L ? r[j] : fill;
+}
+
+// ---------------------------------------------------------------------------
 // he_rs on one big slab, Delta = 2^s and q_l = 2^logql (the reference's test
 // parameters, tests/gpqhe.c:1349-1352): c <- smod(rdiv(c, Delta), q_l), in place.
 //   rdiv: floor(c / 2^s) = arithmetic shift; plus one when (c mod 2^s) > 2^(s-1)

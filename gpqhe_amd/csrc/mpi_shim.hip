@@ -66,17 +66,26 @@ void need_gcrypt() {
   G.ok = true;
 }
 
-// log2 of a power-of-two MPI; dies otherwise (general moduli have no device path yet)
-unsigned log2_exact(MPI q, const char *what) {
+// magnitude of a positive MPI as little-endian words
+std::vector<uint64_t> words_of(MPI q, const char *what) {
   const unsigned nb = G.mpi_get_nbits(q);
   if (!nb || G.mpi_is_neg(q)) die(what);
   std::vector<unsigned char> buf((nb + 7) / 8);
   size_t nw = 0;
   if (G.mpi_print(FMT_USG, buf.data(), buf.size(), &nw, q)) die("gcry_mpi_print failed");
+  std::vector<uint64_t> w((nb + 63) / 64, 0);
+  for (size_t b = 0; b < nw; ++b) w[(nw - 1 - b) >> 3] |= (uint64_t)buf[b] << (8 * ((nw - 1 - b) & 7));
+  return w;
+}
+bool is_pow2(const std::vector<uint64_t> &w) {
   unsigned ones = 0;
-  for (size_t i = 0; i < nw; ++i) ones += __builtin_popcount(buf[i]);
-  if (ones != 1) die(what);
-  return nb - 1;
+  for (uint64_t v : w) ones += __builtin_popcountll(v);
+  return ones == 1;
+}
+// log2 of a power-of-two MPI; dies otherwise (he_mul / he_rs need q_l and Delta = 2^k on the device)
+unsigned log2_exact(MPI q, const char *what) {
+  if (!is_pow2(words_of(q, what))) die(what);
+  return G.mpi_get_nbits(q) - 1;
 }
 
 unsigned max_bits(const poly_mpi_t *a, unsigned n) {
@@ -163,18 +172,22 @@ extern "C" {
 void poly_mul(poly_mpi_t *r, const poly_mpi_t *a, const poly_mpi_t *b, const unsigned int dim, const gpq_MPI q) {
   need_gcrypt();
   gpq_ctx *c = engine();
-  const unsigned n = polyctx.n, logq = log2_exact(q, "poly_mul: the modulus must be a power of two");
+  const unsigned n = polyctx.n;
+  const std::vector<uint64_t> qw = words_of(q, "poly_mul: the modulus must be positive");
+  const unsigned nbq = G.mpi_get_nbits(q);
   unsigned bits = max_bits(a, n), bb = max_bits(b, n);
   if (bb > bits) bits = bb;
-  if (logq > bits) bits = logq;
+  if (nbq > bits) bits = nbq;
   const unsigned W = bits / 64 + 1;
   if (W > 32) die("poly_mul: coefficients wider than 2047 bits");
   std::vector<uint64_t> ha((size_t)W * n), hb((size_t)W * n), hr((size_t)W * n);
   to_slab(ha.data(), a, n, W);
   to_slab(hb.data(), b, n, W);
-  DevBuf da(ha.size() * 8), db(hb.size() * 8), dr(hr.size() * 8), ws(gpq_poly_mul_workspace_bytes(c, dim, 1));
+  DevBuf da(ha.size() * 8), db(hb.size() * 8), dr(hr.size() * 8), ws(gpq_poly_mul_general_workspace_bytes(c, dim, 1));
   up(da, ha); up(db, hb);
-  if (gpq_poly_mul(c, dr.u64(), da.u64(), db.u64(), W, dim, logq, 1, ws.p, nullptr) != GPQ_OK) die("poly_mul failed");
+  const int rc = is_pow2(qw) ? gpq_poly_mul(c, dr.u64(), da.u64(), db.u64(), W, dim, nbq - 1, 1, ws.p, nullptr)
+                             : gpq_poly_mul_general(c, dr.u64(), da.u64(), db.u64(), W, dim, qw.data(), (unsigned)qw.size(), 1, ws.p, nullptr);
+  if (rc != GPQ_OK) die("poly_mul failed");   // q = P*q_L in he_genswk (src/he-kem.c:95) takes the general path
   down(hr, dr);
   from_slab(r, hr.data(), n, W);
 }

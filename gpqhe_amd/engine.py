@@ -105,6 +105,17 @@ class PolyContext:
         _native.check(self.lib.gpq_poly_mul(self.h, _ptr(r), _ptr(a), _ptr(b), W, dim, logq, batch, _ptr(ws), _stream()), "gpq_poly_mul")
         return r
 
+    def poly_mul_general(self, r, a, b, W, dim, q):
+        """src/poly.c:84-107 on big slabs for an arbitrary modulus q (Python int)."""
+        torch = _torch()
+        batch = a.numel() // (W * self.n)
+        Lq = (q.bit_length() + 63) // 64
+        qw = (_native.u64 * Lq)(*[(q >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(Lq)])
+        ws = torch.empty(self.lib.gpq_poly_mul_general_workspace_bytes(self.h, dim, batch) // 8 + 8, dtype=torch.int64, device="cuda")
+        _native.check(self.lib.gpq_poly_mul_general(self.h, _ptr(r), _ptr(a), _ptr(b), W, dim, qw, Lq, batch, _ptr(ws), _stream()),
+                      "gpq_poly_mul_general")
+        return r
+
     def he_rs(self, c0, c1, W, logDelta, logql):
         """src/he-rescale.c:33-54 with Delta = 2^logDelta, q_l = 2^logql, in place."""
         batch = c0.numel() // (W * self.n)

@@ -155,6 +155,15 @@ int gpq_set_exact_crt(gpq_ctx *ctx, int on);
 size_t gpq_poly_mul_workspace_bytes(const gpq_ctx *ctx, unsigned dim, unsigned batch);
 int gpq_poly_mul(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned W, unsigned dim, unsigned logq,
                  unsigned batch, void *workspace, void *stream);
+/* The same two for ANY modulus q (little-endian words q_words[0..Lq)): he_genswk calls poly_mul with
+ * q = P*q_L (src/he-kem.c:95).  Second centring by multiword Barrett reduction; a key-generation path,
+ * not tuned (Horner over Lq-word blocks, one Barrett step each). */
+size_t gpq_poly_mul_general_workspace_bytes(gpq_ctx *ctx, unsigned dim, unsigned batch);
+int gpq_rns_reconstruct_general(gpq_ctx *ctx, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned dim, unsigned batch,
+                                const uint64_t *q_words, unsigned Lq, void *scratch, void *stream);
+int gpq_poly_mul_general(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned W, unsigned dim,
+                         const uint64_t *q_words, unsigned Lq, unsigned batch, void *workspace, void *stream);
+
 /* he_rs, src/he-rescale.c:33-54 (decl src/gpqhe.h:136), Delta = 2^logDelta, q_l = 2^logql: c0, c1 of
  * `batch` ciphertexts in place: mpi_rdiv by Delta then mpi_smod q_l.  The l / nu / B bookkeeping
  * (:36-38) stays with the caller.  gpq_he_rescale is the north-star spelling of the same call. */

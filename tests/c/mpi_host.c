@@ -23,6 +23,7 @@ void gcry_mpi_release(MPI a);
 MPI gcry_mpi_set_ui(MPI w, unsigned long u);
 MPI gcry_mpi_copy(const MPI a);
 void gcry_mpi_mul(MPI w, MPI u, MPI v);
+void gcry_mpi_add(MPI w, MPI u, MPI v);
 void gcry_mpi_mul_ui(MPI w, MPI u, unsigned long v);
 void gcry_mpi_lshift(MPI x, MPI a, unsigned int n);
 void gcry_mpi_rshift(MPI x, MPI a, unsigned int n);
@@ -75,12 +76,13 @@ static void ctx_init(unsigned logn, unsigned logq)         /* the RNS part of po
   polyctx.rns = nodes;
 }
 
-static int polymul(void)
+static int polymul(int odd_modulus)
 {
   ctx_init(7, 61);                                          /* tests/polymul.c:84-93 */
   MPI q = gcry_mpi_new(0);
-  gcry_mpi_set_ui(q, 1);
+  gcry_mpi_set_ui(q, odd_modulus ? 3 : 1);
   gcry_mpi_lshift(q, q, 61);
+  if (odd_modulus) { MPI seven = gcry_mpi_new(0); gcry_mpi_set_ui(seven, 7); gcry_mpi_add(q, q, seven); }   /* q = 3*2^61 + 7 */
   polyctx.q = q;
   poly_mpi_t a, b, r;
   poly_alloc(&a); poly_alloc(&b); poly_alloc(&r);
@@ -184,7 +186,8 @@ static int hemul(const char *path)
 
 int main(int argc, char **argv)
 {
-  if (argc >= 2 && !strcmp(argv[1], "polymul")) return polymul();
+  if (argc >= 2 && !strcmp(argv[1], "polymul")) return polymul(0);
+  if (argc >= 2 && !strcmp(argv[1], "polymulodd")) return polymul(1);
   if (argc >= 3 && !strcmp(argv[1], "hemul")) return hemul(argv[2]);
   return 2;
 }

@@ -153,3 +153,30 @@ def test_fast_crt_path_equals_exact_kernel(engine_ctx, oracle_ctx, dim, logq):
     assert torch.equal(fast, exact)
     exp = poly_rns2mpi([slab[d][:16] for d in range(dim)], basis, 1 << logq)
     assert big_to_ints(to_host(fast), W, n)[0][:16] == exp
+
+
+@pytest.mark.parametrize("logn,dim,q", [
+    (7, 5, (1 << 61)),                       # power of two through the general path: must equal the KAT
+    (7, 5, 3 * (1 << 61) + 7),               # one-word odd modulus, CRT value many times longer
+    (7, 5, (1 << 100) - 3),
+    (7, 9, None),                            # q = P*q_L as he_genswk uses (src/he-kem.c:80,95), built below
+])
+def test_poly_mul_general_modulus(engine_ctx, oracle_ctx, logn, dim, q):
+    torch = _torch()
+    g = engine_ctx(logn, max(dim, 9))
+    n = g.n
+    if q is None:
+        P = RnsBasis(g.p[:3]).P
+        q = P << 120                          # P * 2^120
+        dim = (q.bit_length() + logn) // 59 + 1
+    rng = random.Random(q % 1000003)
+    h = q // 2
+    a = [rng.randrange(-h, h) for _ in range(n)]
+    b = [rng.randrange(-3, 4) for _ in range(n)]           # small second factor, like a secret key
+    a[:3] = [0, h - 1, -h]
+    W = (q.bit_length() + 64) // 64
+    da, db = to_device(ints_to_big(a, W)), to_device(ints_to_big(b, W))
+    r = torch.empty_like(da)
+    g.poly_mul_general(r, da, db, W, dim, q)
+    exp = [mpi_smod(v, q) for v in negacyclic_mul(a, b)]   # |a*b| < n*3*q/2 < P/2 of the dim-limb basis
+    assert big_to_ints(to_host(r), W, n)[0] == exp

@@ -42,6 +42,19 @@ def test_polymul_c_kat_through_reference_signature(mpi_host, oracle_ctx):
         assert [got[127], got[126], got[125]] == lead
 
 
+def test_poly_mul_general_modulus_through_reference_signature(mpi_host, oracle_ctx):
+    """poly_mul accepts any modulus (he_genswk passes P*q_L, src/he-kem.c:95): q = 3*2^61 + 7 here."""
+    res = subprocess.run([mpi_host, "polymulodd"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    vals = _ints(res.stdout.split())
+    o = oracle_ctx(7, 5)
+    N, Q = 128, 3 * (1 << 61) + 7
+    cases = [([i + 2 for i in range(N)], [i + 3 for i in range(N)]),
+             ([o.p[0] - i - 1 for i in range(N)], [o.p[1] - i - 1 for i in range(N)])]
+    for t, (a, b) in enumerate(cases):
+        assert vals[t * N:(t + 1) * N] == [ref.mpi_smod(v, Q) for v in ref.negacyclic_mul(a, b)]
+
+
 def test_he_mul_he_rs_he_moddown_with_real_mpis(mpi_host, oracle_ctx, tmp_path):
     logn, logq, logDelta = 7, 120, 30
     n, L = 1 << logn, logq // logDelta
