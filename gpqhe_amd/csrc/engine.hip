@@ -382,13 +382,18 @@ int inverse_slabs(const gpq_ctx *c, PassArgs a, unsigned dim, unsigned polys, hi
 
 }  // namespace
 
+constexpr unsigned kMaxPolysPerLaunch = 16384;   // gridDim.y <= 65535 with up to 4 slabs per launch
+
 extern "C" int gpq_ntt(gpq_ctx *c, uint64_t *slab, unsigned dim, unsigned batch, void *stream) {
   int rc = check_shape(c, dim, batch, "gpq_ntt");
   if (rc) return rc;
   if (!slab) return gpq_fail(GPQ_ERR_INVALID, "gpq_ntt: null slab");
-  PassArgs a = make_args(c, dim, 1);
-  a.src[0] = slab; a.dst[0] = slab;
-  if ((rc = forward_slabs(c, a, dim, batch, (hipStream_t)stream)) != GPQ_OK) return rc;
+  for (unsigned k0 = 0; k0 < batch; k0 += kMaxPolysPerLaunch) {
+    const unsigned polys = batch - k0 < kMaxPolysPerLaunch ? batch - k0 : kMaxPolysPerLaunch;
+    PassArgs a = make_args(c, dim, 1);
+    a.src[0] = a.dst[0] = slab + (size_t)k0 * ((size_t)dim << c->logn);
+    if ((rc = forward_slabs(c, a, dim, polys, (hipStream_t)stream)) != GPQ_OK) return rc;
+  }
   return after_launch("gpq_ntt");
 }
 
@@ -396,9 +401,12 @@ extern "C" int gpq_invntt(gpq_ctx *c, uint64_t *slab, unsigned dim, unsigned bat
   int rc = check_shape(c, dim, batch, "gpq_invntt");
   if (rc) return rc;
   if (!slab) return gpq_fail(GPQ_ERR_INVALID, "gpq_invntt: null slab");
-  PassArgs a = make_args(c, dim, 1);
-  a.src[0] = slab; a.dst[0] = slab;
-  if ((rc = inverse_slabs(c, a, dim, batch, (hipStream_t)stream)) != GPQ_OK) return rc;
+  for (unsigned k0 = 0; k0 < batch; k0 += kMaxPolysPerLaunch) {
+    const unsigned polys = batch - k0 < kMaxPolysPerLaunch ? batch - k0 : kMaxPolysPerLaunch;
+    PassArgs a = make_args(c, dim, 1);
+    a.src[0] = a.dst[0] = slab + (size_t)k0 * ((size_t)dim << c->logn);
+    if ((rc = inverse_slabs(c, a, dim, polys, (hipStream_t)stream)) != GPQ_OK) return rc;
+  }
   return after_launch("gpq_invntt");
 }
 
@@ -408,11 +416,15 @@ static int pointwise_api(gpq_ctx *c, uint64_t *r, const uint64_t *x, const uint6
   int rc = check_shape(c, dim, batch, who);
   if (rc) return rc;
   if (!r || !x || !y) return gpq_fail(GPQ_ERR_INVALID, "%s: null slab", who);
-  PassArgs a = make_args(c, dim, 1);
-  a.src[0] = x; a.src[1] = y; a.dst[0] = r;
   const unsigned bx = c->n >= 512 ? c->n / 512 : 1;
-  ProfScope prof(c, GPQ_K_POINTWISE, (hipStream_t)stream);
-  hipLaunchKernelGGL((pointwise<MUL>), dim3(bx, batch, dim), dim3(256), 0, (hipStream_t)stream, a);
+  for (unsigned k0 = 0; k0 < batch; k0 += kMaxPolysPerLaunch) {
+    const unsigned polys = batch - k0 < kMaxPolysPerLaunch ? batch - k0 : kMaxPolysPerLaunch;
+    const size_t off = (size_t)k0 * ((size_t)dim << c->logn);
+    PassArgs a = make_args(c, dim, 1);
+    a.src[0] = x + off; a.src[1] = y + off; a.dst[0] = r + off;
+    ProfScope prof(c, GPQ_K_POINTWISE, (hipStream_t)stream);
+    hipLaunchKernelGGL((pointwise<MUL>), dim3(bx, polys, dim), dim3(256), 0, (hipStream_t)stream, a);
+  }
   return after_launch(who);
 }
 
@@ -543,7 +555,7 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
 }
 
 extern "C" int gpq_set_chunk(gpq_ctx *c, unsigned chunk) {
-  if (!c || chunk < 1) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_chunk: bad arguments");
+  if (!c || chunk < 1 || chunk > kMaxPolysPerLaunch) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_chunk: bad arguments");
   c->chunk = chunk;
   return GPQ_OK;
 }

@@ -119,3 +119,19 @@ def test_bad_arguments_are_reported_not_fatal(engine_ctx):
         g.poly_ntt(dev, 6)  # dim beyond the context's prime chain
     with pytest.raises(ValueError):
         g.poly_ntt(dev[:100], 5)  # ragged slab
+
+
+def test_unsupported_prime_is_an_error_code_not_a_crash():
+    """Primes outside the 2^59 + c family (c < 3.19e8) have no kernel: GPQ_ERR_UNSUPPORTED, message, no abort."""
+    import ctypes as C
+    lib = gpqhe_amd.load()
+    n = 128
+    p = (1 << 60) - 93                       # a 60-bit prime that is not 2^59 + small
+    z = (C.c_uint64 * n)(*([1] * n))
+    primes = (C.c_uint64 * 1)(p)
+    zz = (C.POINTER(C.c_uint64) * 1)(C.cast(z, C.POINTER(C.c_uint64)))
+    h = C.c_void_p()
+    rc = lib.gpq_ctx_create_from_tables(C.byref(h), 7, 1, primes, zz, zz, 0)
+    assert rc == -3 and b"2^59" in lib.gpq_last_error()
+    rc = lib.gpq_ctx_create(C.byref(h), 18, 4, 0)          # ring degree beyond the supported range
+    assert rc == -1
