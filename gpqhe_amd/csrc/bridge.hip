@@ -164,7 +164,9 @@ int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, uns
     if (need <= 1) launch_low<1>(a, b->WP, c->d_redo, c->n, batch, s);
     else if (need <= 2) launch_low<2>(a, b->WP, c->d_redo, c->n, batch, s);
     else if (need <= 4) launch_low<4>(a, b->WP, c->d_redo, c->n, batch, s);
-    else if (need <= 8) launch_low<8>(a, b->WP, c->d_redo, c->n, batch, s);
+    else if (need <= 7) launch_low<7>(a, b->WP, c->d_redo, c->n, batch, s);     // q up to 2^448 (reference default 2^438)
+    else if (need <= 10) launch_low<10>(a, b->WP, c->d_redo, c->n, batch, s);
+    else if (need <= 14) launch_low<14>(a, b->WP, c->d_redo, c->n, batch, s);   // q up to 2^896 (headline 2^850)
     else launch_low<16>(a, b->WP, c->d_redo, c->n, batch, s);
     a.only = c->d_redo;   // exact kernel below redoes only the flagged coefficients
   }
@@ -183,6 +185,8 @@ int launch_decompose(gpq_ctx *c, uint64_t *slab, const uint64_t *big, unsigned W
   DecomposeArgs a{c->d_tabs, big, slab, W, dim, c->logn, limb0};
   const dim3 grid((c->n + 255) / 256, batch), block(256);
   if (W <= 4) hipLaunchKernelGGL((bridge_decompose<4>), grid, block, 0, s, a);
+  else if (W <= 7) hipLaunchKernelGGL((bridge_decompose<7>), grid, block, 0, s, a);
+  else if (W <= 14) hipLaunchKernelGGL((bridge_decompose<14>), grid, block, 0, s, a);
   else if (W <= 16) hipLaunchKernelGGL((bridge_decompose<16>), grid, block, 0, s, a);
   else if (W <= 32) hipLaunchKernelGGL((bridge_decompose<32>), grid, block, 0, s, a);
   else return gpq_fail(GPQ_ERR_UNSUPPORTED, "decompose: W=%u words (max 32)", W);
