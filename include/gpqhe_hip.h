@@ -21,6 +21,10 @@
  * reference's bit-reversed order; slab element (d, i) lives at d*n + i
  * (src/poly.c:99, src/rns.c:67).
  *
+ * Concurrency: like the reference (SURVEY.md 8b "Threading: none") a context serves one caller at
+ * a time: calls on one context must be issued to one stream at a time (the context owns small
+ * scratch that successive launches reuse in stream order).  Use one context per stream otherwise.
+ *
  * Errors: the slab API returns GPQ_OK or a negative code and records a
  * message (gpq_last_error); it never aborts.  The drop-in symbols keep the
  * reference's convention: void return, errno=EINVAL + message + abort() on

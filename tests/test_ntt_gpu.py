@@ -135,3 +135,28 @@ def test_unsupported_prime_is_an_error_code_not_a_crash():
     assert rc == -3 and b"2^59" in lib.gpq_last_error()
     rc = lib.gpq_ctx_create(C.byref(h), 18, 4, 0)          # ring degree beyond the supported range
     assert rc == -1
+
+
+def test_largest_c_of_the_supported_chains(engine_ctx, oracle_ctx):
+    """The lazy bounds of modarith.hpp are tightest for the largest c = p - 2^59: the 57-prime chain of
+    logn = 17 reaches c = 2^28.13.  Every limb, random and all-(p-1) inputs, forward,
+    inverse and the fused tensor stage against the oracle."""
+    import torch
+    logn, dim = 17, 57
+    o, g = oracle_ctx(logn, dim), engine_ctx(logn, dim)
+    assert max(o.p) - (1 << 59) > 1 << 28
+    n = o.n
+    a = o.gen(99, dim)
+    a[(dim - 1) * n:] = o.p[dim - 1] - 1
+    a[(dim - 2) * n:(dim - 1) * n:2] = o.p[dim - 2] - 1
+    dev = to_device(a)
+    g.poly_ntt(dev, dim)
+    fwd = to_host(dev)
+    assert np.array_equal(fwd, o.ntt_slab(a, dim))
+    g.poly_invntt(dev, dim)
+    assert np.array_equal(to_host(dev), a)
+    b = o.gen(100, dim)
+    outs = [torch.empty_like(dev) for _ in range(3)]
+    g.he_mul_tensor(outs[0], outs[1], outs[2], dev, to_device(b), to_device(b), dev, dim)
+    e0, e1, e2 = o.he_mul_tensor(a, b, b, a, dim)
+    assert np.array_equal(to_host(outs[0]), e0) and np.array_equal(to_host(outs[1]), e1) and np.array_equal(to_host(outs[2]), e2)
