@@ -59,6 +59,10 @@ SIGNATURES = {
     "gpq_he_mul": (C.c_int, [vp] * 9 + [C.c_uint] * 6 + [vp, vp]),
     "gpq_relin_tail_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
     "gpq_relin_tail": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
+    "gpq_he_mulpt_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
+    "gpq_he_mulpt": (C.c_int, [vp] * 6 + [C.c_uint] * 4 + [vp, vp]),
+    "gpq_poly_rot": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, vp]),
+    "gpq_poly_conj": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, vp]),
     "gpq_he_swk_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
     "gpq_he_swk": (C.c_int, [vp] * 7 + [C.c_uint] * 5 + [vp, vp]),
     "gpq_profile_enable": (C.c_int, [vp, C.c_int]),
@@ -86,7 +90,7 @@ SIGNATURES = {
 # exercised from C (tests/c/dropin_host.c)
 EXPORTED_ONLY = ["montgomery_reduce", "barrett_reduce",
                  # MPI-typed surface: driven from C with real libgcrypt MPIs (tests/c/mpi_host.c)
-                 "poly_mul", "he_mul", "he_rs", "he_rescale", "he_moddown"]
+                 "poly_mul", "he_mul", "he_rs", "he_rescale", "he_moddown", "he_mulpt", "he_conj", "he_rot"]
 
 _lib = None
 

@@ -535,3 +535,46 @@ extern "C" int gpq_poly_mul_general(gpq_ctx *c, uint64_t *r, const uint64_t *a, 
   if ((rc = gpq_poly_mul_rns(c, sr, sa, sb, dim, batch, stream))) return rc;
   return gpq_rns_reconstruct_general(c, r, W, sr, dim, batch, q_words, Lq, scratch, stream);
 }
+
+// ---------------------------------------------------------------------------
+// he_mulpt, poly_rot / poly_conj, he_rot / he_conj at the big-slab level
+// ---------------------------------------------------------------------------
+extern "C" size_t gpq_he_mulpt_workspace_bytes(const gpq_ctx *c, unsigned dim, unsigned batch) {
+  return 3ull * batch * ((size_t)dim << c->logn) * 8;
+}
+
+// he_mulpt, src/he-mult.c:159-196 (decl src/gpqhe.h:148): (c0, c1) * m per ciphertext, q_l = 2^logql.
+// dim is the caller's (it depends on log2(pt->nu), a host double, :169).  Bookkeeping (:162-164) stays with the caller.
+extern "C" int gpq_he_mulpt(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *c0, const uint64_t *c1, const uint64_t *m,
+                            unsigned W, unsigned logql, unsigned dim, unsigned batch, void *workspace, void *stream) {
+  int rc = check(c, dim, batch, "gpq_he_mulpt");
+  if (rc) return rc;
+  if (!out_c0 || !out_c1 || !c0 || !c1 || !m || !workspace || !logql) return gpq_fail(GPQ_ERR_INVALID, "gpq_he_mulpt: bad arguments");
+  const size_t poly = (size_t)dim << c->logn;
+  uint64_t *s0 = (uint64_t *)workspace, *s1 = s0 + batch * poly, *sm = s1 + batch * poly;
+  if ((rc = gpq_rns_decompose(c, sm, m, W, dim, batch, stream))) return rc;       // :176
+  if ((rc = gpq_rns_decompose(c, s0, c0, W, dim, batch, stream))) return rc;      // :177
+  if ((rc = gpq_rns_decompose(c, s1, c1, W, dim, batch, stream))) return rc;      // :178
+  if ((rc = gpq_ntt(c, sm, dim, batch, stream)) || (rc = gpq_ntt(c, s0, dim, batch, stream)) || (rc = gpq_ntt(c, s1, dim, batch, stream))) return rc;  // :179-181
+  if ((rc = gpq_rns_mul(c, s0, s0, sm, dim, batch, stream)) || (rc = gpq_invntt(c, s0, dim, batch, stream))) return rc;   // :182-183
+  if ((rc = gpq_rns_mul(c, s1, s1, sm, dim, batch, stream)) || (rc = gpq_invntt(c, s1, dim, batch, stream))) return rc;   // :184-185
+  if ((rc = gpq_rns_reconstruct(c, out_c0, W, s0, dim, batch, logql, stream))) return rc;                                 // :188
+  return gpq_rns_reconstruct(c, out_c1, W, s1, dim, batch, logql, stream);                                                // :189
+}
+
+static int permute(gpq_ctx *c, uint64_t *r, const uint64_t *a, unsigned W, unsigned batch, unsigned long long power, int conj, void *stream) {
+  if (!c || !r || !a || r == a || W < 1 || batch < 1) return gpq_fail(GPQ_ERR_INVALID, "poly_rot/poly_conj: bad arguments (not in place)");
+  PermuteArgs p{a, r, W, c->logn, power, conj};
+  hipLaunchKernelGGL(bridge_permute, dim3((c->n + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, p);
+  return launched("bridge_permute");
+}
+// poly_rot, src/poly.c:263-275 (5^rot as :266-268 computes it, modulo 2^64 -- harmless since 2n divides 2^64)
+extern "C" int gpq_poly_rot(gpq_ctx *c, uint64_t *r, const uint64_t *a, unsigned W, unsigned rot, unsigned batch, void *stream) {
+  unsigned long long power = 1;
+  for (unsigned j = 0; j < rot; ++j) power *= 5;
+  return permute(c, r, a, W, batch, power, 0, stream);
+}
+// poly_conj, src/poly.c:277-283
+extern "C" int gpq_poly_conj(gpq_ctx *c, uint64_t *r, const uint64_t *a, unsigned W, unsigned batch, void *stream) {
+  return permute(c, r, a, W, batch, 1, 1, stream);
+}

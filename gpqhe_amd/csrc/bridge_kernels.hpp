@@ -453,6 +453,35 @@ __global__ __launch_bounds__(64) void bridge_smod_general(SmodArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// poly_rot / poly_conj (src/poly.c:263-283) on big slabs: signed permutations of the coefficients.
+//   rot : r[k] = a[i] (k < n) or r[k-n] = -a[i],  k = i * 5^rot mod 2n
+//   conj: r[0] = a[0], r[i] = -a[n-i]
+// One thread per source coefficient; negation is two's complement over the W words.
+// ---------------------------------------------------------------------------
+struct PermuteArgs { const uint64_t *a; uint64_t *r; unsigned W, logn; unsigned long long power; int conj; };
+
+__global__ __launch_bounds__(256) void bridge_permute(PermuteArgs p) {
+  const unsigned n = 1u << p.logn;
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  unsigned dst;
+  bool neg;
+  if (p.conj) { dst = i ? n - i : 0; neg = i != 0; }
+  else {
+    const unsigned k = (unsigned)(((unsigned long long)i * p.power) & (2ull * n - 1));
+    neg = k >= n;
+    dst = neg ? k - n : k;
+  }
+  const size_t base = (size_t)blockIdx.y * p.W << p.logn;
+  uint64_t carry = neg;
+  for (unsigned j = 0; j < p.W; ++j) {
+    uint64_t w = p.a[base + ((size_t)j << p.logn) + i];
+    if (neg) { w = ~w + carry; carry = carry && w == 0; }
+    p.r[base + ((size_t)j << p.logn) + dst] = w;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // he_rs on one big slab, Delta = 2^s and q_l = 2^logql (the reference's test
 // parameters, tests/gpqhe.c:1349-1352): c <- smod(rdiv(c, Delta), q_l), in place.
 //   rdiv: floor(c / 2^s) = arithmetic shift; plus one when (c mod 2^s) > 2^(s-1)

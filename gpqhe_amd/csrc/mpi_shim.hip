@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cerrno>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -249,6 +250,58 @@ static void rescale_common(he_ct_t *ct, bool divide) {
   ct->l = lnew;
   if (divide) { ct->nu /= hectx.Delta; ct->B = ct->B / hectx.Delta + hectx.bnd.Brs; }             // :37-38
 }
+
+// src/he-mult.c:159-196
+void he_mulpt(struct he_ct *dest, const struct he_ct *src, const struct he_pt *pt) {
+  need_gcrypt();
+  if (&hectx == nullptr || !hectx.q) die("`hectx` is not initialised (hectx_init first)");
+  gpq_ctx *c = engine();
+  const unsigned n = polyctx.n, l = src->l;
+  const double nu = src->nu * pt->nu, B = src->B * pt->nu;                                      // :163-164
+  const unsigned logql = log2_exact(hectx.q[l], "he_mulpt: q_l must be a power of two");
+  const unsigned dim = (unsigned)((logql + 1 + log2(pt->nu) + polyctx.logn) / 59u + 1);        // :169, evaluated in double as there
+  unsigned bits = max_bits(&pt->m, n);
+  if (logql > bits) bits = logql;
+  const unsigned W = bits / 64 + 1;
+  const size_t big = (size_t)W * n;
+  std::vector<uint64_t> h0(big), h1(big), hm(big);
+  to_slab(h0.data(), &src->c0, n, W); to_slab(h1.data(), &src->c1, n, W); to_slab(hm.data(), &pt->m, n, W);
+  DevBuf d0(big * 8), d1(big * 8), dm(big * 8), o0(big * 8), o1(big * 8), ws(gpq_he_mulpt_workspace_bytes(c, dim, 1));
+  up(d0, h0); up(d1, h1); up(dm, hm);
+  if (gpq_he_mulpt(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), dm.u64(), W, logql, dim, 1, ws.p, nullptr) != GPQ_OK) die("he_mulpt failed");
+  down(h0, o0); down(h1, o1);
+  from_slab(&dest->c0, h0.data(), n, W);
+  from_slab(&dest->c1, h1.data(), n, W);
+  dest->l = l; dest->nu = nu; dest->B = B;                                                      // :162-164
+}
+
+// he_rot / he_conj, src/he-automorphism.c:87-115: permute both polynomials, then he_swk (:40-85) in place
+static void automorphism(he_ct_t *ct, const he_evk_t *key, bool conj, unsigned rot) {
+  need_gcrypt();
+  if (&hectx == nullptr || !hectx.q) die("`hectx` is not initialised (hectx_init first)");
+  gpq_ctx *c = engine();
+  const unsigned n = polyctx.n, l = ct->l;
+  const unsigned logql = log2_exact(hectx.q[l], "he_rot/he_conj: q_l must be a power of two");
+  const unsigned nbq = logql + 1, nbPqL = G.mpi_get_nbits(hectx.PqL);
+  const unsigned dimB = (nbq + nbPqL + polyctx.logn) / 59 + 1, dimP = hectx.dim;                // src/he-automorphism.c:52
+  const unsigned W = logql / 64 + 1;
+  const size_t big = (size_t)W * n, evk = (size_t)dimB * n;
+  std::vector<uint64_t> h0(big), h1(big);
+  to_slab(h0.data(), &ct->c0, n, W); to_slab(h1.data(), &ct->c1, n, W);
+  DevBuf a0(big * 8), a1(big * 8), r0(big * 8), r1(big * 8), o0(big * 8), o1(big * 8), k0(evk * 8), k1(evk * 8),
+      ws(gpq_he_swk_workspace_bytes(c, W, dimB, dimP, 1));
+  up(a0, h0); up(a1, h1);
+  if (gpq_upload(k0.p, key->p0.coeffs, evk * 8, nullptr) != GPQ_OK || gpq_upload(k1.p, key->p1.coeffs, evk * 8, nullptr) != GPQ_OK) die("upload failed");
+  int rc = conj ? gpq_poly_conj(c, r0.u64(), a0.u64(), W, 1, nullptr) : gpq_poly_rot(c, r0.u64(), a0.u64(), W, rot, 1, nullptr);      // :95-96 / :108-109
+  if (rc == GPQ_OK) rc = conj ? gpq_poly_conj(c, r1.u64(), a1.u64(), W, 1, nullptr) : gpq_poly_rot(c, r1.u64(), a1.u64(), W, rot, 1, nullptr);
+  if (rc == GPQ_OK) rc = gpq_he_swk(c, o0.u64(), o1.u64(), r0.u64(), r1.u64(), k0.u64(), k1.u64(), W, logql, dimB, dimP, 1, ws.p, nullptr);  // :97 / :110
+  if (rc != GPQ_OK) die("he_rot/he_conj failed");
+  down(h0, o0); down(h1, o1);
+  from_slab(&ct->c0, h0.data(), n, W);
+  from_slab(&ct->c1, h1.data(), n, W);
+}
+void he_conj(he_ct_t *ct, const he_evk_t *ck) { automorphism(ct, ck, true, 0); }
+void he_rot(he_ct_t *ct, const int rot, const he_evk_t *rk) { automorphism(ct, &rk[rot], false, (unsigned)rot); }   // rk[rot], :110
 
 void he_rs(struct he_ct *ct) { rescale_common(ct, true); }        // src/he-rescale.c:33-54
 void he_rescale(struct he_ct *ct) { rescale_common(ct, true); }

@@ -156,6 +156,22 @@ class PolyContext:
                                           W, logql, dimB, dimP, batch, _ptr(ws), _stream()), "gpq_he_swk")
         return ws
 
+    def he_mulpt(self, out_c0, out_c1, c0, c1, m, W, logql, dim):
+        """src/he-mult.c:159-196 on big slabs."""
+        torch = _torch()
+        batch = c0.numel() // (W * self.n)
+        ws = torch.empty(self.lib.gpq_he_mulpt_workspace_bytes(self.h, dim, batch) // 8 + 8, dtype=torch.int64, device="cuda")
+        _native.check(self.lib.gpq_he_mulpt(self.h, _ptr(out_c0), _ptr(out_c1), _ptr(c0), _ptr(c1), _ptr(m), W, logql, dim, batch,
+                                            _ptr(ws), _stream()), "gpq_he_mulpt")
+
+    def poly_rot(self, r, a, W, rot):
+        _native.check(self.lib.gpq_poly_rot(self.h, _ptr(r), _ptr(a), W, rot, a.numel() // (W * self.n), _stream()), "gpq_poly_rot")
+        return r
+
+    def poly_conj(self, r, a, W):
+        _native.check(self.lib.gpq_poly_conj(self.h, _ptr(r), _ptr(a), W, a.numel() // (W * self.n), _stream()), "gpq_poly_conj")
+        return r
+
     def phat_invmp(self, dim):
         return [self.lib.gpq_ctx_phat_invmp(self.h, dim, d) for d in range(dim)]
 

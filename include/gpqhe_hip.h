@@ -204,6 +204,16 @@ int gpq_he_swk(gpq_ctx *ctx, uint64_t *out_c0, uint64_t *out_c1, const uint64_t 
                const uint64_t *swk0, const uint64_t *swk1, unsigned W, unsigned logql, unsigned dimB, unsigned dimP,
                unsigned batch, void *workspace, void *stream);
 
+/* he_mulpt, src/he-mult.c:159-196 (decl src/gpqhe.h:148): ciphertext times plaintext polynomial m on big slabs,
+ * q_l = 2^logql, over `dim` limbs (the reference derives dim from log2(pt->nu), :169: caller's). */
+size_t gpq_he_mulpt_workspace_bytes(const gpq_ctx *ctx, unsigned dim, unsigned batch);
+int gpq_he_mulpt(gpq_ctx *ctx, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *c0, const uint64_t *c1, const uint64_t *m,
+                 unsigned W, unsigned logql, unsigned dim, unsigned batch, void *workspace, void *stream);
+/* poly_rot / poly_conj, src/poly.c:263-283, on big slabs (r must not alias a): with gpq_he_swk they are he_rot / he_conj,
+ * src/he-automorphism.c:87-115. */
+int gpq_poly_rot(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, unsigned W, unsigned rot, unsigned batch, void *stream);
+int gpq_poly_conj(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, unsigned W, unsigned batch, void *stream);
+
 /* ---- per-kernel profile ----------------------------------------------------
  * When enabled every kernel launch of this context is bracketed by two HIP
  * events on its own stream.  gpq_profile_collect waits for them and adds the

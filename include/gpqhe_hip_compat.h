@@ -83,6 +83,7 @@ struct he_ctx {                                                   /* src/gpqhe.h
 };
 typedef struct he_evk { poly_rns_t p0, p1; } he_evk_t;            /* src/gpqhe.h:78-82 */
 typedef struct he_ct { unsigned int l; double nu, B; poly_mpi_t c0, c1; } he_ct_t;   /* src/gpqhe.h:84-91 */
+typedef struct he_pt { double nu; poly_mpi_t m; } he_pt_t;                            /* src/gpqhe.h:93-97 */
 #endif
 
 /* src/ntt.c:37,54 -- in place on one limb of n = polyctx.n coefficients (host
@@ -118,6 +119,9 @@ void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t 
 void he_rs(struct he_ct *ct);                                                           /* src/gpqhe.h:136  */
 void he_rescale(struct he_ct *ct);                                                      /* north-star name of he_rs */
 void he_moddown(he_ct_t *ct);                                                           /* src/gpqhe.h:137  */
+void he_mulpt(struct he_ct *dest, const struct he_ct *src, const struct he_pt *pt);     /* src/gpqhe.h:148  */
+void he_conj(he_ct_t *ct, const he_evk_t *ck);                                          /* src/gpqhe.h:151  */
+void he_rot(he_ct_t *ct, const int rot, const he_evk_t *rk);                            /* src/gpqhe.h:152  */
 
 /* When the host program has no `polyctx` symbol (the library references it
  * weakly), the ring degree for the drop-in calls is set here instead. */

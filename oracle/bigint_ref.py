@@ -144,3 +144,36 @@ def he_swk(o, d0, d1, swk0, swk1, dimP, dimB, logql):
     ql = 1 << logql
     c0h, c1h = o.keyswitch(_slab(o, d1, dimB), swk0, swk1, dimB)
     return he_relin_tail(o, c0h, c1h, d0, None, dimP, dimB, ql)
+
+
+def poly_rot(a, rot):
+    """src/poly.c:263-275"""
+    n = len(a)
+    power = pow(5, rot, 1 << 64)
+    r = [0] * n
+    for i in range(n):
+        k = (i * power) % (2 * n)
+        if k < n:
+            r[k] = a[i]
+        else:
+            r[k - n] = -a[i]
+    return r
+
+
+def poly_conj(a):
+    """src/poly.c:277-283"""
+    n = len(a)
+    return [a[0]] + [-a[n - i] for i in range(1, n)]
+
+
+def he_mulpt(o, ct, m, dim, logql):
+    """src/he-mult.c:159-196 for q_l = 2^logql."""
+    n, ql = o.n, 1 << logql
+    basis = RnsBasis(o.p[:dim])
+    mh = o.ntt_slab(_slab(o, m, dim), dim)
+    out = []
+    for c in ct:
+        ch = o.ntt_slab(_slab(o, c, dim), dim)
+        prod = _np.concatenate([o.rns_mul(ch[d * n:(d + 1) * n], mh[d * n:(d + 1) * n], d) for d in range(dim)])
+        out.append(poly_rns2mpi(_limbs(o.ntt_slab(prod, dim, inverse=True), dim, n), basis, ql))
+    return out

@@ -181,6 +181,43 @@ static int hemul(const char *path)
   printf("he_sq %u\n", ct.l);
   for (unsigned i = 0; i < polyctx.n; i++) print_mpi(ct.c0.coeffs[i]);
   for (unsigned i = 0; i < polyctx.n; i++) print_mpi(ct.c1.coeffs[i]);
+
+  /* rotation / conjugation keys: rk[rot] and ck, synthetic NTT-domain slabs like rlk */
+  he_evk_t rk[2], ck;
+  he_evk_t *keys[2] = {&rk[1], &ck};
+  uint64_t seeds[2][2] = {{5002, 5003}, {6000, 6001}};
+  rk[0].p0.coeffs = rk[0].p1.coeffs = NULL;
+  for (int t = 0; t < 2; t++) {
+    keys[t]->p0.coeffs = malloc((size_t)hectx.dimevk * polyctx.n * 8); keys[t]->p1.coeffs = malloc((size_t)hectx.dimevk * polyctx.n * 8);
+    r = polyctx.rns;
+    for (unsigned d = 0; d < hectx.dimevk; d++, r = r->next)
+      for (unsigned i = 0; i < polyctx.n; i++) {
+        keys[t]->p0.coeffs[(size_t)d * polyctx.n + i] = splitmix64(&seeds[t][0]) % r->p;
+        keys[t]->p1.coeffs[(size_t)d * polyctx.n + i] = splitmix64(&seeds[t][1]) % r->p;
+      }
+  }
+  he_rot(&ct, 1, rk);                                        /* tests/gpqhe.c rot; rk[rot] */
+  printf("he_rot %u\n", ct.l);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(ct.c0.coeffs[i]);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(ct.c1.coeffs[i]);
+  he_conj(&ct, &ck);
+  printf("he_conj %u\n", ct.l);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(ct.c0.coeffs[i]);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(ct.c1.coeffs[i]);
+  he_pt_t pt;
+  poly_alloc(&pt.m);
+  pt.nu = 1024.0;
+  for (unsigned i = 0; i < polyctx.n; i++) {                 /* a plaintext polynomial with signed ~2^30 coefficients */
+    gcry_mpi_set_ui(pt.m.coeffs[i], ((unsigned long)(i + 1) << 20) + 12345u * i);
+    if (i & 1) gcry_mpi_neg(pt.m.coeffs[i], pt.m.coeffs[i]);
+  }
+  he_ct_t prod;
+  poly_alloc(&prod.c0); poly_alloc(&prod.c1);
+  ct.nu = 2.0; ct.B = 3.0;
+  he_mulpt(&prod, &ct, &pt);                                 /* tests/gpqhe.c:516 */
+  printf("he_mulpt %u %.17g %.17g\n", prod.l, prod.nu, prod.B);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(prod.c0.coeffs[i]);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(prod.c1.coeffs[i]);
   return 0;
 }
 

@@ -142,3 +142,37 @@ def test_he_mul_by_one_is_identity_full_size(engine_ctx):
     assert torch.equal(o0, c0) and torch.equal(o1, c1)
     g.he_mul(o0, o1, one, zero, c0, c1, rlk0, rlk1, W, logq, dimA, dimB, dimP)
     assert torch.equal(o0, c0) and torch.equal(o1, c1)
+
+
+@pytest.mark.parametrize("logn,W", [(7, 2), (9, 14)])
+def test_poly_rot_and_conj_on_big_slabs(engine_ctx, logn, W):
+    """src/poly.c:263-283 as signed permutations of big slabs (two polynomials per call)."""
+    torch = _torch()
+    g = engine_ctx(logn, 5)
+    n = g.n
+    rng = random.Random(8 + W)
+    lim = 1 << (64 * W - 2)
+    polys = [[rng.randrange(-lim, lim) for _ in range(n)] for _ in range(2)]
+    polys[0][:3] = [0, -1, lim - 1]
+    a = to_device(np.concatenate([ints_to_big(p, W) for p in polys]))
+    r = torch.empty_like(a)
+    for rot in (0, 1, 3, 7):
+        g.poly_rot(r, a, W, rot)
+        assert big_to_ints(to_host(r), W, n) == [ref.poly_rot(p, rot) for p in polys]
+    g.poly_conj(r, a, W)
+    assert big_to_ints(to_host(r), W, n) == [ref.poly_conj(p) for p in polys]
+
+
+def test_he_mulpt_matches_reference_semantics(engine_ctx, oracle_ctx):
+    torch = _torch()
+    logn, logql, dim = 8, 150, 4
+    g, o = engine_ctx(logn, 12), oracle_ctx(logn, 12)
+    n, W = g.n, 3
+    rng = random.Random(17)
+    ct = [_centred(rng, logql, n) for _ in range(2)]
+    m = [rng.randrange(-(1 << 40), 1 << 40) for _ in range(n)]
+    d0, d1, dm = (to_device(ints_to_big(v, W)) for v in (ct[0], ct[1], m))
+    o0, o1 = torch.empty_like(d0), torch.empty_like(d0)
+    g.he_mulpt(o0, o1, d0, d1, dm, W, logql, dim)
+    e0, e1 = ref.he_mulpt(o, ct, m, dim, logql)
+    assert big_to_ints(to_host(o0), W, n)[0] == e0 and big_to_ints(to_host(o1), W, n)[0] == e1

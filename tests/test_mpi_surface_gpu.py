@@ -111,3 +111,26 @@ def test_he_mul_he_rs_he_moddown_with_real_mpis(mpi_host, oracle_ctx, tmp_path):
     dP2, dA2, dB2, _ = ref.he_dims(logn, o.p, logq, logql)
     s0, s1 = ref.he_mul(o, (m0, m1), (m0, m1), rlk0[: dB2 * n], rlk1[: dB2 * n], dP2, dA2, dB2, logql)
     assert _ints(lines[base + 1:base + 1 + n]) == s0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == s1
+
+    # he_rot(ct, 1, rk): poly_rot both polynomials, he_swk with rk[1] (src/he-automorphism.c:100-115)
+    base += 1 + 2 * n
+    assert lines[base].split() == ["he_rot", str(level - 2)]
+    rk0, rk1 = o.gen(5002, dimevk), o.gen(5003, dimevk)
+    t0, t1 = ref.he_swk(o, ref.poly_rot(s0, 1), ref.poly_rot(s1, 1), rk0[: dB2 * n], rk1[: dB2 * n], dP2, dB2, logql)
+    assert _ints(lines[base + 1:base + 1 + n]) == t0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == t1
+
+    # he_conj(ct, ck) (src/he-automorphism.c:87-98)
+    base += 1 + 2 * n
+    assert lines[base].split() == ["he_conj", str(level - 2)]
+    ck0, ck1 = o.gen(6000, dimevk), o.gen(6001, dimevk)
+    u0, u1 = ref.he_swk(o, ref.poly_conj(t0), ref.poly_conj(t1), ck0[: dB2 * n], ck1[: dB2 * n], dP2, dB2, logql)
+    assert _ints(lines[base + 1:base + 1 + n]) == u0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == u1
+
+    # he_mulpt (src/he-mult.c:159-196): dim from log2(pt->nu) as :169; nu, B as :163-164
+    base += 1 + 2 * n
+    hdr = lines[base].split()
+    assert hdr[0] == "he_mulpt" and int(hdr[1]) == level - 2 and float(hdr[2]) == 2.0 * 1024.0 and float(hdr[3]) == 3.0 * 1024.0
+    m = [(((i + 1) << 20) + 12345 * i) * (-1 if i & 1 else 1) for i in range(n)]
+    dim_pt = int((logql + 1 + 10.0 + logn) / 59 + 1)
+    v0, v1 = ref.he_mulpt(o, (u0, u1), m, dim_pt, logql)
+    assert _ints(lines[base + 1:base + 1 + n]) == v0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == v1
