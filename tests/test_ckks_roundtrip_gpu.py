@@ -1,0 +1,79 @@
+"""Semantic check of the MPI-level he_mul, independent of the restated he_relin: a miniature CKKS round trip
+in the spirit of tests/gpqhe.c:422-537 (encrypt -> he_mul -> [he_rs] -> decrypt, error small against the scale).
+
+Keys follow the reference's construction: secret s with small coefficients; relinearisation key as he_genswk
+builds it (src/he-kem.c:74-118): p1 uniform mod P*q_L, p0 = -p1*s + e + P*s^2 mod P*q_L, both stored as NTT-domain
+slabs over dimevk limbs (:103-110).  Messages are integer polynomials at scale Delta (the encoder is out of scope).
+Everything around the device call is Python integers."""
+import random
+
+import numpy as np
+import pytest
+
+from gpqhe_amd import big_to_ints, ints_to_big, to_device, to_host
+from oracle import bigint_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _negacyclic_mod(a, b, q):
+    return [ref.centred_mod(v, q) for v in ref.negacyclic_mul(a, b)]
+
+
+def _evk_slab(o, poly, dimevk):
+    """rns_decompose + ntt per limb, src/he-kem.c:103-110"""
+    slab = np.array([v % o.p[d] for d in range(dimevk) for v in poly], dtype=np.uint64)
+    return o.ntt_slab(slab, dimevk)
+
+
+@pytest.mark.parametrize("logn,logq,logDelta", [(7, 120, 30), (8, 150, 40)])
+def test_encrypt_mul_rescale_decrypt(engine_ctx, oracle_ctx, logn, logq, logDelta):
+    import torch
+    n, q, Delta = 1 << logn, 1 << logq, 1 << logDelta
+    probe = engine_ctx(logn, 12)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logq, logq)
+    g, o = engine_ctx(logn, dimevk), oracle_ctx(logn, dimevk)
+    rng = random.Random(2024 + logn)
+    P = ref.RnsBasis(o.p[:dimP]).P
+    PqL = P * q
+
+    small = lambda: [rng.choice((-1, 0, 0, 1)) for _ in range(n)]            # secret / error shape (sampler out of scope)
+    err = lambda: [rng.randrange(-8, 9) for _ in range(n)]
+    s = small()
+    s2 = ref.negacyclic_mul(s, s)
+    # relinearisation key, src/he-kem.c:80-101 with sp = s^2
+    p1 = [rng.randrange(PqL) for _ in range(n)]
+    e = err()
+    p0 = [ref.mpi_smod(-a + b + P * c, PqL) for a, b, c in zip(ref.negacyclic_mul(p1, s), e, s2)]
+    p1c = [ref.mpi_smod(v, PqL) for v in p1]
+    rlk0, rlk1 = _evk_slab(o, p0, dimevk), _evk_slab(o, p1c, dimevk)
+
+    def encrypt(m):                                                          # he_enc_sk shape, src/he-encrypt.c:80-99
+        a = [rng.randrange(q) for _ in range(n)]
+        c0 = [ref.centred_mod(-x + mm + ee, q) for x, mm, ee in zip(ref.negacyclic_mul(a, s), m, err())]
+        return c0, [ref.centred_mod(v, q) for v in a]
+
+    def decrypt(c0, c1, ql):                                                 # he_dec, src/he-encrypt.c:105-123
+        return [ref.centred_mod(x + y, ql) for x, y in zip(c0, ref.negacyclic_mul(c1, s))]
+
+    m1 = [rng.randrange(-50, 51) * Delta for _ in range(n)]
+    m2 = [rng.randrange(-50, 51) * Delta for _ in range(n)]
+    ct1, ct2 = encrypt(m1), encrypt(m2)
+    assert max(abs(x - y) for x, y in zip(decrypt(*ct1, q), m1)) < 2**10    # sanity of the miniature scheme itself
+
+    W = logq // 64 + 1
+    dev = [to_device(ints_to_big(v, W)) for v in (ct1[0], ct1[1], ct2[0], ct2[1])]
+    o0, o1 = torch.empty_like(dev[0]), torch.empty_like(dev[0])
+    g.he_mul(o0, o1, *dev, to_device(rlk0), to_device(rlk1), W, logq, dimA, dimB, dimP)   # src/he-mult.c:88-156
+    c0, c1 = big_to_ints(to_host(o0), W, n)[0], big_to_ints(to_host(o1), W, n)[0]
+    want = _negacyclic_mod(m1, m2, q)                                        # scale Delta^2
+    got = decrypt(c0, c1, q)
+    noise = max(abs(x - y) for x, y in zip(got, want))
+    assert noise < Delta * 2**22, "he_mul does not decrypt to m1*m2: relative error 2^%.1f" % (noise.bit_length() - 2 * logDelta)
+    assert noise < (max(abs(v) for v in want) >> 12)                         # < 2^-12 relative, tests/gpqhe.c uses 1e-5 on decoded values
+
+    g.he_rs(o0, o1, W, logDelta, logq - logDelta)                            # src/he-rescale.c:33-54
+    r0, r1 = big_to_ints(to_host(o0), W, n)[0], big_to_ints(to_host(o1), W, n)[0]
+    got_rs = decrypt(r0, r1, q >> logDelta)
+    want_rs = [ref.centred_mod(ref.mpi_rdiv(v, Delta), q >> logDelta) for v in want]
+    assert max(abs(x - y) for x, y in zip(got_rs, want_rs)) < 2**24          # back at scale Delta, small absolute noise
