@@ -578,3 +578,27 @@ extern "C" int gpq_poly_rot(gpq_ctx *c, uint64_t *r, const uint64_t *a, unsigned
 extern "C" int gpq_poly_conj(gpq_ctx *c, uint64_t *r, const uint64_t *a, unsigned W, unsigned batch, void *stream) {
   return permute(c, r, a, W, batch, 1, 1, stream);
 }
+
+// he_add / he_sub / he_neg on one polynomial (src/he-add.c), q_l = 2^logql; r may alias a or b.
+static int addsub(gpq_ctx *c, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned W, unsigned logql, unsigned mode, unsigned batch, void *stream) {
+  if (!c || !r || !a || (mode < 2 && !b) || W < 1 || batch < 1 || !logql || logql > 64 * W) return gpq_fail(GPQ_ERR_INVALID, "gpq_big_add/sub/neg: bad arguments");
+  AddSubArgs p{r, a, b, W, c->logn, logql, mode};
+  hipLaunchKernelGGL(bridge_addsub, dim3((c->n + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, p);
+  return launched("bridge_addsub");
+}
+extern "C" int gpq_big_add(gpq_ctx *c, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned W, unsigned logql, unsigned batch, void *stream) {
+  return addsub(c, r, a, b, W, logql, 0, batch, stream);
+}
+extern "C" int gpq_big_sub(gpq_ctx *c, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned W, unsigned logql, unsigned batch, void *stream) {
+  return addsub(c, r, a, b, W, logql, 1, batch, stream);
+}
+extern "C" int gpq_big_neg(gpq_ctx *c, uint64_t *r, const uint64_t *a, unsigned W, unsigned logql, unsigned batch, void *stream) {
+  return addsub(c, r, a, nullptr, W, logql, 2, batch, stream);
+}
+
+// Key slabs as he_genswk stores them (src/he-kem.c:103-110): rns_decompose + ntt of a centred big-slab polynomial
+// over dimevk limbs.  evk = uint64_t[batch][dimevk][n].
+extern "C" int gpq_evk_pack(gpq_ctx *c, uint64_t *evk, const uint64_t *big, unsigned W, unsigned dimevk, unsigned batch, void *stream) {
+  int rc = gpq_rns_decompose(c, evk, big, W, dimevk, batch, stream);
+  return rc ? rc : gpq_ntt(c, evk, dimevk, batch, stream);
+}

@@ -482,6 +482,37 @@ __global__ __launch_bounds__(256) void bridge_permute(PermuteArgs p) {
 }
 
 // ---------------------------------------------------------------------------
+// he_add / he_sub / he_neg on big slabs (src/he-add.c:32-142): mpi_addm / mpi_subm then mpi_smod, q_l = 2^k.
+// mode 0: a + b, 1: a - b, 2: -a.  Not on the NTT path; here so that a ciphertext can stay in HBM between
+// multiplications.
+// ---------------------------------------------------------------------------
+struct AddSubArgs { uint64_t *r; const uint64_t *a; const uint64_t *b; unsigned W, logn, logql, mode; };
+
+__global__ __launch_bounds__(256) void bridge_addsub(AddSubArgs p) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (1u << p.logn)) return;
+  const size_t base = ((size_t)blockIdx.y * p.W << p.logn) + i;
+  const unsigned sb = p.logql - 1;
+  uint64_t carry = p.mode ? 1 : 0, qsign = 0;
+  for (unsigned j = 0; j < p.W; ++j) {
+    const size_t o = base + ((size_t)j << p.logn);
+    const uint64_t x = p.mode == 2 ? 0 : p.a[o];
+    const uint64_t y = p.mode == 0 ? p.b[o] : ~(p.mode == 2 ? p.a[o] : p.b[o]);   // x - y = x + ~y + 1
+    const u128 t = (u128)x + y + carry;
+    uint64_t v = (uint64_t)t;
+    carry = (uint64_t)(t >> 64);
+    const unsigned lo = 64 * j;
+    if (lo + 64 > sb && lo <= sb) qsign = 0 - ((v >> (sb - lo)) & 1);
+    if (lo >= p.logql) v = qsign;
+    else if (lo + 64 > p.logql) {
+      const uint64_t mask = (1ull << (p.logql - lo)) - 1;
+      v = (v & mask) | (qsign & ~mask);
+    }
+    p.r[o] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // he_rs on one big slab, Delta = 2^s and q_l = 2^logql (the reference's test
 // parameters, tests/gpqhe.c:1349-1352): c <- smod(rdiv(c, Delta), q_l), in place.
 //   rdiv: floor(c / 2^s) = arithmetic shift; plus one when (c mod 2^s) > 2^(s-1)

@@ -214,6 +214,14 @@ int gpq_he_mulpt(gpq_ctx *ctx, uint64_t *out_c0, uint64_t *out_c1, const uint64_
 int gpq_poly_rot(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, unsigned W, unsigned rot, unsigned batch, void *stream);
 int gpq_poly_conj(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, unsigned W, unsigned batch, void *stream);
 
+/* he_add / he_sub / he_neg on one big-slab polynomial (src/he-add.c:32-142: mpi_addm / mpi_subm + mpi_smod), q_l = 2^logql.
+ * Not NTT work; offered so that ciphertexts can stay in HBM between multiplications.  r may alias a or b. */
+int gpq_big_add(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned W, unsigned logql, unsigned batch, void *stream);
+int gpq_big_sub(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned W, unsigned logql, unsigned batch, void *stream);
+int gpq_big_neg(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, unsigned W, unsigned logql, unsigned batch, void *stream);
+/* The storage step of he_genswk (src/he-kem.c:103-110): a centred key polynomial (big slab) -> NTT-domain slab of dimevk limbs. */
+int gpq_evk_pack(gpq_ctx *ctx, uint64_t *evk, const uint64_t *big, unsigned W, unsigned dimevk, unsigned batch, void *stream);
+
 /* ---- per-kernel profile ----------------------------------------------------
  * When enabled every kernel launch of this context is bracketed by two HIP
  * events on its own stream.  gpq_profile_collect waits for them and adds the

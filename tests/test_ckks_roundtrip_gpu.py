@@ -77,3 +77,31 @@ def test_encrypt_mul_rescale_decrypt(engine_ctx, oracle_ctx, logn, logq, logDelt
     got_rs = decrypt(r0, r1, q >> logDelta)
     want_rs = [ref.centred_mod(ref.mpi_rdiv(v, Delta), q >> logDelta) for v in want]
     assert max(abs(x - y) for x, y in zip(got_rs, want_rs)) < 2**24          # back at scale Delta, small absolute noise
+
+
+def test_add_sub_neg_and_evk_pack(engine_ctx, oracle_ctx):
+    """src/he-add.c semantics (mpi_addm/mpi_subm + mpi_smod) on big slabs, and the key-slab storage of
+    src/he-kem.c:103-110 (decompose + ntt over dimevk limbs)."""
+    import ctypes as C
+    import torch
+    logn, logql, W, dimevk = 7, 100, 2, 6
+    g, o = engine_ctx(logn, 12), oracle_ctx(logn, 12)
+    n, ql = g.n, 1 << logql
+    rng = random.Random(4)
+    h = ql // 2
+    a = [rng.randrange(-h, h) for _ in range(n)]
+    b = [rng.randrange(-h, h) for _ in range(n)]
+    a[:4], b[:4] = [h - 1, -h, -h, 0], [h - 1, -h, h - 1, 0]
+    da, db = to_device(ints_to_big(a, W)), to_device(ints_to_big(b, W))
+    r = torch.empty_like(da)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert g.lib.gpq_big_add(g.h, P(r), P(da), P(db), W, logql, 1, st) == 0
+    assert big_to_ints(to_host(r), W, n)[0] == [ref.mpi_smod((x + y) % ql, ql) for x, y in zip(a, b)]      # he_add, src/he-add.c:40-45
+    assert g.lib.gpq_big_sub(g.h, P(r), P(da), P(db), W, logql, 1, st) == 0
+    assert big_to_ints(to_host(r), W, n)[0] == [ref.mpi_smod((x - y) % ql, ql) for x, y in zip(a, b)]      # he_sub
+    assert g.lib.gpq_big_neg(g.h, P(r), P(da), W, logql, 1, st) == 0
+    assert big_to_ints(to_host(r), W, n)[0] == [ref.mpi_smod(-x, ql) for x in a]                           # he_neg
+    evk = torch.empty(dimevk * n, dtype=torch.int64, device="cuda")
+    assert g.lib.gpq_evk_pack(g.h, P(evk), P(da), W, dimevk, 1, st) == 0
+    assert np.array_equal(to_host(evk), _evk_slab(o, a, dimevk))
