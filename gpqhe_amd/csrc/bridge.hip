@@ -429,7 +429,6 @@ extern "C" int gpq_he_swk(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
   TailPlan tp;
   if ((rc = tail_plan(c, W, dimP, dimB, m, &tp))) return rc;
   char *w = (char *)workspace;
-  w += align64((size_t)m * 7 * 1 * n * 8) * 0;  // same carving as gpq_he_mul with dimA unused
   uint64_t *sB = (uint64_t *)w; w += align64((size_t)m * 3 * dimB * n * 8);
   void *wsK = w; w += align64(gpq_keyswitch_workspace_bytes(c, dimB, m));
   void *wsTail = w;
@@ -514,9 +513,7 @@ extern "C" int gpq_rns_reconstruct_general(gpq_ctx *c, uint64_t *big, unsigned W
   uint64_t *xfull = (uint64_t *)scratch, *dconst = xfull + (size_t)batch * ((size_t)Wx << c->logn);
   HIP_TRY(hipMemcpyAsync(dconst, consts.data(), consts.size() * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));   // consts is a local
-  const bool was = c->exact_crt;
   if ((rc = launch_reconstruct(c, b, xfull, Wx, slab, dim, 0, batch, 0, true, nullptr, s))) return rc;   // centred mod P, full width
-  (void)was;
   SmodArgs a{xfull, big, dconst, dconst + 64, dconst + 128, Wx, Wout, L, c->logn};
   hipLaunchKernelGGL(bridge_smod_general, dim3((c->n + 63) / 64, batch), dim3(64), 0, s, a);
   return launched("gpq_rns_reconstruct_general");

@@ -294,8 +294,6 @@ struct ProfScope {
   }
 };
 
-struct Shape { unsigned dim, batch; };
-
 int check_shape(const gpq_ctx *c, unsigned dim, unsigned batch, const char *who) {
   if (!c) return gpq_fail(GPQ_ERR_INVALID, "%s: null context", who);
   if (dim < 1 || dim > c->nprimes) return gpq_fail(GPQ_ERR_INVALID, "%s: dim=%u outside 1..%u", who, dim, c->nprimes);
