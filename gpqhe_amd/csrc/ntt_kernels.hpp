@@ -273,12 +273,6 @@ __device__ __forceinline__ void load_l(uint64_t (&x)[16], const uint64_t *__rest
 #pragma unroll
   for (int e = 0; e < 8; ++e) { ulonglong2 t = v[e]; x[2 * e] = t.x; x[2 * e + 1] = t.y; }
 }
-__device__ __forceinline__ void store_l(uint64_t *__restrict__ p, const uint64_t (&x)[16], const ContigLane &ln) {
-  ulonglong2 *v = reinterpret_cast<ulonglong2 *>(p + ln.lbase);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = make_ulonglong2(x[2 * e], x[2 * e + 1]);
-}
-
 struct ContigBlock {       // per-workgroup addressing shared by the contiguous kernels
   unsigned wave0;          // limb-relative index of the wave's first coefficient
   unsigned limb;           // prime index

@@ -97,3 +97,41 @@ def test_linearity_full_size(engine_ctx, oracle_ctx):
     assert np.array_equal(e0, (d0 + f0) % p)
     assert np.array_equal(e1, (d1 + f1) % p)
     assert np.array_equal(e2, d2) and not f2.any()
+
+
+def test_repeatable_under_load(engine_ctx, oracle_ctx):
+    """The contiguous kernels exchange registers through wave-private LDS regions without workgroup barriers,
+    and the strided ones through one barrier: run the full-size core back to back (every CU busy, several
+    launch groups in flight) and require identical bits every time; spot-check one ciphertext against the oracle."""
+    import torch
+    logn, dA, dB, batch = 16, 30, 45, 24
+    g, o = engine_ctx(logn, 45), oracle_ctx(logn, 45)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(77)
+
+    def slab(dim, polys):
+        out = torch.empty((polys, dim, g.n), dtype=torch.int64, device="cuda")
+        for d in range(dim):
+            out[:, d, :] = torch.randint(0, g.p[d], (polys, g.n), dtype=torch.int64, device="cuda", generator=gen)
+        return out.reshape(-1)
+
+    ins = [slab(dA, batch) for _ in range(4)]
+    x, e0, e1 = slab(dB, batch), slab(dB, 1), slab(dB, 1)
+    outs = [torch.empty_like(ins[0]) for _ in range(3)]
+    cs = [torch.empty_like(x) for _ in range(2)]
+    wsA, wsB = g.tensor_workspace(dA, batch), g.keyswitch_workspace(dB, batch)
+    g.set_chunk(8)                      # three launch groups per call
+    g.he_mul_tensor(*outs, *ins, dA, wsA)
+    g.he_keyswitch(*cs, x, e0, e1, dB, wsB)
+    first = [t.clone() for t in outs + cs]
+    for _ in range(12):
+        g.he_mul_tensor(*outs, *ins, dA, wsA)
+        g.he_keyswitch(*cs, x, e0, e1, dB, wsB)
+        for got, ref0 in zip(outs + cs, first):
+            assert torch.equal(got, ref0), "results changed between identical launches"
+    g.set_chunk(16)
+    k, perA, perB = batch - 1, dA * g.n, dB * g.n
+    d = o.he_mul_tensor(*[to_host(v[k * perA:(k + 1) * perA]) for v in ins], dA)
+    c = o.keyswitch(to_host(x[k * perB:(k + 1) * perB]), to_host(e0), to_host(e1), dB)
+    for got, exp, per in zip(first, list(d) + list(c), (perA, perA, perA, perB, perB)):
+        assert np.array_equal(to_host(got[k * per:(k + 1) * per]), exp)
