@@ -63,6 +63,12 @@ SIGNATURES = {
     "gpq_he_mulpt": (C.c_int, [vp] * 6 + [C.c_uint] * 4 + [vp, vp]),
     "gpq_poly_rot": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, vp]),
     "gpq_poly_conj": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, vp]),
+    "gpq_he_general_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
+    "gpq_he_rs_general": (C.c_int, [vp, vp, vp, C.c_uint, C.c_ulonglong, C.POINTER(u64), C.c_uint, C.c_uint, vp, vp]),
+    "gpq_relin_tail_general": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.POINTER(u64), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
+    "gpq_he_mul_general": (C.c_int, [vp] * 9 + [C.c_uint, C.POINTER(u64), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
+    "gpq_he_mulpt_general": (C.c_int, [vp] * 6 + [C.c_uint, C.POINTER(u64), C.c_uint, C.c_uint, C.c_uint, vp, vp]),
+    "gpq_he_swk_general": (C.c_int, [vp] * 7 + [C.c_uint, C.POINTER(u64), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
     "gpq_big_add": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, vp]),
     "gpq_big_sub": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, vp]),
     "gpq_big_neg": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, vp]),

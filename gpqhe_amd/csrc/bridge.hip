@@ -489,33 +489,44 @@ extern "C" size_t gpq_poly_mul_general_workspace_bytes(gpq_ctx *c, unsigned dim,
   return gpq_poly_mul_workspace_bytes(c, dim, batch) + (size_t)batch * ((size_t)(b->WP + 1) << c->logn) * 8 + 3 * 8 * 64 + 64;
 }
 
+constexpr size_t kModConstWords = 3 * 64;   // M, mu, floor(M/2) of a general modulus, device side
+
+// mpi_smod(x, q, floor(q/2)) of a big slab for an arbitrary q (host words): uploads the Barrett constants into
+// `dconst` (kModConstWords device words) and launches the kernel.  x and out may be the same slab.
+int launch_smod_general(gpq_ctx *c, uint64_t *out, unsigned Wout, const uint64_t *x, unsigned Wx, const uint64_t *q_words, unsigned Lq,
+                        unsigned batch, uint64_t *dconst, hipStream_t s) {
+  if (!q_words || Lq < 1 || Lq > (unsigned)SMOD_MAXW / 2) return gpq_fail(GPQ_ERR_INVALID, "general modulus: bad word count %u", Lq);
+  Big M(q_words, q_words + Lq);
+  while (M.size() > 1 && M.back() == 0) M.pop_back();
+  const unsigned L = (unsigned)M.size();
+  if (L == 1 && M[0] == 0) return gpq_fail(GPQ_ERR_INVALID, "zero modulus");
+  if (Wx > (unsigned)SMOD_MAXW) return gpq_fail(GPQ_ERR_UNSUPPORTED, "general modulus: value of %u words", Wx);
+  if (Wout < L) return gpq_fail(GPQ_ERR_INVALID, "general modulus: %u words cannot hold a value mod q (%u words)", Wout, L);
+  Big mu = floor_pow2_div(128 * L, M), half = M;
+  shr1(half);
+  std::vector<uint64_t> consts(kModConstWords, 0);
+  put(consts, 0, M, L); put(consts, 64, mu, L + 1); put(consts, 128, half, L);
+  HIP_TRY(hipMemcpyAsync(dconst, consts.data(), consts.size() * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));   // consts is a local: keep it alive until the copy has happened
+  SmodArgs a{x, out, dconst, dconst + 64, dconst + 128, Wx, Wout, L, c->logn};
+  hipLaunchKernelGGL(bridge_smod_general, dim3((c->n + 63) / 64, batch), dim3(64), 0, s, a);
+  return GPQ_OK;
+}
+
 // poly_rns2mpi (src/poly.c:109-120) for an arbitrary q: centred CRT value, then mpi_smod(., q, floor(q/2)).
 // q = q_words[0..Lq) little-endian; `scratch` holds batch*(WP+1)*n words + 3*64 words.
 extern "C" int gpq_rns_reconstruct_general(gpq_ctx *c, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned dim, unsigned batch,
                                            const uint64_t *q_words, unsigned Lq, void *scratch, void *stream) {
   int rc = check(c, dim, batch, "gpq_rns_reconstruct_general");
   if (rc) return rc;
-  if (!big || !slab || !q_words || !scratch || Lq < 1 || Lq > (unsigned)SMOD_MAXW / 2) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct_general: bad arguments");
+  if (!big || !slab || !q_words || !scratch) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct_general: bad arguments");
   gpq_bridge_basis *b;
   if ((rc = get_basis(c, 0, dim, &b))) return rc;
-  Big M(q_words, q_words + Lq);
-  while (M.size() > 1 && M.back() == 0) M.pop_back();
-  const unsigned L = (unsigned)M.size();
-  if (L == 1 && M[0] == 0) return gpq_fail(GPQ_ERR_INVALID, "zero modulus");
   const unsigned Wx = b->WP + 1;
-  if (Wx > (unsigned)SMOD_MAXW) return gpq_fail(GPQ_ERR_UNSUPPORTED, "general modulus: CRT value of %u words", Wx);
-  if (Wout < L) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct_general: %u words cannot hold a value mod q (%u words)", Wout, L);
-  Big mu = floor_pow2_div(128 * L, M), half = M;
-  shr1(half);
-  std::vector<uint64_t> consts(3 * 64, 0);
-  put(consts, 0, M, L); put(consts, 64, mu, L + 1); put(consts, 128, half, L);
   hipStream_t s = (hipStream_t)stream;
   uint64_t *xfull = (uint64_t *)scratch, *dconst = xfull + (size_t)batch * ((size_t)Wx << c->logn);
-  HIP_TRY(hipMemcpyAsync(dconst, consts.data(), consts.size() * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipStreamSynchronize(s));   // consts is a local
   if ((rc = launch_reconstruct(c, b, xfull, Wx, slab, dim, 0, batch, 0, true, nullptr, s))) return rc;   // centred mod P, full width
-  SmodArgs a{xfull, big, dconst, dconst + 64, dconst + 128, Wx, Wout, L, c->logn};
-  hipLaunchKernelGGL(bridge_smod_general, dim3((c->n + 63) / 64, batch), dim3(64), 0, s, a);
+  if ((rc = launch_smod_general(c, big, Wout, xfull, Wx, q_words, Lq, batch, dconst, s))) return rc;
   return launched("gpq_rns_reconstruct_general");
 }
 
@@ -598,4 +609,182 @@ extern "C" int gpq_big_neg(gpq_ctx *c, uint64_t *r, const uint64_t *a, unsigned 
 extern "C" int gpq_evk_pack(gpq_ctx *c, uint64_t *evk, const uint64_t *big, unsigned W, unsigned dimevk, unsigned batch, void *stream) {
   int rc = gpq_rns_decompose(c, evk, big, W, dimevk, batch, stream);
   return rc ? rc : gpq_ntt(c, evk, dimevk, batch, stream);
+}
+
+// ---------------------------------------------------------------------------
+// general q_l (any modulus, little-endian words) and Delta (any uint64_t): the same operations through the
+// Barrett kernel.  Slow-path quality (key generation / unusual parameter sets); results follow the same
+// reference semantics bit for bit.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct GenPlan { unsigned Wr, cnt, WQ, WF; size_t words, bytes; };
+
+int gen_plan(gpq_ctx *c, unsigned W, unsigned dimP, unsigned dimB, unsigned polys, GenPlan *p) {
+  gpq_bridge_basis *bp, *bq;
+  int rc;
+  if (dimB <= dimP) return gpq_fail(GPQ_ERR_INVALID, "relin: dimB=%u must exceed dimP=%u", dimB, dimP);
+  if ((rc = get_basis(c, 0, dimP, &bp)) || (rc = get_basis(c, dimP, dimB - dimP, &bq))) return rc;
+  p->Wr = bp->pbits / 64 + 1;
+  p->cnt = dimB - dimP;
+  p->WQ = bq->WP + 1;
+  p->WF = (p->WQ > W ? p->WQ : W) + 1;
+  p->words = (size_t)polys * ((size_t)(p->Wr + 2 * p->cnt + p->WQ + p->WF) << c->logn) + kModConstWords;
+  p->bytes = p->words * 8 + ((size_t)polys << c->logn) + 64;
+  return GPQ_OK;
+}
+
+int relin_tail_general(gpq_ctx *c, uint64_t *out, const uint64_t *chat, const uint64_t *dbig, unsigned W, unsigned dimP, unsigned dimB,
+                       const uint64_t *ql_words, unsigned Lq, unsigned polys, void *ws, hipStream_t s) {
+  GenPlan gp;
+  int rc = gen_plan(c, W, dimP, dimB, polys, &gp);
+  if (rc) return rc;
+  gpq_bridge_basis *bp, *bq;
+  gpq_relin_tables *rt;
+  if ((rc = get_basis(c, 0, dimP, &bp)) || (rc = get_basis(c, dimP, gp.cnt, &bq)) || (rc = get_relin(c, dimP, dimB, &rt))) return rc;
+  const size_t n = c->n;
+  uint64_t *r = (uint64_t *)ws, *rhat = r + (size_t)polys * gp.Wr * n, *qhat = rhat + (size_t)polys * gp.cnt * n,
+           *qfull = qhat + (size_t)polys * gp.cnt * n, *full = qfull + (size_t)polys * gp.WQ * n, *dconst = full + (size_t)polys * gp.WF * n;
+  unsigned char *tie = (unsigned char *)(dconst + kModConstWords);
+  if ((rc = launch_reconstruct(c, bp, r, gp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s))) return rc;
+  if ((rc = launch_decompose(c, rhat, r, gp.Wr, dimP, gp.cnt, polys, s))) return rc;
+  ExactDivArgs e{c->d_tabs, chat, rhat, qhat, rt->d_pinv, dimB, dimP, gp.cnt, c->logn};
+  hipLaunchKernelGGL(bridge_exactdiv, dim3((c->n + 255) / 256, polys, gp.cnt), dim3(256), 0, s, e);
+  if ((rc = launch_reconstruct(c, bq, qfull, gp.WQ, qhat, gp.cnt, 0, polys, 0, true, tie, s))) return rc;   // floor-quotient, full width
+  AddRoundFullArgs ar{full, qfull, r, dbig, bp->d_phalf, bq->d_pmult + (size_t)5 * (bq->WP + 1), tie, gp.WF, gp.WQ, gp.Wr, W, c->logn};
+  hipLaunchKernelGGL(bridge_addround_full, dim3((c->n + 255) / 256, polys), dim3(256), 0, s, ar);
+  if ((rc = launch_smod_general(c, out, W, full, gp.WF, ql_words, Lq, polys, dconst, s))) return rc;        // addm + smod, src/he-mult.c:73-76
+  return launched("relin_tail_general");
+}
+
+}  // namespace
+
+extern "C" size_t gpq_he_general_workspace_bytes(gpq_ctx *c, unsigned W, unsigned dimA, unsigned dimB, unsigned dimP, unsigned batch) {
+  const unsigned m = batch < c->chunk ? batch : c->chunk;
+  GenPlan gp;
+  gpq_bridge_basis *bA;
+  if (gen_plan(c, W, dimP, dimB, m, &gp) != GPQ_OK || get_basis(c, 0, dimA ? dimA : 1, &bA) != GPQ_OK) return 0;
+  const size_t n = c->n;
+  size_t b = 0;
+  b += align64((size_t)m * 7 * dimA * n * 8);
+  b += align64(gpq_tensor_workspace_bytes(c, dimA ? dimA : 1, m));
+  b += align64((size_t)m * 3 * dimB * n * 8);
+  b += align64(gpq_keyswitch_workspace_bytes(c, dimB, m));
+  b += align64((size_t)m * 3 * W * n * 8);
+  b += align64((size_t)m * (bA->WP + 1) * n * 8 + kModConstWords * 8);   // full-width CRT value of d0/d1/d2
+  b += align64(gp.bytes);
+  return b;
+}
+
+// he_rs for any Delta (uint64_t, as hectx_init takes it) and any q_l; scratch = 3*64 words.
+extern "C" int gpq_he_rs_general(gpq_ctx *c, uint64_t *c0, uint64_t *c1, unsigned W, unsigned long long delta, const uint64_t *ql_words,
+                                 unsigned Lq, unsigned batch, void *scratch, void *stream) {
+  if (!c || !c0 || !c1 || !scratch || W < 1 || batch < 1 || !delta) return gpq_fail(GPQ_ERR_INVALID, "gpq_he_rs_general: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  for (uint64_t *p : {c0, c1}) {
+    RdivWordArgs a{p, p, W, c->logn, delta};                                                            // src/he-rescale.c:45-46
+    hipLaunchKernelGGL(bridge_rdiv_word, dim3((c->n + 255) / 256, batch), dim3(256), 0, s, a);
+    if ((rc = launch_smod_general(c, p, W, p, W, ql_words, Lq, batch, (uint64_t *)scratch, s))) return rc;  // :47-48
+  }
+  return launched("gpq_he_rs_general");
+}
+
+extern "C" int gpq_relin_tail_general(gpq_ctx *c, uint64_t *out, const uint64_t *chat, const uint64_t *d, unsigned W, const uint64_t *ql_words,
+                                      unsigned Lq, unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream) {
+  int rc = check(c, dimB, batch, "gpq_relin_tail_general");
+  if (rc) return rc;
+  if (!out || !chat || !workspace || !ql_words) return gpq_fail(GPQ_ERR_INVALID, "gpq_relin_tail_general: bad arguments");
+  return relin_tail_general(c, out, chat, d, W, dimP, dimB, ql_words, Lq, batch, workspace, (hipStream_t)stream);
+}
+
+// he_mul for any q_l (src/he-mult.c:88-156); workspace from gpq_he_general_workspace_bytes.
+extern "C" int gpq_he_mul_general(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *ct1c0, const uint64_t *ct1c1,
+                                  const uint64_t *ct2c0, const uint64_t *ct2c1, const uint64_t *rlk0, const uint64_t *rlk1, unsigned W,
+                                  const uint64_t *ql_words, unsigned Lq, unsigned dimA, unsigned dimB, unsigned dimP, unsigned batch,
+                                  void *workspace, void *stream) {
+  int rc = check(c, dimA, batch, "gpq_he_mul_general");
+  if (rc || (rc = check(c, dimB, batch, "gpq_he_mul_general"))) return rc;
+  if (!out_c0 || !out_c1 || !ct1c0 || !ct1c1 || !ct2c0 || !ct2c1 || !rlk0 || !rlk1 || !workspace || !ql_words)
+    return gpq_fail(GPQ_ERR_INVALID, "gpq_he_mul_general: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = c->n, bigpoly = (size_t)W * n;
+  const unsigned m = batch < c->chunk ? batch : c->chunk;
+  GenPlan gp;
+  gpq_bridge_basis *bA;
+  if ((rc = gen_plan(c, W, dimP, dimB, m, &gp)) || (rc = get_basis(c, 0, dimA, &bA))) return rc;
+  char *w = (char *)workspace;
+  uint64_t *sA = (uint64_t *)w; w += align64((size_t)m * 7 * dimA * n * 8);
+  void *wsT = w; w += align64(gpq_tensor_workspace_bytes(c, dimA, m));
+  uint64_t *sB = (uint64_t *)w; w += align64((size_t)m * 3 * dimB * n * 8);
+  void *wsK = w; w += align64(gpq_keyswitch_workspace_bytes(c, dimB, m));
+  uint64_t *dbig = (uint64_t *)w; w += align64((size_t)m * 3 * W * n * 8);
+  uint64_t *xfull = (uint64_t *)w; w += align64((size_t)m * (bA->WP + 1) * n * 8 + kModConstWords * 8);
+  void *wsTail = w;
+  const unsigned Wx = bA->WP + 1;
+  for (unsigned k0 = 0; k0 < batch; k0 += m) {
+    const unsigned polys = batch - k0 < m ? batch - k0 : m;
+    const size_t pa = (size_t)polys * dimA * n, pb = (size_t)polys * dimB * n;
+    uint64_t *h[4] = {sA, sA + pa, sA + 2 * pa, sA + 3 * pa};
+    uint64_t *dh[3] = {sA + 4 * pa, sA + 5 * pa, sA + 6 * pa};   // d0hat, d1hat, d2hat
+    const uint64_t *in[4] = {ct1c0, ct1c1, ct2c0, ct2c1};
+    for (int i = 0; i < 4; ++i)
+      if ((rc = launch_decompose(c, h[i], in[i] + k0 * bigpoly, W, 0, dimA, polys, s))) return rc;
+    if ((rc = gpq_he_mul_tensor(c, dh[0], dh[1], dh[2], h[0], h[1], h[2], h[3], dimA, polys, wsT, stream))) return rc;
+    uint64_t *dd[3] = {dbig, dbig + polys * bigpoly, dbig + 2 * polys * bigpoly};
+    uint64_t *dconst = xfull + (size_t)polys * Wx * n;
+    for (int i = 0; i < 3; ++i) {                                                                   // :139-141
+      if ((rc = launch_reconstruct(c, bA, xfull, Wx, dh[i], dimA, 0, polys, 0, true, nullptr, s))) return rc;
+      if ((rc = launch_smod_general(c, dd[i], W, xfull, Wx, ql_words, Lq, polys, dconst, s))) return rc;
+    }
+    uint64_t *d2hat = sB, *c0hat = sB + pb, *c1hat = sB + 2 * pb;
+    if ((rc = launch_decompose(c, d2hat, dd[2], W, 0, dimB, polys, s))) return rc;
+    if ((rc = gpq_keyswitch(c, c0hat, c1hat, d2hat, rlk0, rlk1, dimB, polys, wsK, stream))) return rc;
+    if ((rc = relin_tail_general(c, out_c0 + k0 * bigpoly, c0hat, dd[0], W, dimP, dimB, ql_words, Lq, polys, wsTail, s))) return rc;
+    if ((rc = relin_tail_general(c, out_c1 + k0 * bigpoly, c1hat, dd[1], W, dimP, dimB, ql_words, Lq, polys, wsTail, s))) return rc;
+  }
+  return launched("gpq_he_mul_general");
+}
+
+// he_swk for any q_l (src/he-automorphism.c:40-85); workspace from gpq_he_general_workspace_bytes with dimA = 0.
+extern "C" int gpq_he_swk_general(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *d0, const uint64_t *d1,
+                                  const uint64_t *swk0, const uint64_t *swk1, unsigned W, const uint64_t *ql_words, unsigned Lq,
+                                  unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream) {
+  int rc = check(c, dimB, batch, "gpq_he_swk_general");
+  if (rc) return rc;
+  if (!out_c0 || !out_c1 || !d0 || !d1 || !swk0 || !swk1 || !workspace || !ql_words) return gpq_fail(GPQ_ERR_INVALID, "gpq_he_swk_general: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = c->n, bigpoly = (size_t)W * n;
+  const unsigned m = batch < c->chunk ? batch : c->chunk;
+  char *w = (char *)workspace;
+  uint64_t *sB = (uint64_t *)w; w += align64((size_t)m * 3 * dimB * n * 8);
+  void *wsK = w; w += align64(gpq_keyswitch_workspace_bytes(c, dimB, m));
+  void *wsTail = w;
+  for (unsigned k0 = 0; k0 < batch; k0 += m) {
+    const unsigned polys = batch - k0 < m ? batch - k0 : m;
+    const size_t pb = (size_t)polys * dimB * n;
+    uint64_t *d1hat = sB, *c0hat = sB + pb, *c1hat = sB + 2 * pb;
+    if ((rc = launch_decompose(c, d1hat, d1 + k0 * bigpoly, W, 0, dimB, polys, s))) return rc;
+    if ((rc = gpq_keyswitch(c, c0hat, c1hat, d1hat, swk0, swk1, dimB, polys, wsK, stream))) return rc;
+    if ((rc = relin_tail_general(c, out_c0 + k0 * bigpoly, c0hat, d0 + k0 * bigpoly, W, dimP, dimB, ql_words, Lq, polys, wsTail, s))) return rc;
+    if ((rc = relin_tail_general(c, out_c1 + k0 * bigpoly, c1hat, nullptr, W, dimP, dimB, ql_words, Lq, polys, wsTail, s))) return rc;
+  }
+  return launched("gpq_he_swk_general");
+}
+
+// he_mulpt for any q_l; workspace = gpq_he_mulpt_workspace_bytes + gpq_poly_mul_general_workspace_bytes.
+extern "C" int gpq_he_mulpt_general(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *c0, const uint64_t *c1, const uint64_t *m,
+                                    unsigned W, const uint64_t *ql_words, unsigned Lq, unsigned dim, unsigned batch, void *workspace, void *stream) {
+  int rc = check(c, dim, batch, "gpq_he_mulpt_general");
+  if (rc) return rc;
+  if (!out_c0 || !out_c1 || !c0 || !c1 || !m || !workspace || !ql_words) return gpq_fail(GPQ_ERR_INVALID, "gpq_he_mulpt_general: bad arguments");
+  const size_t poly = (size_t)dim << c->logn;
+  uint64_t *s0 = (uint64_t *)workspace, *s1 = s0 + batch * poly, *sm = s1 + batch * poly, *scratch = sm + batch * poly;
+  if ((rc = gpq_rns_decompose(c, sm, m, W, dim, batch, stream)) || (rc = gpq_rns_decompose(c, s0, c0, W, dim, batch, stream)) ||
+      (rc = gpq_rns_decompose(c, s1, c1, W, dim, batch, stream))) return rc;
+  if ((rc = gpq_ntt(c, sm, dim, batch, stream)) || (rc = gpq_ntt(c, s0, dim, batch, stream)) || (rc = gpq_ntt(c, s1, dim, batch, stream))) return rc;
+  if ((rc = gpq_rns_mul(c, s0, s0, sm, dim, batch, stream)) || (rc = gpq_invntt(c, s0, dim, batch, stream))) return rc;
+  if ((rc = gpq_rns_mul(c, s1, s1, sm, dim, batch, stream)) || (rc = gpq_invntt(c, s1, dim, batch, stream))) return rc;
+  if ((rc = gpq_rns_reconstruct_general(c, out_c0, W, s0, dim, batch, ql_words, Lq, scratch, stream))) return rc;
+  return gpq_rns_reconstruct_general(c, out_c1, W, s1, dim, batch, ql_words, Lq, scratch, stream);
 }

@@ -482,6 +482,88 @@ __global__ __launch_bounds__(256) void bridge_permute(PermuteArgs p) {
 }
 
 // ---------------------------------------------------------------------------
+// mpi_rdiv(x, m) for a one-word divisor m (hectx.p = Delta is a uint64_t, src/gpqhe.h:100, src/precomp.c:448):
+// floor(x/m), plus one when the remainder is strictly above floor(m/2) (src/types.c:115-128).  Long division of
+// |x| by words from the top; floor semantics for negative x restored afterwards.  In place allowed.
+// ---------------------------------------------------------------------------
+struct RdivWordArgs { const uint64_t *x; uint64_t *out; unsigned W, logn; unsigned long long m; };
+
+__global__ __launch_bounds__(256) void bridge_rdiv_word(RdivWordArgs a) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (1u << a.logn)) return;
+  const size_t base = ((size_t)blockIdx.y * a.W << a.logn) + i;
+  const bool neg = a.x[base + ((size_t)(a.W - 1) << a.logn)] >> 63;
+  // magnitude, most significant word first; the negation carry needs the low words first, so two sweeps
+  uint64_t carry = neg;
+  for (unsigned j = 0; j < a.W; ++j) {
+    uint64_t w = a.x[base + ((size_t)j << a.logn)];
+    if (neg) { w = ~w + carry; carry = carry && w == 0; }
+    a.out[base + ((size_t)j << a.logn)] = w;
+  }
+  uint64_t rem = 0;
+  for (int j = (int)a.W - 1; j >= 0; --j) {
+    const u128 cur = ((u128)rem << 64) | a.out[base + ((size_t)j << a.logn)];
+    a.out[base + ((size_t)j << a.logn)] = (uint64_t)(cur / a.m);
+    rem = (uint64_t)(cur % a.m);
+  }
+  // x = s*(Q*m + rem): floor and remainder of the signed value, then the rounding rule
+  uint64_t add = 0;                 // added to the magnitude Q before restoring the sign
+  bool roundup;
+  if (!neg) roundup = rem > a.m / 2;
+  else if (rem == 0) roundup = false;
+  else { add = 1; roundup = (a.m - rem) > a.m / 2; }           // floor = -(Q+1), remainder m - rem
+  // result = neg ? -(Q + add) + roundup : Q + roundup
+  uint64_t c1 = neg ? add : (roundup ? 1 : 0);
+  for (unsigned j = 0; j < a.W && c1; ++j) {
+    uint64_t &w = a.out[base + ((size_t)j << a.logn)];
+    w += c1; c1 = w == 0;
+  }
+  if (neg) {
+    uint64_t c = 1;
+    for (unsigned j = 0; j < a.W; ++j) { uint64_t &w = a.out[base + ((size_t)j << a.logn)]; w = ~w + c; c = c && w == 0; }
+    uint64_t c2 = roundup ? 1 : 0;
+    for (unsigned j = 0; j < a.W && c2; ++j) { uint64_t &w = a.out[base + ((size_t)j << a.logn)]; w += c2; c2 = w == 0; }
+  }
+}
+
+// General-modulus tail of he_relin: full = Q + [r > floor(P/2)] + d (+ Pi' on the wrap corner), WF words, signed.
+struct AddRoundFullArgs {
+  uint64_t *full;              // [polys][WF][n]
+  const uint64_t *q;           // [polys][WQ][n]   centred quotient, full width
+  const uint64_t *r;           // [polys][Wr][n]
+  const uint64_t *d;           // [polys][W][n] or null
+  const uint64_t *phalf;       // [Wr]
+  const uint64_t *piq;         // [WQ]  Pi'
+  const unsigned char *tie;
+  unsigned WF, WQ, Wr, W, logn;
+};
+
+__global__ __launch_bounds__(256) void bridge_addround_full(AddRoundFullArgs a) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (1u << a.logn)) return;
+  const uint64_t *__restrict__ r = a.r + ((size_t)blockIdx.y * a.Wr << a.logn) + i;
+  int cmp = 0;
+  for (int j = (int)a.Wr - 1; j >= 0 && cmp == 0; --j) {
+    const uint64_t rv = r[(size_t)j << a.logn], hv = a.phalf[j];
+    cmp = rv > hv ? 1 : (rv < hv ? -1 : 0);
+  }
+  const bool fix = a.tie[((size_t)blockIdx.y << a.logn) + i] && cmp < 0;
+  const uint64_t *__restrict__ q = a.q + ((size_t)blockIdx.y * a.WQ << a.logn) + i;
+  const uint64_t *__restrict__ d = a.d ? a.d + ((size_t)blockIdx.y * a.W << a.logn) + i : nullptr;
+  const uint64_t qs = (uint64_t)((int64_t)q[(size_t)(a.WQ - 1) << a.logn] >> 63);
+  const uint64_t ds = d ? (uint64_t)((int64_t)d[(size_t)(a.W - 1) << a.logn] >> 63) : 0;
+  uint64_t carry = cmp > 0;
+  for (unsigned j = 0; j < a.WF; ++j) {
+    const uint64_t qv = j < a.WQ ? q[(size_t)j << a.logn] : qs;
+    const uint64_t dv = d ? (j < a.W ? d[(size_t)j << a.logn] : ds) : 0;
+    const uint64_t pv = fix && j < a.WQ ? a.piq[j] : 0;
+    const u128 t = (u128)qv + dv + pv + carry;
+    a.full[(((size_t)blockIdx.y * a.WF + j) << a.logn) + i] = (uint64_t)t;
+    carry = (uint64_t)(t >> 64);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // he_add / he_sub / he_neg on big slabs (src/he-add.c:32-142): mpi_addm / mpi_subm then mpi_smod, q_l = 2^k.
 // mode 0: a + b, 1: a - b, 2: -a.  Not on the NTT path; here so that a ciphertext can stay in HBM between
 // multiplications.

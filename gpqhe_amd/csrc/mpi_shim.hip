@@ -83,12 +83,6 @@ bool is_pow2(const std::vector<uint64_t> &w) {
   for (uint64_t v : w) ones += __builtin_popcountll(v);
   return ones == 1;
 }
-// log2 of a power-of-two MPI; dies otherwise (he_mul / he_rs need q_l and Delta = 2^k on the device)
-unsigned log2_exact(MPI q, const char *what) {
-  if (!is_pow2(words_of(q, what))) die(what);
-  return G.mpi_get_nbits(q) - 1;
-}
-
 unsigned max_bits(const poly_mpi_t *a, unsigned n) {
   unsigned m = 0;
   for (unsigned i = 0; i < n; ++i) { const unsigned b = G.mpi_get_nbits(a->coeffs[i]); if (b > m) m = b; }
@@ -202,8 +196,9 @@ void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t 
   const unsigned n = polyctx.n, l = ct1->l;
   const double nu = ct1->nu * ct2->nu;                                                        // :93
   const double B = ct1->nu * ct2->B + ct2->nu * ct1->B + ct1->B * ct2->B + hectx.bnd.Bmult[l];  // :94-95
-  const unsigned logql = log2_exact(hectx.q[l], "he_mul: q_l must be a power of two");
-  const unsigned nbq = logql + 1, nbPqL = G.mpi_get_nbits(hectx.PqL);
+  const std::vector<uint64_t> qw = words_of(hectx.q[l], "he_mul: q_l must be positive");
+  const bool pow2 = is_pow2(qw);
+  const unsigned nbq = G.mpi_get_nbits(hectx.q[l]), logql = nbq - 1, nbPqL = G.mpi_get_nbits(hectx.PqL);
   const unsigned dimA = (nbq * 2 + polyctx.logn) / 59 + 1;                                     // :99
   const unsigned dimB = (nbq + nbPqL + polyctx.logn) / 59 + 1;                                 // :51
   const unsigned dimP = hectx.dim;                                                             // hectx.P, src/precomp.c:401-404
@@ -214,11 +209,14 @@ void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t 
   const poly_mpi_t *in[4] = {&ct1->c0, &ct1->c1, &ct2->c0, &ct2->c1};
   for (int i = 0; i < 4; ++i) to_slab(h[i].data(), in[i], n, W);
   DevBuf d0(big * 8), d1(big * 8), d2(big * 8), d3(big * 8), o0(big * 8), o1(big * 8), k0(evk * 8), k1(evk * 8),
-      ws(gpq_he_mul_workspace_bytes(c, W, dimA, dimB, dimP, 1));
+      ws(pow2 ? gpq_he_mul_workspace_bytes(c, W, dimA, dimB, dimP, 1) : gpq_he_general_workspace_bytes(c, W, dimA, dimB, dimP, 1));
   up(d0, h[0]); up(d1, h[1]); up(d2, h[2]); up(d3, h[3]);
   if (gpq_upload(k0.p, rlk->p0.coeffs, evk * 8, nullptr) != GPQ_OK || gpq_upload(k1.p, rlk->p1.coeffs, evk * 8, nullptr) != GPQ_OK) die("upload failed");
-  if (gpq_he_mul(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), d2.u64(), d3.u64(), k0.u64(), k1.u64(), W, logql, dimA, dimB, dimP, 1, ws.p,
-                 nullptr) != GPQ_OK) die("he_mul failed");
+  const int rc = pow2 ? gpq_he_mul(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), d2.u64(), d3.u64(), k0.u64(), k1.u64(), W, logql, dimA, dimB, dimP,
+                                   1, ws.p, nullptr)
+                      : gpq_he_mul_general(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), d2.u64(), d3.u64(), k0.u64(), k1.u64(), W, qw.data(),
+                                           (unsigned)qw.size(), dimA, dimB, dimP, 1, ws.p, nullptr);
+  if (rc != GPQ_OK) die("he_mul failed");
   down(h[0], o0); down(h[1], o1);
   from_slab(&ct->c0, h[0].data(), n, W);
   from_slab(&ct->c1, h[1].data(), n, W);
@@ -232,18 +230,25 @@ static void rescale_common(he_ct_t *ct, bool divide) {
   const unsigned n = polyctx.n;
   if (ct->l == 0) die("he_rs / he_moddown: already at level 0");
   const unsigned lnew = ct->l - 1;                                                             // src/he-rescale.c:36, :59
-  const unsigned logql = log2_exact(hectx.q[lnew], "he_rs: q_l must be a power of two");
-  const unsigned s = divide ? log2_exact(hectx.p, "he_rs: Delta must be a power of two") : 0;
+  const std::vector<uint64_t> qw = words_of(hectx.q[lnew], "he_rs: q_l must be positive");
+  const std::vector<uint64_t> dw = words_of(hectx.p, "he_rs: Delta must be positive");
+  if (dw.size() != 1) die("he_rs: Delta wider than 64 bits");          // hectx_init takes a uint64_t, src/gpqhe.h:100
+  const bool pow2 = is_pow2(qw) && (!divide || is_pow2(dw));
+  const unsigned logql = G.mpi_get_nbits(hectx.q[lnew]) - 1;
+  const unsigned s = divide ? G.mpi_get_nbits(hectx.p) - 1 : 0;
   unsigned bits = max_bits(&ct->c0, n), b1 = max_bits(&ct->c1, n);
   if (b1 > bits) bits = b1;
-  if (logql > bits) bits = logql;
+  if (logql + 1 > bits) bits = logql + 1;
   const unsigned W = bits / 64 + 1;
   std::vector<uint64_t> h0((size_t)W * n), h1((size_t)W * n);
   to_slab(h0.data(), &ct->c0, n, W);
   to_slab(h1.data(), &ct->c1, n, W);
   DevBuf d0(h0.size() * 8), d1(h1.size() * 8);
   up(d0, h0); up(d1, h1);
-  if (gpq_he_rs(c, d0.u64(), d1.u64(), W, s, logql, 1, nullptr) != GPQ_OK) die("he_rs failed");    // :45-48 / :64-65
+  DevBuf scratch(192 * 8);
+  const int rc = pow2 ? gpq_he_rs(c, d0.u64(), d1.u64(), W, s, logql, 1, nullptr)                                  // :45-48 / :64-65
+                      : gpq_he_rs_general(c, d0.u64(), d1.u64(), W, divide ? dw[0] : 1ull, qw.data(), (unsigned)qw.size(), 1, scratch.p, nullptr);
+  if (rc != GPQ_OK) die("he_rs failed");
   down(h0, d0); down(h1, d1);
   from_slab(&ct->c0, h0.data(), n, W);
   from_slab(&ct->c1, h1.data(), n, W);
@@ -258,17 +263,22 @@ void he_mulpt(struct he_ct *dest, const struct he_ct *src, const struct he_pt *p
   gpq_ctx *c = engine();
   const unsigned n = polyctx.n, l = src->l;
   const double nu = src->nu * pt->nu, B = src->B * pt->nu;                                      // :163-164
-  const unsigned logql = log2_exact(hectx.q[l], "he_mulpt: q_l must be a power of two");
+  const std::vector<uint64_t> qw = words_of(hectx.q[l], "he_mulpt: q_l must be positive");
+  const bool pow2 = is_pow2(qw);
+  const unsigned logql = G.mpi_get_nbits(hectx.q[l]) - 1;
   const unsigned dim = (unsigned)((logql + 1 + log2(pt->nu) + polyctx.logn) / 59u + 1);        // :169, evaluated in double as there
   unsigned bits = max_bits(&pt->m, n);
-  if (logql > bits) bits = logql;
+  if (logql + 1 > bits) bits = logql + 1;
   const unsigned W = bits / 64 + 1;
   const size_t big = (size_t)W * n;
   std::vector<uint64_t> h0(big), h1(big), hm(big);
   to_slab(h0.data(), &src->c0, n, W); to_slab(h1.data(), &src->c1, n, W); to_slab(hm.data(), &pt->m, n, W);
-  DevBuf d0(big * 8), d1(big * 8), dm(big * 8), o0(big * 8), o1(big * 8), ws(gpq_he_mulpt_workspace_bytes(c, dim, 1));
+  DevBuf d0(big * 8), d1(big * 8), dm(big * 8), o0(big * 8), o1(big * 8),
+      ws(gpq_he_mulpt_workspace_bytes(c, dim, 1) + gpq_poly_mul_general_workspace_bytes(c, dim, 1));
   up(d0, h0); up(d1, h1); up(dm, hm);
-  if (gpq_he_mulpt(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), dm.u64(), W, logql, dim, 1, ws.p, nullptr) != GPQ_OK) die("he_mulpt failed");
+  const int rc = pow2 ? gpq_he_mulpt(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), dm.u64(), W, logql, dim, 1, ws.p, nullptr)
+                      : gpq_he_mulpt_general(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), dm.u64(), W, qw.data(), (unsigned)qw.size(), dim, 1, ws.p, nullptr);
+  if (rc != GPQ_OK) die("he_mulpt failed");
   down(h0, o0); down(h1, o1);
   from_slab(&dest->c0, h0.data(), n, W);
   from_slab(&dest->c1, h1.data(), n, W);
@@ -281,20 +291,24 @@ static void automorphism(he_ct_t *ct, const he_evk_t *key, bool conj, unsigned r
   if (&hectx == nullptr || !hectx.q) die("`hectx` is not initialised (hectx_init first)");
   gpq_ctx *c = engine();
   const unsigned n = polyctx.n, l = ct->l;
-  const unsigned logql = log2_exact(hectx.q[l], "he_rot/he_conj: q_l must be a power of two");
-  const unsigned nbq = logql + 1, nbPqL = G.mpi_get_nbits(hectx.PqL);
+  const std::vector<uint64_t> qw = words_of(hectx.q[l], "he_rot/he_conj: q_l must be positive");
+  const bool pow2 = is_pow2(qw);
+  const unsigned nbq = G.mpi_get_nbits(hectx.q[l]), logql = nbq - 1, nbPqL = G.mpi_get_nbits(hectx.PqL);
   const unsigned dimB = (nbq + nbPqL + polyctx.logn) / 59 + 1, dimP = hectx.dim;                // src/he-automorphism.c:52
   const unsigned W = logql / 64 + 1;
   const size_t big = (size_t)W * n, evk = (size_t)dimB * n;
   std::vector<uint64_t> h0(big), h1(big);
   to_slab(h0.data(), &ct->c0, n, W); to_slab(h1.data(), &ct->c1, n, W);
   DevBuf a0(big * 8), a1(big * 8), r0(big * 8), r1(big * 8), o0(big * 8), o1(big * 8), k0(evk * 8), k1(evk * 8),
-      ws(gpq_he_swk_workspace_bytes(c, W, dimB, dimP, 1));
+      ws(pow2 ? gpq_he_swk_workspace_bytes(c, W, dimB, dimP, 1) : gpq_he_general_workspace_bytes(c, W, 0, dimB, dimP, 1));
   up(a0, h0); up(a1, h1);
   if (gpq_upload(k0.p, key->p0.coeffs, evk * 8, nullptr) != GPQ_OK || gpq_upload(k1.p, key->p1.coeffs, evk * 8, nullptr) != GPQ_OK) die("upload failed");
   int rc = conj ? gpq_poly_conj(c, r0.u64(), a0.u64(), W, 1, nullptr) : gpq_poly_rot(c, r0.u64(), a0.u64(), W, rot, 1, nullptr);      // :95-96 / :108-109
   if (rc == GPQ_OK) rc = conj ? gpq_poly_conj(c, r1.u64(), a1.u64(), W, 1, nullptr) : gpq_poly_rot(c, r1.u64(), a1.u64(), W, rot, 1, nullptr);
-  if (rc == GPQ_OK) rc = gpq_he_swk(c, o0.u64(), o1.u64(), r0.u64(), r1.u64(), k0.u64(), k1.u64(), W, logql, dimB, dimP, 1, ws.p, nullptr);  // :97 / :110
+  if (rc == GPQ_OK)                                                                                                                       // :97 / :110
+    rc = pow2 ? gpq_he_swk(c, o0.u64(), o1.u64(), r0.u64(), r1.u64(), k0.u64(), k1.u64(), W, logql, dimB, dimP, 1, ws.p, nullptr)
+              : gpq_he_swk_general(c, o0.u64(), o1.u64(), r0.u64(), r1.u64(), k0.u64(), k1.u64(), W, qw.data(), (unsigned)qw.size(), dimB, dimP, 1,
+                                   ws.p, nullptr);
   if (rc != GPQ_OK) die("he_rot/he_conj failed");
   down(h0, o0); down(h1, o1);
   from_slab(&ct->c0, h0.data(), n, W);

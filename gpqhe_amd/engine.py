@@ -156,6 +156,37 @@ class PolyContext:
                                           W, logql, dimB, dimP, batch, _ptr(ws), _stream()), "gpq_he_swk")
         return ws
 
+    @staticmethod
+    def _words(q):
+        L = (q.bit_length() + 63) // 64
+        return (_native.u64 * L)(*[(q >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(L)]), L
+
+    def he_mul_general(self, out_c0, out_c1, ct1c0, ct1c1, ct2c0, ct2c1, rlk0, rlk1, W, ql, dimA, dimB, dimP):
+        """src/he-mult.c:88-156 for an arbitrary q_l (Python int)."""
+        torch = _torch()
+        batch = ct1c0.numel() // (W * self.n)
+        qw, L = self._words(ql)
+        ws = torch.empty(self.lib.gpq_he_general_workspace_bytes(self.h, W, dimA, dimB, dimP, batch) // 8 + 8, dtype=torch.int64, device="cuda")
+        _native.check(self.lib.gpq_he_mul_general(self.h, _ptr(out_c0), _ptr(out_c1), _ptr(ct1c0), _ptr(ct1c1), _ptr(ct2c0), _ptr(ct2c1),
+                                                  _ptr(rlk0), _ptr(rlk1), W, qw, L, dimA, dimB, dimP, batch, _ptr(ws), _stream()),
+                      "gpq_he_mul_general")
+
+    def he_swk_general(self, out_c0, out_c1, d0, d1, swk0, swk1, W, ql, dimB, dimP):
+        torch = _torch()
+        batch = d0.numel() // (W * self.n)
+        qw, L = self._words(ql)
+        ws = torch.empty(self.lib.gpq_he_general_workspace_bytes(self.h, W, 0, dimB, dimP, batch) // 8 + 8, dtype=torch.int64, device="cuda")
+        _native.check(self.lib.gpq_he_swk_general(self.h, _ptr(out_c0), _ptr(out_c1), _ptr(d0), _ptr(d1), _ptr(swk0), _ptr(swk1),
+                                                  W, qw, L, dimB, dimP, batch, _ptr(ws), _stream()), "gpq_he_swk_general")
+
+    def he_rs_general(self, c0, c1, W, delta, ql):
+        """src/he-rescale.c:33-54 for any Delta (< 2^64) and any q_l."""
+        torch = _torch()
+        batch = c0.numel() // (W * self.n)
+        qw, L = self._words(ql)
+        scratch = torch.empty(192, dtype=torch.int64, device="cuda")
+        _native.check(self.lib.gpq_he_rs_general(self.h, _ptr(c0), _ptr(c1), W, delta, qw, L, batch, _ptr(scratch), _stream()), "gpq_he_rs_general")
+
     def he_mulpt(self, out_c0, out_c1, c0, c1, m, W, logql, dim):
         """src/he-mult.c:159-196 on big slabs."""
         torch = _torch()

@@ -214,6 +214,25 @@ int gpq_he_mulpt(gpq_ctx *ctx, uint64_t *out_c0, uint64_t *out_c1, const uint64_
 int gpq_poly_rot(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, unsigned W, unsigned rot, unsigned batch, void *stream);
 int gpq_poly_conj(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, unsigned W, unsigned batch, void *stream);
 
+/* ---- general moduli: any q_l (little-endian words ql_words[0..Lq)) and any Delta (uint64_t, as hectx_init takes it,
+ * src/gpqhe.h:100).  Same reference semantics, through the multiword Barrett kernel: slow-path quality, meant for parameter
+ * sets outside the powers of two that the fast entry points above cover. */
+size_t gpq_he_general_workspace_bytes(gpq_ctx *ctx, unsigned W, unsigned dimA, unsigned dimB, unsigned dimP, unsigned batch);
+int gpq_he_rs_general(gpq_ctx *ctx, uint64_t *c0, uint64_t *c1, unsigned W, unsigned long long delta, const uint64_t *ql_words,
+                      unsigned Lq, unsigned batch, void *scratch /* 192 words */, void *stream);
+int gpq_relin_tail_general(gpq_ctx *ctx, uint64_t *out, const uint64_t *chat, const uint64_t *d, unsigned W, const uint64_t *ql_words,
+                           unsigned Lq, unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream);
+int gpq_he_mul_general(gpq_ctx *ctx, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *ct1c0, const uint64_t *ct1c1,
+                       const uint64_t *ct2c0, const uint64_t *ct2c1, const uint64_t *rlk0, const uint64_t *rlk1, unsigned W,
+                       const uint64_t *ql_words, unsigned Lq, unsigned dimA, unsigned dimB, unsigned dimP, unsigned batch,
+                       void *workspace, void *stream);
+/* workspace: gpq_he_mulpt_workspace_bytes + gpq_poly_mul_general_workspace_bytes */
+int gpq_he_mulpt_general(gpq_ctx *ctx, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *c0, const uint64_t *c1, const uint64_t *m,
+                         unsigned W, const uint64_t *ql_words, unsigned Lq, unsigned dim, unsigned batch, void *workspace, void *stream);
+int gpq_he_swk_general(gpq_ctx *ctx, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *d0, const uint64_t *d1,
+                       const uint64_t *swk0, const uint64_t *swk1, unsigned W, const uint64_t *ql_words, unsigned Lq,
+                       unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream);
+
 /* he_add / he_sub / he_neg on one big-slab polynomial (src/he-add.c:32-142: mpi_addm / mpi_subm + mpi_smod), q_l = 2^logql.
  * Not NTT work; offered so that ciphertexts can stay in HBM between multiplications.  r may alias a or b. */
 int gpq_big_add(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned W, unsigned logql, unsigned batch, void *stream);

@@ -110,9 +110,9 @@ uint64_t barrett_reduce(gpq_u128 a, uint64_t q, uint64_t qinv);
  * The five names BASELINE.json's north_star lists, with the reference's own signatures and its
  * libgcrypt types.  Coefficients travel MPI -> device big slab -> MPI through libgcrypt's runtime
  * ABI (gcry_mpi_print / gcry_mpi_scan, resolved with dlsym from the libgcrypt the host program
- * already links).  `polyctx` and `hectx` are read like the reference reads them.  Moduli must be
- * powers of two (every parameter set of the reference's tests); otherwise these abort with the
- * reference's error convention -- there is no CPU path behind them. */
+ * already links).  `polyctx` and `hectx` are read like the reference reads them.  Power-of-two moduli
+ * (every parameter set of the reference's tests) take the tuned kernels, any other q / q_l / 64-bit
+ * Delta the general ones; misuse aborts with the reference's error convention -- there is no CPU path. */
 void poly_mul(poly_mpi_t *r, const poly_mpi_t *a, const poly_mpi_t *b,
               const unsigned int dim, const gpq_MPI q);                                 /* src/poly.h:86-87 */
 void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t *rlk);  /* src/gpqhe.h:147  */

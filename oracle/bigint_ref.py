@@ -126,9 +126,10 @@ def he_relin_tail(o, c0hat, c1hat, d0, d1, dimP, dimB, ql):
     return out
 
 
-def he_mul(o, ct1, ct2, rlk0, rlk1, dimP, dimA, dimB, logql):
-    """src/he-mult.c:88-156 for q_l = 2^logql; ct = (c0, c1) lists of centred ints; o = oracle.OracleCtx."""
-    n, ql = o.n, 1 << logql
+def he_mul(o, ct1, ct2, rlk0, rlk1, dimP, dimA, dimB, logql, ql=None):
+    """src/he-mult.c:88-156 for q_l = 2^logql (or any integer ql); ct = (c0, c1) lists of centred ints; o = oracle.OracleCtx."""
+    n = o.n
+    ql = ql if ql is not None else 1 << logql
     ins = [_slab(o, c, dimA) for c in (ct1[0], ct1[1], ct2[0], ct2[1])]  # :117-120
     d0h, d1h, d2h = o.he_mul_tensor(*ins, dimA)                          # :121-136
     basisA = RnsBasis(o.p[:dimA])
@@ -139,9 +140,9 @@ def he_mul(o, ct1, ct2, rlk0, rlk1, dimP, dimA, dimB, logql):
     return he_relin_tail(o, c0h, c1h, d0, d1, dimP, dimB, ql)
 
 
-def he_swk(o, d0, d1, swk0, swk1, dimP, dimB, logql):
-    """src/he-automorphism.c:40-85 for q_l = 2^logql."""
-    ql = 1 << logql
+def he_swk(o, d0, d1, swk0, swk1, dimP, dimB, logql, ql=None):
+    """src/he-automorphism.c:40-85 for q_l = 2^logql (or any integer ql)."""
+    ql = ql if ql is not None else 1 << logql
     c0h, c1h = o.keyswitch(_slab(o, d1, dimB), swk0, swk1, dimB)
     return he_relin_tail(o, c0h, c1h, d0, None, dimP, dimB, ql)
 
@@ -166,9 +167,10 @@ def poly_conj(a):
     return [a[0]] + [-a[n - i] for i in range(1, n)]
 
 
-def he_mulpt(o, ct, m, dim, logql):
-    """src/he-mult.c:159-196 for q_l = 2^logql."""
-    n, ql = o.n, 1 << logql
+def he_mulpt(o, ct, m, dim, logql, ql=None):
+    """src/he-mult.c:159-196 for q_l = 2^logql (or any integer ql)."""
+    n = o.n
+    ql = ql if ql is not None else 1 << logql
     basis = RnsBasis(o.p[:dim])
     mh = o.ntt_slab(_slab(o, m, dim), dim)
     out = []

@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "gpqhe_hip.h"
 #include "gpqhe_hip_compat.h"
@@ -89,6 +90,15 @@ int main(int argc, char **argv)
     poly_rns_mul(ahat, ahat, bhat, rns);        /* aliased output, src/he-mult.c:130 */
     poly_invntt(ahat, rns);
     rns = (d < dim - 1) ? rns->next : rns;
+  }
+  if (argc > 4) {                               /* PCIe-inclusive latency of the single-limb symbols */
+    struct timespec t0, t1;
+    const int reps = atoi(argv[4]);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int k = 0; k < reps; k++) { ntt(b, polyctx.rns); invntt(b, polyctx.rns); }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double us = ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 1e3 / (2.0 * reps);
+    printf("latency_us %.1f\n", us);
   }
   printf("ntt_b %016llx\nmul %016llx\nadd %016llx\nalias %016llx\n", (unsigned long long)fnv(b, dim * n),
          (unsigned long long)fnv(r, dim * n), (unsigned long long)fnv(s, dim * n), (unsigned long long)fnv(a, dim * n));

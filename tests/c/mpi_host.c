@@ -24,6 +24,7 @@ MPI gcry_mpi_set_ui(MPI w, unsigned long u);
 MPI gcry_mpi_copy(const MPI a);
 void gcry_mpi_mul(MPI w, MPI u, MPI v);
 void gcry_mpi_add(MPI w, MPI u, MPI v);
+void gcry_mpi_div(MPI q, MPI r, MPI dividend, MPI divisor, int round);
 void gcry_mpi_mul_ui(MPI w, MPI u, unsigned long v);
 void gcry_mpi_lshift(MPI x, MPI a, unsigned int n);
 void gcry_mpi_rshift(MPI x, MPI a, unsigned int n);
@@ -124,23 +125,26 @@ static void read_poly(FILE *f, poly_mpi_t *a)
 static int hemul(const char *path)
 {
   FILE *f = fopen(path, "r");
-  unsigned logn, logq, logDelta, level;
-  if (!f || fscanf(f, "%u %u %u %u\n", &logn, &logq, &logDelta, &level) != 4) return 3;
+  unsigned logn, level;
+  unsigned long long Delta;
+  char qhex[2048];
+  if (!f || fscanf(f, "%u %2047s %llu %u\n", &logn, qhex, &Delta, &level) != 4) return 3;
+  MPI q = NULL;
+  gcry_mpi_scan(&q, FMT_HEX, qhex, 0, NULL);
+  const unsigned logq = gcry_mpi_get_nbits(q) - 1;           /* polyctx.logq, src/precomp.c:337 */
   ctx_init(logn, logq);
-  /* qtable_init, src/precomp.c:386-409 */
-  MPI q = gcry_mpi_new(0);
-  gcry_mpi_set_ui(q, 1); gcry_mpi_lshift(q, q, logq);
+  /* qtable_init, src/precomp.c:386-409: q[l] = floor(q[l+1] / Delta), L = floor(logq / logDelta) */
   polyctx.q = q;
   hectx.p = gcry_mpi_new(0);
-  gcry_mpi_set_ui(hectx.p, 1); gcry_mpi_lshift(hectx.p, hectx.p, logDelta);
-  hectx.Delta = (double)(1ull << logDelta);
-  hectx.L = logq / logDelta;
+  gcry_mpi_set_ui(hectx.p, Delta);
+  hectx.Delta = (double)Delta;
+  hectx.L = logq / (gcry_mpi_get_nbits(hectx.p) - 1);
   hectx.q = malloc((hectx.L + 1) * sizeof(MPI)); hectx.qh = malloc((hectx.L + 1) * sizeof(MPI));
   MPI cur = gcry_mpi_copy(q);
   for (int l = (int)hectx.L; l >= 0; l--) {
     hectx.q[l] = gcry_mpi_copy(cur);
     hectx.qh[l] = gcry_mpi_new(0); gcry_mpi_rshift(hectx.qh[l], cur, 1);
-    gcry_mpi_rshift(cur, cur, logDelta);
+    gcry_mpi_div(cur, NULL, cur, hectx.p, 0);                /* positive operands: unaffected by libgcrypt 1.9's floor bug */
   }
   hectx.dim = (gcry_mpi_get_nbits(hectx.q[hectx.L]) + logn) / 59 + 1;
   hectx.P = gcry_mpi_new(0); gcry_mpi_set_ui(hectx.P, 1);

@@ -176,3 +176,65 @@ def test_he_mulpt_matches_reference_semantics(engine_ctx, oracle_ctx):
     g.he_mulpt(o0, o1, d0, d1, dm, W, logql, dim)
     e0, e1 = ref.he_mulpt(o, ct, m, dim, logql)
     assert big_to_ints(to_host(o0), W, n)[0] == e0 and big_to_ints(to_host(o1), W, n)[0] == e1
+
+
+def _general_setup(logn, qL, ql):
+    """dims as src/precomp.c:401,407 and src/he-mult.c:99,51 compute them from bit lengths, for arbitrary moduli"""
+    nbL, nbl = qL.bit_length(), ql.bit_length()
+    dimP = (nbL + logn) // 59 + 1
+    return dimP, nbL, nbl
+
+
+@pytest.mark.parametrize("logn,Delta,L,lvl", [(7, 1000003, 5, 5), (7, (1 << 30) - 35, 4, 3)])
+def test_general_moduli_he_mul_swk_rs(engine_ctx, oracle_ctx, logn, Delta, L, lvl):
+    """Delta not a power of two: q_L = Delta^L * 2^20-ish odd modulus, q_l = floor(q_{l+1}/Delta) (src/precomp.c:394-400)."""
+    torch = _torch()
+    qL = Delta ** L * 1048573
+    q = [0] * (L + 1)
+    cur = qL
+    for l in range(L, -1, -1):
+        q[l] = cur
+        cur //= Delta
+    ql = q[lvl]
+    probe = engine_ctx(logn, 12)
+    dimP, nbL, nbl = _general_setup(logn, qL, ql)
+    P = ref.RnsBasis(probe.p[:dimP]).P
+    nbPqL = (P * qL).bit_length()
+    dimA = (2 * nbl + logn) // 59 + 1
+    dimB = (nbl + nbPqL + logn) // 59 + 1
+    dimevk = (nbL + nbPqL + logn) // 59 + 1
+    g, o = engine_ctx(logn, dimevk), oracle_ctx(logn, dimevk)
+    n, W = g.n, ql.bit_length() // 64 + 1
+    rng = random.Random(Delta % 9973)
+    h = ql // 2
+    cts = [[rng.randrange(-h, ql - h) for _ in range(n)] for _ in range(4)]   # centred as mpi_smod leaves them
+    cts = [[ref.mpi_smod(v, ql) for v in c] for c in cts]
+    rlk0, rlk1 = o.gen(3000, dimevk), o.gen(3001, dimevk)
+    dev = [to_device(ints_to_big(c, W)) for c in cts]
+    o0, o1 = torch.empty_like(dev[0]), torch.empty_like(dev[0])
+    g.he_mul_general(o0, o1, *dev, to_device(rlk0), to_device(rlk1), W, ql, dimA, dimB, dimP)
+    e0, e1 = ref.he_mul(o, (cts[0], cts[1]), (cts[2], cts[3]), rlk0[: dimB * n], rlk1[: dimB * n], dimP, dimA, dimB, 0, ql=ql)
+    assert big_to_ints(to_host(o0), W, n)[0] == e0 and big_to_ints(to_host(o1), W, n)[0] == e1
+    # he_swk on the product
+    g.he_swk_general(o0, o1, to_device(ints_to_big(e0, W)), to_device(ints_to_big(e1, W)), to_device(rlk1), to_device(rlk0), W, ql, dimB, dimP)
+    s0, s1 = ref.he_swk(o, e0, e1, rlk1[: dimB * n], rlk0[: dimB * n], dimP, dimB, 0, ql=ql)
+    assert big_to_ints(to_host(o0), W, n)[0] == s0 and big_to_ints(to_host(o1), W, n)[0] == s1
+    # he_rs: mpi_rdiv by Delta (ties: remainder == Delta/2 exactly only when Delta is even) then mpi_smod q_{l-1}
+    c0 = to_device(ints_to_big(e0, W))
+    c1 = to_device(ints_to_big(e1, W))
+    g.he_rs_general(c0, c1, W, Delta, q[lvl - 1])
+    assert big_to_ints(to_host(c0), W, n)[0] == [ref.mpi_smod(ref.mpi_rdiv(v, Delta), q[lvl - 1]) for v in e0]
+    assert big_to_ints(to_host(c1), W, n)[0] == [ref.mpi_smod(ref.mpi_rdiv(v, Delta), q[lvl - 1]) for v in e1]
+
+
+def test_rdiv_word_ties(engine_ctx):
+    """even Delta: remainder exactly Delta/2 must not round up; negative values floor first (src/types.c:115-128)."""
+    g = engine_ctx(7, 5)
+    n, W, Delta = g.n, 2, 1000
+    ql = 10 ** 30 + 57
+    vals = [0, 499, 500, 501, 1500, -1, -499, -500, -501, -1500, -1000, 999999, -999999, 10 ** 25 + 500, -(10 ** 25) - 500]
+    vals += [(-1) ** k * (k * 7919 + 250 * k) for k in range(n - len(vals))]
+    c0, c1 = to_device(ints_to_big(vals, W)), to_device(ints_to_big([-v for v in vals], W))
+    g.he_rs_general(c0, c1, W, Delta, ql)
+    assert big_to_ints(to_host(c0), W, n)[0] == [ref.mpi_smod(ref.mpi_rdiv(v, Delta), ql) for v in vals]
+    assert big_to_ints(to_host(c1), W, n)[0] == [ref.mpi_smod(ref.mpi_rdiv(-v, Delta), ql) for v in vals]

@@ -55,18 +55,29 @@ def test_poly_mul_general_modulus_through_reference_signature(mpi_host, oracle_c
         assert vals[t * N:(t + 1) * N] == [ref.mpi_smod(v, Q) for v in ref.negacyclic_mul(a, b)]
 
 
-def test_he_mul_he_rs_he_moddown_with_real_mpis(mpi_host, oracle_ctx, tmp_path):
-    logn, logq, logDelta = 7, 120, 30
-    n, L = 1 << logn, logq // logDelta
+@pytest.mark.parametrize("logn,qL,Delta", [
+    (7, 1 << 120, 1 << 30),                       # the reference's test family: powers of two (tests/gpqhe.c:1349-1352)
+    (7, 1000003 ** 5 * 1048573, 1000003),         # Delta and every q_l odd: the general-modulus kernels
+])
+def test_he_chain_with_real_mpis(mpi_host, oracle_ctx, tmp_path, logn, qL, Delta):
+    """he_mul -> he_rescale -> he_moddown -> he_mul(&ct,&ct,&ct) -> he_rot -> he_conj -> he_mulpt on real libgcrypt MPIs."""
+    n = 1 << logn
+    logq, logDelta = qL.bit_length() - 1, Delta.bit_length() - 1
+    L = logq // logDelta                                      # src/precomp.c:391
+    q = [0] * (L + 1)
+    cur = qL
+    for l in range(L, -1, -1):
+        q[l] = cur
+        cur //= Delta                                         # :394-400
     level = L
     rng = random.Random(42)
-    h = 1 << (logq - 1)
-    polys = [[rng.randrange(-h, h) for _ in range(n)] for _ in range(4)]
+    h = qL // 2
+    polys = [[ref.mpi_smod(rng.randrange(qL), qL) for _ in range(n)] for _ in range(4)]
     for p in polys:
-        p[:4] = [0, -1, h - 1, -h]
+        p[:4] = [0, -1, ref.mpi_smod(h - 1, qL), ref.mpi_smod(h, qL)]
     path = tmp_path / "in.txt"
     with open(path, "w") as f:
-        f.write("%d %d %d %d\n" % (logn, logq, logDelta, level))
+        f.write("%d %X %d %d\n" % (logn, qL, Delta, level))
         for p in polys:
             for v in p:
                 f.write(("-%X\n" % -v) if v < 0 else ("%X\n" % v))
@@ -75,7 +86,15 @@ def test_he_mul_he_rs_he_moddown_with_real_mpis(mpi_host, oracle_ctx, tmp_path):
     lines = res.stdout.split("\n")
     dimub = (1 + logn + 4 * logq) // 59 + 1
     o = oracle_ctx(logn, dimub)
-    dimP, dimA, dimB, dimevk = ref.he_dims(logn, o.p, logq, logq)
+
+    def dims(ql):                                             # src/precomp.c:401,407; src/he-mult.c:99,51
+        nbL, nbl = qL.bit_length(), ql.bit_length()
+        dimP = (nbL + logn) // 59 + 1
+        P = ref.RnsBasis(o.p[:dimP]).P
+        nbPqL = (P * qL).bit_length()
+        return dimP, (2 * nbl + logn) // 59 + 1, (nbl + nbPqL + logn) // 59 + 1, (nbL + nbPqL + logn) // 59 + 1
+
+    dimP, dimA, dimB, dimevk = dims(q[level])
     assert lines[0].split() == ["dims", str(dimP), str(dimevk), str(L)]
     rlk0, rlk1 = o.gen(3000, dimevk), o.gen(3001, dimevk)
 
@@ -84,46 +103,44 @@ def test_he_mul_he_rs_he_moddown_with_real_mpis(mpi_host, oracle_ctx, tmp_path):
     assert hdr[0] == "he_mul" and int(hdr[1]) == level
     assert float(hdr[2]) == 3.0 * 7.0 and float(hdr[3]) == 3.0 * 11.0 + 7.0 * 5.0 + 5.0 * 11.0 + (100.0 + level)
     c0, c1 = _ints(lines[2:2 + n]), _ints(lines[2 + n:2 + 2 * n])
-    e0, e1 = ref.he_mul(o, (polys[0], polys[1]), (polys[2], polys[3]), rlk0[: dimB * n], rlk1[: dimB * n], dimP, dimA, dimB, logq)
+    e0, e1 = ref.he_mul(o, (polys[0], polys[1]), (polys[2], polys[3]), rlk0[: dimB * n], rlk1[: dimB * n], dimP, dimA, dimB, 0, ql=q[level])
     assert c0 == e0 and c1 == e1
 
     # he_rescale = he_rs (src/he-rescale.c:33-54)
     base = 2 + 2 * n
     hdr = lines[base].split()
     assert hdr[0] == "he_rs" and int(hdr[1]) == level - 1
-    assert float(hdr[2]) == 21.0 / 2.0**logDelta
-    ql1 = 1 << (logq - logDelta)
-    r0 = [ref.mpi_smod(ref.mpi_rdiv(v, 1 << logDelta), ql1) for v in e0]
-    r1 = [ref.mpi_smod(ref.mpi_rdiv(v, 1 << logDelta), ql1) for v in e1]
+    assert float(hdr[2]) == 21.0 / float(Delta)
+    r0 = [ref.mpi_smod(ref.mpi_rdiv(v, Delta), q[level - 1]) for v in e0]
+    r1 = [ref.mpi_smod(ref.mpi_rdiv(v, Delta), q[level - 1]) for v in e1]
     assert _ints(lines[base + 1:base + 1 + n]) == r0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == r1
 
     # he_moddown (src/he-rescale.c:56-70)
     base += 1 + 2 * n
     assert lines[base].split() == ["he_moddown", str(level - 2)]
-    ql2 = 1 << (logq - 2 * logDelta)
-    m0, m1 = [ref.mpi_smod(v, ql2) for v in r0], [ref.mpi_smod(v, ql2) for v in r1]
+    ql = q[level - 2]
+    m0, m1 = [ref.mpi_smod(v, ql) for v in r0], [ref.mpi_smod(v, ql) for v in r1]
     assert _ints(lines[base + 1:base + 1 + n]) == m0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == m1
 
     # he_mul(&ct, &ct, &ct, rlk): output aliases both operands (src/he-algo.c:151), level L-2
     base += 1 + 2 * n
     assert lines[base].split() == ["he_sq", str(level - 2)]
-    logql = logq - 2 * logDelta
-    dP2, dA2, dB2, _ = ref.he_dims(logn, o.p, logq, logql)
-    s0, s1 = ref.he_mul(o, (m0, m1), (m0, m1), rlk0[: dB2 * n], rlk1[: dB2 * n], dP2, dA2, dB2, logql)
+    dP2, dA2, dB2, _ = dims(ql)
+    s0, s1 = ref.he_mul(o, (m0, m1), (m0, m1), rlk0[: dB2 * n], rlk1[: dB2 * n], dP2, dA2, dB2, 0, ql=ql)
     assert _ints(lines[base + 1:base + 1 + n]) == s0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == s1
 
     # he_rot(ct, 1, rk): poly_rot both polynomials, he_swk with rk[1] (src/he-automorphism.c:100-115)
     base += 1 + 2 * n
     assert lines[base].split() == ["he_rot", str(level - 2)]
     rk0, rk1 = o.gen(5002, dimevk), o.gen(5003, dimevk)
-    t0, t1 = ref.he_swk(o, ref.poly_rot(s0, 1), ref.poly_rot(s1, 1), rk0[: dB2 * n], rk1[: dB2 * n], dP2, dB2, logql)
+    t0, t1 = ref.he_swk(o, ref.poly_rot(s0, 1), ref.poly_rot(s1, 1), rk0[: dB2 * n], rk1[: dB2 * n], dP2, dB2, 0, ql=ql)
     assert _ints(lines[base + 1:base + 1 + n]) == t0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == t1
 
     # he_conj(ct, ck) (src/he-automorphism.c:87-98)
     base += 1 + 2 * n
     assert lines[base].split() == ["he_conj", str(level - 2)]
     ck0, ck1 = o.gen(6000, dimevk), o.gen(6001, dimevk)
-    u0, u1 = ref.he_swk(o, ref.poly_conj(t0), ref.poly_conj(t1), ck0[: dB2 * n], ck1[: dB2 * n], dP2, dB2, logql)
+    u0, u1 = ref.he_swk(o, ref.poly_conj(t0), ref.poly_conj(t1), ck0[: dB2 * n], ck1[: dB2 * n], dP2, dB2, 0, ql=ql)
     assert _ints(lines[base + 1:base + 1 + n]) == u0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == u1
 
     # he_mulpt (src/he-mult.c:159-196): dim from log2(pt->nu) as :169; nu, B as :163-164
@@ -131,6 +148,6 @@ def test_he_mul_he_rs_he_moddown_with_real_mpis(mpi_host, oracle_ctx, tmp_path):
     hdr = lines[base].split()
     assert hdr[0] == "he_mulpt" and int(hdr[1]) == level - 2 and float(hdr[2]) == 2.0 * 1024.0 and float(hdr[3]) == 3.0 * 1024.0
     m = [(((i + 1) << 20) + 12345 * i) * (-1 if i & 1 else 1) for i in range(n)]
-    dim_pt = int((logql + 1 + 10.0 + logn) / 59 + 1)
-    v0, v1 = ref.he_mulpt(o, (u0, u1), m, dim_pt, logql)
+    dim_pt = int((ql.bit_length() + 10.0 + logn) / 59 + 1)
+    v0, v1 = ref.he_mulpt(o, (u0, u1), m, dim_pt, 0, ql=ql)
     assert _ints(lines[base + 1:base + 1 + n]) == v0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == v1
