@@ -135,9 +135,10 @@ int gpq_keyswitch(gpq_ctx *ctx, uint64_t *c0, uint64_t *c1, const uint64_t *x,
  * The reference keeps coefficients as libgcrypt MPIs.  On the device a polynomial of
  * big integers is a "big slab": uint64_t[batch][W][n], word j of coefficient i at
  * j*n + i, little-endian words, two's complement over 64*W bits (centred
- * coefficients are signed).  Moduli q, Delta are powers of two here, as in every
- * parameter set of the reference's tests (tests/gpqhe.c:1349-1352, tests/polymul.c:84-87);
- * other moduli return GPQ_ERR_UNSUPPORTED / are not offered.
+ * coefficients are signed).  The entry points with a `logq` / `logql` / `logDelta` argument are the
+ * tuned ones for power-of-two moduli, as in every parameter set of the reference's tests
+ * (tests/gpqhe.c:1349-1352, tests/polymul.c:84-87); the `*_general` entry points further down take
+ * any modulus as little-endian words and any 64-bit Delta.
  */
 unsigned gpq_big_words(unsigned bits);
 /* rns->phat_invmp[d] of the node with `dim` limbs (src/precomp.c:288-289); bit length of its P. */
