@@ -238,3 +238,30 @@ def test_rdiv_word_ties(engine_ctx):
     g.he_rs_general(c0, c1, W, Delta, ql)
     assert big_to_ints(to_host(c0), W, n)[0] == [ref.mpi_smod(ref.mpi_rdiv(v, Delta), ql) for v in vals]
     assert big_to_ints(to_host(c1), W, n)[0] == [ref.mpi_smod(ref.mpi_rdiv(-v, Delta), ql) for v in vals]
+
+
+def test_he_mul_headline_dims_against_restated_reference(engine_ctx, oracle_ctx):
+    """The headline limb counts (q = 2^850: dimP/dimA/dimB = 15/30/45, 14-word coefficients) through the two-pass NTT
+    kernels and the fast CRT path, at n = 2^13 so that the Python-integer side of the restated reference finishes in
+    seconds: every coefficient of he_mul must match src/he-mult.c:88-156, then he_rs src/he-rescale.c:33-54."""
+    torch = _torch()
+    logn, logq, logDelta = 13, 850, 50
+    probe = engine_ctx(logn, 16)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logq, logq)
+    assert (dimP, dimA, dimB, dimevk) == (15, 30, 45, 45)
+    g, o = engine_ctx(logn, dimevk), oracle_ctx(logn, dimevk)
+    n, W = g.n, 14
+    rng = random.Random(850)
+    h = 1 << (logq - 1)
+    cts = [[rng.randrange(-h, h) for _ in range(n)] for _ in range(4)]
+    rlk0, rlk1 = o.gen(3000, dimevk), o.gen(3001, dimevk)
+    dev = [to_device(ints_to_big(c, W)) for c in cts]
+    o0, o1 = torch.empty_like(dev[0]), torch.empty_like(dev[0])
+    g.he_mul(o0, o1, *dev, to_device(rlk0), to_device(rlk1), W, logq, dimA, dimB, dimP)
+    e0, e1 = ref.he_mul(o, (cts[0], cts[1]), (cts[2], cts[3]), rlk0, rlk1, dimP, dimA, dimB, logq)
+    assert big_to_ints(to_host(o0), W, n)[0] == e0
+    assert big_to_ints(to_host(o1), W, n)[0] == e1
+    g.he_rs(o0, o1, W, logDelta, logq - logDelta)
+    ql = 1 << (logq - logDelta)
+    assert big_to_ints(to_host(o0), W, n)[0] == [ref.mpi_smod(ref.mpi_rdiv(v, 1 << logDelta), ql) for v in e0]
+    assert big_to_ints(to_host(o1), W, n)[0] == [ref.mpi_smod(ref.mpi_rdiv(v, 1 << logDelta), ql) for v in e1]

@@ -81,3 +81,27 @@ def test_reduce_edge_cases(oracle_ctx):
                 rs = c.rns_add(np.full(c.n, a, np.uint64), np.full(c.n, b, np.uint64), c.p.index(p))
                 assert int(rs[0]) == (a + b) % p
         assert Rinv * (1 << 64) % p == 1
+
+
+def test_golden_fixture_is_a_faithful_transcription_of_the_survey(golden):
+    """tests/golden/survey_8c.json carries the values SURVEY.md section 8c recorded from the compiled reference
+    (the reference cannot be rebuilt here: no <gcrypt.h>).  Every number and digest in the fixture must occur
+    verbatim in SURVEY.md, so the pin is the survey's capture and not something re-derived from our own code."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "SURVEY.md")).read()
+    missing = []
+
+    def walk(v):
+        if isinstance(v, dict):
+            for k, x in v.items():
+                if not k.startswith("_"):
+                    walk(x)
+        elif isinstance(v, list):
+            for x in v:
+                walk(x)
+        elif isinstance(v, str) and len(v) >= 8 and v not in text:
+            missing.append(v)
+
+    walk({k: v for k, v in golden.items() if k != "context_dims"})
+    assert not missing, missing
