@@ -114,6 +114,29 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=3):
             "ms_per_batch": round(ms, 3), "he_mul_per_s": round(batch / (ms * 1e-3), 1)}
 
 
+def keyswitch_n17_rate(torch, gpqhe_amd, batch=16, iters=3):
+    """BASELINE configs[4] shape: the key-switch inner product (he_swk loop, src/he-automorphism.c:59-67) at n = 2^17, 44 limbs."""
+    logn, dim = 17, 44
+    ctx = gpqhe_amd.PolyContext(logn, dim)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(17)
+    x = rand_slab(torch, ctx, dim, batch, gen)
+    e0, e1 = rand_slab(torch, ctx, dim, 1, gen), rand_slab(torch, ctx, dim, 1, gen)
+    c0, c1 = torch.empty_like(x), torch.empty_like(x)
+    ws = ctx.keyswitch_workspace(dim, batch)
+    ctx.he_keyswitch(c0, c1, x, e0, e1, dim, ws)
+    t = gpqhe_amd.StreamTimer()
+    t.start()
+    for _ in range(iters):
+        ctx.he_keyswitch(c0, c1, x, e0, e1, dim, ws)
+    t.stop()
+    ms = t.elapsed_ms() / iters
+    algo = 5 * dim * (8 << logn) * batch
+    ctx.close()
+    return {"shape": "n=2^17, 44 limbs, batch %d" % batch, "ms_per_batch": round(ms, 3), "keyswitch_per_s": round(batch / (ms * 1e-3), 1),
+            "algo_GBps": round(algo / (ms * 1e-3) / 1e9, 1)}
+
+
 def cpu_baseline(ctx, host_inputs, gpu_outputs, sample):
     """The oracle (CPU restatement of the reference loops) timed on this host, one
     thread like the reference, on `sample` ciphertexts of the same workload; its
@@ -145,7 +168,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="ciphertext multiplications per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="polynomials per fused launch group (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=2, help="ciphertexts the CPU baseline replays (0 = skip)")
-    ap.add_argument("--no-ntt", action="store_true", help="skip the NTT GB/s legs (run after the timed region)")
+    ap.add_argument("--no-ntt", action="store_true", help="skip the secondary legs run after the timed region (NTT GB/s, MPI-level he_mul, n=2^17 key switch)")
     ap.add_argument("--streams", type=int, default=1, help="2: tensor stage and key-switch stage on separate HIP streams")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path with several ranks on one GPU)")
@@ -269,6 +292,7 @@ def main():
             del a0, a1, b0, b1, x, d0, d1, d2, c0, c1, wsA, wsB
             torch.cuda.empty_cache()
             out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, 16)
+            out["keyswitch_n17"] = keyswitch_n17_rate(torch, gpqhe_amd)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
