@@ -45,7 +45,9 @@ SIGNATURES = {
     "gpq_ctx_phat_invmp": (u64, [vp, C.c_uint, C.c_uint]),
     "gpq_ctx_pbits": (C.c_uint, [vp, C.c_uint]),
     "gpq_rns_decompose": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, vp]),
+    "gpq_rns_decompose_limbs": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp]),
     "gpq_rns_reconstruct": (C.c_int, [vp, vp, C.c_uint, vp, C.c_uint, C.c_uint, C.c_uint, vp]),
+    "gpq_rns_reconstruct_one": (C.c_int, [vp, C.POINTER(u64), C.c_uint, C.POINTER(u64), C.c_uint]),
     "gpq_set_exact_crt": (C.c_int, [vp, C.c_int]),
     "gpq_poly_mul_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
     "gpq_poly_mul": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
@@ -100,7 +102,7 @@ SIGNATURES = {
 # exercised from C (tests/c/dropin_host.c)
 EXPORTED_ONLY = ["montgomery_reduce", "barrett_reduce",
                  # MPI-typed surface: driven from C with real libgcrypt MPIs (tests/c/mpi_host.c)
-                 "poly_mul", "he_mul", "he_rs", "he_rescale", "he_moddown", "he_mulpt", "he_conj", "he_rot"]
+                 "rns_decompose", "rns_reconstruct", "poly_rns2mpi", "poly_mul", "he_mul", "he_rs", "he_rescale", "he_moddown", "he_mulpt", "he_conj", "he_rot"]
 
 _lib = None
 

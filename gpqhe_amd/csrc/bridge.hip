@@ -147,35 +147,36 @@ void launch_low(const ReconstructArgs &a, unsigned WPstride, unsigned char *redo
 }
 
 int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned slab_dim,
-                       unsigned slab_first, unsigned batch, unsigned logq, bool centre, unsigned char *tie, hipStream_t s) {
+                       unsigned slab_first, unsigned batch, unsigned logq, bool centre, unsigned char *tie, hipStream_t s, int logn_override = -1) {
+  const unsigned logn = logn_override < 0 ? c->logn : (unsigned)logn_override, n = 1u << logn;
   ReconstructArgs a{c->d_tabs, slab, big, b->d_phat, b->d_phat_inv, b->d_pmult, b->d_phalf, tie, nullptr, b->d_inv128,
-                    b->dim, c->logn, Wout, logq, b->first, slab_dim, slab_first, centre ? 1u : 0u};
+                    b->dim, logn, Wout, logq, b->first, slab_dim, slab_first, centre ? 1u : 0u};
   // fast path: centred result modulo a power of two that needs fewer words than P has
   const unsigned need = (logq + 63) / 64;
   // (the centring threshold floor(P/2)/P differs from 1/2 by 1/(2P): negligible against the 2^-61 slack only for large P)
   const bool fast = logq && centre && !c->exact_crt && need + 1 < (unsigned)b->WP && need <= 16 && b->pbits >= 160;
   if (fast) {
-    const size_t flags = (size_t)batch << c->logn;
+    const size_t flags = (size_t)batch << logn;
     if (flags > c->redo_cap) {
       if (c->d_redo) HIP_TRY(hipFree(c->d_redo));
       HIP_TRY(hipMalloc((void **)&c->d_redo, flags));
       c->redo_cap = flags;
     }
-    if (need <= 1) launch_low<1>(a, b->WP, c->d_redo, c->n, batch, s);
-    else if (need <= 2) launch_low<2>(a, b->WP, c->d_redo, c->n, batch, s);
-    else if (need <= 4) launch_low<4>(a, b->WP, c->d_redo, c->n, batch, s);
-    else if (need <= 7) launch_low<7>(a, b->WP, c->d_redo, c->n, batch, s);     // q up to 2^448 (reference default 2^438)
-    else if (need <= 10) launch_low<10>(a, b->WP, c->d_redo, c->n, batch, s);
-    else if (need <= 14) launch_low<14>(a, b->WP, c->d_redo, c->n, batch, s);   // q up to 2^896 (headline 2^850)
-    else launch_low<16>(a, b->WP, c->d_redo, c->n, batch, s);
+    if (need <= 1) launch_low<1>(a, b->WP, c->d_redo, n, batch, s);
+    else if (need <= 2) launch_low<2>(a, b->WP, c->d_redo, n, batch, s);
+    else if (need <= 4) launch_low<4>(a, b->WP, c->d_redo, n, batch, s);
+    else if (need <= 7) launch_low<7>(a, b->WP, c->d_redo, n, batch, s);     // q up to 2^448 (reference default 2^438)
+    else if (need <= 10) launch_low<10>(a, b->WP, c->d_redo, n, batch, s);
+    else if (need <= 14) launch_low<14>(a, b->WP, c->d_redo, n, batch, s);   // q up to 2^896 (headline 2^850)
+    else launch_low<16>(a, b->WP, c->d_redo, n, batch, s);
     a.only = c->d_redo;   // exact kernel below redoes only the flagged coefficients
   }
   switch (b->WP) {
-    case 8: launch_exact<8>(a, c->n, batch, s); break;
-    case 16: launch_exact<16>(a, c->n, batch, s); break;
-    case 32: launch_exact<32>(a, c->n, batch, s); break;
-    case 48: launch_exact<48>(a, c->n, batch, s); break;
-    case 56: launch_exact<56>(a, c->n, batch, s); break;
+    case 8: launch_exact<8>(a, n, batch, s); break;
+    case 16: launch_exact<16>(a, n, batch, s); break;
+    case 32: launch_exact<32>(a, n, batch, s); break;
+    case 48: launch_exact<48>(a, n, batch, s); break;
+    case 56: launch_exact<56>(a, n, batch, s); break;
     default: return gpq_fail(GPQ_ERR_UNSUPPORTED, "reconstruct: WP=%d", b->WP);
   }
   return GPQ_OK;
@@ -249,6 +250,40 @@ extern "C" int gpq_rns_reconstruct(gpq_ctx *c, uint64_t *big, unsigned Wout, con
   if (!logq && Wout * 64 < b->pbits + 1) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct: %u words cannot hold a value mod P (%u bits)", Wout, b->pbits);
   if ((rc = launch_reconstruct(c, b, big, Wout, slab, dim, 0, batch, logq, true, nullptr, (hipStream_t)stream))) return rc;
   return launched("gpq_rns_reconstruct");
+}
+
+// rns_reconstruct for ONE coefficient (src/rns.c:60-75 is per coefficient): host residues in, host words out, value in [0, P).
+extern "C" int gpq_rns_reconstruct_one(gpq_ctx *c, uint64_t *words, unsigned Wout, const uint64_t *residues, unsigned dim) {
+  int rc = check(c, dim, 1, "gpq_rns_reconstruct_one");
+  if (rc) return rc;
+  if (!words || !residues) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct_one: null argument");
+  gpq_bridge_basis *b;
+  if ((rc = get_basis(c, 0, dim, &b))) return rc;
+  if (Wout * 64 < b->pbits + 1) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct_one: %u words cannot hold a value mod P (%u bits)", Wout, b->pbits);
+  for (unsigned d = 0; d < dim; ++d)
+    if (residues[d] >= c->p[d]) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct_one: residue %u is not reduced", d);
+  HIP_TRY(hipSetDevice(c->device));
+  uint64_t *dev = nullptr;
+  HIP_TRY(hipMalloc((void **)&dev, (size_t)(dim + Wout) * 8));
+  hipError_t e = hipMemcpy(dev, residues, (size_t)dim * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    rc = launch_reconstruct(c, b, dev + dim, Wout, dev, dim, 0, 1, 0, false, nullptr, nullptr, 0);
+    if (rc == GPQ_OK) rc = launched("gpq_rns_reconstruct_one");
+    if (rc == GPQ_OK) e = hipMemcpy(words, dev + dim, (size_t)Wout * 8, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(dev);
+  if (e != hipSuccess) return gpq_fail(GPQ_ERR_HIP, "gpq_rns_reconstruct_one: %s", hipGetErrorString(e));
+  return rc;
+}
+
+// rns_decompose for the limbs first .. first+count-1 only (src/rns.c:37-48 is per limb): slab[k][d][i], d < count.
+extern "C" int gpq_rns_decompose_limbs(gpq_ctx *c, uint64_t *slab, const uint64_t *big, unsigned W, unsigned first, unsigned count,
+                                       unsigned batch, void *stream) {
+  int rc = check(c, count, batch, "gpq_rns_decompose_limbs");
+  if (rc) return rc;
+  if (!slab || !big || W < 1 || first + count > c->nprimes) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_decompose_limbs: bad arguments");
+  if ((rc = launch_decompose(c, slab, big, W, first, count, batch, (hipStream_t)stream))) return rc;
+  return launched("gpq_rns_decompose_limbs");
 }
 
 extern "C" size_t gpq_poly_mul_workspace_bytes(const gpq_ctx *c, unsigned dim, unsigned batch) {

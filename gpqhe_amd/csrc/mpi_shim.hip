@@ -163,6 +163,67 @@ void down(std::vector<uint64_t> &h, const DevBuf &d) {
 
 extern "C" {
 
+// index of this node's prime in the chain: a node with `dim` limbs carries prime dim-1 (src/precomp.c:266-293)
+static unsigned limb_of(gpq_ctx *c, const struct rns_ctx *rns, const char *who) {
+  if (!rns || rns->dim < 1 || rns->dim > gpq_ctx_nprimes(c) || gpq_ctx_const(c, rns->dim - 1, 0) != rns->p) die(who);
+  return rns->dim - 1;
+}
+
+// src/rns.c:37-48 -- one limb: ahat[i] = a[i] mod rns->p, non-negative
+void rns_decompose(uint64_t ahat[], const gpq_MPI a[], const struct rns_ctx *rns) {
+  need_gcrypt();
+  gpq_ctx *c = engine();
+  const unsigned n = polyctx.n, limb = limb_of(c, rns, "rns_decompose: the node is not one of the caller's prime chain");
+  poly_mpi_t view{const_cast<gpq_MPI *>(a)};
+  const unsigned W = max_bits(&view, n) / 64 + 1;
+  if (W > 32) die("rns_decompose: coefficients wider than 2047 bits");
+  std::vector<uint64_t> h((size_t)W * n);
+  to_slab(h.data(), &view, n, W);
+  DevBuf big(h.size() * 8), out((size_t)n * 8);
+  up(big, h);
+  if (gpq_rns_decompose_limbs(c, out.u64(), big.u64(), W, limb, 1, 1, nullptr) != GPQ_OK) die("rns_decompose failed");
+  if (gpq_download(ahat, out.p, (size_t)n * 8, nullptr) != GPQ_OK || gpq_stream_sync(nullptr) != GPQ_OK) die("download failed");
+}
+
+static void set_from_words(MPI r, const uint64_t *w, unsigned W) {
+  poly_mpi_t one{&r};
+  from_slab(&one, w, 1, W);
+}
+
+// src/rns.c:60-75 -- coefficient i of a slab with rns->dim limbs, value in [0, P)
+void rns_reconstruct(gpq_MPI a, const uint64_t ahat[], const unsigned int i, const struct rns_ctx *rns) {
+  need_gcrypt();
+  gpq_ctx *c = engine();
+  const unsigned n = polyctx.n;
+  (void)limb_of(c, rns, "rns_reconstruct: the node is not one of the caller's prime chain");
+  if (i >= n) die("rns_reconstruct: coefficient index out of range");
+  const unsigned dim = rns->dim, W = gpq_ctx_pbits(c, dim) / 64 + 2;
+  std::vector<uint64_t> col(dim), w(W);
+  for (unsigned d = 0; d < dim; ++d) col[d] = ahat[(size_t)d * n + i];
+  if (gpq_rns_reconstruct_one(c, w.data(), W, col.data(), dim) != GPQ_OK) die("rns_reconstruct failed");
+  set_from_words(a, w.data(), W);
+}
+
+// src/poly.c:109-120 -- every coefficient: reconstruct, centre mod P, centre mod q
+void poly_rns2mpi(poly_mpi_t *r, const poly_rns_t *rhat, const struct rns_ctx *rns, const gpq_MPI q) {
+  need_gcrypt();
+  gpq_ctx *c = engine();
+  const unsigned n = polyctx.n;
+  (void)limb_of(c, rns, "poly_rns2mpi: the node is not one of the caller's prime chain");
+  const unsigned dim = rns->dim;
+  const std::vector<uint64_t> qw = words_of(q, "poly_rns2mpi: the modulus must be positive");
+  const unsigned nbq = G.mpi_get_nbits(q), W = nbq / 64 + 1;
+  if (qw.size() > 48) die("poly_rns2mpi: modulus wider than 48 words");
+  DevBuf slab((size_t)dim * n * 8), big((size_t)W * n * 8), scratch(gpq_poly_mul_general_workspace_bytes(c, dim, 1));
+  if (gpq_upload(slab.p, rhat->coeffs, (size_t)dim * n * 8, nullptr) != GPQ_OK) die("upload failed");
+  const int rc = is_pow2(qw) ? gpq_rns_reconstruct(c, big.u64(), W, slab.u64(), dim, 1, nbq - 1, nullptr)
+                             : gpq_rns_reconstruct_general(c, big.u64(), W, slab.u64(), dim, 1, qw.data(), (unsigned)qw.size(), scratch.p, nullptr);
+  if (rc != GPQ_OK) die("poly_rns2mpi failed");
+  std::vector<uint64_t> h((size_t)W * n);
+  down(h, big);
+  from_slab(r, h.data(), n, W);
+}
+
 // src/poly.c:84-107
 void poly_mul(poly_mpi_t *r, const poly_mpi_t *a, const poly_mpi_t *b, const unsigned int dim, const gpq_MPI q) {
   need_gcrypt();

@@ -147,6 +147,12 @@ unsigned gpq_ctx_pbits(gpq_ctx *ctx, unsigned dim);
 
 /* rns_decompose for every limb at once, src/rns.c:37-48: slab[k][d][i] = big[k][.][i] mod p_d (>= 0). */
 int gpq_rns_decompose(gpq_ctx *ctx, uint64_t *slab, const uint64_t *big, unsigned W, unsigned dim, unsigned batch, void *stream);
+/* The same for limbs first .. first+count-1 only (the reference's rns_decompose is per limb): slab[k][d][i], d < count. */
+int gpq_rns_decompose_limbs(gpq_ctx *ctx, uint64_t *slab, const uint64_t *big, unsigned W, unsigned first, unsigned count,
+                            unsigned batch, void *stream);
+/* rns_reconstruct, src/rns.c:60-75, for ONE coefficient: `dim` reduced residues in host memory -> value in [0, P) as
+ * Wout host words (64*Wout > bits of P).  Synchronous; the per-coefficient spelling of the reference, kept for its callers. */
+int gpq_rns_reconstruct_one(gpq_ctx *ctx, uint64_t *words, unsigned Wout, const uint64_t *residues, unsigned dim);
 /* poly_rns2mpi, src/poly.c:109-120, with q = 2^logq: rns_reconstruct (src/rns.c:60-75), centre
  * mod P, centre mod q.  logq = 0 stops after centring mod P (Wout must then hold P's bits + 1). */
 int gpq_rns_reconstruct(gpq_ctx *ctx, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned dim, unsigned batch,

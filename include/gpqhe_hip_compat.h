@@ -107,12 +107,17 @@ uint64_t barrett_inv(uint64_t q);
 uint64_t barrett_reduce(gpq_u128 a, uint64_t q, uint64_t qinv);
 
 /* ---- MPI-typed surface (mpi_shim.hip) ---------------------------------------------------
- * The five names BASELINE.json's north_star lists, with the reference's own signatures and its
+ * The five names BASELINE.json's north_star lists and the CRT bridge of src/rns.c, with the reference's own signatures and its
  * libgcrypt types.  Coefficients travel MPI -> device big slab -> MPI through libgcrypt's runtime
  * ABI (gcry_mpi_print / gcry_mpi_scan, resolved with dlsym from the libgcrypt the host program
  * already links).  `polyctx` and `hectx` are read like the reference reads them.  Power-of-two moduli
  * (every parameter set of the reference's tests) take the tuned kernels, any other q / q_l / 64-bit
  * Delta the general ones; misuse aborts with the reference's error convention -- there is no CPU path. */
+void rns_decompose(uint64_t ahat[], const gpq_MPI a[], const struct rns_ctx *rns);      /* src/rns.c:37: one limb, ahat[i] = a[i] mod rns->p */
+void rns_reconstruct(gpq_MPI a, const uint64_t ahat[], const unsigned int i,
+                     const struct rns_ctx *rns);                                        /* src/rns.c:60: ONE coefficient, in [0, P); use poly_rns2mpi for a slab */
+void poly_rns2mpi(poly_mpi_t *r, const poly_rns_t *rhat, const struct rns_ctx *rns,
+                  const gpq_MPI q);                                                     /* src/poly.h:88 */
 void poly_mul(poly_mpi_t *r, const poly_mpi_t *a, const poly_mpi_t *b,
               const unsigned int dim, const gpq_MPI q);                                 /* src/poly.h:86-87 */
 void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t *rlk);  /* src/gpqhe.h:147  */

@@ -4,6 +4,7 @@
  * GPQHE's own tests/polymul.c and tests/gpqhe.c drive the reference's.
  *
  *   mpi_host polymul                     the two products of tests/polymul.c:59-76 (n = 128, 5 limbs, q = 2^61)
+ *   mpi_host crt                         rns_decompose per limb, rns_reconstruct per coefficient, poly_rns2mpi (tests/crt.c:76-109)
  *   mpi_host hemul  <in.txt>             he_mul on ciphertexts read as hex, then he_rs, then he_moddown
  *
  * It owns `polyctx` and `hectx` (as src/precomp.c:41,47 do) and fills the fields the hot path reads,
@@ -95,6 +96,44 @@ static int polymul(int odd_modulus)
     poly_mul(&r, &a, &b, polyctx.dimub, polyctx.q);         /* :64, :75 */
     for (unsigned i = 0; i < polyctx.n; i++) print_mpi(r.coeffs[i]);
   }
+  return 0;
+}
+
+static int crt(void)
+{
+  ctx_init(7, 61);
+  const unsigned dim = polyctx.dimub;                       /* 5 limbs */
+  struct rns_ctx *rns = polyctx.rns;
+  MPI P3 = gcry_mpi_new(0);
+  gcry_mpi_set_ui(P3, 1);
+  for (unsigned d = 0; d < 3; d++, rns = rns->next) gcry_mpi_mul_ui(P3, P3, rns->p);
+  poly_mpi_t a, r;
+  poly_alloc(&a); poly_alloc(&r);
+  MPI t = gcry_mpi_new(0);
+  for (unsigned i = 0; i < polyctx.n; i++) {                /* a[i] = P[2] - i - 1 (tests/crt.c:79-81), every odd one negated */
+    gcry_mpi_set_ui(t, i + 1);
+    gcry_mpi_neg(t, t);
+    gcry_mpi_add(a.coeffs[i], P3, t);
+    if (i & 1) gcry_mpi_neg(a.coeffs[i], a.coeffs[i]);
+  }
+  poly_rns_t ahat;
+  ahat.coeffs = malloc((size_t)dim * polyctx.n * 8);
+  rns = polyctx.rns;
+  for (unsigned d = 0; d < dim; d++, rns = rns->next) rns_decompose(&ahat.coeffs[d * polyctx.n], a.coeffs, rns);   /* :96-99 */
+  for (unsigned d = 0; d < dim; d++)
+    for (unsigned i = 0; i < polyctx.n; i++) printf("%llu\n", (unsigned long long)ahat.coeffs[d * polyctx.n + i]);
+  for (rns = polyctx.rns; rns->dim < dim; rns = rns->next);
+  for (unsigned i = 0; i < polyctx.n; i++) { rns_reconstruct(r.coeffs[i], ahat.coeffs, i, rns); print_mpi(r.coeffs[i]); }  /* :107-109 */
+  MPI q = gcry_mpi_new(0);
+  gcry_mpi_set_ui(q, 1);
+  gcry_mpi_lshift(q, q, 61);
+  poly_rns2mpi(&r, &ahat, rns, q);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(r.coeffs[i]);
+  gcry_mpi_set_ui(q, 1000003);                              /* an odd modulus takes the general second centring */
+  gcry_mpi_mul_ui(q, q, 1000003);
+  gcry_mpi_mul_ui(q, q, 1000003);
+  poly_rns2mpi(&r, &ahat, rns, q);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(r.coeffs[i]);
   return 0;
 }
 
@@ -229,6 +268,7 @@ int main(int argc, char **argv)
 {
   if (argc >= 2 && !strcmp(argv[1], "polymul")) return polymul(0);
   if (argc >= 2 && !strcmp(argv[1], "polymulodd")) return polymul(1);
+  if (argc >= 2 && !strcmp(argv[1], "crt")) return crt();
   if (argc >= 3 && !strcmp(argv[1], "hemul")) return hemul(argv[2]);
   return 2;
 }

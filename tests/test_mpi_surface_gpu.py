@@ -55,6 +55,27 @@ def test_poly_mul_general_modulus_through_reference_signature(mpi_host, oracle_c
         assert vals[t * N:(t + 1) * N] == [ref.mpi_smod(v, Q) for v in ref.negacyclic_mul(a, b)]
 
 
+def test_crt_bridge_through_reference_signatures(mpi_host, oracle_ctx):
+    """rns_decompose per limb, rns_reconstruct per coefficient and poly_rns2mpi with the signatures of src/rns.c:37,60 and
+    src/poly.h:88, driven like tests/crt.c:76-109 but on the production 60-bit chain and with negative coefficients."""
+    res = subprocess.run([mpi_host, "crt"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    out = res.stdout.split()
+    o = oracle_ctx(7, 5)
+    N, dim = 128, 5
+    P3 = o.p[0] * o.p[1] * o.p[2]
+    P5 = P3 * o.p[3] * o.p[4]
+    a = [(P3 - i - 1) * (-1 if i & 1 else 1) for i in range(N)]
+    assert [int(v) for v in out[:dim * N]] == [a[i] % o.p[d] for d in range(dim) for i in range(N)]     # floor-mod, src/rns.c:43
+    pos = dim * N
+    assert _ints(out[pos:pos + N]) == [v % P5 for v in a]                                               # [0, P), src/rns.c:64-72
+    pos += N
+    for q in (1 << 61, 1000003 ** 3):
+        assert _ints(out[pos:pos + N]) == [ref.mpi_smod(ref.mpi_smod(v % P5, P5), q) for v in a]        # src/poly.c:115-117
+        pos += N
+    assert pos == len(out)
+
+
 @pytest.mark.parametrize("logn,qL,Delta", [
     (7, 1 << 120, 1 << 30),                       # the reference's test family: powers of two (tests/gpqhe.c:1349-1352)
     (7, 1000003 ** 5 * 1048573, 1000003),         # Delta and every q_l odd: the general-modulus kernels
