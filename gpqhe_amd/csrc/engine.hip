@@ -6,6 +6,7 @@
 #include "ntt_kernels.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -149,8 +150,33 @@ static int upload_tables(gpq_ctx *c) {
     LimbTab &t = tabs[d];
     t.k.p = p; t.k.p2 = 2 * p; t.k.p4 = 4 * p; t.k.c = (uint32_t)(p - (1ull << 59)); t.k.c1 = t.k.c + 1;
     t.k.kx0 = t.k.c1; t.k.kx1 = (uint64_t)t.k.c1 - 4 * p; t.k.ky = 4 * p - 2 * (uint64_t)t.k.c1;
+    t.k.kx1s = (uint64_t)t.k.c1 - 2 * p; t.k.kys = 2 * p - 2 * (uint64_t)t.k.c1;
     t.ninv = from_mont(c->ninv_mont[d]);
     t.winv1_ninv = n >= 2 ? mulm(wistd[d * n + 1], t.ninv, p) : t.ninv;
+    t.ninv_s = t.winv1_ninv_s = TwS{0, 0};
+  }
+  // split-twiddle pairs (p - w, p - w*2^31 mod p) for the leading limbs whose c allows the single fold
+  const char *nosplit = getenv("GPQHE_NO_SPLIT");   // dev switch: A/B against the 7-mad butterflies
+  c->nsplit = 0;
+  if (!(nosplit && nosplit[0] == '1'))
+    while (c->nsplit < np && c->p[c->nsplit] - (1ull << 59) < GPQ_SPLIT_CMAX) ++c->nsplit;
+  if (c->nsplit) {
+    const size_t ns = c->nsplit;
+    std::vector<TwS> ws(ns * n), wis(ns * n);
+    auto pair_of = [](uint64_t w, uint64_t p) { return TwS{p - w, p - (uint64_t)(((u128h)w << 31) % p)}; };
+    for (size_t d = 0; d < ns; ++d) {
+      const uint64_t p = c->p[d];
+      for (size_t i = 0; i < n; ++i) {
+        ws[d * n + i] = pair_of(wstd[d * n + i], p);
+        wis[d * n + i] = pair_of(wistd[d * n + i], p);
+      }
+      tabs[d].ninv_s = pair_of(tabs[d].ninv, p);
+      tabs[d].winv1_ninv_s = pair_of(tabs[d].winv1_ninv, p);
+    }
+    HIP_TRY(hipMalloc((void **)&c->d_ws, ns * n * sizeof(TwS)));
+    HIP_TRY(hipMalloc((void **)&c->d_winvs, ns * n * sizeof(TwS)));
+    HIP_TRY(hipMemcpy(c->d_ws, ws.data(), ns * n * sizeof(TwS), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_winvs, wis.data(), ns * n * sizeof(TwS), hipMemcpyHostToDevice));
   }
   HIP_TRY(hipMemcpy(c->d_w, wstd.data(), np * n * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_winv, wistd.data(), np * n * 8, hipMemcpyHostToDevice));
@@ -228,6 +254,8 @@ extern "C" void gpq_ctx_destroy(gpq_ctx *c) {
   if (!c) return;
   if (c->d_w) (void)hipFree(c->d_w);
   if (c->d_winv) (void)hipFree(c->d_winv);
+  if (c->d_ws) (void)hipFree(c->d_ws);
+  if (c->d_winvs) (void)hipFree(c->d_winvs);
   if (c->d_tabs) (void)hipFree(c->d_tabs);
   gpq_bridge_release(c);
   for (gpq_prof_rec &r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -307,6 +335,8 @@ PassArgs make_args(const gpq_ctx *c, unsigned dim, unsigned nslab) {
   a.tabs = c->d_tabs;
   a.w = c->d_w;
   a.winv = c->d_winv;
+  a.ws = c->d_ws;
+  a.winvs = c->d_winvs;
   a.poly_stride = (unsigned long long)dim << c->logn;
   a.logn = c->logn;
   a.limb0 = 0;
@@ -314,43 +344,71 @@ PassArgs make_args(const gpq_ctx *c, unsigned dim, unsigned nslab) {
   return a;
 }
 
-template <int M1, int EL, bool INV, bool CANON>
+// A pass over the limbs 0..dim-1 of its slabs is launched once for the leading limbs that have
+// split-twiddle tables and once for the rest (none at n <= 2^16): f(twiddle type tag, args, limbs).
+template <typename F>
+int for_limb_ranges(const gpq_ctx *c, PassArgs a, unsigned dim, const uint64_t **evk0, const uint64_t **evk1, F f) {
+  const unsigned first = a.limb0 < c->nsplit ? a.limb0 : c->nsplit;
+  const unsigned ns = c->nsplit - first < dim ? c->nsplit - first : dim;   // split limbs among limb0 .. limb0+dim-1
+  int rc;
+  if (ns && (rc = f(TwS{}, a, ns))) return rc;
+  if (dim > ns) {
+    const size_t shift = (size_t)ns << c->logn;
+    a.limb0 += ns;
+    for (int i = 0; i < GPQ_MAX_SLABS; ++i) { if (a.src[i]) a.src[i] += shift; if (a.dst[i]) a.dst[i] += shift; }
+    if (evk0) *evk0 += shift;
+    if (evk1) *evk1 += shift;
+    if ((rc = f(uint64_t{}, a, dim - ns))) return rc;
+  }
+  return GPQ_OK;
+}
+
+template <int M1, int EL, bool INV, bool CANON, typename TW>
 int launch_strided_t(const PassArgs &a, dim3 grid, hipStream_t s) {
   using G = StridedGeom<M1, EL>;
-  hipLaunchKernelGGL((strided_pass<M1, EL, INV, CANON>), grid, dim3(G::T), 0, s, a);
+  hipLaunchKernelGGL((strided_pass<M1, EL, INV, CANON, TW>), grid, dim3(G::T), 0, s, a);
   return GPQ_OK;
 }
 
 // strided pass over `polys` polynomials of each of a.nslab slabs, all `dim` limbs
 template <bool INV>
-int launch_strided(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned polys, hipStream_t s) {
-  const dim3 grid(16, polys * a.nslab, dim);
-  ProfScope prof(c, INV ? GPQ_K_STRIDED_INV : GPQ_K_STRIDED_FWD, s);
-  switch (c->logn) {
-    case 13: return launch_strided_t<5, 4, INV, false>(a, grid, s);
-    case 14: return launch_strided_t<6, 4, INV, false>(a, grid, s);
-    case 15: return launch_strided_t<7, 4, INV, false>(a, grid, s);
-    case 16: return launch_strided_t<8, 4, INV, false>(a, grid, s);
-    case 17: return launch_strided_t<9, 5, INV, false>(a, grid, s);
-  }
-  return gpq_fail(GPQ_ERR_INVALID, "two-pass NTT needs 13 <= logn <= 17 (got %u)", c->logn);
+int launch_strided(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigned polys, hipStream_t s) {
+  return for_limb_ranges(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
+    using TW = decltype(tag);
+    const dim3 grid(16, polys * a.nslab, limbs);
+    ProfScope prof(c, INV ? GPQ_K_STRIDED_INV : GPQ_K_STRIDED_FWD, s);
+    switch (c->logn) {
+      case 13: return launch_strided_t<5, 4, INV, false, TW>(a, grid, s);
+      case 14: return launch_strided_t<6, 4, INV, false, TW>(a, grid, s);
+      case 15: return launch_strided_t<7, 4, INV, false, TW>(a, grid, s);
+      case 16: return launch_strided_t<8, 4, INV, false, TW>(a, grid, s);
+      case 17: return launch_strided_t<9, 5, INV, false, TW>(a, grid, s);
+    }
+    return gpq_fail(GPQ_ERR_INVALID, "two-pass NTT needs 13 <= logn <= 17 (got %u)", c->logn);
+  });
 }
 
 template <bool INV>
-int launch_contig(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned polys, hipStream_t s) {
-  if (a.nslab != 1) return gpq_fail(GPQ_ERR_INVALID, "contig_pass walks one slab");
-  const dim3 grid(c->n >> 12, (polys + CONTIG_POLYS - 1) / CONTIG_POLYS, dim);
-  ProfScope prof(c, INV ? GPQ_K_CONTIG_INV : GPQ_K_CONTIG_FWD, s);
-  hipLaunchKernelGGL((contig_pass<INV>), grid, dim3(CONTIG_WAVES * 64), 0, s, a, polys);
-  return GPQ_OK;
+int launch_contig(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigned polys, hipStream_t s) {
+  if (args.nslab != 1) return gpq_fail(GPQ_ERR_INVALID, "contig_pass walks one slab");
+  return for_limb_ranges(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
+    using TW = decltype(tag);
+    const dim3 grid(c->n >> 12, (polys + CONTIG_POLYS - 1) / CONTIG_POLYS, limbs);
+    ProfScope prof(c, INV ? GPQ_K_CONTIG_INV : GPQ_K_CONTIG_FWD, s);
+    hipLaunchKernelGGL((contig_pass<INV, TW>), grid, dim3(CONTIG_WAVES * 64), 0, s, a, polys);
+    return (int)GPQ_OK;
+  });
 }
 
 template <bool INV>
-int launch_small(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned polys, hipStream_t s) {
-  const dim3 grid(1, polys * a.nslab, dim);
-  ProfScope prof(c, GPQ_K_SMALL, s);
-  hipLaunchKernelGGL((small_ntt<INV>), grid, dim3(256), 0, s, a);
-  return GPQ_OK;
+int launch_small(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigned polys, hipStream_t s) {
+  return for_limb_ranges(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
+    using TW = decltype(tag);
+    const dim3 grid(1, polys * a.nslab, limbs);
+    ProfScope prof(c, GPQ_K_SMALL, s);
+    hipLaunchKernelGGL((small_ntt<INV, TW>), grid, dim3(256), 0, s, a);
+    return (int)GPQ_OK;
+  });
 }
 
 inline bool two_pass(const gpq_ctx *c) { return c->logn > (unsigned)SMALL_MAX_LOGN; }
@@ -498,10 +556,12 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
     PassArgs m = make_args(c, dim, 1);
     for (int i = 0; i < 4; ++i) m.src[i] = f.dst[i];
     m.dst[0] = d0 + k0 * poly; m.dst[1] = d1 + k0 * poly; m.dst[2] = d2 + k0 * poly;
-    {
-      ProfScope prof(c, GPQ_K_TENSOR_MID, s);
-      hipLaunchKernelGGL(tensor_mid, dim3(c->n >> 12, polys, dim), dim3(CONTIG_WAVES * 64), 0, s, m);
-    }
+    if ((rc = for_limb_ranges(c, m, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
+          using TW = decltype(tag);
+          ProfScope prof(c, GPQ_K_TENSOR_MID, s);
+          hipLaunchKernelGGL((tensor_mid<TW>), dim3(c->n >> 12, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, a);
+          return (int)GPQ_OK;
+        }))) return rc;
     // 3. strided inverse pass in place on the three outputs
     PassArgs b = make_args(c, dim, 3);
     for (int i = 0; i < 3; ++i) { b.src[i] = m.dst[i]; b.dst[i] = m.dst[i]; }
@@ -541,10 +601,13 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
     m.p = make_args(c, dim, 1);
     m.p.src[0] = ws; m.p.dst[0] = c0 + k0 * poly; m.p.dst[1] = c1 + k0 * poly;
     m.evk0 = evk0; m.evk1 = evk1;
-    {
-      ProfScope prof(c, GPQ_K_KEYSWITCH_MID, s);
-      hipLaunchKernelGGL(keyswitch_mid, dim3(c->n >> 12, polys, dim), dim3(CONTIG_WAVES * 64), 0, s, m);
-    }
+    if ((rc = for_limb_ranges(c, m.p, dim, &m.evk0, &m.evk1, [&](auto tag, const PassArgs &a, unsigned limbs) {
+          using TW = decltype(tag);
+          KeyswitchArgs ka{a, m.evk0, m.evk1};
+          ProfScope prof(c, GPQ_K_KEYSWITCH_MID, s);
+          hipLaunchKernelGGL((keyswitch_mid<TW>), dim3(c->n >> 12, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, ka);
+          return (int)GPQ_OK;
+        }))) return rc;
     PassArgs b = make_args(c, dim, 2);
     for (int i = 0; i < 2; ++i) { b.src[i] = m.p.dst[i]; b.dst[i] = m.p.dst[i]; }
     if ((rc = launch_strided<true>(c, b, dim, polys, s))) return rc;

@@ -45,11 +45,13 @@ constexpr int tw_off(int EL, int BHI, int b) { return (1 << (EL - b - 1)) - (1 <
 // register index is a compile-time constant (a plain nested loop over 32
 // registers is not always unrolled completely, and a runtime-indexed register
 // array goes to scratch: measured 8x slower on the n=2^17 forward pass).
-template <int EL, int BHI, int B, int BLO, bool UNIFORM, int NTW>
-__device__ __forceinline__ void load_tw_bits(uint64_t (&tw)[NTW], unsigned ibase, int rs, unsigned logn,
-                                             const uint64_t *__restrict__ w) {
+// TW is the table entry type: uint64_t (plain twiddle, 7-mad multiply, data < 8p / < 4p) or
+// TwS (split pair, 5-mad multiply, data < 4p / < 2p); the butterflies are overloaded on it.
+template <int EL, int BHI, int B, int BLO, bool UNIFORM, int NTW, typename TW>
+__device__ __forceinline__ void load_tw_bits(TW (&tw)[NTW], unsigned ibase, int rs, unsigned logn,
+                                             const TW *__restrict__ w) {
   const int sh = rs + B + 1;                                          // i / (2 len)
-  const uint64_t *wp = w + (1u << (logn - sh)) + (UNIFORM ? 0u : (ibase >> sh));
+  const TW *wp = w + (1u << (logn - sh)) + (UNIFORM ? 0u : (ibase >> sh));
 #pragma unroll
   for (int j = 0; j < (1 << (EL - B - 1)); ++j) tw[tw_off(EL, BHI, B) + j] = wp[j];
   if constexpr (B > BLO) load_tw_bits<EL, BHI, B - 1, BLO, UNIFORM>(tw, ibase, rs, logn, w);
@@ -57,47 +59,88 @@ __device__ __forceinline__ void load_tw_bits(uint64_t (&tw)[NTW], unsigned ibase
 
 // Fetch the twiddles of a group into registers ahead of the butterflies: stage on
 // bit b uses table[n/(2 len) + i/(2 len)], i.e. 2^(EL-b-1) consecutive entries per thread.
-template <int EL, int BHI, int BLO, bool UNIFORM>
-__device__ __forceinline__ void load_tw(uint64_t (&tw)[tw_count(EL, BHI, BLO)], unsigned ibase, int rs, unsigned logn,
-                                        const uint64_t *__restrict__ w) {
+template <int EL, int BHI, int BLO, bool UNIFORM, typename TW>
+__device__ __forceinline__ void load_tw(TW (&tw)[tw_count(EL, BHI, BLO)], unsigned ibase, int rs, unsigned logn,
+                                        const TW *__restrict__ w) {
   load_tw_bits<EL, BHI, BHI, BLO, UNIFORM>(tw, ibase, rs, logn, w);
 }
 
-template <int EL, int BHI, int B, int BLO, int NTW>
-__device__ __forceinline__ void ct_bits(uint64_t (&x)[1 << EL], const uint64_t (&tw)[NTW], const PrimeK &k) {
+template <int EL, int BHI, int B, int BLO, int NTW, typename TW>
+__device__ __forceinline__ void ct_bits(uint64_t (&x)[1 << EL], const TW (&tw)[NTW], const PrimeK &k) {
 #pragma unroll
   for (int e = 0; e < (1 << EL); ++e)
     if (!(e & (1 << B))) ct_bfly(x[e], x[e + (1 << B)], tw[tw_off(EL, BHI, B) + (e >> (B + 1))], k);
   if constexpr (B > BLO) ct_bits<EL, BHI, B - 1, BLO>(x, tw, k);
 }
-template <int EL, int BHI, int BLO>
-__device__ __forceinline__ void ct_group(uint64_t (&x)[1 << EL], const uint64_t (&tw)[tw_count(EL, BHI, BLO)],
+template <int EL, int BHI, int BLO, typename TW>
+__device__ __forceinline__ void ct_group(uint64_t (&x)[1 << EL], const TW (&tw)[tw_count(EL, BHI, BLO)],
                                          const PrimeK &k) {
   ct_bits<EL, BHI, BHI, BLO>(x, tw, k);
 }
 
 // Inverse: stages run from bit BLO up to BHI; tw[] is laid out as load_tw fills it (BHI first).
-template <int EL, int BHI, int B, int NTW>
-__device__ __forceinline__ void gs_bits(uint64_t (&x)[1 << EL], const uint64_t (&tw)[NTW], const PrimeK &k) {
+template <int EL, int BHI, int B, int NTW, typename TW>
+__device__ __forceinline__ void gs_bits(uint64_t (&x)[1 << EL], const TW (&tw)[NTW], const PrimeK &k) {
 #pragma unroll
   for (int e = 0; e < (1 << EL); ++e)
     if (!(e & (1 << B))) gs_bfly(x[e], x[e + (1 << B)], tw[tw_off(EL, BHI, B) + (e >> (B + 1))], k);
   if constexpr (B < BHI) gs_bits<EL, BHI, B + 1>(x, tw, k);
 }
-template <int EL, int BHI, int BLO>
-__device__ __forceinline__ void gs_group(uint64_t (&x)[1 << EL], const uint64_t (&tw)[tw_count(EL, BHI, BLO)],
+template <int EL, int BHI, int BLO, typename TW>
+__device__ __forceinline__ void gs_group(uint64_t (&x)[1 << EL], const TW (&tw)[tw_count(EL, BHI, BLO)],
                                          const PrimeK &k) {
   gs_bits<EL, BHI, BLO>(x, tw, k);
 }
 
 // Last inverse stage (len = n/2, twiddle winv[1]) with the n^-1 scaling of
 // src/ntt.c:71-72 folded in, canonical outputs.  in: x,y < 4p.
-__device__ __forceinline__ void gs_last(uint64_t &x, uint64_t &y, const LimbTab &t) {
+// The two constants are taken by value (LastK is copied out of the LimbTab at kernel entry, next to
+// PrimeK): read through the table reference inside the unrolled tail they were re-fetched with
+// vector loads for every pair.
+template <typename TW> struct LastK;
+template <> struct LastK<uint64_t> {
+  uint64_t ninv, winv1_ninv;
+  __device__ __forceinline__ explicit LastK(const LimbTab &t) : ninv(t.ninv), winv1_ninv(t.winv1_ninv) {}
+};
+template <> struct LastK<TwS> {
+  TwS ninv, winv1_ninv;
+  __device__ __forceinline__ explicit LastK(const LimbTab &t) : ninv(t.ninv_s), winv1_ninv(t.winv1_ninv_s) {}
+};
+__device__ __forceinline__ void gs_last(uint64_t &x, uint64_t &y, const LastK<uint64_t> &t, const PrimeK &k) {
   const uint64_t s = x + y;                 // < 8p
-  const uint64_t d = x + t.k.p4 - y;        // (0, 8p)
-  x = canon4(mulmod_lazy(s, t.ninv, t.k), t.k);
-  y = canon4(mulmod_lazy(d, t.winv1_ninv, t.k), t.k);
+  const uint64_t d = x + k.p4 - y;          // (0, 8p)
+  x = canon4(mulmod_lazy(s, t.ninv, k), k);
+  y = canon4(mulmod_lazy(d, t.winv1_ninv, k), k);
 }
+__device__ __forceinline__ void gs_last(uint64_t &x, uint64_t &y, const LastK<TwS> &t, const PrimeK &k) {   // in: x,y < 2p
+  const uint64_t s = x + y;                 // < 4p
+  const uint64_t d = x + k.p2 - y;          // (0, 4p)
+  x = csub(mulmod_split(s, t.ninv, k) + k.c1, k.p);
+  y = csub(mulmod_split(d, t.winv1_ninv, k) + k.c1, k.p);
+}
+
+// Per twiddle type: the table pointers of a launch and the lazy ranges the butterflies keep.
+template <typename TW> struct TwTraits;
+template <> struct TwTraits<uint64_t> {
+  __device__ static __forceinline__ const uint64_t *table(const PassArgs &a, bool inv) { return inv ? a.winv : a.w; }
+  __device__ static __forceinline__ uint64_t canon_fwd(uint64_t x, const PrimeK &k) { return canon8(x, k); }   // forward data < 8p
+  __device__ static __forceinline__ uint64_t canon_inv(uint64_t x, const PrimeK &k) { return canon4(x, k); }   // inverse data < 4p
+  // into the inverse range from a value < 4p / < 8p
+  __device__ static __forceinline__ uint64_t inv_from4(uint64_t x, const PrimeK &) { return x; }
+  __device__ static __forceinline__ uint64_t inv_from8(uint64_t x, const PrimeK &k) { return csub(x, k.p4); }
+  // a forward-range value as the left (< 2p) / right (< 4p) operand of a variable*variable mulmod_lazy
+  __device__ static __forceinline__ uint64_t left(uint64_t x, const PrimeK &k) { return csub(csub(x, k.p4), k.p2); }
+  __device__ static __forceinline__ uint64_t right(uint64_t x, const PrimeK &k) { return csub(x, k.p4); }
+};
+template <> struct TwTraits<TwS> {
+  __device__ static __forceinline__ const TwS *table(const PassArgs &a, bool inv) { return inv ? a.winvs : a.ws; }
+  __device__ static __forceinline__ uint64_t canon_fwd(uint64_t x, const PrimeK &k) { return canon4(x, k); }   // forward data < 4p
+  __device__ static __forceinline__ uint64_t canon_inv(uint64_t x, const PrimeK &k) { return csub(x, k.p); }   // inverse data < 2p
+  __device__ static __forceinline__ uint64_t inv_from4(uint64_t x, const PrimeK &k) { return csub(x, k.p2); }
+  __device__ static __forceinline__ uint64_t inv_from8(uint64_t x, const PrimeK &k) { return csub(csub(x, k.p4), k.p2); }
+  __device__ static __forceinline__ uint64_t left(uint64_t x, const PrimeK &k) { return csub(x, k.p2); }
+  __device__ static __forceinline__ uint64_t right(uint64_t x, const PrimeK &) { return x; }
+};
 
 // ---------------------------------------------------------------------------
 // Strided pass: the M1 = logn-8 stages with len >= 256.
@@ -118,7 +161,7 @@ struct StridedGeom {
   __device__ static __forceinline__ unsigned pad(unsigned l) { return l + ((l >> (EL + 4)) << 4); }
 };
 
-template <int M1, int EL, bool INV, bool CANON_OUT>
+template <int M1, int EL, bool INV, bool CANON_OUT, typename TW>
 __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArgs a) {
   using G = StridedGeom<M1, EL>;
   constexpr int E = G::E;
@@ -128,7 +171,8 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
   const unsigned limb = a.limb0 + blockIdx.z;
   const LimbTab &tab = a.tabs[limb];
   const PrimeK k = tab.k;
-  const uint64_t *__restrict__ wt = (INV ? a.winv : a.w) + ((size_t)limb << logn);
+  const LastK<TW> last(tab);
+  const TW *__restrict__ wt = TwTraits<TW>::table(a, INV) + ((size_t)limb << logn);
   const unsigned slab = blockIdx.y % a.nslab, poly = blockIdx.y / a.nslab;
   const size_t off = (size_t)poly * a.poly_stride + ((size_t)blockIdx.z << logn);
   const uint64_t *__restrict__ src = a.src[slab] + off;
@@ -141,10 +185,10 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
   const unsigned iA = (q << 8) + col, iB = (q << (EL + 8)) + col;
   constexpr unsigned strideA = 1u << (G::S2 + 8), strideB = 1u << 8;
   uint64_t x[E];
-  uint64_t twB[tw_count(EL, G::BB, 0)];
+  TW twB[tw_count(EL, G::BB, 0)];
 
   if (!INV) {
-    uint64_t twA[tw_count(EL, EL - 1, 0)];
+    TW twA[tw_count(EL, EL - 1, 0)];
 #pragma unroll
     for (int e = 0; e < E; ++e) x[e] = src[iA + e * strideA];
     load_tw<EL, EL - 1, 0, true>(twA, iA, G::S2 + 8, logn, wt);
@@ -158,14 +202,14 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
       for (int e = 0; e < E; ++e) x[e] = lds[G::pad((q << (EL + 4)) + (e << 4) + (tid & 15))];
       ct_group<EL, G::BB, 0>(x, twB, k);
 #pragma unroll
-      for (int e = 0; e < E; ++e) dst[iB + e * strideB] = CANON_OUT ? canon8(x[e], k) : x[e];
+      for (int e = 0; e < E; ++e) dst[iB + e * strideB] = CANON_OUT ? TwTraits<TW>::canon_fwd(x[e], k) : x[e];
     } else {
 #pragma unroll
-      for (int e = 0; e < E; ++e) dst[iA + e * strideA] = CANON_OUT ? canon8(x[e], k) : x[e];
+      for (int e = 0; e < E; ++e) dst[iA + e * strideA] = CANON_OUT ? TwTraits<TW>::canon_fwd(x[e], k) : x[e];
     }
   } else {
     // top EL row bits; the very last one (len = n/2) carries the n^-1 scaling and is done by gs_last
-    uint64_t twA[tw_count(EL, (EL > 1 ? EL - 2 : 0), 0)];
+    TW twA[tw_count(EL, (EL > 1 ? EL - 2 : 0), 0)];
     if (G::S2 > 0) {
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = src[iB + e * strideB];
@@ -184,7 +228,7 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
     }
     if (EL > 1) gs_group<EL, (EL > 1 ? EL - 2 : 0), 0>(x, twA, k);
 #pragma unroll
-    for (int e = 0; e < E / 2; ++e) gs_last(x[e], x[e + E / 2], tab);
+    for (int e = 0; e < E / 2; ++e) gs_last(x[e], x[e + E / 2], last, k);
 #pragma unroll
     for (int e = 0; e < E; ++e) dst[iA + e * strideA] = x[e];
   }
@@ -238,27 +282,19 @@ struct ContigLane {
   }
 };
 
-// The 30 twiddles one lane needs for the 8 low stages of one direction.
+// The 30 twiddles one lane needs for the 8 low stages of one direction: 15 for the H group, 15 for
+// the L group.  Kernels that hold several polynomials run one group on all of them before fetching
+// the other group's twiddles, so only 15 entries are live at a time (split pairs are 4 VGPRs each).
+template <typename TW>
 struct ContigTw {
-  uint64_t h[15], l[15];
-  __device__ __forceinline__ void load(const ContigLane &ln, unsigned wave0, unsigned logn, const uint64_t *__restrict__ w) {
-    load_tw<4, 3, 0, false>(h, wave0 + ln.hbase, 4, logn, w);
-    load_tw<4, 3, 0, false>(l, wave0 + ln.lbase, 0, logn, w);
+  TW t[15];
+  __device__ __forceinline__ void load_h(const ContigLane &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
+    load_tw<4, 3, 0, false>(t, wave0 + ln.hbase, 4, logn, w);
+  }
+  __device__ __forceinline__ void load_l(const ContigLane &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
+    load_tw<4, 3, 0, false>(t, wave0 + ln.lbase, 0, logn, w);
   }
 };
-
-// forward: coefficients (H layout, < 8p) -> NTT domain (L layout, < 8p)
-__device__ __forceinline__ void contig_fwd(uint64_t (&x)[16], const ContigLane &ln, const ContigTw &tw, const PrimeK &k) {
-  ct_group<4, 3, 0>(x, tw.h, k);
-  ln.h_to_l(x);
-  ct_group<4, 3, 0>(x, tw.l, k);
-}
-// inverse: NTT domain (L layout, < 4p) -> coefficients after the 8 low stages (H layout, < 4p)
-__device__ __forceinline__ void contig_inv(uint64_t (&x)[16], const ContigLane &ln, const ContigTw &tw, const PrimeK &k) {
-  gs_group<4, 3, 0>(x, tw.l, k);
-  ln.l_to_h(x);
-  gs_group<4, 3, 0>(x, tw.h, k);
-}
 
 __device__ __forceinline__ void load_h(uint64_t (&x)[16], const uint64_t *__restrict__ p, const ContigLane &ln) {
 #pragma unroll
@@ -300,8 +336,9 @@ constexpr int CONTIG_POLYS = 4;
 #ifndef GPQ_CONTIG_MINWAVES
 #define GPQ_CONTIG_MINWAVES 2
 #endif
-template <bool INV>
+template <bool INV, typename TW>
 __global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_CONTIG_MINWAVES) void contig_pass(PassArgs a, unsigned polys) {
+  using TT = TwTraits<TW>;
   __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
   const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
   const unsigned wave0 = (blockIdx.x * CONTIG_WAVES + (threadIdx.x >> 6)) << 10;
@@ -313,26 +350,76 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_CONTIG_MINWAVES) void contig
   const size_t off = (size_t)p0 * a.poly_stride + ((size_t)blockIdx.z << a.logn) + wave0;
   const uint64_t *__restrict__ src = a.src[0] + off;
   uint64_t *__restrict__ dst = a.dst[0] + off;
-  uint64_t x[16], nx[16];
-  ContigTw tw;
-  // Global accesses use the H layout only (16 lanes = 128 contiguous bytes); the L layout
-  // (each lane on its own 128-byte line) is reached through one more LDS exchange instead.
-  load_h(x, src, ln);
-  tw.load(ln, wave0, a.logn, (INV ? a.winv : a.w) + ((size_t)limb << a.logn));
-  for (unsigned i = 0; i < cnt; ++i) {
-    if (i + 1 < cnt) load_h(nx, src + (size_t)(i + 1) * a.poly_stride, ln);
-    if (!INV) {
-      contig_fwd(x, ln, tw, k);
-      ln.l_to_h(x);
+  const TW *__restrict__ wt = TT::table(a, INV) + ((size_t)limb << a.logn);
+  if constexpr (sizeof(TW) == 8) {
+    // plain twiddles: all 30 of a lane stay in registers and the next polynomial's coefficients
+    // are fetched under the current one's butterflies
+    uint64_t x[16], nx[16];
+    ContigTw<TW> twh, twl;
+    // Global accesses use the H layout only (16 lanes = 128 contiguous bytes); the L layout
+    // (each lane on its own 128-byte line) is reached through one more LDS exchange instead.
+    load_h(x, src, ln);
+    twh.load_h(ln, wave0, a.logn, wt);
+    twl.load_l(ln, wave0, a.logn, wt);
+    for (unsigned i = 0; i < cnt; ++i) {
+      if (i + 1 < cnt) load_h(nx, src + (size_t)(i + 1) * a.poly_stride, ln);
+      if (!INV) {
+        ct_group<4, 3, 0>(x, twh.t, k);
+        ln.h_to_l(x);
+        ct_group<4, 3, 0>(x, twl.t, k);
+        ln.l_to_h(x);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) x[e] = canon8(x[e], k);
-    } else {
-      ln.h_to_l(x);
-      contig_inv(x, ln, tw, k);
+        for (int e = 0; e < 16; ++e) x[e] = TT::canon_fwd(x[e], k);
+      } else {
+        ln.h_to_l(x);
+        gs_group<4, 3, 0>(x, twl.t, k);
+        ln.l_to_h(x);
+        gs_group<4, 3, 0>(x, twh.t, k);
+      }
+      store_h(dst + (size_t)i * a.poly_stride, x, ln);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) x[e] = nx[e];
     }
-    store_h(dst + (size_t)i * a.poly_stride, x, ln);
+  } else {
+    // split pairs are 4 VGPRs each: the CONTIG_POLYS polynomials are held together and one twiddle
+    // group (15 pairs) at a time runs over all of them, as in tensor_mid
+    uint64_t x[CONTIG_POLYS][16];
+    ContigTw<TW> tw;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = nx[e];
+    for (int j = 0; j < CONTIG_POLYS; ++j)
+      if (j < (int)cnt) load_h(x[j], src + (size_t)j * a.poly_stride, ln);
+    if (!INV) {
+      tw.load_h(ln, wave0, a.logn, wt);
+#pragma unroll
+      for (int j = 0; j < CONTIG_POLYS; ++j) if (j < (int)cnt) ct_group<4, 3, 0>(x[j], tw.t, k);
+      tw.load_l(ln, wave0, a.logn, wt);
+#pragma unroll
+      for (int j = 0; j < CONTIG_POLYS; ++j)
+        if (j < (int)cnt) {
+          ln.h_to_l(x[j]);
+          ct_group<4, 3, 0>(x[j], tw.t, k);
+          ln.l_to_h(x[j]);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) x[j][e] = TT::canon_fwd(x[j][e], k);
+          store_h(dst + (size_t)j * a.poly_stride, x[j], ln);
+        }
+    } else {
+      tw.load_l(ln, wave0, a.logn, wt);
+#pragma unroll
+      for (int j = 0; j < CONTIG_POLYS; ++j)
+        if (j < (int)cnt) {
+          ln.h_to_l(x[j]);
+          gs_group<4, 3, 0>(x[j], tw.t, k);
+          ln.l_to_h(x[j]);
+        }
+      tw.load_h(ln, wave0, a.logn, wt);
+#pragma unroll
+      for (int j = 0; j < CONTIG_POLYS; ++j)
+        if (j < (int)cnt) {
+          gs_group<4, 3, 0>(x[j], tw.t, k);
+          store_h(dst + (size_t)j * a.poly_stride, x[j], ln);
+        }
+    }
   }
 }
 
@@ -344,39 +431,52 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_CONTIG_MINWAVES) void contig
 //   low 8 inverse stages of d0, d1, d2
 // src[0..3] = a0,a1,b0,b1 after the strided forward pass; dst[0..2] = d0,d1,d2.
 // ---------------------------------------------------------------------------
+template <typename TW>
 __global__ __launch_bounds__(CONTIG_WAVES * 64, 2) void tensor_mid(PassArgs a) {
+  using TT = TwTraits<TW>;
   __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
   const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
   const ContigBlock cb(a);           // nslab == 1 here: blockIdx.y = poly
   const LimbTab &tab = a.tabs[cb.limb];
   const PrimeK k = tab.k;
+  const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
   uint64_t a0[16], a1[16], b0[16], b1[16];
-  ContigTw tw;
+  ContigTw<TW> tw;
   load_h(a0, a.src[0] + cb.off, ln);
-  tw.load(ln, cb.wave0, a.logn, a.w + cb.toff);
+  tw.load_h(ln, cb.wave0, a.logn, wf);
   load_h(b0, a.src[2] + cb.off, ln);
   load_h(a1, a.src[1] + cb.off, ln);
   load_h(b1, a.src[3] + cb.off, ln);
-  contig_fwd(a0, ln, tw, k);
-  contig_fwd(b0, ln, tw, k);
-  contig_fwd(a1, ln, tw, k);
-  contig_fwd(b1, ln, tw, k);
-  tw.load(ln, cb.wave0, a.logn, a.winv + cb.toff);   // inverse twiddles arrive under the products
+  // forward, group H on all four, then group L on all four (15 twiddles live at a time)
+  ct_group<4, 3, 0>(a0, tw.t, k);
+  ct_group<4, 3, 0>(b0, tw.t, k);
+  ct_group<4, 3, 0>(a1, tw.t, k);
+  ct_group<4, 3, 0>(b1, tw.t, k);
+  tw.load_l(ln, cb.wave0, a.logn, wf);
+  ln.h_to_l(a0); ct_group<4, 3, 0>(a0, tw.t, k);
+  ln.h_to_l(b0); ct_group<4, 3, 0>(b0, tw.t, k);
+  ln.h_to_l(a1); ct_group<4, 3, 0>(a1, tw.t, k);
+  ln.h_to_l(b1); ct_group<4, 3, 0>(b1, tw.t, k);
+  tw.load_l(ln, cb.wave0, a.logn, wi);               // inverse twiddles arrive under the products
   // products: left operand < 2p, right operand < 4p  =>  a*b < 8p^2, as mulmod_lazy needs
   uint64_t d1[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const uint64_t u0 = csub(csub(a0[e], k.p4), k.p2), u1 = csub(csub(a1[e], k.p4), k.p2);
-    const uint64_t v0 = csub(b0[e], k.p4), v1 = csub(b1[e], k.p4);
-    a0[e] = mulmod_lazy(u0, v0, k);                                   // d0 < 4p
-    d1[e] = csub(mulmod_lazy(u0, v1, k) + mulmod_lazy(u1, v0, k), k.p4);  // d1 < 4p
-    a1[e] = mulmod_lazy(u1, v1, k);                                   // d2 < 4p
+    const uint64_t u0 = TT::left(a0[e], k), u1 = TT::left(a1[e], k);
+    const uint64_t v0 = TT::right(b0[e], k), v1 = TT::right(b1[e], k);
+    a0[e] = TT::inv_from4(mulmod_lazy(u0, v0, k), k);                                   // d0
+    d1[e] = TT::inv_from8(mulmod_lazy(u0, v1, k) + mulmod_lazy(u1, v0, k), k);          // d1
+    a1[e] = TT::inv_from4(mulmod_lazy(u1, v1, k), k);                                   // d2
   }
-  contig_inv(a0, ln, tw, k);
+  gs_group<4, 3, 0>(a0, tw.t, k); ln.l_to_h(a0);
+  gs_group<4, 3, 0>(d1, tw.t, k); ln.l_to_h(d1);
+  gs_group<4, 3, 0>(a1, tw.t, k); ln.l_to_h(a1);
+  tw.load_h(ln, cb.wave0, a.logn, wi);
+  gs_group<4, 3, 0>(a0, tw.t, k);
   store_h(a.dst[0] + cb.off, a0, ln);
-  contig_inv(d1, ln, tw, k);
+  gs_group<4, 3, 0>(d1, tw.t, k);
   store_h(a.dst[1] + cb.off, d1, ln);
-  contig_inv(a1, ln, tw, k);
+  gs_group<4, 3, 0>(a1, tw.t, k);
   store_h(a.dst[2] + cb.off, a1, ln);
 }
 
@@ -388,31 +488,40 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 2) void tensor_mid(PassArgs a) {
 // ---------------------------------------------------------------------------
 struct KeyswitchArgs { PassArgs p; const uint64_t *evk0; const uint64_t *evk1; };
 
+template <typename TW>
 __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid(KeyswitchArgs ka) {
+  using TT = TwTraits<TW>;
   __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
   const PassArgs &a = ka.p;
   const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
   const ContigBlock cb(a);
   const LimbTab &tab = a.tabs[cb.limb];
   const PrimeK k = tab.k;
+  const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
   const size_t koff = ((size_t)blockIdx.z << a.logn) + cb.wave0;
   uint64_t x[16], e0[16], e1[16];
-  ContigTw tw;
+  ContigTw<TW> tw;
   load_h(x, a.src[0] + cb.off, ln);
-  tw.load(ln, cb.wave0, a.logn, a.w + cb.toff);
-  contig_fwd(x, ln, tw, k);
+  tw.load_h(ln, cb.wave0, a.logn, wf);
+  ct_group<4, 3, 0>(x, tw.t, k);
+  tw.load_l(ln, cb.wave0, a.logn, wf);
+  ln.h_to_l(x);
+  ct_group<4, 3, 0>(x, tw.t, k);
   load_l(e0, ka.evk0 + koff, ln);   // measured faster than H-layout loads + two more LDS exchanges here
   load_l(e1, ka.evk1 + koff, ln);
-  tw.load(ln, cb.wave0, a.logn, a.winv + cb.toff);
+  tw.load_l(ln, cb.wave0, a.logn, wi);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const uint64_t u = csub(x[e], k.p4);           // < 4p ; evk limbs are canonical (< p)
-    e0[e] = mulmod_lazy(u, e0[e], k);
-    e1[e] = mulmod_lazy(u, e1[e], k);
+    const uint64_t u = TT::right(x[e], k);         // < 4p ; evk limbs are canonical (< p)
+    e0[e] = TT::inv_from4(mulmod_lazy(u, e0[e], k), k);
+    e1[e] = TT::inv_from4(mulmod_lazy(u, e1[e], k), k);
   }
-  contig_inv(e0, ln, tw, k);
+  gs_group<4, 3, 0>(e0, tw.t, k); ln.l_to_h(e0);
+  gs_group<4, 3, 0>(e1, tw.t, k); ln.l_to_h(e1);
+  tw.load_h(ln, cb.wave0, a.logn, wi);
+  gs_group<4, 3, 0>(e0, tw.t, k);
   store_h(a.dst[0] + cb.off, e0, ln);
-  contig_inv(e1, ln, tw, k);
+  gs_group<4, 3, 0>(e1, tw.t, k);
   store_h(a.dst[1] + cb.off, e1, ln);
 }
 
@@ -442,13 +551,15 @@ __global__ __launch_bounds__(256) void pointwise(PassArgs a) {
 // ---------------------------------------------------------------------------
 constexpr int SMALL_MAX_LOGN = 12;
 
-template <bool INV>
+template <bool INV, typename TW>
 __global__ __launch_bounds__(256) void small_ntt(PassArgs a) {
+  using TT = TwTraits<TW>;
   __shared__ uint64_t s[1 << SMALL_MAX_LOGN];
   const LimbTab &tab = a.tabs[a.limb0 + blockIdx.z];
   const PrimeK k = tab.k;
+  const LastK<TW> last(tab);
   const unsigned n = 1u << a.logn;
-  const uint64_t *__restrict__ wt = (INV ? a.winv : a.w) + ((size_t)(a.limb0 + blockIdx.z) << a.logn);
+  const TW *__restrict__ wt = TT::table(a, INV) + ((size_t)(a.limb0 + blockIdx.z) << a.logn);
   const unsigned slab = blockIdx.y % a.nslab, poly = blockIdx.y / a.nslab;
   const size_t off = (size_t)poly * a.poly_stride + ((size_t)blockIdx.z << a.logn);
   const uint64_t *__restrict__ src = a.src[slab] + off;
@@ -461,7 +572,7 @@ __global__ __launch_bounds__(256) void small_ntt(PassArgs a) {
         const unsigned blk = b / len, j = blk * 2 * len + (b % len);
         uint64_t x = s[j], y = s[j + len];
         ct_bfly(x, y, wt[n / (2 * len) + blk], k);
-        s[j] = canon8(x, k); s[j + len] = canon8(y, k);
+        s[j] = TT::canon_fwd(x, k); s[j + len] = TT::canon_fwd(y, k);
       }
       __syncthreads();
     }
@@ -471,14 +582,14 @@ __global__ __launch_bounds__(256) void small_ntt(PassArgs a) {
         const unsigned blk = b / len, j = blk * 2 * len + (b % len);
         uint64_t x = s[j], y = s[j + len];
         gs_bfly(x, y, wt[n / (2 * len) + blk], k);
-        s[j] = canon4(x, k); s[j + len] = canon4(y, k);
+        s[j] = TT::canon_inv(x, k); s[j + len] = TT::canon_inv(y, k);
       }
       __syncthreads();
     }
     if (n >= 2) {
       for (unsigned b = threadIdx.x; b < (n >> 1); b += 256) {
         uint64_t x = s[b], y = s[b + (n >> 1)];
-        gs_last(x, y, tab);
+        gs_last(x, y, last, k);
         s[b] = x; s[b + (n >> 1)] = y;
       }
       __syncthreads();

@@ -8,6 +8,7 @@ struct LimbTab {           // per-prime scalars, array resident in HBM (read wit
   PrimeK k;
   uint64_t ninv;           // n^-1 mod p, standard form (reference: rns->ninv is n^-1*2^64, src/precomp.c:248)
   uint64_t winv1_ninv;     // winv[1]*n^-1 mod p : last inverse stage with the scaling folded in
+  TwS ninv_s, winv1_ninv_s;  // the same two as split-twiddle constants (modarith.hpp); unset for c >= GPQ_SPLIT_CMAX
 };
 
 #define GPQ_MAX_SLABS 4
@@ -18,6 +19,10 @@ struct PassArgs {
   // global memory, so uniform reads become s_load and the rest global_load.
   const uint64_t *w;
   const uint64_t *winv;
+  // The same tables as split-twiddle pairs (modarith.hpp) for the leading limbs whose c allows it
+  // ([nsplit][n]); a launch covers either split limbs only or plain limbs only.
+  const TwS *ws;
+  const TwS *winvs;
   const uint64_t *src[GPQ_MAX_SLABS];
   uint64_t *dst[GPQ_MAX_SLABS];
   unsigned long long poly_stride;    // elements between consecutive polynomials of a slab (= limbs_in_slab * n)

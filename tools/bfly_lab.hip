@@ -100,8 +100,39 @@ __device__ __forceinline__ void ct_v5(uint64_t &x, uint64_t &y, uint64_t w, cons
   y = hi ^ mid; x ^= m00;
 }
 
+// v12..: split-twiddle multiply.  (w, w2 = w*2^31 mod p) both precomputed, a = ah*2^31 + al:
+//   a*w == al*w + ah*w2; for a < 4p the sum is < 2^90.6, so ONE fold (th < 2^31.6) finishes: 5 mads.
+// Twiddles negated (p-w, p-w2) so that the fold's subtraction turns into the complement trick.
+__device__ __forceinline__ uint64_t mulmod_split(uint64_t a, uint64_t wn, uint64_t w2n, const PrimeK &k) {
+  const uint32_t al = (uint32_t)a & 0x7fffffffu;
+  const uint32_t ah = __builtin_amdgcn_alignbit((uint32_t)(a >> 32), (uint32_t)a, 31);
+  uint64_t t0 = mad_u64(al, (uint32_t)wn, 0);
+  t0 = mad_u64(ah, (uint32_t)w2n, t0);
+  asm volatile("" : "+v"(t0));
+  uint64_t t1 = mad_u64(al, (uint32_t)(wn >> 32), (uint32_t)(t0 >> 32));
+  asm volatile("" : "+v"(t1));
+  t1 = mad_u64(ah, (uint32_t)(w2n >> 32), t1);
+  const uint32_t t1lo = (uint32_t)t1, t1hi = (uint32_t)(t1 >> 32);
+  const uint32_t th = __builtin_amdgcn_alignbit(t1hi, t1lo, 27);
+  const uint64_t ntl = pack64(~(uint32_t)t0, ~t1lo & 0x7ffffffu);
+  return mad_u64(k.c, th, ntl);            // a*w == this + (c+1)  (mod p), < 2p for c < 2^27.3
+}
+// data in [0,4p): xs = csub(x,2p) + (c+1)
+__device__ __forceinline__ void ct_split(uint64_t &x, uint64_t &y, uint64_t wn, uint64_t w2n, const PrimeK &k, uint64_t kx0, uint64_t kx1, uint64_t ky) {
+  const uint64_t t = mulmod_split(y, wn, w2n, k);
+  const uint64_t xs = x + (x >= k.p2 ? kx1 : kx0);
+  x = xs + t; y = xs + ky - t;
+}
+// data in [0,2p)
+__device__ __forceinline__ void gs_split(uint64_t &x, uint64_t &y, uint64_t wn, uint64_t w2n, const PrimeK &k) {
+  const uint64_t v = x + y;
+  const uint64_t d = x + k.p2 - y;
+  x = v + (v >= k.p2 ? (uint64_t)0 - k.p2 : (uint64_t)0);
+  y = mulmod_split(d, wn, w2n, k) + k.c1;
+}
+
 template <int V>
-__global__ __launch_bounds__(256) void probe(uint64_t *out, uint64_t seed, PrimeK k) {
+__global__ __launch_bounds__(256) void probe(uint64_t *out, uint64_t seed, PrimeK k, PrimeK k2) {
   uint64_t v[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = seed * (threadIdx.x + 1 + 64 * i) + blockIdx.x;
@@ -140,6 +171,9 @@ __global__ __launch_bounds__(256) void probe(uint64_t *out, uint64_t seed, Prime
       if (V == 7) ct_v6(v[i], v[i + 4], w, k);
       if (V == 8) ct_v7(v[i], v[i + 4], w, k);
       if (V == 9) ct_v8(v[i], v[i + 4], w, k);
+      if (V == 12) { v[i] &= 0x0fffffffffffffffull; v[i + 4] &= 0x0fffffffffffffffull; ct_split(v[i], v[i + 4], w, w - 77 - seed, k, k2.kx0, k2.kx1, k2.ky); }
+      if (V == 13) { v[i] &= 0x0fffffffffffffffull; v[i + 4] &= 0x0fffffffffffffffull; gs_split(v[i], v[i + 4], w, w - 77 - seed, k); }
+      if (V == 14) { v[i + 4] = mulmod_split(v[i + 4] & 0x0fffffffffffffffull, w, w - 77 - seed, k); v[i] ^= v[i + 4]; }
     }
   }
   uint64_t acc = 0;
@@ -150,13 +184,14 @@ __global__ __launch_bounds__(256) void probe(uint64_t *out, uint64_t seed, Prime
 
 template <int V>
 int run(const char *name, uint64_t *d_out, PrimeK k, int blocks_per_cu) {
+  PrimeK k2 = k; k2.kx0 = k.c1; k2.kx1 = (uint64_t)k.c1 - k.p2; k2.ky = k.p2 - 2 * (uint64_t)k.c1;
   const int blocks = 256 * blocks_per_cu;
   hipEvent_t a, b;
   CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
-  hipLaunchKernelGGL(probe<V>, dim3(blocks), dim3(256), 0, 0, d_out, 0x9e3779b97f4a7c15ull, k);
+  hipLaunchKernelGGL(probe<V>, dim3(blocks), dim3(256), 0, 0, d_out, 0x9e3779b97f4a7c15ull, k, k2);
   CHECK(hipDeviceSynchronize());
   CHECK(hipEventRecord(a));
-  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(probe<V>, dim3(blocks), dim3(256), 0, 0, d_out, 0x9e3779b97f4a7c15ull + r, k);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(probe<V>, dim3(blocks), dim3(256), 0, 0, d_out, 0x9e3779b97f4a7c15ull + r, k, k2);
   CHECK(hipEventRecord(b));
   CHECK(hipEventSynchronize(b));
   float ms; CHECK(hipEventElapsedTime(&ms, a, b));
@@ -173,6 +208,7 @@ int main() {
     if (w == 8) { run<0>("ct v0 (first formulation)", d_out, k, 8); run<1>("ct v1 (current)", d_out, k, 8); run<2>("ct v2 (approx csub)", d_out, k, 8);
                   run<3>("ct v3 (no csub)", d_out, k, 8); run<4>("mulmod only", d_out, k, 8); run<5>("4-mad product only", d_out, k, 8); run<6>("gs (current)", d_out, k, 8);
                   run<7>("ct v6 (pinned mid)", d_out, k, 8); run<8>("ct v7 (pinned + approx csub)", d_out, k, 8); run<9>("ct v8 (v7, y via ~t)", d_out, k, 8);
+                  run<12>("ct split-twiddle (5 mads)", d_out, k, 8); run<13>("gs split-twiddle (5 mads)", d_out, k, 8); run<14>("mulmod split only", d_out, k, 8);
                   run<10>("2 stages, csub(4p) each", d_out, k, 8); run<11>("2 stages, one csub(6p)", d_out, k, 8); }
     if (w == 4) { run<0>("ct v0", d_out, k, 4); run<1>("ct v1", d_out, k, 4); }
     if (w == 2) { run<0>("ct v0", d_out, k, 2); run<1>("ct v1", d_out, k, 2); }
