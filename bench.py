@@ -54,7 +54,7 @@ def pmc_traffic(kernel, chunk):
     try:
         data = json.load(open(files[-1]))
         for name, v in data.items():
-            if kernel in name.replace("strided_pass<8, 4, false, false>", "strided_fwd").replace("strided_pass<8, 4, true, false>", "strided_inv"):
+            if kernel in name.replace("strided_pass<8, 4, false", "strided_fwd").replace("strided_pass<8, 4, true", "strided_inv"):
                 return int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 * chunk / data.get("_chunk", 4))
     except Exception:
         return None
