@@ -4,7 +4,10 @@
 #include "../../include/gpqhe_hip.h"
 #include "engine_internal.hpp"
 #include "bridge_kernels.hpp"
+#include "bridge_mfma.hpp"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 using namespace gpq;
@@ -117,6 +120,7 @@ int get_basis(gpq_ctx *c, unsigned first, unsigned dim, gpq_bridge_basis **out) 
   HIP_TRY(hipMemcpy(b.d_inv128, inv128.data(), inv128.size() * 8, hipMemcpyHostToDevice));
   b.h_phat_inv = pinv;
   b.h_P = P;
+  b.h_phat = phat;
   *out = &(c->bases[key] = b);
   return GPQ_OK;
 }
@@ -146,6 +150,102 @@ void launch_low(const ReconstructArgs &a, unsigned WPstride, unsigned char *redo
   hipLaunchKernelGGL((bridge_reconstruct_low<WL>), dim3((n + 255) / 256, batch), dim3(256), 0, s, a, WPstride, redo);
 }
 
+// balanced base-256 digits of a little-endian multiword value, `nd` digits (the final carry is dropped: mod 256^nd)
+void balanced_digits(const uint64_t *words, size_t nwords, int8_t *out, size_t nd) {
+  unsigned carry = 0;
+  for (size_t i = 0; i < nd; ++i) {
+    const unsigned byte = i / 8 < nwords ? (unsigned)((words[i / 8] >> (8 * (i % 8))) & 0xff) : 0;
+    const unsigned t = byte + carry;
+    if (t >= 128) { out[i] = (int8_t)((int)t - 256); carry = 1; } else { out[i] = (int8_t)t; carry = 0; }
+  }
+}
+
+// constant matrix, offsets and multiples of P for bridge_reconstruct_low_mfma<WL> on basis b
+int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out) {
+  auto it = b->mfma.find(WL);
+  if (it != b->mfma.end()) { *out = &it->second; return GPQ_OK; }
+  gpq_recon_mfma t;
+  const unsigned dim = b->dim, NT = (8 * WL + 14 + 31) / 32, ncol = 32 * NT;
+  t.KS = (dim + 3) / 4;
+  t.lds_bytes = (size_t)t.KS * NT * 1024 + (size_t)t.KS * 64 + 8 * 2 * (size_t)MFMA_TILE_WORDS * 4;
+  if (t.lds_bytes <= 156 * 1024) {
+    std::vector<int8_t> bf((size_t)t.KS * NT * 1024, 0);
+    std::vector<uint64_t> lk((size_t)t.KS * 8, 0), kc(WL + 2, 0), pm((size_t)65 * WL, 0);
+    std::vector<int8_t> beta(8 * (size_t)WL), phi(8);
+    Big sum_phat(WL, 0);
+    u128h sum_inv = 0;
+    for (unsigned d = 0; d < dim; ++d) {
+      const uint64_t pd = c->p[b->first + d];
+      lk[2 * (size_t)d] = pd;
+      lk[2 * (size_t)d + 1] = b->h_phat_inv[d];
+      const uint64_t *ph = &b->h_phat[(size_t)d * b->WP];
+      balanced_digits(ph, (size_t)b->WP < (size_t)WL ? b->WP : WL, beta.data(), beta.size());
+      const uint64_t inv = (uint64_t)((((u128h)1) << 104) / pd);                       // < 2^46
+      balanced_digits(&inv, 1, phi.data(), 8);
+      uint64_t cy = 0;                                                                   // sum_phat += phat_d mod 2^(64 WL)
+      for (int j = 0; j < WL; ++j) {
+        const u128h s2 = (u128h)sum_phat[j] + (j < b->WP ? ph[j] : 0) + cy;
+        sum_phat[j] = (uint64_t)s2; cy = (uint64_t)(s2 >> 64);
+      }
+      sum_inv += inv;
+      for (unsigned i = 0; i < 8; ++i) {
+        const unsigned k = 8 * d + i, s = k / 32, h = (k % 32) / 16, tt = k % 16;
+        for (unsigned col = 0; col < ncol; ++col) {
+          int8_t v = 0;
+          if (col < 8u * WL) { if (col >= i) v = beta[col - i]; }
+          else { const unsigned m = col - 8u * WL; if (m >= i && m - i < 8 && m < 14) v = phi[m - i]; }
+          if (!v) continue;
+          const unsigned nt = col / 32, lane = 32 * h + col % 32;
+          bf[(((size_t)s * NT + nt) * 64 + lane) * 16 + tt] = v;
+        }
+      }
+    }
+    // offsets of the signed bytes: 0x8080..80 * sum phat_d (mod 2^(64 WL)) and 0x8080..80 * sum inv_d
+    Big kcS = sum_phat;
+    mul_small(kcS, 0x8080808080808080ull);
+    for (int j = 0; j < WL; ++j) kc[j] = (size_t)j < kcS.size() ? kcS[j] : 0;
+    const u128h lo = (u128h)(uint64_t)sum_inv * 0x8080808080808080ull;
+    const u128h hi = (u128h)(uint64_t)(sum_inv >> 64) * 0x8080808080808080ull;
+    const u128h kf = lo + (hi << 64);
+    kc[WL] = (uint64_t)kf; kc[WL + 1] = (uint64_t)(kf >> 64);
+    Big mP{0};
+    for (unsigned m = 0; m <= 64; ++m) {
+      for (int j = 0; j < WL; ++j) pm[(size_t)m * WL + j] = (size_t)j < mP.size() ? mP[j] : 0;
+      Big nxt(std::max(mP.size(), b->h_P.size()) + 1, 0);                                // mP += P
+      uint64_t cy = 0;
+      for (size_t j = 0; j < nxt.size(); ++j) {
+        const u128h s2 = (u128h)(j < mP.size() ? mP[j] : 0) + (j < b->h_P.size() ? b->h_P[j] : 0) + cy;
+        nxt[j] = (uint64_t)s2; cy = (uint64_t)(s2 >> 64);
+      }
+      mP = nxt;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(&t.d_bfrag, bf.size()));
+    HIP_TRY(hipMalloc((void **)&t.d_lk, lk.size() * 8));
+    HIP_TRY(hipMalloc((void **)&t.d_kc, kc.size() * 8));
+    HIP_TRY(hipMalloc((void **)&t.d_pm, pm.size() * 8));
+    HIP_TRY(hipMemcpy(t.d_bfrag, bf.data(), bf.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.d_lk, lk.data(), lk.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.d_kc, kc.data(), kc.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.d_pm, pm.data(), pm.size() * 8, hipMemcpyHostToDevice));
+  }
+  *out = &(b->mfma[WL] = t);
+  return GPQ_OK;
+}
+
+template <int WL>
+int launch_low_mfma(const ReconMfmaArgs &a, size_t lds, hipStream_t s) {
+  static bool raised = false;
+  if (!raised) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&bridge_reconstruct_low_mfma<WL>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    raised = true;
+  }
+  unsigned blocks = 256;                                   // one 8-wave workgroup per CU (LDS), persistent over the groups
+  if (blocks > (a.total_groups + 7) / 8) blocks = (a.total_groups + 7) / 8;
+  hipLaunchKernelGGL((bridge_reconstruct_low_mfma<WL>), dim3(blocks), dim3(512), lds, s, a);
+  return GPQ_OK;
+}
+
 int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned slab_dim,
                        unsigned slab_first, unsigned batch, unsigned logq, bool centre, unsigned char *tie, hipStream_t s, int logn_override = -1) {
   const unsigned logn = logn_override < 0 ? c->logn : (unsigned)logn_override, n = 1u << logn;
@@ -162,7 +262,31 @@ int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, uns
       HIP_TRY(hipMalloc((void **)&c->d_redo, flags));
       c->redo_cap = flags;
     }
-    if (need <= 1) launch_low<1>(a, b->WP, c->d_redo, n, batch, s);
+    bool done = false;
+    if (c->bridge_mfma && logn >= 6 && b->dim >= 4) {      // CRT sum as bytes x constant matrix on the matrix cores
+      const int WL = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 7 ? 7 : need <= 10 ? 10 : need <= 14 ? 14 : 16;
+      gpq_recon_mfma *t;
+      int rc = get_recon_mfma(c, const_cast<gpq_bridge_basis *>(b), WL, &t);
+      if (rc) return rc;
+      if (t->d_bfrag) {
+        const unsigned gpp = n >> 6;
+        ReconMfmaArgs m{slab, big, (const v4i *)t->d_bfrag, t->d_lk, t->d_kc, t->d_pm, c->d_redo, tie, b->dim, t->KS, logn, Wout, logq,
+                        slab_dim, slab_first, gpp, gpp * batch};
+        switch (WL) {
+          case 1: rc = launch_low_mfma<1>(m, t->lds_bytes, s); break;
+          case 2: rc = launch_low_mfma<2>(m, t->lds_bytes, s); break;
+          case 4: rc = launch_low_mfma<4>(m, t->lds_bytes, s); break;
+          case 7: rc = launch_low_mfma<7>(m, t->lds_bytes, s); break;
+          case 10: rc = launch_low_mfma<10>(m, t->lds_bytes, s); break;
+          case 14: rc = launch_low_mfma<14>(m, t->lds_bytes, s); break;
+          default: rc = launch_low_mfma<16>(m, t->lds_bytes, s); break;
+        }
+        if (rc) return rc;
+        done = true;
+      }
+    }
+    if (done) {}
+    else if (need <= 1) launch_low<1>(a, b->WP, c->d_redo, n, batch, s);
     else if (need <= 2) launch_low<2>(a, b->WP, c->d_redo, n, batch, s);
     else if (need <= 4) launch_low<4>(a, b->WP, c->d_redo, n, batch, s);
     else if (need <= 7) launch_low<7>(a, b->WP, c->d_redo, n, batch, s);     // q up to 2^448 (reference default 2^438)
@@ -182,7 +306,93 @@ int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, uns
   return GPQ_OK;
 }
 
+// balanced base-256 digits of v < 2^63: v = sum_b d_b 256^b, d_b in [-128, 127] (top digit small and positive)
+void balanced8(uint64_t v, int8_t out[8]) {
+  const uint64_t t = v + 0x0080808080808080ull;
+  for (int b = 0; b < 7; ++b) out[b] = (int8_t)(((t >> (8 * b)) & 0xff) ^ 0x80);
+  out[7] = (int8_t)(t >> 56);
+}
+
+constexpr size_t kMfmaLdsMax = 96 * 1024;   // of the CU's 160 KB: one workgroup always fits, two when the tables are small
+
+// constant matrix of bridge_decompose_mfma for the primes limb0 .. limb0+dim-1 and W-word inputs
+int get_decomp_mfma(gpq_ctx *c, unsigned limb0, unsigned dim, unsigned W, gpq_decomp_mfma **out) {
+  const auto key = std::make_pair(std::make_pair(limb0, dim), W);
+  auto it = c->decomps.find(key);
+  if (it != c->decomps.end()) { *out = &it->second; return GPQ_OK; }
+  gpq_decomp_mfma t;
+  const unsigned KB = 8 * W;
+  t.KS = W <= 4 ? 1 : W <= 8 ? 2 : W <= 16 ? 4 : 8;
+  t.NT = ((dim + 3) / 4 + 3) / 4 * 4;
+  t.lds_bytes = (size_t)t.NT * t.KS * 1024 + (size_t)t.NT * 96 + 4 * (size_t)MFMA_TILE_WORDS * 4;
+  if (t.lds_bytes <= kMfmaLdsMax) {
+    std::vector<int8_t> bf((size_t)t.NT * t.KS * 1024, 0);
+    std::vector<uint64_t> pk((size_t)t.NT * 12, 0);
+    std::vector<int8_t> dig((size_t)KB * 8);
+    for (unsigned j = 0; j < dim; ++j) {
+      const uint64_t p = c->p[limb0 + j];
+      uint64_t T = 1, K = 0;                               // 256^k mod p ; sum_{k < KB-1} 256^k mod p
+      for (unsigned k = 0; k < KB; ++k) {
+        balanced8(T, &dig[(size_t)k * 8]);
+        if (k + 1 < KB) K = (K + T) % p;
+        T = (uint64_t)(((u128h)T << 8) % p);
+      }
+      K = (uint64_t)(((u128h)K << 7) % p);                 // 128 * sum
+      const uint64_t off = 1ull << 50;
+      pk[3 * (size_t)j] = p;
+      pk[3 * (size_t)j + 1] = off + (K + p - off % p) % p;
+      pk[3 * (size_t)j + 2] = p - (1ull << 59);
+      const unsigned nt = j / 4, pq = j % 4;
+      for (unsigned k = 0; k < KB; ++k) {
+        const unsigned s = k / 32, h = (k % 32) / 16, tt = k % 16;
+        for (unsigned b = 0; b < 8; ++b) {
+          const unsigned lane = 32 * h + 8 * pq + b;       // B[k][col]: lane = (col, h), byte tt
+          bf[(((size_t)nt * t.KS + s) * 64 + lane) * 16 + tt] = dig[(size_t)k * 8 + b];
+        }
+      }
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(&t.d_bfrag, bf.size()));
+    HIP_TRY(hipMalloc((void **)&t.d_pk, pk.size() * 8));
+    HIP_TRY(hipMemcpy(t.d_bfrag, bf.data(), bf.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.d_pk, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
+  }
+  *out = &(c->decomps[key] = t);
+  return GPQ_OK;
+}
+
+template <int KS>
+int launch_decompose_mfma_t(const DecomposeMfmaArgs &a, size_t lds, hipStream_t s) {
+  static bool raised = false;
+  if (!raised) {   // dynamic LDS above 64 KB needs the attribute once per kernel
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&bridge_decompose_mfma<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfmaLdsMax));
+    raised = true;
+  }
+  unsigned per_cu = (unsigned)((160 * 1024) / lds);     // workgroups a CU's LDS holds; the registers allow 3
+  if (per_cu > 3) per_cu = 3;
+  if (per_cu < 1) per_cu = 1;
+  unsigned blocks = 256 * per_cu;
+  if (blocks > (a.total_groups + 3) / 4) blocks = (a.total_groups + 3) / 4;
+  hipLaunchKernelGGL((bridge_decompose_mfma<KS>), dim3(blocks), dim3(256), lds, s, a);
+  return GPQ_OK;
+}
+
 int launch_decompose(gpq_ctx *c, uint64_t *slab, const uint64_t *big, unsigned W, unsigned limb0, unsigned dim, unsigned batch, hipStream_t s) {
+  if (c->bridge_mfma && c->logn >= 6 && W <= 32 && dim >= 4) {
+    gpq_decomp_mfma *t;
+    int rc = get_decomp_mfma(c, limb0, dim, W, &t);
+    if (rc) return rc;
+    if (t->d_bfrag) {
+      const unsigned gpp = c->n >> 6;
+      DecomposeMfmaArgs m{big, slab, (const v4i *)t->d_bfrag, t->d_pk, W, dim, c->logn, t->NT, gpp, gpp * batch};
+      switch (t->KS) {
+        case 1: return launch_decompose_mfma_t<1>(m, t->lds_bytes, s);
+        case 2: return launch_decompose_mfma_t<2>(m, t->lds_bytes, s);
+        case 4: return launch_decompose_mfma_t<4>(m, t->lds_bytes, s);
+        default: return launch_decompose_mfma_t<8>(m, t->lds_bytes, s);
+      }
+    }
+  }
   DecomposeArgs a{c->d_tabs, big, slab, W, dim, c->logn, limb0};
   const dim3 grid((c->n + 255) / 256, batch), block(256);
   if (W <= 4) hipLaunchKernelGGL((bridge_decompose<4>), grid, block, 0, s, a);
@@ -211,12 +421,26 @@ void gpq_bridge_release(gpq_ctx *c) {
   for (auto &kv : c->bases) {
     (void)hipFree(kv.second.d_phat); (void)hipFree(kv.second.d_phat_inv);
     (void)hipFree(kv.second.d_pmult); (void)hipFree(kv.second.d_phalf); (void)hipFree(kv.second.d_inv128);
+    for (auto &m : kv.second.mfma) {
+      if (m.second.d_bfrag) (void)hipFree(m.second.d_bfrag);
+      if (m.second.d_lk) (void)hipFree(m.second.d_lk);
+      if (m.second.d_kc) (void)hipFree(m.second.d_kc);
+      if (m.second.d_pm) (void)hipFree(m.second.d_pm);
+    }
   }
   if (c->d_redo) (void)hipFree(c->d_redo);
   c->d_redo = nullptr; c->redo_cap = 0;
   c->bases.clear();
   for (auto &kv : c->relins) (void)hipFree(kv.second.d_pinv);
   c->relins.clear();
+  for (auto &kv : c->decomps) { if (kv.second.d_bfrag) (void)hipFree(kv.second.d_bfrag); if (kv.second.d_pk) (void)hipFree(kv.second.d_pk); }
+  c->decomps.clear();
+}
+
+extern "C" int gpq_set_bridge_mfma(gpq_ctx *c, int on) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_bridge_mfma: null context");
+  c->bridge_mfma = on != 0;
+  return GPQ_OK;
 }
 
 extern "C" unsigned gpq_big_words(unsigned bits) { return (bits + 63) / 64; }

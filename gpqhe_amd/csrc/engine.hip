@@ -156,6 +156,8 @@ static int upload_tables(gpq_ctx *c) {
     t.ninv_s = t.winv1_ninv_s = TwS{0, 0};
   }
   // split-twiddle pairs (p - w, p - w*2^31 mod p) for the leading limbs whose c allows the single fold
+  const char *nomfma = getenv("GPQHE_NO_MFMA");     // dev switch: bridge on the VALU kernels
+  c->bridge_mfma = !(nomfma && nomfma[0] == '1');
   const char *nosplit = getenv("GPQHE_NO_SPLIT");   // dev switch: A/B against the 7-mad butterflies
   c->nsplit = 0;
   if (!(nosplit && nosplit[0] == '1'))

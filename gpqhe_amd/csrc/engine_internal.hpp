@@ -11,6 +11,14 @@ struct gpq_prof_rec { int kernel; hipEvent_t a, b; };
 enum { GPQ_K_STRIDED_FWD = 0, GPQ_K_STRIDED_INV, GPQ_K_CONTIG_FWD, GPQ_K_CONTIG_INV, GPQ_K_TENSOR_MID,
        GPQ_K_KEYSWITCH_MID, GPQ_K_POINTWISE, GPQ_K_SMALL, GPQ_K_COUNT };
 
+// Constant matrix of the matrix-core CRT fast path for one basis and result width WL (bridge_mfma.hpp)
+struct gpq_recon_mfma {
+  void *d_bfrag = nullptr;
+  uint64_t *d_lk = nullptr, *d_kc = nullptr, *d_pm = nullptr;
+  unsigned KS = 0;
+  size_t lds_bytes = 0;
+};
+
 // CRT constants of one prefix of the prime chain (bridge.hip)
 struct gpq_bridge_basis {
   unsigned first = 0, dim = 0, pbits = 0;
@@ -18,6 +26,16 @@ struct gpq_bridge_basis {
   uint64_t *d_phat = nullptr, *d_phat_inv = nullptr, *d_pmult = nullptr, *d_phalf = nullptr, *d_inv128 = nullptr;
   std::vector<uint64_t> h_phat_inv;
   std::vector<uint64_t> h_P;          // the product itself, little-endian words
+  std::vector<uint64_t> h_phat;       // [dim][WP]
+  std::map<int, gpq_recon_mfma> mfma; // by result width WL
+};
+
+// Constant matrix of the matrix-core rns_decompose for (first limb, limbs, words) (bridge_mfma.hpp)
+struct gpq_decomp_mfma {
+  void *d_bfrag = nullptr;
+  uint64_t *d_pk = nullptr;
+  unsigned NT = 0, KS = 0;
+  size_t lds_bytes = 0;
 };
 
 // P^-1 mod p_d for the limbs above a P of dimP limbs (exact division in he_relin / he_swk)
@@ -39,6 +57,8 @@ struct gpq_ctx {
   gpq::LimbTab *d_tabs = nullptr;
   std::map<std::pair<unsigned, unsigned>, gpq_bridge_basis> bases;   // by (first limb, count), built on first use
   std::map<std::pair<unsigned, unsigned>, gpq_relin_tables> relins;  // by (dimP, dimB)
+  std::map<std::pair<std::pair<unsigned, unsigned>, unsigned>, gpq_decomp_mfma> decomps;  // by ((first limb, limbs), W)
+  bool bridge_mfma = true;            // matrix-core decompose (GPQHE_NO_MFMA=1 or gpq_set_bridge_mfma(ctx, 0): VALU kernels)
   unsigned char *d_redo = nullptr;    // per-coefficient "redo exactly" flags of the fast CRT path
   size_t redo_cap = 0;
   bool exact_crt = false;             // force the exact CRT kernel (tests)

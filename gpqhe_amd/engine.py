@@ -94,6 +94,10 @@ class PolyContext:
         _native.check(self.lib.gpq_rns_reconstruct(self.h, _ptr(big), Wout, _ptr(slab), dim, batch, logq, _stream()), "gpq_rns_reconstruct")
         return big
 
+    def set_bridge_mfma(self, on):
+        """matrix-core (default) or integer-VALU rns_decompose; both are exact, the tests compare them"""
+        _native.check(self.lib.gpq_set_bridge_mfma(self.h, 1 if on else 0), "gpq_set_bridge_mfma")
+
     def set_exact_crt(self, on):
         _native.check(self.lib.gpq_set_exact_crt(self.h, 1 if on else 0), "gpq_set_exact_crt")
 

@@ -161,6 +161,9 @@ int gpq_rns_reconstruct(gpq_ctx *ctx, uint64_t *big, unsigned Wout, const uint64
  * (rare) coefficients whose rounding it cannot decide with the exact full-width kernel; this forces the
  * exact kernel for everything (used by the tests to cross-check the two). */
 int gpq_set_exact_crt(gpq_ctx *ctx, int on);
+/* rns_decompose is a product of the coefficients' bytes with a fixed matrix (256^k mod p_j) and runs on the matrix cores
+ * (v_mfma_i32_32x32x32_i8, exact) by default; 0 selects the integer-VALU kernel instead (the tests cross-check the two). */
+int gpq_set_bridge_mfma(gpq_ctx *ctx, int on);
 
 /* poly_mul, src/poly.c:84-107 (decl src/poly.h:86-87), q = 2^logq, on big slabs of W words. */
 size_t gpq_poly_mul_workspace_bytes(const gpq_ctx *ctx, unsigned dim, unsigned batch);

@@ -28,18 +28,55 @@ def _edge_values(bits, rng, count):
     return vals[:count]
 
 
-@pytest.mark.parametrize("logn,dim,W,bits", [(7, 5, 1, 62), (7, 5, 2, 128), (7, 3, 4, 200), (8, 6, 14, 851), (7, 4, 16, 1024), (7, 2, 28, 1737)])
-def test_rns_decompose_matches_floor_mod(engine_ctx, logn, dim, W, bits):
+@pytest.mark.parametrize("mfma", [True, False])
+@pytest.mark.parametrize("logn,dim,W,bits", [(7, 5, 1, 62), (7, 5, 2, 128), (7, 3, 4, 200), (8, 6, 14, 851), (7, 4, 16, 1024), (7, 2, 28, 1737),
+                                             (6, 7, 4, 256), (7, 9, 8, 512), (7, 13, 28, 1737), (7, 8, 32, 2047), (6, 45, 14, 851)])
+def test_rns_decompose_matches_floor_mod(engine_ctx, logn, dim, W, bits, mfma):
+    """both implementations: bytes x (256^k mod p) on the matrix cores, and the 59-bit-digit Horner on the VALU"""
     g = engine_ctx(logn, max(dim, 6))
-    rng = random.Random(1234 + W)
-    polys = [_edge_values(bits, rng, g.n) for _ in range(2)]
-    big = np.concatenate([ints_to_big(v, W) for v in polys])
-    slab = _torch().empty(2 * dim * g.n, dtype=_torch().int64, device="cuda")
-    g.rns_decompose(slab, to_device(big), W, dim)
-    got = to_host(slab).reshape(2, dim, g.n)
-    for k in range(2):
-        for d in range(dim):
-            assert [int(x) for x in got[k, d]] == rns_decompose(polys[k], g.p[d]), (k, d)  # src/rns.c:44-45
+    g.set_bridge_mfma(mfma)
+    try:
+        rng = random.Random(1234 + W)
+        polys = [_edge_values(bits, rng, g.n) for _ in range(2)]
+        big = np.concatenate([ints_to_big(v, W) for v in polys])
+        slab = _torch().empty(2 * dim * g.n, dtype=_torch().int64, device="cuda")
+        g.rns_decompose(slab, to_device(big), W, dim)
+        got = to_host(slab).reshape(2, dim, g.n)
+        for k in range(2):
+            for d in range(dim):
+                assert [int(x) for x in got[k, d]] == rns_decompose(polys[k], g.p[d]), (k, d)  # src/rns.c:44-45
+    finally:
+        g.set_bridge_mfma(True)
+
+
+@pytest.mark.parametrize("dim,W,batch", [(30, 14, 3), (45, 14, 2), (15, 14, 1), (58, 16, 1)])
+def test_rns_decompose_matrix_core_equals_valu_at_full_size(engine_ctx, dim, W, batch):
+    """n = 2^16: every word pattern incl. all-ones / all-zero bytes (the extremes of the i32 accumulators)"""
+    torch = _torch()
+    g = engine_ctx(16, 58)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(77 + dim)
+    big = torch.randint(-(1 << 63), (1 << 63) - 1, (batch, W, g.n), dtype=torch.int64, device="cuda", generator=gen)
+    big[0, :, 0:64] = -1                # x = -1: every byte 0xff
+    big[0, :, 64:128] = 0
+    big[0, :, 128:192] = 0x7f7f7f7f7f7f7f7f
+    big[0, :, 192:256] = -0x7f7f7f7f7f7f7f80   # 0x8080...80
+    big = big.reshape(-1).contiguous()
+    out = []
+    try:
+        for mfma in (True, False):
+            g.set_bridge_mfma(mfma)
+            slab = torch.empty(batch * dim * g.n, dtype=torch.int64, device="cuda")
+            g.rns_decompose(slab, big, W, dim)
+            out.append(slab)
+    finally:
+        g.set_bridge_mfma(True)
+    assert torch.equal(out[0], out[1])
+    host = to_host(out[0]).reshape(batch, dim, g.n)
+    words = to_host(big).reshape(batch, W, g.n)
+    for i in (0, 64, 128, 192, 300):     # spot values against Python integers
+        v = big_to_ints(np.ascontiguousarray(words[0][:, i:i + 1]).reshape(-1), W, 1)[0][0]
+        assert [int(host[0, d, i]) for d in range(dim)] == [v % g.p[d] for d in range(dim)]
 
 
 def test_phat_invmp_matches_reference_printout(golden, engine_ctx):
@@ -106,6 +143,35 @@ def test_he_rs_matches_rdiv_smod(engine_ctx, logn, W, s, logql):
     assert big_to_ints(to_host(c1), W, g.n)[0] == exp1
 
 
+def test_crt_matrix_core_equals_valu_at_full_size(engine_ctx):
+    """n = 2^16, 30 and 45 limbs, uniform residues (values all over [0, P)): both fast paths must agree word for word"""
+    torch = _torch()
+    g = engine_ctx(16, 58)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(99)
+    for dim, logq, batch in ((30, 850, 2), (45, 850, 1), (15, 438, 2)):
+        W = (logq + 63) // 64
+        slab = torch.empty((batch, dim, g.n), dtype=torch.int64, device="cuda")
+        for d in range(dim):
+            slab[:, d, :] = torch.randint(0, g.p[d], (batch, g.n), dtype=torch.int64, device="cuda", generator=gen)
+        slab[0, :, :128] = 0                                   # x = 0
+        for d in range(dim):
+            slab[0, d, 128:256] = g.p[d] - 1                   # x = P - 1 (== -1)
+        slab = slab.reshape(-1).contiguous()
+        out = []
+        try:
+            for mfma in (True, False):
+                g.set_bridge_mfma(mfma)
+                big = torch.empty(batch * W * g.n, dtype=torch.int64, device="cuda")
+                g.rns_reconstruct(big, W, slab, dim, logq)
+                out.append(big)
+        finally:
+            g.set_bridge_mfma(True)
+        assert torch.equal(out[0], out[1]), (dim, logq)
+        vals = big_to_ints(to_host(out[0]), W, g.n)[0]
+        assert vals[0] == 0 and vals[200] == -1
+
+
 def test_roundtrip_full_size(engine_ctx):
     """Size-independent property at the headline shape (n = 2^16, 30 limbs, 851-bit coefficients):
     poly_rns2mpi(rns_decompose(a)) == a for every centred a, including negatives."""
@@ -126,14 +192,16 @@ def test_roundtrip_full_size(engine_ctx):
     assert bool((slab >= 0).all())
 
 
-@pytest.mark.parametrize("dim,logq", [(30, 850), (30, 61), (45, 850), (9, 200)])
-def test_fast_crt_path_equals_exact_kernel(engine_ctx, oracle_ctx, dim, logq):
+@pytest.mark.parametrize("mfma", [True, False])
+@pytest.mark.parametrize("dim,logq", [(30, 850), (30, 61), (45, 850), (9, 200), (15, 100), (30, 440), (45, 620), (58, 1000), (12, 128)])
+def test_fast_crt_path_equals_exact_kernel(engine_ctx, oracle_ctx, dim, logq, mfma):
     """gpq_rns_reconstruct's low-word fast path (fixed-point quotient, flagged coefficients redone exactly)
     against the full-width kernel on the same slabs, including residues of values that sit on the
     rounding boundaries (x = k*P/2 +- small), where the fast path must hand over to the exact one."""
     torch = _torch()
     logn = 8
-    g, o = engine_ctx(logn, 45), oracle_ctx(logn, 45)
+    g, o = engine_ctx(logn, 58), oracle_ctx(logn, 58)
+    g.set_bridge_mfma(mfma)          # the CRT sum on the matrix cores (default) or on the VALU
     basis = RnsBasis(g.p[:dim])
     n = g.n
     slab = o.gen(77, dim).reshape(dim, n).copy()
@@ -146,10 +214,13 @@ def test_fast_crt_path_equals_exact_kernel(engine_ctx, oracle_ctx, dim, logq):
     dev = to_device(slab.reshape(-1))
     fast = torch.empty(W * n, dtype=torch.int64, device="cuda")
     exact = torch.empty_like(fast)
-    g.rns_reconstruct(fast, W, dev, dim, logq)
-    g.set_exact_crt(True)
-    g.rns_reconstruct(exact, W, dev, dim, logq)
-    g.set_exact_crt(False)
+    try:
+        g.rns_reconstruct(fast, W, dev, dim, logq)
+        g.set_exact_crt(True)
+        g.rns_reconstruct(exact, W, dev, dim, logq)
+    finally:
+        g.set_exact_crt(False)
+        g.set_bridge_mfma(True)
     assert torch.equal(fast, exact)
     exp = poly_rns2mpi([slab[d][:16] for d in range(dim)], basis, 1 << logq)
     assert big_to_ints(to_host(fast), W, n)[0][:16] == exp
