@@ -246,11 +246,24 @@ int launch_low_mfma(const ReconMfmaArgs &a, size_t lds, hipStream_t s) {
   return GPQ_OK;
 }
 
+// Options of the relinearisation tail: `only` restricts the exact kernel to flagged coefficients; `prescaled` says the slab
+// already holds y_d; `addend`/`rflags` ask the matrix-core fast path to finish the tail itself (then *fused is set and the
+// coefficients it handed to the exact kernel -- c->d_redo -- still need bridge_addround).
+struct ReconExtra {
+  const unsigned char *only = nullptr;
+  bool prescaled = false;
+  const uint64_t *addend = nullptr;
+  const unsigned char *rflags = nullptr;
+  bool *fused = nullptr;
+};
+
 int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned slab_dim,
-                       unsigned slab_first, unsigned batch, unsigned logq, bool centre, unsigned char *tie, hipStream_t s, int logn_override = -1) {
+                       unsigned slab_first, unsigned batch, unsigned logq, bool centre, unsigned char *tie, hipStream_t s, int logn_override = -1,
+                       const ReconExtra &x = ReconExtra()) {
   const unsigned logn = logn_override < 0 ? c->logn : (unsigned)logn_override, n = 1u << logn;
-  ReconstructArgs a{c->d_tabs, slab, big, b->d_phat, b->d_phat_inv, b->d_pmult, b->d_phalf, tie, nullptr, b->d_inv128,
-                    b->dim, logn, Wout, logq, b->first, slab_dim, slab_first, centre ? 1u : 0u};
+  ReconstructArgs a{c->d_tabs, slab, big, b->d_phat, b->d_phat_inv, b->d_pmult, b->d_phalf, tie, x.only, b->d_inv128,
+                    b->dim, logn, Wout, logq, b->first, slab_dim, slab_first, centre ? 1u : 0u, x.prescaled ? 1u : 0u};
+  if (x.fused) *x.fused = false;
   // fast path: centred result modulo a power of two that needs fewer words than P has
   const unsigned need = (logq + 63) / 64;
   // (the centring threshold floor(P/2)/P differs from 1/2 by 1/(2P): negligible against the 2^-61 slack only for large P)
@@ -271,7 +284,8 @@ int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, uns
       if (t->d_bfrag) {
         const unsigned gpp = n >> 6;
         ReconMfmaArgs m{slab, big, (const v4i *)t->d_bfrag, t->d_lk, t->d_kc, t->d_pm, c->d_redo, tie, b->dim, t->KS, logn, Wout, logq,
-                        slab_dim, slab_first, gpp, gpp * batch};
+                        slab_dim, slab_first, gpp, gpp * batch, x.addend, x.rflags, x.prescaled ? 1u : 0u};
+        if (x.fused && x.rflags) *x.fused = true;
         switch (WL) {
           case 1: rc = launch_low_mfma<1>(m, t->lds_bytes, s); break;
           case 2: rc = launch_low_mfma<2>(m, t->lds_bytes, s); break;
@@ -431,7 +445,11 @@ void gpq_bridge_release(gpq_ctx *c) {
   if (c->d_redo) (void)hipFree(c->d_redo);
   c->d_redo = nullptr; c->redo_cap = 0;
   c->bases.clear();
-  for (auto &kv : c->relins) (void)hipFree(kv.second.d_pinv);
+  for (auto &kv : c->relins) {
+    (void)hipFree(kv.second.d_pinv);
+    for (void *q : {kv.second.d_bfrag, (void *)kv.second.d_lk, (void *)kv.second.d_pk, (void *)kv.second.d_tkp, (void *)kv.second.d_kf})
+      if (q) (void)hipFree(q);
+  }
   c->relins.clear();
   for (auto &kv : c->decomps) { if (kv.second.d_bfrag) (void)hipFree(kv.second.d_bfrag); if (kv.second.d_pk) (void)hipFree(kv.second.d_pk); }
   c->decomps.clear();
@@ -564,6 +582,90 @@ int tail_plan(gpq_ctx *c, unsigned W, unsigned dimP, unsigned dimB, unsigned pol
   return GPQ_OK;
 }
 
+// tables of bridge_relin_front_mfma for P = p_0..p_{dimP-1} and the limbs dimP..dimB-1
+int get_relin_front(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables *rt, gpq_bridge_basis *bp, gpq_bridge_basis *bq) {
+  if (rt->front_tried) return GPQ_OK;
+  rt->front_tried = true;
+  const unsigned cnt = dimB - dimP;
+  if (dimP < 4 || dimP > 32 || cnt < 4 || bp->pbits < 160) return GPQ_OK;
+  const unsigned KS = dimP <= 8 ? 2 : dimP <= 16 ? 4 : 8, NTp = (cnt + 3) / 4, NT = NTp + 1;
+  const size_t lds = (size_t)NT * KS * 1024 + (size_t)(8 * KS + 12 * NTp) * 8 + 4 * (size_t)(2 * MFMA_TILE_WORDS + 64) * 4;
+  if (lds > kMfmaLdsMax) return GPQ_OK;
+  std::vector<int8_t> bf((size_t)NT * KS * 1024, 0);
+  std::vector<uint64_t> lk((size_t)8 * KS, 0), pk((size_t)12 * NTp, 0), tkp((size_t)cnt * 64, 0), kf(2, 0);
+  u128h sum_inv = 0;
+  for (unsigned d = 0; d < dimP; ++d) {
+    const uint64_t pd = c->p[d];
+    lk[2 * (size_t)d] = pd;
+    lk[2 * (size_t)d + 1] = bp->h_phat_inv[d];
+    const uint64_t inv = (uint64_t)((((u128h)1) << 104) / pd);
+    sum_inv += inv;
+    int8_t phi[8];
+    balanced_digits(&inv, 1, phi, 8);
+    for (unsigned i = 0; i < 8; ++i) {
+      const unsigned k = 8 * d + i, s = k / 32, h = (k % 32) / 16, tt = k % 16;
+      for (unsigned m = i; m < 14 && m - i < 8; ++m)
+        bf[(((size_t)(NT - 1) * KS + s) * 64 + 32 * h + m) * 16 + tt] = phi[m - i];
+    }
+  }
+  const u128h kfv = (u128h)(uint64_t)sum_inv * 0x8080808080808080ull;
+  kf[0] = (uint64_t)kfv; kf[1] = (uint64_t)(kfv >> 64);
+  for (unsigned j = 0; j < cnt; ++j) {
+    const uint64_t pj = c->p[dimP + j];
+    const uint64_t Pm = mod_small(bp->h_P, pj);
+    const uint64_t Pinv = powm(Pm, pj - 2, pj);
+    uint64_t sum_ph = 0;
+    const unsigned nt = j / 4, pq = j % 4;
+    for (unsigned d = 0; d < dimP; ++d) {
+      Big ph(bp->h_phat.begin() + (size_t)d * bp->WP, bp->h_phat.begin() + (size_t)(d + 1) * bp->WP);
+      uint64_t T = mod_small(ph, pj);                                   // (P/p_d) mod p_j
+      sum_ph = (uint64_t)(((u128h)sum_ph + T) % pj);
+      for (unsigned i = 0; i < 8; ++i) {
+        int8_t dig[8];
+        balanced8(T, dig);
+        const unsigned k = 8 * d + i, s = k / 32, h = (k % 32) / 16, tt = k % 16;
+        for (unsigned b = 0; b < 8; ++b) bf[(((size_t)nt * KS + s) * 64 + 32 * h + 8 * pq + b) * 16 + tt] = dig[b];
+        T = (uint64_t)(((u128h)T << 8) % pj);
+      }
+    }
+    const uint64_t K = (uint64_t)((u128h)(0x8080808080808080ull % pj) * sum_ph % pj);
+    const uint64_t off = 1ull << 50;
+    pk[3 * (size_t)j] = pj;
+    pk[3 * (size_t)j + 1] = off + (K + pj - off % pj) % pj;
+    pk[3 * (size_t)j + 2] = (uint64_t)((u128h)Pinv * bq->h_phat_inv[j] % pj);
+    for (unsigned k = 0; k < 64; ++k) tkp[(size_t)j * 64 + k] = (pj - (uint64_t)((u128h)k * Pm % pj)) % pj;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMalloc(&rt->d_bfrag, bf.size()));
+  HIP_TRY(hipMalloc((void **)&rt->d_lk, lk.size() * 8));
+  HIP_TRY(hipMalloc((void **)&rt->d_pk, pk.size() * 8));
+  HIP_TRY(hipMalloc((void **)&rt->d_tkp, tkp.size() * 8));
+  HIP_TRY(hipMalloc((void **)&rt->d_kf, kf.size() * 8));
+  HIP_TRY(hipMemcpy(rt->d_bfrag, bf.data(), bf.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(rt->d_lk, lk.data(), lk.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(rt->d_pk, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(rt->d_tkp, tkp.data(), tkp.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(rt->d_kf, kf.data(), kf.size() * 8, hipMemcpyHostToDevice));
+  rt->NT = NT; rt->KS = KS; rt->lds_bytes = lds;
+  return GPQ_OK;
+}
+
+template <int KS>
+int launch_relin_front_t(const RelinFrontArgs &a, size_t lds, hipStream_t s) {
+  static bool raised = false;
+  if (!raised) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&bridge_relin_front_mfma<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfmaLdsMax));
+    raised = true;
+  }
+  unsigned per_cu = (unsigned)((160 * 1024) / lds);
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) per_cu = 1;
+  unsigned blocks = 256 * per_cu;
+  if (blocks > (a.total_groups + 3) / 4) blocks = (a.total_groups + 3) / 4;
+  hipLaunchKernelGGL((bridge_relin_front_mfma<KS>), dim3(blocks), dim3(256), lds, s, a);
+  return GPQ_OK;
+}
+
 // src/he-mult.c:67-77 (d != null: c = rdiv(c,P) + d) and src/he-automorphism.c:68-76, for q_l = 2^logql.
 int relin_tail(gpq_ctx *c, uint64_t *out, const uint64_t *chat, const uint64_t *dbig, unsigned W, unsigned dimP, unsigned dimB,
                unsigned logql, unsigned polys, void *ws, hipStream_t s) {
@@ -578,6 +680,42 @@ int relin_tail(gpq_ctx *c, uint64_t *out, const uint64_t *chat, const uint64_t *
   uint64_t *r = (uint64_t *)ws, *rhat = r + (size_t)polys * tp.Wr * n, *qhat = rhat + (size_t)polys * tp.cnt * n,
            *qc = qhat + (size_t)polys * tp.cnt * n;
   unsigned char *tie = (unsigned char *)(qc + (size_t)polys * W * n);
+  const dim3 cgrid((c->n + 255) / 256, polys), cblock(256);
+  const uint64_t *piq = bq->d_pmult + (size_t)5 * (bq->WP + 1);
+
+  if (c->bridge_mfma && c->logn >= 6 && (rc = get_relin_front(c, dimP, dimB, rt, bp, bq))) return rc;
+  if (c->bridge_mfma && c->logn >= 6 && rt->d_bfrag) {
+    // Matrix-core front: Q's (pre-scaled) residues and the round bits straight from chat; the exact kernels only see the
+    // coefficients whose rounding the fixed-point estimates cannot decide.
+    unsigned char *flags = (unsigned char *)rhat, *amb = flags + ((size_t)polys << c->logn);   // rhat's place is free in this flow
+    const unsigned gpp = c->n >> 6;
+    RelinFrontArgs f{chat, qhat, (const v4i *)rt->d_bfrag, rt->d_lk, rt->d_pk, rt->d_tkp, rt->d_kf, flags, amb,
+                     dimB, dimP, tp.cnt, c->logn, rt->NT, gpp, gpp * polys};
+    switch (rt->KS) {
+      case 2: rc = launch_relin_front_t<2>(f, rt->lds_bytes, s); break;
+      case 4: rc = launch_relin_front_t<4>(f, rt->lds_bytes, s); break;
+      default: rc = launch_relin_front_t<8>(f, rt->lds_bytes, s); break;
+    }
+    if (rc) return rc;
+    ReconExtra only_amb;
+    only_amb.only = amb;
+    if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, only_amb))) return rc;
+    RoundFixArgs rf{r, bp->d_phalf, amb, flags, tp.Wr, c->logn};
+    hipLaunchKernelGGL(bridge_roundfix, cgrid, cblock, 0, s, rf);
+    bool fused = false;
+    ReconExtra q;
+    q.prescaled = true; q.fused = &fused;
+    // Fused finish straight into `out` (the exact kernel parks Q of its few coefficients there before bridge_addround
+    // adds d, so `out` must not BE d); otherwise Q goes to qc and bridge_addround finishes every coefficient.
+    const bool direct = dbig != out;
+    if (direct) { q.addend = dbig; q.rflags = flags; }
+    uint64_t *target = direct ? out : qc;
+    if ((rc = launch_reconstruct(c, bq, target, W, qhat, tp.cnt, 0, polys, logql, true, tie, s, -1, q))) return rc;
+    AddRoundArgs ar{out, target, nullptr, dbig, bp->d_phalf, piq, tie, W, tp.Wr, c->logn, logql, fused ? c->d_redo : nullptr, flags};
+    hipLaunchKernelGGL(bridge_addround, cgrid, cblock, 0, s, ar);
+    return launched("relin_tail");
+  }
+
   // r = x mod P from the first dimP limbs, unsigned
   if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s))) return rc;
   if ((rc = launch_decompose(c, rhat, r, tp.Wr, dimP, tp.cnt, polys, s))) return rc;
@@ -585,8 +723,8 @@ int relin_tail(gpq_ctx *c, uint64_t *out, const uint64_t *chat, const uint64_t *
   hipLaunchKernelGGL(bridge_exactdiv, dim3((c->n + 255) / 256, polys, tp.cnt), dim3(256), 0, s, e);
   // Q = (x - r)/P over the remaining limbs, centred, already reduced smod 2^logql
   if ((rc = launch_reconstruct(c, bq, qc, W, qhat, tp.cnt, 0, polys, logql, true, tie, s))) return rc;
-  AddRoundArgs ar{out, qc, r, dbig, bp->d_phalf, bq->d_pmult + (size_t)5 * (bq->WP + 1), tie, W, tp.Wr, c->logn, logql};
-  hipLaunchKernelGGL(bridge_addround, dim3((c->n + 255) / 256, polys), dim3(256), 0, s, ar);
+  AddRoundArgs ar{out, qc, r, dbig, bp->d_phalf, piq, tie, W, tp.Wr, c->logn, logql, nullptr, nullptr};
+  hipLaunchKernelGGL(bridge_addround, cgrid, cblock, 0, s, ar);
   return launched("relin_tail");
 }
 

@@ -104,6 +104,7 @@ struct ReconstructArgs {
   unsigned limb0;              // the basis is primes limb0 .. limb0+dim-1
   unsigned slab_dim, slab_first;    // the slab has slab_dim limbs per polynomial; read limbs slab_first ..
   unsigned centre;             // 0: leave the result in [0, P)
+  unsigned prescaled;          // the slab already holds y_d (bridge_relin_front_mfma writes Q's residues so)
 };
 
 template <int WP>
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
   for (int j = 0; j <= WP; ++j) S[j] = 0;
   for (unsigned d = 0; d < a.dim; ++d) {
     const PrimeK k = a.tabs[a.limb0 + d].k;
-    const uint64_t y = mulmod_canon(src[(size_t)d << a.logn], a.phat_inv[d], k);
+    const uint64_t xd = src[(size_t)d << a.logn];
+    const uint64_t y = a.prescaled ? xd : mulmod_canon(xd, a.phat_inv[d], k);
     const uint64_t *__restrict__ ph = a.phat + (size_t)d * WP;
     uint64_t carry = 0;
 #pragma unroll
@@ -218,7 +220,8 @@ __global__ __launch_bounds__(256) void bridge_reconstruct_low(ReconstructArgs a,
   uint64_t f0 = 0, f1 = 0, f2 = 0;
   for (unsigned d = 0; d < a.dim; ++d) {
     const PrimeK k = a.tabs[a.limb0 + d].k;
-    const uint64_t y = mulmod_canon(src[(size_t)d << a.logn], a.phat_inv[d], k);
+    const uint64_t xd = src[(size_t)d << a.logn];
+    const uint64_t y = a.prescaled ? xd : mulmod_canon(xd, a.phat_inv[d], k);
     const uint64_t *__restrict__ ph = a.phat + (size_t)d * WPstride;
     uint64_t carry = 0;
 #pragma unroll
@@ -309,17 +312,25 @@ struct AddRoundArgs {
   const uint64_t *piq;         // [>= W words of Pi' (low words)]
   const unsigned char *tie;    // [polys][n]
   unsigned W, Wr, logn, logql;
+  const unsigned char *only;   // optional [polys][n]: when given, coefficients with 0 are skipped
+  const unsigned char *rflags; // optional [polys][n]: r against floor(P/2) as RF_GT / RF_LT bits instead of the words of r
 };
 
 __global__ __launch_bounds__(256) void bridge_addround(AddRoundArgs a) {
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
   if (i >= (1u << a.logn)) return;
-  const uint64_t *__restrict__ r = a.r + ((size_t)blockIdx.y * a.Wr << a.logn) + i;
-  // compare r with floor(P/2), most significant word first
+  if (a.only && !a.only[((size_t)blockIdx.y << a.logn) + i]) return;
   int cmp = 0;
-  for (int j = (int)a.Wr - 1; j >= 0 && cmp == 0; --j) {
-    const uint64_t rv = r[(size_t)j << a.logn], hv = a.phalf[j];
-    cmp = rv > hv ? 1 : (rv < hv ? -1 : 0);
+  if (a.rflags) {
+    const unsigned char f = a.rflags[((size_t)blockIdx.y << a.logn) + i];
+    cmp = (f & 1) ? 1 : ((f & 2) ? -1 : 0);
+  } else {
+    const uint64_t *__restrict__ r = a.r + ((size_t)blockIdx.y * a.Wr << a.logn) + i;
+    // compare r with floor(P/2), most significant word first
+    for (int j = (int)a.Wr - 1; j >= 0 && cmp == 0; --j) {
+      const uint64_t rv = r[(size_t)j << a.logn], hv = a.phalf[j];
+      cmp = rv > hv ? 1 : (rv < hv ? -1 : 0);
+    }
   }
   uint64_t carry = cmp > 0;                               // mpi_rdiv: round up when r > floor(P/2)
   const bool fix = a.tie[((size_t)blockIdx.y << a.logn) + i] && cmp < 0;
@@ -340,6 +351,29 @@ __global__ __launch_bounds__(256) void bridge_addround(AddRoundArgs a) {
     }
     a.out[o] = v;
   }
+}
+
+// Round bits of the coefficients bridge_relin_front_mfma could not decide (RF_AMB): r, made exactly by
+// bridge_reconstruct for these coefficients only, against floor(P/2).
+struct RoundFixArgs {
+  const uint64_t *r;           // [polys][Wr][n]   in [0, P), valid where amb != 0
+  const uint64_t *phalf;       // [Wr]
+  const unsigned char *amb;    // [polys][n]
+  unsigned char *flags;        // [polys][n]
+  unsigned Wr, logn;
+};
+__global__ __launch_bounds__(256) void bridge_roundfix(RoundFixArgs a) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (1u << a.logn)) return;
+  const size_t at = ((size_t)blockIdx.y << a.logn) + i;
+  if (!a.amb[at]) return;
+  const uint64_t *__restrict__ r = a.r + ((size_t)blockIdx.y * a.Wr << a.logn) + i;
+  int cmp = 0;
+  for (int j = (int)a.Wr - 1; j >= 0 && cmp == 0; --j) {
+    const uint64_t rv = r[(size_t)j << a.logn], hv = a.phalf[j];
+    cmp = rv > hv ? 1 : (rv < hv ? -1 : 0);
+  }
+  a.flags[at] = cmp > 0 ? 1 : (cmp < 0 ? 2 : 0);
 }
 
 // ---------------------------------------------------------------------------

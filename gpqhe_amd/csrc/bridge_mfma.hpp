@@ -177,7 +177,14 @@ struct ReconMfmaArgs {
   unsigned char *tie;        // optional, cleared
   unsigned dim, KS, logn, Wout, logq, slab_dim, slab_first;
   unsigned groups_per_poly, total_groups;
+  // tail of he_relin / he_swk fused in (bridge_addround's work for the coefficients decided here):
+  const uint64_t *addend;        // optional [polys][Wout][n]: d of src/he-mult.c:72-76
+  const unsigned char *rflags;   // optional [polys][n]: RF_GT = round the quotient up (mpi_rdiv)
+  unsigned prescaled;            // the slab already holds y_d = ahat_d * phat_invmp_d (bridge_relin_front_mfma writes it so)
 };
+
+// per-coefficient flags of the relinearisation tail: r = x mod P against floor(P/2)
+constexpr unsigned char RF_GT = 1, RF_LT = 2, RF_AMB = 4;
 
 // 8 byte columns (signed 32-bit sums) + carry in -> one 64-bit word + carry out
 __device__ __forceinline__ uint64_t fold8(const int (&c)[32], int at, int64_t &carry) {
@@ -237,8 +244,8 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
         PrimeK k;
         k.p = p; k.p2 = p << 1; k.c = (uint32_t)p; k.c1 = k.c + 1;   // p = 2^59 + c: c is the low word
         const uint64_t m = p ? ~0ull : 0ull;
-        y[e] = (mulmod_canon(x[e], w, k) ^ 0x8080808080808080ull) & m;
-        y[2 + e] = (mulmod_canon(x[2 + e], w, k) ^ 0x8080808080808080ull) & m;
+        y[e] = ((a.prescaled ? x[e] : mulmod_canon(x[e], w, k)) ^ 0x8080808080808080ull) & m;
+        y[2 + e] = ((a.prescaled ? x[2 + e] : mulmod_canon(x[2 + e], w, k)) ^ 0x8080808080808080ull) & m;
       }
       const v4i A0 = v4i{(int)(uint32_t)y[0], (int)(uint32_t)(y[0] >> 32), (int)(uint32_t)y[1], (int)(uint32_t)(y[1] >> 32)};
       const v4i A1 = v4i{(int)(uint32_t)y[2], (int)(uint32_t)(y[2] >> 32), (int)(uint32_t)y[3], (int)(uint32_t)(y[3] >> 32)};
@@ -250,6 +257,13 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
       }
     }
     // epilogue: lane = coefficient coef0 + lane (row r of tile h)
+    constexpr bool EARLY_D = WL <= 14;                     // (no registers left for it at WL = 16)
+    uint64_t dd[WL];                                       // d of the fused tail, fetched under the column folding
+    if (EARLY_D && a.rflags && a.addend) {
+      const uint64_t *__restrict__ dp = a.addend + ((size_t)poly * a.Wout << a.logn) + coef0 + lane;
+#pragma unroll
+      for (int j = 0; j < WL; ++j) dd[j] = dp[(size_t)(j < (int)a.Wout ? j : 0) << a.logn];
+    }
     uint64_t V[4 * NT];
     int64_t carry = 0;
 #pragma unroll
@@ -294,6 +308,19 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
         V[j] = (uint64_t)t;
         borrow = (uint64_t)(t >> 64) & 1;
       }
+      if (a.rflags) {                                    // + [r > floor(P/2)] + d   (mod 2^logq: only the low words matter)
+        if (!EARLY_D && a.addend) {
+          const uint64_t *__restrict__ dp = a.addend + ((size_t)poly * a.Wout << a.logn) + coef0 + lane;
+#pragma unroll
+          for (int j = 0; j < WL; ++j) dd[j] = dp[(size_t)(j < (int)a.Wout ? j : 0) << a.logn];
+        }
+        uint64_t cr = a.rflags[flag_at] & RF_GT;
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+          const u128 t = (u128)V[j] + cr + ((a.addend && j < (int)a.Wout) ? dd[j] : 0);
+          V[j] = (uint64_t)t; cr = (uint64_t)(t >> 64);
+        }
+      }
       uint64_t *__restrict__ dst = a.big + ((size_t)poly * a.Wout << a.logn) + coef0 + lane;
       const unsigned sb = a.logq - 1;
       uint64_t qsign = 0;
@@ -315,6 +342,168 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
       for (unsigned j = WL; j < a.Wout; ++j) dst[(size_t)j << a.logn] = qsign;
     }
     (void)n;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Front of the relinearisation tail (src/he-mult.c:67-77, src/he-automorphism.c:68-76; see bridge_exactdiv
+// for the exact-division argument).  x = CRT(chat) over dimB limbs, P = p_0..p_{dimP-1}, r = x mod P,
+// Q = (x - r)/P limb-wise on the limbs j >= dimP.  With y_d = chat_d * phat_invmp_d (d < dimP) and
+// S = sum_d y_d * (P/p_d) = r + k P:
+//   S mod p_j        by the matrix cores: bytes(y) x balanced digits of ((P/p_d) 256^i mod p_j)   (like rns_decompose)
+//   k, [r > P/2]     from F = sum_d y_d floor(2^104/p_d) (14 more columns): k = F >> 104, round bit = bit 103
+//   r mod p_j        = S mod p_j - k (P mod p_j)
+//   yq_j             = (chat_j - r) * (P^-1 * phat'_invmp_j) mod p_j : Q's residue, already scaled for the CRT over the j limbs
+// F underestimates by < 2^66.  If that makes k one too small, r comes out as r + P and rounds UP, Q one less: the sum
+// Q + round is the same -- only the 1/2 boundary matters.  Coefficients with frac(F) in [1/2 - 2^-38, 1/2) are marked
+// RF_AMB; the exact kernel settles their round bits afterwards (k stays consistent either way).
+// No big r, no decompose of it, no separate exact-division pass.
+// ---------------------------------------------------------------------------
+struct RelinFrontArgs {
+  const uint64_t *chat;      // [polys][dimB][n]
+  uint64_t *yq;              // [polys][cnt][n]
+  const v4i *bfrag;          // [NT][KS][64]; column tile NT-1 holds the 14 F columns
+  const uint64_t *lk;        // [4 KS][2]: p_d, phat_invmp_d (d < dimP; p = 0 padding)
+  const uint64_t *pk;        // [4 (NT-1)][3]: p_j, Kq_j, w_j = P^-1 phat'_invmp_j mod p_j
+  const uint64_t *tkp;       // [cnt][64]: (p_j - (k P mod p_j)) mod p_j
+  const uint64_t *kf;        // [2]
+  unsigned char *flags;      // [polys][n]  RF_*
+  unsigned char *amb;        // [polys][n]  1 where RF_AMB
+  unsigned dimB, dimP, cnt, logn, NT, groups_per_poly, total_groups;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void bridge_relin_front_mfma(RelinFrontArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  v4i *Bl = reinterpret_cast<v4i *>(smem);
+  const unsigned nB = a.NT * KS * 64;
+  uint64_t *lkl = reinterpret_cast<uint64_t *>(smem + (size_t)nB * 16);                 // 8 KS words
+  uint64_t *pkl = lkl + 8 * KS;                                                          // 12 (NT-1) words
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned char *wbase = smem + (size_t)nB * 16 + (size_t)(8 * KS + 12 * (a.NT - 1)) * 8;
+  int *tile = reinterpret_cast<int *>(wbase) + wave * (2 * MFMA_TILE_WORDS + 64);
+  int *kbuf = tile + 2 * MFMA_TILE_WORDS;
+  for (unsigned i = threadIdx.x; i < nB; i += 256) Bl[i] = a.bfrag[i];
+  for (unsigned i = threadIdx.x; i < 8u * KS; i += 256) lkl[i] = a.lk[i];
+  for (unsigned i = threadIdx.x; i < 12 * (a.NT - 1); i += 256) pkl[i] = a.pk[i];
+  __syncthreads();
+  const unsigned r = lane & 31, h = lane >> 5;
+  const uint64_t kf0 = a.kf[0], kf1 = a.kf[1];
+  for (unsigned g = blockIdx.x * 4 + wave; g < a.total_groups; g += gridDim.x * 4) {
+    const unsigned poly = g / a.groups_per_poly, coef0 = (g % a.groups_per_poly) << 6;
+    const uint64_t *__restrict__ src = a.chat + ((size_t)poly * a.dimB << a.logn) + coef0;
+    uint64_t *__restrict__ dst = a.yq + ((size_t)poly * a.cnt << a.logn) + coef0;
+    // A fragments: y of limbs 4s+2h, 4s+2h+1 for rows r (tile 0) and 32+r (tile 1)
+    v4i A[2][KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      uint64_t y[4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned d = 4 * s + 2 * h + e, dc = d < a.dimP ? d : a.dimP - 1;
+        const uint64_t p = lkl[2 * d], w = lkl[2 * d + 1];
+        PrimeK k;
+        k.p = p; k.p2 = p << 1; k.c = (uint32_t)p; k.c1 = k.c + 1;
+        const uint64_t m = p ? ~0ull : 0ull;
+        y[e] = (mulmod_canon(src[((size_t)dc << a.logn) + r], w, k) ^ 0x8080808080808080ull) & m;
+        y[2 + e] = (mulmod_canon(src[((size_t)dc << a.logn) + 32 + r], w, k) ^ 0x8080808080808080ull) & m;
+      }
+      A[0][s] = v4i{(int)(uint32_t)y[0], (int)(uint32_t)(y[0] >> 32), (int)(uint32_t)y[1], (int)(uint32_t)(y[1] >> 32)};
+      A[1][s] = v4i{(int)(uint32_t)y[2], (int)(uint32_t)(y[2] >> 32), (int)(uint32_t)y[3], (int)(uint32_t)(y[3] >> 32)};
+    }
+    // residues chat_j of the items of one column tile: (tile t, u) -> limb dimP + 4q + h + 2u, row 32t + r; fetched one
+    // column tile ahead so that the loads are under the previous tile's work
+    uint64_t xn[4];
+    auto fetch_x = [&](unsigned q) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned j = 4 * q + h + 2 * u, jc = j < a.cnt ? j : a.cnt - 1;
+          xn[2 * t + u] = src[((size_t)(a.dimP + jc) << a.logn) + 32 * t + r];
+        }
+    };
+    fetch_x(0);
+    // column tile NT-1 first: F -> k and the round bit of every coefficient (lane = coefficient)
+    {
+      v16i f0, f1;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { f0[e] = 0; f1[e] = 0; }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const v4i b = Bl[((a.NT - 1) * KS + s) * 64 + lane];
+        f0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][s], b, f0, 0, 0, 0);
+        f1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], b, f1, 0, 0, 0);
+      }
+      tile_store(tile, f0, lane);
+      tile_store(tile + MFMA_TILE_WORDS, f1, lane);
+      mfma_wave_sync();
+      int c[32];
+      const int *row = tile + h * MFMA_TILE_WORDS + r * MFMA_TILE_RS;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const v4i v = *reinterpret_cast<const v4i *>(row + 4 * e);
+        c[4 * e] = v[0]; c[4 * e + 1] = v[1]; c[4 * e + 2] = v[2]; c[4 * e + 3] = v[3];
+      }
+#pragma unroll
+      for (int e = 16; e < 32; ++e) c[e] = 0;
+      int64_t carry = 0;
+      const uint64_t F0 = fold8(c, 0, carry), F1 = fold8(c, 8, carry);
+      const u128 F = (((u128)F1 << 64) | F0) + (((u128)kf1 << 64) | kf0);
+      const uint64_t f_hi = (uint64_t)(F >> 64);
+      const bool ambiguous = ((f_hi >> 2) & ((1ull << 38) - 1)) == ((1ull << 37) - 1);
+      const unsigned gt = (unsigned)(f_hi >> 39) & 1;
+      const size_t flag_at = ((size_t)poly << a.logn) + coef0 + lane;
+      a.flags[flag_at] = (unsigned char)(ambiguous ? RF_AMB : (gt ? RF_GT : RF_LT));
+      a.amb[flag_at] = ambiguous;
+      kbuf[lane] = (int)(f_hi >> 40);
+      mfma_wave_sync();
+    }
+    for (unsigned q = 0; q + 1 < a.NT; ++q) {
+      uint64_t xc[4], tk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xc[e] = xn[e];
+      if (q + 2 < a.NT) fetch_x(q + 1);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned j = 4 * q + h + 2 * u, jc = j < a.cnt ? j : a.cnt - 1;
+          tk[2 * t + u] = a.tkp[(size_t)jc * 64 + (unsigned)kbuf[32 * t + r]];
+        }
+      v16i acc0, acc1;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc0[e] = 0; acc1[e] = 0; }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const v4i b = Bl[(q * KS + s) * 64 + lane];
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][s], b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], b, acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        tile_store(tile, t ? acc1 : acc0, lane);
+        mfma_wave_sync();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned pq = h + 2 * u, j = 4 * q + pq;                   // item = (row r, limb dimP + j)
+          const v4i lo = *reinterpret_cast<const v4i *>(tile + r * MFMA_TILE_RS + 8 * pq);
+          const v4i hi = *reinterpret_cast<const v4i *>(tile + r * MFMA_TILE_RS + 8 * pq + 4);
+          const uint64_t p = pkl[3 * j], kq = pkl[3 * j + 1], w = pkl[3 * j + 2];
+          PrimeK k;
+          k.p = p; k.p2 = p << 1; k.c = (uint32_t)p; k.c1 = k.c + 1;
+          const int64_t H = (int64_t)(hi[3] * 256 + hi[2]) * 65536 + (hi[1] * 256 + hi[0]);
+          const int64_t L = (int64_t)(lo[3] * 256 + lo[2]) * 65536 + (lo[1] * 256 + lo[0]);
+          const int Hh = (int)(H >> 27);
+          const uint64_t Hl = (uint64_t)H & 0x7ffffffu;
+          uint64_t v = (Hl << 32) + (uint64_t)L + kq;
+          v = (uint64_t)((int64_t)(-(int)k.c) * Hh + (int64_t)v) + tk[2 * t + u];   // r mod p_j, lazily: in (0, 4p)
+          const uint64_t yq = mulmod_canon_lazy(xc[2 * t + u] + (p << 2) - v, w, k);  // (x - r) in (0, 5p)
+          if (j < a.cnt) dst[((size_t)j << a.logn) + 32 * t + r] = yq;
+        }
+        mfma_wave_sync();
+      }
+    }
   }
 }
 

@@ -41,6 +41,12 @@ struct gpq_decomp_mfma {
 // P^-1 mod p_d for the limbs above a P of dimP limbs (exact division in he_relin / he_swk)
 struct gpq_relin_tables {
   uint64_t *d_pinv = nullptr;
+  // bridge_relin_front_mfma (bridge_mfma.hpp): constant matrix and per-limb tables, built on first use
+  bool front_tried = false;
+  void *d_bfrag = nullptr;
+  uint64_t *d_lk = nullptr, *d_pk = nullptr, *d_tkp = nullptr, *d_kf = nullptr;
+  unsigned NT = 0, KS = 0;
+  size_t lds_bytes = 0;
 };
 
 struct gpq_ctx {

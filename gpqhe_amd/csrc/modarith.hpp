@@ -169,6 +169,10 @@ __device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, const TwS &w, 
 __device__ __forceinline__ uint64_t mulmod_canon(uint64_t a, uint64_t b, const PrimeK &k) {
   return canon4(mulmod_lazy(a, b, k), k);
 }
+// Exact a*b mod p for a < 8p, b canonical.
+__device__ __forceinline__ uint64_t mulmod_canon_lazy(uint64_t a, uint64_t b, const PrimeK &k) {
+  return canon4(mulmod_lazy(a, b, k), k);
+}
 // Exact a+b mod p for canonical a,b (poly_rns_add, src/poly.c:71-76).
 __device__ __forceinline__ uint64_t addmod_canon(uint64_t a, uint64_t b, const PrimeK &k) {
   return csub(a + b, k.p);

@@ -75,16 +75,19 @@ def test_he_swk_matches_reference_semantics(engine_ctx, oracle_ctx, logn, logqL,
     assert big_to_ints(to_host(out1), W, n)[0] == e1
 
 
-def test_relin_tail_rounding_ties_and_wrap_corner(engine_ctx, oracle_ctx):
+@pytest.mark.parametrize("mfma", [True, False])
+@pytest.mark.parametrize("logqL", [120, 200, 438, 610])
+def test_relin_tail_rounding_ties_and_wrap_corner(engine_ctx, oracle_ctx, logqL, mfma):
     """mpi_rdiv rounds up only when the remainder is strictly above floor(P/2) (src/types.c:124): key-switch
     outputs are built so that x mod P is floor(P/2)-1, floor(P/2), floor(P/2)+1, 0, P-1, and so that the quotient
     sits exactly on floor(Pi'/2), where the centring of x -- not of the quotient -- decides the sign."""
     torch = _torch()
-    logn, logqL = 7, 120
+    logn = 7
     probe = engine_ctx(logn, 12)
-    dimP, dimA, dimB, dimevk = probe.he_dims(logqL, logqL)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logqL, logqL)       # dimP = 3 (VALU tail only), 4, 8, 11 (matrix-core front)
     g, o = engine_ctx(logn, dimevk), oracle_ctx(logn, dimevk)
-    n, W, ql = g.n, 2, 1 << logqL
+    g.set_bridge_mfma(mfma)
+    n, W, ql = g.n, (logqL + 64) // 64, 1 << logqL
     P = ref.RnsBasis(o.p[:dimP]).P
     PiB = ref.RnsBasis(o.p[:dimB]).P
     Piq = PiB // P
@@ -106,10 +109,16 @@ def test_relin_tail_rounding_ties_and_wrap_corner(engine_ctx, oracle_ctx):
     dvals = [rng.randrange(-(ql // 2), ql // 2) for _ in range(n)]
     exp = ref.he_relin_tail(o, chat, chat, dvals, None, dimP, dimB, ql)
     out = torch.empty(W * n, dtype=torch.int64, device="cuda")
-    g.relin_tail(out, to_device(chat), to_device(ints_to_big(dvals, W)), W, logqL, dimB, dimP)
-    assert big_to_ints(to_host(out), W, n)[0] == exp[0]
-    g.relin_tail(out, to_device(chat), None, W, logqL, dimB, dimP)
-    assert big_to_ints(to_host(out), W, n)[0] == exp[1]
+    try:
+        g.relin_tail(out, to_device(chat), to_device(ints_to_big(dvals, W)), W, logqL, dimB, dimP)
+        assert big_to_ints(to_host(out), W, n)[0] == exp[0]
+        g.relin_tail(out, to_device(chat), None, W, logqL, dimB, dimP)
+        assert big_to_ints(to_host(out), W, n)[0] == exp[1]
+        inplace = to_device(ints_to_big(dvals, W))               # c0 += d0 in place, as he_swk may be called
+        g.relin_tail(inplace, to_device(chat), inplace, W, logqL, dimB, dimP)
+        assert big_to_ints(to_host(inplace), W, n)[0] == exp[0]
+    finally:
+        g.set_bridge_mfma(True)
 
 
 def test_he_mul_by_one_is_identity_full_size(engine_ctx):
