@@ -167,7 +167,7 @@ int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out
   gpq_recon_mfma t;
   const unsigned dim = b->dim, NT = (8 * WL + 14 + 31) / 32, ncol = 32 * NT;
   t.KS = (dim + 3) / 4;
-  t.lds_bytes = (size_t)t.KS * NT * 1024 + (size_t)t.KS * 64 + 8 * 2 * (size_t)MFMA_TILE_WORDS * 4;
+  t.lds_bytes = (size_t)t.KS * NT * 1024 + (size_t)t.KS * 64;
   if (t.lds_bytes <= 156 * 1024) {
     std::vector<int8_t> bf((size_t)t.KS * NT * 1024, 0);
     std::vector<uint64_t> lk((size_t)t.KS * 8, 0), kc(WL + 2, 0), pm((size_t)65 * WL, 0);
@@ -337,8 +337,8 @@ int get_decomp_mfma(gpq_ctx *c, unsigned limb0, unsigned dim, unsigned W, gpq_de
   gpq_decomp_mfma t;
   const unsigned KB = 8 * W;
   t.KS = W <= 4 ? 1 : W <= 8 ? 2 : W <= 16 ? 4 : 8;
-  t.NT = ((dim + 3) / 4 + 3) / 4 * 4;
-  t.lds_bytes = (size_t)t.NT * t.KS * 1024 + (size_t)t.NT * 96 + 4 * (size_t)MFMA_TILE_WORDS * 4;
+  t.NT = (dim + 3) / 4;
+  t.lds_bytes = (size_t)t.NT * t.KS * 1024 + (size_t)t.NT * 96;
   if (t.lds_bytes <= kMfmaLdsMax) {
     std::vector<int8_t> bf((size_t)t.NT * t.KS * 1024, 0);
     std::vector<uint64_t> pk((size_t)t.NT * 12, 0);
@@ -589,7 +589,7 @@ int get_relin_front(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables *
   const unsigned cnt = dimB - dimP;
   if (dimP < 4 || dimP > 32 || cnt < 4 || bp->pbits < 160) return GPQ_OK;
   const unsigned KS = dimP <= 8 ? 2 : dimP <= 16 ? 4 : 8, NTp = (cnt + 3) / 4, NT = NTp + 1;
-  const size_t lds = (size_t)NT * KS * 1024 + (size_t)(8 * KS + 12 * NTp) * 8 + 4 * (size_t)(2 * MFMA_TILE_WORDS + 64) * 4;
+  const size_t lds = (size_t)NT * KS * 1024 + (size_t)(8 * KS + 12 * NTp) * 8;
   if (lds > kMfmaLdsMax) return GPQ_OK;
   std::vector<int8_t> bf((size_t)NT * KS * 1024, 0);
   std::vector<uint64_t> lk((size_t)8 * KS, 0), pk((size_t)12 * NTp, 0), tkp((size_t)cnt * 64, 0), kf(2, 0);

@@ -24,23 +24,34 @@ namespace gpq {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int MFMA_TILE_RS = 36;                        // words per row of a 32x32 i32 tile in LDS (16-B aligned rows)
-constexpr int MFMA_TILE_WORDS = 32 * MFMA_TILE_RS;
+// Orientation.  The CONSTANT matrix is the A operand (rows = output byte columns) and the coefficients are the
+// B operand (columns = coefficients): D[row][col] puts a coefficient on the lane (col = l & 31) and the byte
+// columns in the registers, rows (g&3) + 8(g>>2) + 4h.  Registers 4w..4w+3 of lane half h are byte columns
+// 8w+4h .. 8w+4h+3: the low half of 64-bit word w (or of prime w's eight digits) sits in the lower 32 lanes,
+// the high half in the upper 32.  With two coefficient tiles per wave one v_permlane32_swap per register pair
+// hands every lane both halves of ITS coefficient (lower lanes finish tile 0, upper lanes tile 1): the
+// recombination needs no LDS and every lane stays busy.  LDS only holds the constant fragments.
 
-// A wave's LDS instructions execute in issue order, so its reads see its earlier writes; this only stops
-// the compiler from moving LDS accesses across the exchange.  (A wavefront-scope fence also waits for the
-// outstanding GLOBAL stores -- vmcnt(0) -- at every tile: measured 8x slower here.)
-__device__ __forceinline__ void mfma_wave_sync() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("" ::: "memory");
+// four signed byte-column sums -> their value sum_b c_b 256^b (46 bits)
+__device__ __forceinline__ int64_t horner4(int c0, int c1, int c2, int c3) {
+  return (int64_t)(c3 * 256 + c2) * 65536 + (c1 * 256 + c0);
 }
 
-// one 32x32 accumulator tile -> the wave's LDS tile, [row][col]
-__device__ __forceinline__ void tile_store(int *tile, const v16i &acc, unsigned lane) {
-  const unsigned c = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int g = 0; g < 16; ++g) tile[((g & 3) + 8 * (g >> 2) + 4 * h) * MFMA_TILE_RS + c] = acc[g];
+// Lane half h holds p0 = half-word of tile 0, p1 = of tile 1 (low halves in lanes 0-31, high halves in 32-63).
+// Afterwards every lane has L and H of the coefficient it finishes (tile = its half).
+__device__ __forceinline__ void swap_halves(int64_t p0, int64_t p1, int64_t &L, int64_t &H) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)(uint64_t)p0, (unsigned)(uint64_t)p1, false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)((uint64_t)p0 >> 32), (unsigned)((uint64_t)p1 >> 32), false, false);
+  L = (int64_t)(((uint64_t)hi[0] << 32) | lo[0]);
+  H = (int64_t)(((uint64_t)hi[1] << 32) | lo[1]);
+}
+
+// L + H 2^32 + carry in -> one 64-bit word + signed carry out
+__device__ __forceinline__ uint64_t fold_word(int64_t L, int64_t H, int64_t &carry) {
+  const int64_t T = carry + L;
+  const uint64_t lo = (uint64_t)T + ((uint64_t)H << 32);
+  carry = (H >> 32) + (T >> 63) + (lo < (uint64_t)T ? 1 : 0);
+  return lo;
 }
 
 // ---------------------------------------------------------------------------
@@ -58,11 +69,9 @@ struct DecomposeMfmaArgs {
   uint64_t *slab;            // [polys][dim][n]
   const v4i *bfrag;          // [NT][KS][64]: the B fragment of lane l for (column tile, k step)
   const uint64_t *pk;        // [4 NT][3]: p_j, Kq_j = 2^50 + ((K_j - 2^50) mod p_j), c_j   (zeros for padding primes)
-  unsigned W, dim, logn, NT;               // NT: column tiles of 4 primes, a multiple of 4
+  unsigned W, dim, logn, NT;               // NT: row tiles of 4 primes
   unsigned groups_per_poly, total_groups;  // groups of 64 coefficients
 };
-
-constexpr int NTG = 1;   // column tiles (of 4 primes) per accumulator group: 2 tiles x 2 row tiles x 16 = 64 accumulator registers
 
 template <int KS>
 __global__ __launch_bounds__(256, 2) void bridge_decompose_mfma(DecomposeMfmaArgs a) {
@@ -71,14 +80,13 @@ __global__ __launch_bounds__(256, 2) void bridge_decompose_mfma(DecomposeMfmaArg
   const unsigned nB = a.NT * KS * 64;
   uint64_t *pkl = reinterpret_cast<uint64_t *>(smem + (size_t)nB * 16);
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int *tile = reinterpret_cast<int *>(smem + (size_t)nB * 16 + (size_t)a.NT * 4 * 24) + wave * MFMA_TILE_WORDS;
   for (unsigned i = threadIdx.x; i < nB; i += 256) Bl[i] = a.bfrag[i];
   for (unsigned i = threadIdx.x; i < a.NT * 12; i += 256) pkl[i] = a.pk[i];
   __syncthreads();
   const unsigned r = lane & 31, h = lane >> 5;
-  v4i A[2][KS];
-  // the A fragments of a group of 64 coefficients: lane (r, h) holds words 4s+2h, 4s+2h+1 of row r of each tile
-  auto load_A = [&](unsigned g) {
+  v4i X[2][KS];
+  // the data fragments of a group of 64 coefficients: lane (r, h) holds words 4s+2h, 4s+2h+1 of coefficients r and 32+r
+  auto load_X = [&](unsigned g) {
     const unsigned poly = g / a.groups_per_poly, coef0 = (g % a.groups_per_poly) << 6;
     const uint64_t *__restrict__ src = a.big + ((size_t)poly * a.W << a.logn) + coef0 + r;
 #pragma unroll
@@ -95,59 +103,42 @@ __global__ __launch_bounds__(256, 2) void bridge_decompose_mfma(DecomposeMfmaArg
           const uint64_t v = src[((size_t)wc << a.logn) + 32 * t];
           x[e] = (v ^ m) & (w < a.W ? ~0ull : 0ull);
         }
-        A[t][s] = v4i{(int)(uint32_t)x[0], (int)(uint32_t)(x[0] >> 32), (int)(uint32_t)x[1], (int)(uint32_t)(x[1] >> 32)};
+        X[t][s] = v4i{(int)(uint32_t)x[0], (int)(uint32_t)(x[0] >> 32), (int)(uint32_t)x[1], (int)(uint32_t)(x[1] >> 32)};
       }
   };
   const unsigned g0 = blockIdx.x * 4 + wave, gstep = gridDim.x * 4;
-  if (g0 < a.total_groups) load_A(g0);
+  if (g0 < a.total_groups) load_X(g0);
   for (unsigned g = g0; g < a.total_groups; g += gstep) {
     const unsigned poly = g / a.groups_per_poly, coef0 = (g % a.groups_per_poly) << 6;
-    uint64_t *__restrict__ dst = a.slab + ((size_t)poly * a.dim << a.logn) + coef0;
-    if (KS >= 8 && g != g0) load_A(g);                 // 32-word inputs: no registers left for the early fetch
-    for (unsigned ng = 0; ng < a.NT; ng += NTG) {
-      v16i acc[2][NTG];
+    uint64_t *__restrict__ dst = a.slab + ((size_t)poly * a.dim << a.logn) + coef0 + lane;   // this lane finishes coefficient coef0 + lane
+    if (KS >= 8 && g != g0) load_X(g);                 // 32-word inputs: no registers left for the early fetch
+    for (unsigned q = 0; q < a.NT; ++q) {
+      v16i acc0, acc1;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int e = 0; e < 16; ++e) { acc0[e] = 0; acc1[e] = 0; }
 #pragma unroll
-        for (int q = 0; q < NTG; ++q)
+      for (int s = 0; s < KS; ++s) {
+        const v4i cf = Bl[(q * KS + s) * 64 + lane];
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[0][s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[1][s], acc1, 0, 0, 0);
+      }
+      // the fragments are dead after the last row tile: fetch the next group's under this one's epilogue
+      if (KS < 8 && q + 1 == a.NT && g + gstep < a.total_groups) load_X(g + gstep);
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[t][q][e] = 0;
-#pragma unroll
-      for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int q = 0; q < NTG; ++q) {
-          const v4i b = Bl[((ng + q) * KS + s) * 64 + lane];
-          acc[0][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][s], b, acc[0][q], 0, 0, 0);
-          acc[1][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], b, acc[1][q], 0, 0, 0);
-        }
-      // the fragments are dead after the last column group: fetch the next group's under this one's epilogue
-      if (KS < 8 && ng + NTG >= a.NT && g + gstep < a.total_groups) load_A(g + gstep);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int q = 0; q < NTG; ++q) {
-          tile_store(tile, acc[t][q], lane);
-          mfma_wave_sync();
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const unsigned pq = h + 2 * u, j = 4 * (ng + q) + pq;          // item = (row r, prime j)
-            const v4i lo = *reinterpret_cast<const v4i *>(tile + r * MFMA_TILE_RS + 8 * pq);
-            const v4i hi = *reinterpret_cast<const v4i *>(tile + r * MFMA_TILE_RS + 8 * pq + 4);
-            if (j < a.dim) {
-              const uint64_t p = pkl[3 * j], kq = pkl[3 * j + 1];
-              const int c = (int)(uint32_t)pkl[3 * j + 2];
-              const int64_t H = (int64_t)(hi[3] * 256 + hi[2]) * 65536 + (hi[1] * 256 + hi[0]);
-              const int64_t L = (int64_t)(lo[3] * 256 + lo[2]) * 65536 + (lo[1] * 256 + lo[0]);
-              const int Hh = (int)(H >> 27);
-              const uint64_t Hl = (uint64_t)H & 0x7ffffffu;
-              uint64_t v = (Hl << 32) + (uint64_t)L + kq;
-              v = (uint64_t)((int64_t)(-c) * Hh + (int64_t)v);             // in (0, 3p)
-              v = csub(csub(v, p << 1), p);
-              dst[((size_t)j << a.logn) + 32 * t + r] = v;
-            }
-          }
-          mfma_wave_sync();
-        }
+      for (int w = 0; w < 4; ++w) {                    // prime j = 4q + w: digits 0-3 in the lower lanes, 4-7 in the upper
+        int64_t L, H;
+        swap_halves(horner4(acc0[4 * w], acc0[4 * w + 1], acc0[4 * w + 2], acc0[4 * w + 3]),
+                    horner4(acc1[4 * w], acc1[4 * w + 1], acc1[4 * w + 2], acc1[4 * w + 3]), L, H);
+        const unsigned j = 4 * q + w;
+        const uint64_t p = pkl[3 * j], kq = pkl[3 * j + 1];
+        const int c = (int)(uint32_t)pkl[3 * j + 2];
+        const int Hh = (int)(H >> 27);
+        const uint64_t Hl = (uint64_t)H & 0x7ffffffu;
+        uint64_t v = (Hl << 32) + (uint64_t)L + kq;
+        v = (uint64_t)((int64_t)(-c) * Hh + (int64_t)v);               // in (0, 3p)
+        v = csub(csub(v, p << 1), p);
+        if (j < a.dim) dst[(size_t)j << a.logn] = v;
+      }
     }
   }
 }
@@ -162,9 +153,9 @@ __global__ __launch_bounds__(256, 2) void bridge_decompose_mfma(DecomposeMfmaArg
 //   F underestimates 2^104 S/P by less than dim 2^60 < 2^66:  k = F >> 104, centred <=> bit 103,
 //   coefficients with frac(F) in [1/2 - 2^-38, 1/2) are flagged for the exact kernel (as bridge_reconstruct_low does
 //   with its 2^-61 window); result = S - (k + centred) P, masked and sign-extended at logq.
-// K-outer loop: the accumulators of all column tiles stay in registers (2 row tiles x NT x 16), the A
-// fragments of one k step (4 limbs) are made on the fly.  Epilogue: lane = coefficient, the byte columns
-// are folded 8 at a time into words with a running signed carry.
+// K-outer loop: the accumulators of all row tiles stay in registers (2 coefficient tiles x NT x 16), the data
+// fragments of one k step (4 limbs) are made on the fly.  Epilogue: the half-words are exchanged between the
+// lane halves (swap_halves), then every lane folds the words of its coefficient with a running signed carry.
 // ---------------------------------------------------------------------------
 struct ReconMfmaArgs {
   const uint64_t *slab;      // [polys][slab_dim][n]
@@ -186,16 +177,6 @@ struct ReconMfmaArgs {
 // per-coefficient flags of the relinearisation tail: r = x mod P against floor(P/2)
 constexpr unsigned char RF_GT = 1, RF_LT = 2, RF_AMB = 4;
 
-// 8 byte columns (signed 32-bit sums) + carry in -> one 64-bit word + carry out
-__device__ __forceinline__ uint64_t fold8(const int (&c)[32], int at, int64_t &carry) {
-  const int64_t H = (int64_t)(c[at + 7] * 256 + c[at + 6]) * 65536 + (c[at + 5] * 256 + c[at + 4]);
-  const int64_t L = (int64_t)(c[at + 3] * 256 + c[at + 2]) * 65536 + (c[at + 1] * 256 + c[at + 0]);
-  const int64_t T = carry + L;
-  const uint64_t lo = (uint64_t)T + ((uint64_t)H << 32);
-  carry = (H >> 32) + (T >> 63) + (lo < (uint64_t)T ? 1 : 0);
-  return lo;
-}
-
 template <int WL>
 __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs a) {
   constexpr int NT = (8 * WL + 14 + 31) / 32;
@@ -204,7 +185,6 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
   const unsigned nB = a.KS * NT * 64;
   uint64_t *lkl = reinterpret_cast<uint64_t *>(smem + (size_t)nB * 16);
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int *tile = reinterpret_cast<int *>(smem + (size_t)nB * 16 + (size_t)a.KS * 64) + wave * 2 * MFMA_TILE_WORDS;
   for (unsigned i = threadIdx.x; i < nB; i += 512) Bl[i] = a.bfrag[i];
   for (unsigned i = threadIdx.x; i < a.KS * 8; i += 512) lkl[i] = a.lk[i];
   __syncthreads();
@@ -252,11 +232,11 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
 #pragma unroll
       for (int q = 0; q < NT; ++q) {
         const v4i b = Bl[(s * NT + q) * 64 + lane];
-        acc[0][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, b, acc[0][q], 0, 0, 0);
-        acc[1][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, b, acc[1][q], 0, 0, 0);
+        acc[0][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A0, acc[0][q], 0, 0, 0);
+        acc[1][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A1, acc[1][q], 0, 0, 0);
       }
     }
-    // epilogue: lane = coefficient coef0 + lane (row r of tile h)
+    // epilogue: this lane finishes coefficient coef0 + lane (tile h, column r)
     constexpr bool EARLY_D = WL <= 14;                     // (no registers left for it at WL = 16)
     uint64_t dd[WL];                                       // d of the fused tail, fetched under the column folding
     if (EARLY_D && a.rflags && a.addend) {
@@ -267,24 +247,15 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
     uint64_t V[4 * NT];
     int64_t carry = 0;
 #pragma unroll
-    for (int q = 0; q < NT; ++q) {
-      tile_store(tile, acc[0][q], lane);
-      tile_store(tile + MFMA_TILE_WORDS, acc[1][q], lane);
-      mfma_wave_sync();
-      int c[32];
-      const int *row = tile + h * MFMA_TILE_WORDS + r * MFMA_TILE_RS;
+    for (int q = 0; q < NT; ++q)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const v4i v = *reinterpret_cast<const v4i *>(row + 4 * e);
-        c[4 * e] = v[0]; c[4 * e + 1] = v[1]; c[4 * e + 2] = v[2]; c[4 * e + 3] = v[3];
+      for (int w = 0; w < 4; ++w) {
+        int64_t L, H;
+        swap_halves(horner4(acc[0][q][4 * w], acc[0][q][4 * w + 1], acc[0][q][4 * w + 2], acc[0][q][4 * w + 3]),
+                    horner4(acc[1][q][4 * w], acc[1][q][4 * w + 1], acc[1][q][4 * w + 2], acc[1][q][4 * w + 3]), L, H);
+        if (4 * q + w == WL) carry = 0;                  // the F columns start their own carry chain
+        V[4 * q + w] = fold_word(L, H, carry);
       }
-      mfma_wave_sync();
-#pragma unroll
-      for (int wq = 0; wq < 4; ++wq) {
-        if (4 * q + wq == WL) carry = 0;                 // the F columns start their own carry chain
-        V[4 * q + wq] = fold8(c, 8 * wq, carry);
-      }
-    }
     // constants of the signed-byte offsets
     uint64_t cy = 0;
 #pragma unroll
@@ -380,75 +351,80 @@ __global__ __launch_bounds__(256, 2) void bridge_relin_front_mfma(RelinFrontArgs
   uint64_t *lkl = reinterpret_cast<uint64_t *>(smem + (size_t)nB * 16);                 // 8 KS words
   uint64_t *pkl = lkl + 8 * KS;                                                          // 12 (NT-1) words
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned char *wbase = smem + (size_t)nB * 16 + (size_t)(8 * KS + 12 * (a.NT - 1)) * 8;
-  int *tile = reinterpret_cast<int *>(wbase) + wave * (2 * MFMA_TILE_WORDS + 64);
-  int *kbuf = tile + 2 * MFMA_TILE_WORDS;
   for (unsigned i = threadIdx.x; i < nB; i += 256) Bl[i] = a.bfrag[i];
   for (unsigned i = threadIdx.x; i < 8u * KS; i += 256) lkl[i] = a.lk[i];
   for (unsigned i = threadIdx.x; i < 12 * (a.NT - 1); i += 256) pkl[i] = a.pk[i];
   __syncthreads();
   const unsigned r = lane & 31, h = lane >> 5;
   const uint64_t kf0 = a.kf[0], kf1 = a.kf[1];
-  for (unsigned g = blockIdx.x * 4 + wave; g < a.total_groups; g += gridDim.x * 4) {
+  // raw residues of the limbs below dimP for the data fragments: lane (r, h) holds limbs 4s+2h, 4s+2h+1 of
+  // coefficients r and 32+r; the next group's are fetched under the current group's work
+  uint64_t raw[KS][4];
+  auto load_raw = [&](unsigned g) {
     const unsigned poly = g / a.groups_per_poly, coef0 = (g % a.groups_per_poly) << 6;
-    const uint64_t *__restrict__ src = a.chat + ((size_t)poly * a.dimB << a.logn) + coef0;
-    uint64_t *__restrict__ dst = a.yq + ((size_t)poly * a.cnt << a.logn) + coef0;
-    // A fragments: y of limbs 4s+2h, 4s+2h+1 for rows r (tile 0) and 32+r (tile 1)
-    v4i A[2][KS];
+    const uint64_t *__restrict__ src = a.chat + ((size_t)poly * a.dimB << a.logn) + coef0 + r;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned d = 4 * s + 2 * h + e, dc = d < a.dimP ? d : a.dimP - 1;
+        raw[s][e] = src[(size_t)dc << a.logn];
+        raw[s][2 + e] = src[((size_t)dc << a.logn) + 32];
+      }
+  };
+  const unsigned g0 = blockIdx.x * 4 + wave, gstep = gridDim.x * 4;
+  if (g0 < a.total_groups) load_raw(g0);
+  for (unsigned g = g0; g < a.total_groups; g += gstep) {
+    const unsigned poly = g / a.groups_per_poly, coef0 = (g % a.groups_per_poly) << 6;
+    // from here on this lane finishes coefficient coef0 + lane
+    const uint64_t *__restrict__ src = a.chat + (((size_t)poly * a.dimB + a.dimP) << a.logn) + coef0 + lane;
+    uint64_t *__restrict__ dst = a.yq + ((size_t)poly * a.cnt << a.logn) + coef0 + lane;
+    if (KS >= 8 && g != g0) load_raw(g);               // no registers for the early fetch with 32 limbs in P
+    v4i X[2][KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       uint64_t y[4];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const unsigned d = 4 * s + 2 * h + e, dc = d < a.dimP ? d : a.dimP - 1;
+        const unsigned d = 4 * s + 2 * h + e;
         const uint64_t p = lkl[2 * d], w = lkl[2 * d + 1];
         PrimeK k;
         k.p = p; k.p2 = p << 1; k.c = (uint32_t)p; k.c1 = k.c + 1;
         const uint64_t m = p ? ~0ull : 0ull;
-        y[e] = (mulmod_canon(src[((size_t)dc << a.logn) + r], w, k) ^ 0x8080808080808080ull) & m;
-        y[2 + e] = (mulmod_canon(src[((size_t)dc << a.logn) + 32 + r], w, k) ^ 0x8080808080808080ull) & m;
+        y[e] = (mulmod_canon(raw[s][e], w, k) ^ 0x8080808080808080ull) & m;
+        y[2 + e] = (mulmod_canon(raw[s][2 + e], w, k) ^ 0x8080808080808080ull) & m;
       }
-      A[0][s] = v4i{(int)(uint32_t)y[0], (int)(uint32_t)(y[0] >> 32), (int)(uint32_t)y[1], (int)(uint32_t)(y[1] >> 32)};
-      A[1][s] = v4i{(int)(uint32_t)y[2], (int)(uint32_t)(y[2] >> 32), (int)(uint32_t)y[3], (int)(uint32_t)(y[3] >> 32)};
+      X[0][s] = v4i{(int)(uint32_t)y[0], (int)(uint32_t)(y[0] >> 32), (int)(uint32_t)y[1], (int)(uint32_t)(y[1] >> 32)};
+      X[1][s] = v4i{(int)(uint32_t)y[2], (int)(uint32_t)(y[2] >> 32), (int)(uint32_t)y[3], (int)(uint32_t)(y[3] >> 32)};
+      __builtin_amdgcn_sched_barrier(0);   // four multiplies at a time: interleaving all 4 KS of them spills
     }
-    // residues chat_j of the items of one column tile: (tile t, u) -> limb dimP + 4q + h + 2u, row 32t + r; fetched one
-    // column tile ahead so that the loads are under the previous tile's work
+    if (KS < 8 && g + gstep < a.total_groups) load_raw(g + gstep);
+    // residues chat_j of this lane's coefficient, one row tile (4 limbs) ahead
     uint64_t xn[4];
     auto fetch_x = [&](unsigned q) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const unsigned j = 4 * q + h + 2 * u, jc = j < a.cnt ? j : a.cnt - 1;
-          xn[2 * t + u] = src[((size_t)(a.dimP + jc) << a.logn) + 32 * t + r];
-        }
+      for (int w = 0; w < 4; ++w) {
+        const unsigned j = 4 * q + w, jc = j < a.cnt ? j : a.cnt - 1;
+        xn[w] = src[(size_t)jc << a.logn];
+      }
     };
     fetch_x(0);
-    // column tile NT-1 first: F -> k and the round bit of every coefficient (lane = coefficient)
+    // row tile NT-1 first: F -> k and the round bit
+    unsigned kk;
     {
       v16i f0, f1;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { f0[e] = 0; f1[e] = 0; }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const v4i b = Bl[((a.NT - 1) * KS + s) * 64 + lane];
-        f0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][s], b, f0, 0, 0, 0);
-        f1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], b, f1, 0, 0, 0);
+        const v4i cf = Bl[((a.NT - 1) * KS + s) * 64 + lane];
+        f0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[0][s], f0, 0, 0, 0);
+        f1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[1][s], f1, 0, 0, 0);
       }
-      tile_store(tile, f0, lane);
-      tile_store(tile + MFMA_TILE_WORDS, f1, lane);
-      mfma_wave_sync();
-      int c[32];
-      const int *row = tile + h * MFMA_TILE_WORDS + r * MFMA_TILE_RS;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const v4i v = *reinterpret_cast<const v4i *>(row + 4 * e);
-        c[4 * e] = v[0]; c[4 * e + 1] = v[1]; c[4 * e + 2] = v[2]; c[4 * e + 3] = v[3];
-      }
-#pragma unroll
-      for (int e = 16; e < 32; ++e) c[e] = 0;
-      int64_t carry = 0;
-      const uint64_t F0 = fold8(c, 0, carry), F1 = fold8(c, 8, carry);
+      int64_t L0, H0, L1, H1, carry = 0;
+      swap_halves(horner4(f0[0], f0[1], f0[2], f0[3]), horner4(f1[0], f1[1], f1[2], f1[3]), L0, H0);
+      swap_halves(horner4(f0[4], f0[5], f0[6], f0[7]), horner4(f1[4], f1[5], f1[6], f1[7]), L1, H1);
+      const uint64_t F0 = fold_word(L0, H0, carry), F1 = fold_word(L1, H1, carry);
       const u128 F = (((u128)F1 << 64) | F0) + (((u128)kf1 << 64) | kf0);
       const uint64_t f_hi = (uint64_t)(F >> 64);
       const bool ambiguous = ((f_hi >> 2) & ((1ull << 38) - 1)) == ((1ull << 37) - 1);
@@ -456,52 +432,41 @@ __global__ __launch_bounds__(256, 2) void bridge_relin_front_mfma(RelinFrontArgs
       const size_t flag_at = ((size_t)poly << a.logn) + coef0 + lane;
       a.flags[flag_at] = (unsigned char)(ambiguous ? RF_AMB : (gt ? RF_GT : RF_LT));
       a.amb[flag_at] = ambiguous;
-      kbuf[lane] = (int)(f_hi >> 40);
-      mfma_wave_sync();
+      kk = (unsigned)(f_hi >> 40);
     }
     for (unsigned q = 0; q + 1 < a.NT; ++q) {
       uint64_t xc[4], tk[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) xc[e] = xn[e];
+      for (int w = 0; w < 4; ++w) {
+        const unsigned j = 4 * q + w, jc = j < a.cnt ? j : a.cnt - 1;
+        xc[w] = xn[w];
+        tk[w] = a.tkp[(size_t)jc * 64 + kk];
+      }
       if (q + 2 < a.NT) fetch_x(q + 1);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const unsigned j = 4 * q + h + 2 * u, jc = j < a.cnt ? j : a.cnt - 1;
-          tk[2 * t + u] = a.tkp[(size_t)jc * 64 + (unsigned)kbuf[32 * t + r]];
-        }
       v16i acc0, acc1;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc0[e] = 0; acc1[e] = 0; }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const v4i b = Bl[(q * KS + s) * 64 + lane];
-        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][s], b, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], b, acc1, 0, 0, 0);
+        const v4i cf = Bl[(q * KS + s) * 64 + lane];
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[0][s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[1][s], acc1, 0, 0, 0);
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        tile_store(tile, t ? acc1 : acc0, lane);
-        mfma_wave_sync();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const unsigned pq = h + 2 * u, j = 4 * q + pq;                   // item = (row r, limb dimP + j)
-          const v4i lo = *reinterpret_cast<const v4i *>(tile + r * MFMA_TILE_RS + 8 * pq);
-          const v4i hi = *reinterpret_cast<const v4i *>(tile + r * MFMA_TILE_RS + 8 * pq + 4);
-          const uint64_t p = pkl[3 * j], kq = pkl[3 * j + 1], w = pkl[3 * j + 2];
-          PrimeK k;
-          k.p = p; k.p2 = p << 1; k.c = (uint32_t)p; k.c1 = k.c + 1;
-          const int64_t H = (int64_t)(hi[3] * 256 + hi[2]) * 65536 + (hi[1] * 256 + hi[0]);
-          const int64_t L = (int64_t)(lo[3] * 256 + lo[2]) * 65536 + (lo[1] * 256 + lo[0]);
-          const int Hh = (int)(H >> 27);
-          const uint64_t Hl = (uint64_t)H & 0x7ffffffu;
-          uint64_t v = (Hl << 32) + (uint64_t)L + kq;
-          v = (uint64_t)((int64_t)(-(int)k.c) * Hh + (int64_t)v) + tk[2 * t + u];   // r mod p_j, lazily: in (0, 4p)
-          const uint64_t yq = mulmod_canon_lazy(xc[2 * t + u] + (p << 2) - v, w, k);  // (x - r) in (0, 5p)
-          if (j < a.cnt) dst[((size_t)j << a.logn) + 32 * t + r] = yq;
-        }
-        mfma_wave_sync();
+      for (int w = 0; w < 4; ++w) {                                        // limb dimP + j, j = 4q + w
+        int64_t L, H;
+        swap_halves(horner4(acc0[4 * w], acc0[4 * w + 1], acc0[4 * w + 2], acc0[4 * w + 3]),
+                    horner4(acc1[4 * w], acc1[4 * w + 1], acc1[4 * w + 2], acc1[4 * w + 3]), L, H);
+        const unsigned j = 4 * q + w;
+        const uint64_t p = pkl[3 * j], kq = pkl[3 * j + 1], wj = pkl[3 * j + 2];
+        PrimeK k;
+        k.p = p; k.p2 = p << 1; k.c = (uint32_t)p; k.c1 = k.c + 1;
+        const int Hh = (int)(H >> 27);
+        const uint64_t Hl = (uint64_t)H & 0x7ffffffu;
+        uint64_t v = (Hl << 32) + (uint64_t)L + kq;
+        v = (uint64_t)((int64_t)(-(int)k.c) * Hh + (int64_t)v) + tk[w];     // r mod p_j, lazily: in (0, 4p)
+        const uint64_t yq = mulmod_canon_lazy(xc[w] + (p << 2) - v, wj, k);  // (x - r) in (0, 5p)
+        if (j < a.cnt) dst[(size_t)j << a.logn] = yq;
       }
     }
   }
