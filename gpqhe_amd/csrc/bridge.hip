@@ -383,7 +383,7 @@ int launch_decompose_mfma_t(const DecomposeMfmaArgs &a, size_t lds, hipStream_t 
     raised = true;
   }
   unsigned per_cu = (unsigned)((160 * 1024) / lds);     // workgroups a CU's LDS holds; the registers allow 3
-  if (per_cu > 3) per_cu = 3;
+  if (per_cu > 4) per_cu = 4;
   if (per_cu < 1) per_cu = 1;
   unsigned blocks = 256 * per_cu;
   if (blocks > (a.total_groups + 3) / 4) blocks = (a.total_groups + 3) / 4;
