@@ -188,11 +188,27 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
   for (unsigned i = threadIdx.x; i < nB; i += 512) Bl[i] = a.bfrag[i];
   for (unsigned i = threadIdx.x; i < a.KS * 8; i += 512) lkl[i] = a.lk[i];
   __syncthreads();
-  const unsigned r = lane & 31, h = lane >> 5, n = 1u << a.logn;
-  const unsigned gstep = gridDim.x * 8;
-  for (unsigned g = blockIdx.x * 8 + wave; g < a.total_groups; g += gstep) {
+  const unsigned r = lane & 31, h = lane >> 5;
+  const unsigned g0 = blockIdx.x * 8 + wave, gstep = gridDim.x * 8;
+  // residues of k step s of group g: limbs 4s+2h, 4s+2h+1 of coefficients r (tile 0) and 32+r (tile 1); padding limbs and
+  // steps past the end read the last limb.  Two steps are kept in flight (xa, xb), across the group boundary too.
+  uint64_t xa[4], xb[4];
+  auto fetch = [&](unsigned g, unsigned s, uint64_t (&xn)[4]) {
     const unsigned poly = g / a.groups_per_poly, coef0 = (g % a.groups_per_poly) << 6;
     const uint64_t *__restrict__ src = a.slab + (((size_t)poly * a.slab_dim + a.slab_first) << a.logn) + coef0 + r;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const unsigned d = 4 * s + 2 * h + e, dc = d < a.dim ? d : a.dim - 1;
+      xn[e] = src[(size_t)dc << a.logn];
+      xn[2 + e] = src[((size_t)dc << a.logn) + 32];
+    }
+  };
+  constexpr bool CROSS = WL <= 10;      // fetch the next group's first steps under this group's epilogue (registers allowing)
+  if (CROSS && g0 < a.total_groups) { fetch(g0, 0, xa); fetch(g0, 1, xb); }
+  for (unsigned g = g0; g < a.total_groups; g += gstep) {
+    const unsigned poly = g / a.groups_per_poly, coef0 = (g % a.groups_per_poly) << 6;
+    const unsigned gn = g + gstep < a.total_groups ? g + gstep : g;          // next group (or this one again: harmless reads)
+    if (!CROSS) { fetch(g, 0, xa); if (WL <= 14) fetch(g, 1, xb); }
     v16i acc[2][NT];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -200,22 +216,7 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
       for (int q = 0; q < NT; ++q)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][q][e] = 0;
-    // residues of k step s: limbs 4s+2h, 4s+2h+1 of rows r (tile 0) and 32+r (tile 1); padding limbs read limb dim-1
-    uint64_t xn[4];
-    auto fetch = [&](unsigned s) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const unsigned d = 4 * s + 2 * h + e, dc = d < a.dim ? d : a.dim - 1;
-        xn[e] = src[(size_t)dc << a.logn];
-        xn[2 + e] = src[((size_t)dc << a.logn) + 32];
-      }
-    };
-    fetch(0);
-    for (unsigned s = 0; s < a.KS; ++s) {
-      uint64_t x[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) x[e] = xn[e];
-      if (s + 1 < a.KS) fetch(s + 1);
+    auto step = [&](unsigned s, const uint64_t (&x)[4]) {
       uint64_t y[4];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -234,6 +235,29 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
         const v4i b = Bl[(s * NT + q) * 64 + lane];
         acc[0][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A0, acc[0][q], 0, 0, 0);
         acc[1][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A1, acc[1][q], 0, 0, 0);
+      }
+    };
+    if (WL <= 14) {
+      for (unsigned s = 0; s < a.KS; s += 2) {
+        uint64_t x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = xa[e];
+        if (s + 2 < a.KS) fetch(g, s + 2, xa); else if (CROSS) fetch(gn, 0, xa);
+        step(s, x);
+        if (s + 1 < a.KS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = xb[e];
+        }
+        if (s + 3 < a.KS) fetch(g, s + 3, xb); else if (CROSS) fetch(gn, 1, xb);
+        if (s + 1 < a.KS) step(s + 1, x);
+      }
+    } else {                                               // WL = 16: one step ahead only (registers)
+      for (unsigned s = 0; s < a.KS; ++s) {
+        uint64_t x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = xa[e];
+        if (s + 1 < a.KS) fetch(g, s + 1, xa);
+        step(s, x);
       }
     }
     // epilogue: this lane finishes coefficient coef0 + lane (tile h, column r)
@@ -312,7 +336,6 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
       }
       for (unsigned j = WL; j < a.Wout; ++j) dst[(size_t)j << a.logn] = qsign;
     }
-    (void)n;
   }
 }
 
