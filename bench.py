@@ -86,7 +86,7 @@ def ntt_rate(torch, gpqhe_amd, logn, dim, batch, iters=5):
             "roundtrip_identity": ok}
 
 
-def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=3):
+def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6):
     """Whole he_mul of src/he-mult.c:88-156 on device big slabs (q = 2^850: decompose, tensor, CRT, relinearise
     with exact division by P, centre) -- SURVEY.md 8f rank 1-2, reported beside the RNS-core headline."""
     logq, W = 850, 14
@@ -103,15 +103,24 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=3):
     cts = [centred() for _ in range(4)]
     rlk0, rlk1 = rand_slab(torch, ctx, dimB, 1, gen), rand_slab(torch, ctx, dimB, 1, gen)
     o0, o1 = torch.empty_like(cts[0]), torch.empty_like(cts[0])
-    ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
+    for _ in range(3):
+        ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
     t = gpqhe_amd.StreamTimer()
     t.start()
     for _ in range(iters):
         ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
     t.stop()
     ms = t.elapsed_ms() / iters
+    # BASELINE configs[2] is "he_mul + he_rescale": the same with he_rs (src/he-rescale.c:33-54, Delta = 2^50) after each product
+    t.start()
+    for _ in range(iters):
+        ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
+        ctx.he_rs(o0, o1, W, 50, logq - 50)
+    t.stop()
+    ms_rs = t.elapsed_ms() / iters
     return {"shape": "n=2^16, q=2^850 (W=14 words), dimA/dimB/dimP=%d/%d/%d, batch %d" % (dimA, dimB, dimP, batch),
-            "ms_per_batch": round(ms, 3), "he_mul_per_s": round(batch / (ms * 1e-3), 1)}
+            "ms_per_batch": round(ms, 3), "he_mul_per_s": round(batch / (ms * 1e-3), 1),
+            "he_mul_plus_he_rescale_per_s": round(batch / (ms_rs * 1e-3), 1)}
 
 
 def keyswitch_n17_rate(torch, gpqhe_amd, batch=16, iters=3):
