@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2, help="ciphertexts the CPU baseline replays (0 = skip)")
     ap.add_argument("--no-ntt", action="store_true", help="skip the secondary legs run after the timed region (NTT GB/s, MPI-level he_mul, n=2^17 key switch)")
     ap.add_argument("--streams", type=int, default=1, help="2: tensor stage and key-switch stage on separate HIP streams")
+    ap.add_argument("--scatter-gather", action="store_true", help="N>1 only: also time a step with the input slabs scattered from rank 0 "
+                    "and the outputs gathered back (grouped isend/irecv = one RCCL group over xGMI); SURVEY.md 8d config 4")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path with several ranks on one GPU)")
     args = ap.parse_args()
@@ -253,6 +255,35 @@ def main():
         from gpqhe_amd.dist import max_over_ranks
         dt = max_over_ranks(dt)
 
+    sg = None
+    if dist is not None and args.scatter_gather:
+        # BASELINE configs[3] with the transfers inside the timed region: rank 0 owns the whole batch, every rank works on its
+        # shard, results return to rank 0.  A root-GPU scatter is bound by one xGMI link per peer.
+        from gpqhe_amd.dist import scatter_slab, gather_slab, max_over_ranks
+        Bs = min(B, 16)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        per_a, per_b = DIM_A * ctx.n, DIM_B * ctx.n
+        full_in = [torch.cat([v[: Bs * per_a]] * world) if rank == 0 else None for v in (a0, a1, b0, b1)]
+        full_x = torch.cat([x[: Bs * per_b]] * world) if rank == 0 else None
+        barrier()
+        t1 = time.perf_counter()
+        sa = [scatter_slab(f, per_a, Bs * world, 0, dev) for f in full_in]
+        sx = scatter_slab(full_x, per_b, Bs * world, 0, dev)
+        torch.cuda.synchronize()
+        o = [torch.empty_like(sa[0]) for _ in range(3)] + [torch.empty_like(sx) for _ in range(2)]
+        ctx.he_mul_tensor(o[0], o[1], o[2], sa[0], sa[1], sa[2], sa[3], DIM_A, wsA)
+        ctx.he_keyswitch(o[3], o[4], sx, e0, e1, DIM_B, wsB)
+        torch.cuda.synchronize()      # the results must exist before a backend without stream semantics (gloo rehearsal) reads them
+        back = [gather_slab(o[i], per_a if i < 3 else per_b, Bs * world, 0) for i in range(5)]
+        barrier()
+        dsg = max_over_ranks(time.perf_counter() - t1)
+        moved = (4 * per_a + per_b + 3 * per_a + 2 * per_b) * 8 * Bs * (world - 1)
+        sg = {"batch_per_gpu": Bs, "he_mul_per_s": round(Bs * world / dsg, 1), "ms": round(dsg * 1e3, 2), "bytes_over_links": moved,
+              "GBps_root": round(moved / dsg / 1e9, 1)}
+        if rank == 0:   # the shards are copies of the first ciphertexts: every shard's result equals rank 0's own
+            assert all(torch.equal(back[i][: o[i].numel()], back[i][o[i].numel(): 2 * o[i].numel()]) for i in range(5))
+        del full_in, full_x, sa, sx, o, back
+
     if rank == 0:
         total_he_mul = world * B * args.steps
         value = total_he_mul / dt
@@ -288,6 +319,8 @@ def main():
                            "hbm_frac_per_gpu": round(ALGO_BYTES_PER_HE_MUL * value / world / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": kernels,
         }
+        if sg is not None:
+            out["with_scatter_gather"] = sg
         if world == 1 and args.cpu_sample > 0:
             s = args.cpu_sample
             host_in = [gpqhe_amd.to_host(v[: s * DIM_A * ctx.n]) for v in (a0, a1, b0, b1)] + \

@@ -366,9 +366,9 @@ int for_limb_ranges(const gpq_ctx *c, PassArgs a, unsigned dim, const uint64_t *
 }
 
 template <int M1, int EL, bool INV, bool CANON, typename TW>
-int launch_strided_t(const PassArgs &a, dim3 grid, hipStream_t s) {
+int launch_strided_t(const PassArgs &a, unsigned gy, unsigned gz, hipStream_t s) {
   using G = StridedGeom<M1, EL>;
-  hipLaunchKernelGGL((strided_pass<M1, EL, INV, CANON, TW>), grid, dim3(G::T), 0, s, a);
+  hipLaunchKernelGGL((strided_pass<M1, EL, INV, CANON, TW>), dim3(256 >> G::CB, gy, gz), dim3(G::T), 0, s, a);
   return GPQ_OK;
 }
 
@@ -377,14 +377,13 @@ template <bool INV>
 int launch_strided(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigned polys, hipStream_t s) {
   return for_limb_ranges(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
     using TW = decltype(tag);
-    const dim3 grid(16, polys * a.nslab, limbs);
     ProfScope prof(c, INV ? GPQ_K_STRIDED_INV : GPQ_K_STRIDED_FWD, s);
     switch (c->logn) {
-      case 13: return launch_strided_t<5, 4, INV, false, TW>(a, grid, s);
-      case 14: return launch_strided_t<6, 4, INV, false, TW>(a, grid, s);
-      case 15: return launch_strided_t<7, 4, INV, false, TW>(a, grid, s);
-      case 16: return launch_strided_t<8, 4, INV, false, TW>(a, grid, s);
-      case 17: return launch_strided_t<9, 5, INV, false, TW>(a, grid, s);
+      case 13: return launch_strided_t<5, 4, INV, false, TW>(a, polys * a.nslab, limbs, s);
+      case 14: return launch_strided_t<6, 4, INV, false, TW>(a, polys * a.nslab, limbs, s);
+      case 15: return launch_strided_t<7, 4, INV, false, TW>(a, polys * a.nslab, limbs, s);
+      case 16: return launch_strided_t<8, 4, INV, false, TW>(a, polys * a.nslab, limbs, s);
+      case 17: return launch_strided_t<9, 5, INV, false, TW>(a, polys * a.nslab, limbs, s);
     }
     return gpq_fail(GPQ_ERR_INVALID, "two-pass NTT needs 13 <= logn <= 17 (got %u)", c->logn);
   });

@@ -151,14 +151,19 @@ template <> struct TwTraits<TwS> {
 // Forward runs A then B, inverse B then A.  Group A's twiddles are the same
 // for the whole grid (scalar loads); group B's are fetched at kernel entry.
 // ---------------------------------------------------------------------------
+#ifndef GPQ_STRIDED_CB
+#define GPQ_STRIDED_CB 4      /* log2 of the columns of a tile: 16 columns = 128-byte row segments */
+#endif
 template <int M1, int EL>
 struct StridedGeom {
+  static constexpr int CB = M1 <= 8 ? GPQ_STRIDED_CB : 4; // (the 512-row tiles of n = 2^17 fill the LDS with 16 columns already)
+  static constexpr int C = 1 << CB;
   static constexpr int E = 1 << EL;
-  static constexpr int T = 1 << (M1 + 4 - EL);
+  static constexpr int T = 1 << (M1 + CB - EL);
   static constexpr int S2 = M1 - EL;                      // stages left for group B
   static constexpr int BB = S2 > 0 ? S2 - 1 : 0;          // highest register bit group B works on
-  static constexpr int LDS_ELEMS = (1 << (M1 + 4)) + ((S2 > 0) ? (16 << S2) : 0);
-  __device__ static __forceinline__ unsigned pad(unsigned l) { return l + ((l >> (EL + 4)) << 4); }
+  static constexpr int LDS_ELEMS = (1 << (M1 + CB)) + ((S2 > 0) ? (C << S2) : 0);
+  __device__ static __forceinline__ unsigned pad(unsigned l) { return l + ((l >> (EL + CB)) << CB); }
 };
 
 template <int M1, int EL, bool INV, bool CANON_OUT, typename TW>
@@ -174,7 +179,7 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
   unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (!INV) {
     const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), tot = gridDim.x * gridDim.y * gridDim.z;
-    const unsigned logical = (lin & 7) * (tot >> 3) + (lin >> 3);     // gridDim.x = 16: tot is a multiple of 8
+    const unsigned logical = (lin & 7) * (tot >> 3) + (lin >> 3);     // gridDim.x = 8 or 16: tot is a multiple of 8
     bx = logical % gridDim.x; by = (logical / gridDim.x) % gridDim.y; bz = logical / (gridDim.x * gridDim.y);
   }
   const unsigned limb = a.limb0 + bz;
@@ -188,8 +193,9 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
   uint64_t *__restrict__ dst = a.dst[slab] + off;
 
   const unsigned tid = threadIdx.x;
-  const unsigned col = (bx << 4) + (tid & 15);
-  const unsigned q = tid >> 4;
+  constexpr int CB = G::CB;
+  const unsigned col = (bx << CB) + (tid & (G::C - 1));
+  const unsigned q = tid >> CB;
   // group A: element e at row q + (e << S2); group B: row (q << EL) + e
   const unsigned iA = (q << 8) + col, iB = (q << (EL + 8)) + col;
   constexpr unsigned strideA = 1u << (G::S2 + 8), strideB = 1u << 8;
@@ -208,7 +214,7 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
       for (int e = 0; e < E; ++e) lds[G::pad(tid + e * G::T)] = x[e];
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < E; ++e) x[e] = lds[G::pad((q << (EL + 4)) + (e << 4) + (tid & 15))];
+      for (int e = 0; e < E; ++e) x[e] = lds[G::pad((q << (EL + CB)) + (e << CB) + (tid & (G::C - 1)))];
       ct_group<EL, G::BB, 0>(x, twB, k);
 #pragma unroll
       for (int e = 0; e < E; ++e) dst[iB + e * strideB] = CANON_OUT ? TwTraits<TW>::canon_fwd(x[e], k) : x[e];
@@ -226,7 +232,7 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
       if (EL > 1) load_tw<EL, (EL > 1 ? EL - 2 : 0), 0, true>(twA, iA, G::S2 + 8, logn, wt);
       gs_group<EL, G::BB, 0>(x, twB, k);
 #pragma unroll
-      for (int e = 0; e < E; ++e) lds[G::pad((q << (EL + 4)) + (e << 4) + (tid & 15))] = x[e];
+      for (int e = 0; e < E; ++e) lds[G::pad((q << (EL + CB)) + (e << CB) + (tid & (G::C - 1)))] = x[e];
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = lds[G::pad(tid + e * G::T)];

@@ -19,12 +19,12 @@ def shard_range(batch, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def scatter_slab(full, per_ct, batch, src=0):
+def scatter_slab(full, per_ct, batch, src=0, device=None):
     """Rank `src` holds `full` = int64[batch*per_ct] (others pass None); every rank
     gets its own shard int64[(hi-lo)*per_ct].  Ragged shards are allowed."""
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = shard_range(batch, world, rank)
-    device = full.device if full is not None else _default_device()
+    device = full.device if full is not None else (device or _default_device())
     mine = torch.empty((hi - lo) * per_ct, dtype=torch.int64, device=device)
     if world == 1:
         mine.copy_(full)
