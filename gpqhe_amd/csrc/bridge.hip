@@ -210,7 +210,11 @@ int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out
     kc[WL] = (uint64_t)kf; kc[WL + 1] = (uint64_t)(kf >> 64);
     Big mP{0};
     for (unsigned m = 0; m <= 64; ++m) {
-      for (int j = 0; j < WL; ++j) pm[(size_t)m * WL + j] = (size_t)j < mP.size() ? mP[j] : 0;
+      uint64_t bw = 0;                                                                   // (m P - Kc) mod 2^(64 WL)
+      for (int j = 0; j < WL; ++j) {
+        const u128h d2 = (u128h)((size_t)j < mP.size() ? mP[j] : 0) - kc[j] - bw;
+        pm[(size_t)m * WL + j] = (uint64_t)d2; bw = (uint64_t)(d2 >> 64) & 1;
+      }
       Big nxt(std::max(mP.size(), b->h_P.size()) + 1, 0);                                // mP += P
       uint64_t cy = 0;
       for (size_t j = 0; j < nxt.size(); ++j) {

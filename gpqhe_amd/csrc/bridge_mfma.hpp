@@ -136,8 +136,7 @@ __global__ __launch_bounds__(256, 2) void bridge_decompose_mfma(DecomposeMfmaArg
         const uint64_t Hl = (uint64_t)H & 0x7ffffffu;
         uint64_t v = (Hl << 32) + (uint64_t)L + kq;
         v = (uint64_t)((int64_t)(-c) * Hh + (int64_t)v);               // in (0, 3p)
-        v = csub(csub(v, p << 1), p);
-        if (j < a.dim) dst[(size_t)j << a.logn] = v;
+        if (j < a.dim) dst[(size_t)j << a.logn] = canon_fold(v, p, (uint32_t)c);
       }
     }
   }
@@ -162,8 +161,8 @@ struct ReconMfmaArgs {
   uint64_t *big;             // [polys][Wout][n]
   const v4i *bfrag;          // [KS][NT][64]
   const uint64_t *lk;        // [4 KS][2]: p_d, phat_invmp_d   (p = 0: padding limb)
-  const uint64_t *kc;        // [WL + 2]: Kc words, then Kf (2 words)
-  const uint64_t *pm;        // [65][WL]: m * P mod 2^(64 WL)
+  const uint64_t *kc;        // [WL + 2]: (unused: Kc lives in pm), then Kf (2 words)
+  const uint64_t *pm;        // [65][WL]: (m * P - Kc) mod 2^(64 WL), Kc = the offset of the signed bytes of S
   unsigned char *redo;       // [polys][n]
   unsigned char *tie;        // optional, cleared
   unsigned dim, KS, logn, Wout, logq, slab_dim, slab_first;
@@ -225,8 +224,8 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
         PrimeK k;
         k.p = p; k.p2 = p << 1; k.c = (uint32_t)p; k.c1 = k.c + 1;   // p = 2^59 + c: c is the low word
         const uint64_t m = p ? ~0ull : 0ull;
-        y[e] = ((a.prescaled ? x[e] : mulmod_canon(x[e], w, k)) ^ 0x8080808080808080ull) & m;
-        y[2 + e] = ((a.prescaled ? x[2 + e] : mulmod_canon(x[2 + e], w, k)) ^ 0x8080808080808080ull) & m;
+        y[e] = ((a.prescaled ? x[e] : canon_fold(mulmod_lazy(x[e], w, k), p, k.c)) ^ 0x8080808080808080ull) & m;
+        y[2 + e] = ((a.prescaled ? x[2 + e] : canon_fold(mulmod_lazy(x[2 + e], w, k), p, k.c)) ^ 0x8080808080808080ull) & m;
       }
       const v4i A0 = v4i{(int)(uint32_t)y[0], (int)(uint32_t)(y[0] >> 32), (int)(uint32_t)y[1], (int)(uint32_t)(y[1] >> 32)};
       const v4i A1 = v4i{(int)(uint32_t)y[2], (int)(uint32_t)(y[2] >> 32), (int)(uint32_t)y[3], (int)(uint32_t)(y[3] >> 32)};
@@ -280,13 +279,7 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
         if (4 * q + w == WL) carry = 0;                  // the F columns start their own carry chain
         V[4 * q + w] = fold_word(L, H, carry);
       }
-    // constants of the signed-byte offsets
-    uint64_t cy = 0;
-#pragma unroll
-    for (int j = 0; j < WL; ++j) {
-      const u128 t = (u128)V[j] + a.kc[j] + cy;
-      V[j] = (uint64_t)t; cy = (uint64_t)(t >> 64);
-    }
+    // (the offset of the signed bytes of S is folded into the table of multiples of P; F's is added here)
     const u128 F = (((u128)V[WL + 1] << 64) | V[WL]) + (((u128)a.kc[WL + 1] << 64) | a.kc[WL]);
     const uint64_t f1 = (uint64_t)(F >> 64);
     const size_t flag_at = ((size_t)poly << a.logn) + coef0 + lane;
@@ -317,23 +310,16 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
         }
       }
       uint64_t *__restrict__ dst = a.big + ((size_t)poly * a.Wout << a.logn) + coef0 + lane;
-      const unsigned sb = a.logq - 1;
-      uint64_t qsign = 0;
+      // mpi_smod by 2^logq: sign-extend from bit logq-1 (word sw, bit sbit); words above it are the sign
+      const int sw = (int)((a.logq - 1) >> 6);
+      const unsigned up = 63 - ((a.logq - 1) & 63);
+      uint64_t ext = 0;
 #pragma unroll
-      for (int j = 0; j < WL; ++j) if (j == (int)(sb >> 6)) qsign = 0 - ((V[j] >> (sb & 63)) & 1);
+      for (int j = 0; j < WL; ++j) if (j == sw) ext = (uint64_t)((int64_t)(V[j] << up) >> up);
+      const uint64_t qsign = (uint64_t)((int64_t)ext >> 63);
 #pragma unroll
-      for (int j = 0; j < WL; ++j) {
-        if (j < (int)a.Wout) {
-          uint64_t v = V[j];
-          const int lo = 64 * j;
-          if (lo >= (int)a.logq) v = qsign;
-          else if (lo + 64 > (int)a.logq) {
-            const uint64_t mask = (1ull << (a.logq - lo)) - 1;
-            v = (v & mask) | (qsign & ~mask);
-          }
-          dst[(size_t)j << a.logn] = v;
-        }
-      }
+      for (int j = 0; j < WL; ++j)
+        if (j < (int)a.Wout) dst[(size_t)j << a.logn] = j < sw ? V[j] : (j == sw ? ext : qsign);
       for (unsigned j = WL; j < a.Wout; ++j) dst[(size_t)j << a.logn] = qsign;
     }
   }
@@ -414,8 +400,8 @@ __global__ __launch_bounds__(256, 2) void bridge_relin_front_mfma(RelinFrontArgs
         PrimeK k;
         k.p = p; k.p2 = p << 1; k.c = (uint32_t)p; k.c1 = k.c + 1;
         const uint64_t m = p ? ~0ull : 0ull;
-        y[e] = (mulmod_canon(raw[s][e], w, k) ^ 0x8080808080808080ull) & m;
-        y[2 + e] = (mulmod_canon(raw[s][2 + e], w, k) ^ 0x8080808080808080ull) & m;
+        y[e] = (canon_fold(mulmod_lazy(raw[s][e], w, k), p, k.c) ^ 0x8080808080808080ull) & m;
+        y[2 + e] = (canon_fold(mulmod_lazy(raw[s][2 + e], w, k), p, k.c) ^ 0x8080808080808080ull) & m;
       }
       X[0][s] = v4i{(int)(uint32_t)y[0], (int)(uint32_t)(y[0] >> 32), (int)(uint32_t)y[1], (int)(uint32_t)(y[1] >> 32)};
       X[1][s] = v4i{(int)(uint32_t)y[2], (int)(uint32_t)(y[2] >> 32), (int)(uint32_t)y[3], (int)(uint32_t)(y[3] >> 32)};
@@ -488,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void bridge_relin_front_mfma(RelinFrontArgs
         const uint64_t Hl = (uint64_t)H & 0x7ffffffu;
         uint64_t v = (Hl << 32) + (uint64_t)L + kq;
         v = (uint64_t)((int64_t)(-(int)k.c) * Hh + (int64_t)v) + tk[w];     // r mod p_j, lazily: in (0, 4p)
-        const uint64_t yq = mulmod_canon_lazy(xc[w] + (p << 2) - v, wj, k);  // (x - r) in (0, 5p)
+        const uint64_t yq = canon_fold(mulmod_lazy(xc[w] + (p << 2) - v, wj, k), p, k.c);  // (x - r) in (0, 5p)
         if (j < a.cnt) dst[(size_t)j << a.logn] = yq;
       }
     }
