@@ -662,7 +662,7 @@ int launch_relin_front_t(const RelinFrontArgs &a, size_t lds, hipStream_t s) {
     raised = true;
   }
   unsigned per_cu = (unsigned)((160 * 1024) / lds);
-  if (per_cu > 2) per_cu = 2;
+  if (per_cu > 3) per_cu = 3;
   if (per_cu < 1) per_cu = 1;
   unsigned blocks = 256 * per_cu;
   if (blocks > (a.total_groups + 3) / 4) blocks = (a.total_groups + 3) / 4;

@@ -19,6 +19,9 @@
 #include "modarith.hpp"
 #include "tables.hpp"
 
+#ifndef GPQ_FRONT_XG
+#define GPQ_FRONT_XG 8   /* k steps from which the relinearisation front stops fetching the next group early */
+#endif
 namespace gpq {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -352,8 +355,11 @@ struct RelinFrontArgs {
   unsigned dimB, dimP, cnt, logn, NT, groups_per_poly, total_groups;
 };
 
+#ifndef GPQ_FRONT_OCC
+#define GPQ_FRONT_OCC 3   /* waves per SIMD asked of the compiler for P of up to 16 limbs (measured +3 % on the whole he_mul against 2, 28 B of scratch) */
+#endif
 template <int KS>
-__global__ __launch_bounds__(256, 2) void bridge_relin_front_mfma(RelinFrontArgs a) {
+__global__ __launch_bounds__(256, (KS <= 4 ? GPQ_FRONT_OCC : 2)) void bridge_relin_front_mfma(RelinFrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   v4i *Bl = reinterpret_cast<v4i *>(smem);
   const unsigned nB = a.NT * KS * 64;
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void bridge_relin_front_mfma(RelinFrontArgs
     // from here on this lane finishes coefficient coef0 + lane
     const uint64_t *__restrict__ src = a.chat + (((size_t)poly * a.dimB + a.dimP) << a.logn) + coef0 + lane;
     uint64_t *__restrict__ dst = a.yq + ((size_t)poly * a.cnt << a.logn) + coef0 + lane;
-    if (KS >= 8 && g != g0) load_raw(g);               // no registers for the early fetch with 32 limbs in P
+    if (KS >= GPQ_FRONT_XG && g != g0) load_raw(g);     // no registers for the early fetch with 32 limbs in P
     v4i X[2][KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void bridge_relin_front_mfma(RelinFrontArgs
       X[1][s] = v4i{(int)(uint32_t)y[2], (int)(uint32_t)(y[2] >> 32), (int)(uint32_t)y[3], (int)(uint32_t)(y[3] >> 32)};
       __builtin_amdgcn_sched_barrier(0);   // four multiplies at a time: interleaving all 4 KS of them spills
     }
-    if (KS < 8 && g + gstep < a.total_groups) load_raw(g + gstep);
+    if (KS < GPQ_FRONT_XG && g + gstep < a.total_groups) load_raw(g + gstep);
     // residues chat_j of this lane's coefficient, one row tile (4 limbs) ahead
     uint64_t xn[4];
     auto fetch_x = [&](unsigned q) {
@@ -476,6 +482,9 @@ __global__ __launch_bounds__(256, 2) void bridge_relin_front_mfma(RelinFrontArgs
         v = (uint64_t)((int64_t)(-(int)k.c) * Hh + (int64_t)v) + tk[w];     // r mod p_j, lazily: in (0, 4p)
         const uint64_t yq = canon_fold(mulmod_lazy(xc[w] + (p << 2) - v, wj, k), p, k.c);  // (x - r) in (0, 5p)
         if (j < a.cnt) dst[(size_t)j << a.logn] = yq;
+#ifdef GPQ_FRONT_ITEM_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     }
   }
