@@ -160,3 +160,46 @@ def test_largest_c_of_the_supported_chains(engine_ctx, oracle_ctx):
     g.he_mul_tensor(outs[0], outs[1], outs[2], dev, to_device(b), to_device(b), dev, dim)
     e0, e1, e2 = o.he_mul_tensor(a, b, b, a, dim)
     assert np.array_equal(to_host(outs[0]), e0) and np.array_equal(to_host(outs[1]), e1) and np.array_equal(to_host(outs[2]), e2)
+
+
+@pytest.mark.parametrize("logn,dim", [(16, 58), (17, 57), (13, 20)])
+def test_split_twiddle_butterflies_equal_the_seven_mad_ones(logn, dim):
+    """The default contexts use the 5-mad split-twiddle multiply for every limb whose c allows it (all of them up to
+    n = 2^16, a prefix at n = 2^17: one transform then runs both kinds); GPQHE_NO_SPLIT=1 builds the tables for the 7-mad
+    butterflies only.  Same slabs through both, whole he_mul core included: bit-identical."""
+    import os
+    import torch
+    import gpqhe_amd
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4242)
+    outs = []
+    for nosplit in ("0", "1"):
+        os.environ["GPQHE_NO_SPLIT"] = nosplit
+        try:
+            g = gpqhe_amd.PolyContext(logn, dim)
+        finally:
+            del os.environ["GPQHE_NO_SPLIT"]
+        if not outs:
+            batch = 2
+            slabs = []
+            for _ in range(5):
+                s = torch.empty((batch, dim, g.n), dtype=torch.int64, device="cuda")
+                for d in range(dim):
+                    s[:, d, :] = torch.randint(0, g.p[d], (batch, g.n), dtype=torch.int64, device="cuda", generator=gen)
+                s[0, :, :64] = 0
+                for d in range(dim):
+                    s[0, d, 64:128] = g.p[d] - 1
+                slabs.append(s.reshape(-1).contiguous())
+            e0, e1 = slabs[3][: dim * g.n].clone(), slabs[4][: dim * g.n].clone()
+        f = slabs[0].clone()
+        g.poly_ntt(f, dim)
+        i = slabs[1].clone()
+        g.poly_invntt(i, dim)
+        d0, d1, d2 = (torch.empty_like(f) for _ in range(3))
+        g.he_mul_tensor(d0, d1, d2, slabs[0], slabs[1], slabs[2], slabs[3], dim, g.tensor_workspace(dim, batch))
+        c0, c1 = torch.empty_like(f), torch.empty_like(f)
+        g.he_keyswitch(c0, c1, slabs[4], e0, e1, dim, g.keyswitch_workspace(dim, batch))
+        outs.append([f, i, d0, d1, d2, c0, c1])
+        g.close()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
