@@ -290,7 +290,7 @@ def main():
         # dominant kernel by accumulated device time
         kname, (kms, kcnt) = max(prof.items(), key=lambda kv: kv[1][0])
         # strided kernels run for both stages: average units per launch from the launch mix
-        chunk = min(B, args.chunk or 16)
+        chunk = min(B, args.chunk or 32)
         units = {"tensor_mid": DIM_A * chunk, "keyswitch_mid": DIM_B * chunk,
                  "strided_fwd": (4 * DIM_A + 1 * DIM_B) * chunk / 2.0, "strided_inv": (3 * DIM_A + 2 * DIM_B) * chunk / 2.0}
         kernels = {}

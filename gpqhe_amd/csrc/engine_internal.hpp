@@ -52,7 +52,7 @@ struct gpq_relin_tables {
 struct gpq_ctx {
   int device = 0;
   unsigned logn = 0, n = 0, nprimes = 0;
-  unsigned chunk = 16; // polynomials per fused launch group (measured: larger groups amortise launch tails; profiles/r01/sweep_chunk.txt)
+  unsigned chunk = 32; // polynomials per fused launch group (measured: larger groups amortise launch tails; profiles/r01/v9_sweep_chunk.txt)
   // host copies in the reference's own representation (struct rns_ctx, src/poly.h:28-41)
   std::vector<uint64_t> p, pinv_mont, pinv_barr, ninv_mont, psi;
   std::vector<uint64_t> zetas, zetas_inv;  // [nprimes][n], Montgomery form, bit-reversed index

@@ -107,7 +107,7 @@ int gpq_rns_add(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, const uint64_t *b,
 int gpq_poly_mul_rns(gpq_ctx *ctx, uint64_t *r, uint64_t *a, uint64_t *b, unsigned dim, unsigned batch, void *stream);
 
 /* The fused operations process the batch in groups of `chunk` polynomials so
- * that the scratch stays bounded (default 16; larger groups amortise launch tails). */
+ * that the scratch stays bounded (default 32; larger groups amortise launch tails). */
 int gpq_set_chunk(gpq_ctx *ctx, unsigned chunk);
 
 /* Bytes of scratch the two fused operations below need for this shape. */
