@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 extern "C" struct poly_ctx polyctx __attribute__((weak));   // src/precomp.c:41
@@ -89,10 +90,27 @@ unsigned max_bits(const poly_mpi_t *a, unsigned n) {
   return m;
 }
 
+// The conversions are per coefficient and independent (gcry_mpi_print only reads its MPI, gcry_mpi_scan / gcry_mpi_set write
+// the caller's own, distinct MPIs), so large polynomials are cut into ranges for a few host threads: at n = 2^16 the MPI <-> slab
+// conversions are 40 ms of a 42 ms he_mul call on one thread.
+template <typename F>
+void for_ranges(unsigned n, F f) {
+  unsigned nt = n >= 4096 ? std::thread::hardware_concurrency() : 1;
+  if (nt > 16) nt = 16;
+  if (nt < 2) { f(0u, n); return; }
+  std::vector<std::thread> th;
+  const unsigned per = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const unsigned lo = t * per, hi = lo + per < n ? lo + per : n;
+    if (lo < hi) th.emplace_back([=] { f(lo, hi); });
+  }
+  for (auto &x : th) x.join();
+}
+
 // MPI coefficients -> host big slab [W][n], two's complement
-void to_slab(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W) {
+void to_slab_range(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W, unsigned lo, unsigned hi) {
   std::vector<unsigned char> buf(8 * W);
-  for (unsigned i = 0; i < n; ++i) {
+  for (unsigned i = lo; i < hi; ++i) {
     MPI v = a->coeffs[i];
     if (G.mpi_get_nbits(v) > 64 * W - 1) die("coefficient does not fit the big slab");
     size_t nw = 0;
@@ -106,11 +124,14 @@ void to_slab(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W) {
     for (unsigned j = 0; j < W; ++j) dst[(size_t)j * n + i] = w[j];
   }
 }
+void to_slab(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W) {
+  for_ranges(n, [=](unsigned lo, unsigned hi) { to_slab_range(dst, a, n, W, lo, hi); });
+}
 
 // host big slab -> existing MPIs (the caller allocated them, src/poly.c:46-51)
-void from_slab(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W) {
+void from_slab_range(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W, unsigned lo, unsigned hi) {
   std::vector<unsigned char> buf(8 * W);
-  for (unsigned i = 0; i < n; ++i) {
+  for (unsigned i = lo; i < hi; ++i) {
     uint64_t w[64];
     for (unsigned j = 0; j < W; ++j) w[j] = src[(size_t)j * n + i];
     const bool neg = w[W - 1] >> 63;
@@ -129,6 +150,9 @@ void from_slab(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W) {
     G.mpi_release(t);
     if (neg) G.mpi_neg(r->coeffs[i], r->coeffs[i]);
   }
+}
+void from_slab(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W) {
+  for_ranges(n, [=](unsigned lo, unsigned hi) { from_slab_range(r, src, n, W, lo, hi); });
 }
 
 // one engine context per (logn, chain length), checked against the caller's prime list

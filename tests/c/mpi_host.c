@@ -5,6 +5,8 @@
  *
  *   mpi_host polymul                     the two products of tests/polymul.c:59-76 (n = 128, 5 limbs, q = 2^61)
  *   mpi_host crt                         rns_decompose per limb, rns_reconstruct per coefficient, poly_rns2mpi (tests/crt.c:76-109)
+ *   mpi_host polymulmono <logn>          poly_mul of a dense polynomial by -3 x^5 at a size that takes the threaded conversions
+ *   mpi_host hemultime <logn> <logq>     wall time of he_mul / he_rescale through the MPI-typed symbols (conversions and copies included)
  *   mpi_host hemul  <in.txt>             he_mul on ciphertexts read as hex, then he_rs, then he_moddown
  *
  * It owns `polyctx` and `hectx` (as src/precomp.c:41,47 do) and fills the fields the hot path reads,
@@ -161,15 +163,8 @@ static void read_poly(FILE *f, poly_mpi_t *a)
   free(line);
 }
 
-static int hemul(const char *path)
+static void he_ctx_init(unsigned logn, MPI q, unsigned long long Delta)   /* hectx_init, src/precomp.c:386-409 */
 {
-  FILE *f = fopen(path, "r");
-  unsigned logn, level;
-  unsigned long long Delta;
-  char qhex[2048];
-  if (!f || fscanf(f, "%u %2047s %llu %u\n", &logn, qhex, &Delta, &level) != 4) return 3;
-  MPI q = NULL;
-  gcry_mpi_scan(&q, FMT_HEX, qhex, 0, NULL);
   const unsigned logq = gcry_mpi_get_nbits(q) - 1;           /* polyctx.logq, src/precomp.c:337 */
   ctx_init(logn, logq);
   /* qtable_init, src/precomp.c:386-409: q[l] = floor(q[l+1] / Delta), L = floor(logq / logDelta) */
@@ -193,6 +188,18 @@ static int hemul(const char *path)
   hectx.dimevk = (gcry_mpi_get_nbits(hectx.q[hectx.L]) + gcry_mpi_get_nbits(hectx.PqL) + logn) / 59 + 1;
   hectx.bnd.Brs = 11.5; hectx.bnd.Bmult = malloc((hectx.L + 1) * sizeof(double));
   for (unsigned l = 0; l <= hectx.L; l++) hectx.bnd.Bmult[l] = 100.0 + l;
+}
+
+static int hemul(const char *path)
+{
+  FILE *f = fopen(path, "r");
+  unsigned logn, level;
+  unsigned long long Delta;
+  char qhex[2048];
+  if (!f || fscanf(f, "%u %2047s %llu %u\n", &logn, qhex, &Delta, &level) != 4) return 3;
+  MPI q = NULL;
+  gcry_mpi_scan(&q, FMT_HEX, qhex, 0, NULL);
+  he_ctx_init(logn, q, Delta);
   printf("dims %u %u %u\n", hectx.dim, hectx.dimevk, hectx.L);
 
   he_ct_t ct1, ct2, ct;
@@ -202,7 +209,7 @@ static int hemul(const char *path)
   he_evk_t rlk;                                              /* he_alloc_evk, src/he-mem.c:42-46; synthetic NTT-domain key */
   rlk.p0.coeffs = malloc((size_t)hectx.dimevk * polyctx.n * 8); rlk.p1.coeffs = malloc((size_t)hectx.dimevk * polyctx.n * 8);
   uint64_t s0 = 3000, s1 = 3001;
-  r = polyctx.rns;
+  struct rns_ctx *r = polyctx.rns;
   for (unsigned d = 0; d < hectx.dimevk; d++, r = r->next)
     for (unsigned i = 0; i < polyctx.n; i++) {
       rlk.p0.coeffs[(size_t)d * polyctx.n + i] = splitmix64(&s0) % r->p;
@@ -264,11 +271,87 @@ static int hemul(const char *path)
   return 0;
 }
 
+/* poly_mul at a size where the shim converts coefficients on several host threads: dense a (seeded, signed, ~100 bits) times the
+ * monomial -3 x^5, so that the expected product is a signed shift of a (cheap to restate exactly) */
+static int polymulmono(unsigned logn)
+{
+  ctx_init(logn, 109);
+  MPI q = gcry_mpi_new(0);
+  gcry_mpi_set_ui(q, 1);
+  gcry_mpi_lshift(q, q, 109);
+  polyctx.q = q;
+  poly_mpi_t a, b, r;
+  poly_alloc(&a); poly_alloc(&b); poly_alloc(&r);
+  uint64_t st = 4096;
+  for (unsigned i = 0; i < polyctx.n; i++) {
+    unsigned char buf[12];
+    const uint64_t v0 = splitmix64(&st), v1 = splitmix64(&st);
+    memcpy(buf, &v0, 8); memcpy(buf + 8, &v1, 4);
+    MPI t = NULL;
+    gcry_mpi_scan(&t, 5, buf, 12, NULL);                      /* 96-bit magnitude, big-endian bytes of the two words */
+    if (v1 >> 63) gcry_mpi_neg(t, t);
+    gcry_mpi_release(a.coeffs[i]); a.coeffs[i] = t;
+    gcry_mpi_set_ui(b.coeffs[i], i == 5 ? 3 : 0);
+  }
+  gcry_mpi_neg(b.coeffs[5], b.coeffs[5]);
+  poly_mul(&r, &a, &b, polyctx.dimub, polyctx.q);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(a.coeffs[i]);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(r.coeffs[i]);
+  return 0;
+}
+
+#include <time.h>
+static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+
+/* wall time of the MPI-typed he_mul (host conversions and PCIe copies included) on random centred ciphertexts */
+static int hemultime(unsigned logn, unsigned logq)
+{
+  MPI q = gcry_mpi_new(0);
+  gcry_mpi_set_ui(q, 1);
+  gcry_mpi_lshift(q, q, logq);
+  he_ctx_init(logn, q, 1ull << 50);
+  he_ct_t ct1, ct2, ct;
+  poly_mpi_t *ps[6] = {&ct1.c0, &ct1.c1, &ct2.c0, &ct2.c1, &ct.c0, &ct.c1};
+  for (int i = 0; i < 6; i++) poly_alloc(ps[i]);
+  uint64_t st = 99;
+  unsigned char *buf = malloc(logq / 8 + 8);
+  for (int i = 0; i < 4; i++)
+    for (unsigned k = 0; k < polyctx.n; k++) {
+      const unsigned nb = (logq - 2) / 8;                     /* |coefficient| < 2^(logq-2) < q/2 */
+      for (unsigned b = 0; b < nb; b += 8) { uint64_t v = splitmix64(&st); memcpy(buf + b, &v, 8); }
+      MPI t = NULL;
+      gcry_mpi_scan(&t, 5, buf, nb, NULL);
+      if (splitmix64(&st) & 1) gcry_mpi_neg(t, t);
+      gcry_mpi_release(ps[i]->coeffs[k]);
+      ps[i]->coeffs[k] = t;
+    }
+  ct1.l = ct2.l = hectx.L; ct1.nu = ct2.nu = 1.0; ct1.B = ct2.B = 1.0;
+  he_evk_t rlk;
+  rlk.p0.coeffs = malloc((size_t)hectx.dimevk * polyctx.n * 8); rlk.p1.coeffs = malloc((size_t)hectx.dimevk * polyctx.n * 8);
+  struct rns_ctx *r = polyctx.rns;
+  for (unsigned d = 0; d < hectx.dimevk; d++, r = r->next)
+    for (unsigned i = 0; i < polyctx.n; i++) {
+      rlk.p0.coeffs[(size_t)d * polyctx.n + i] = splitmix64(&st) % r->p;
+      rlk.p1.coeffs[(size_t)d * polyctx.n + i] = splitmix64(&st) % r->p;
+    }
+  he_mul(&ct, &ct1, &ct2, &rlk);                              /* first call builds the device tables */
+  const double t0 = now_ms();
+  for (int i = 0; i < 3; i++) he_mul(&ct, &ct1, &ct2, &rlk);
+  const double dt = (now_ms() - t0) / 3;
+  const double t1 = now_ms();
+  for (int i = 0; i < 3; i++) { ct.l = hectx.L; he_rescale(&ct); }
+  const double dr = (now_ms() - t1) / 3;
+  printf("he_mul(MPI) n=2^%u logq=%u dims %u/%u: %.1f ms per call; he_rescale %.1f ms\n", logn, logq, hectx.dim, hectx.dimevk, dt, dr);
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
   if (argc >= 2 && !strcmp(argv[1], "polymul")) return polymul(0);
   if (argc >= 2 && !strcmp(argv[1], "polymulodd")) return polymul(1);
   if (argc >= 2 && !strcmp(argv[1], "crt")) return crt();
   if (argc >= 3 && !strcmp(argv[1], "hemul")) return hemul(argv[2]);
+  if (argc >= 3 && !strcmp(argv[1], "polymulmono")) return polymulmono(atoi(argv[2]));
+  if (argc >= 4 && !strcmp(argv[1], "hemultime")) return hemultime(atoi(argv[2]), atoi(argv[3]));
   return 2;
 }

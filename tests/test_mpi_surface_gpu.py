@@ -55,6 +55,19 @@ def test_poly_mul_general_modulus_through_reference_signature(mpi_host, oracle_c
         assert vals[t * N:(t + 1) * N] == [ref.mpi_smod(v, Q) for v in ref.negacyclic_mul(a, b)]
 
 
+def test_poly_mul_at_a_size_with_threaded_conversions(mpi_host):
+    """n = 2^13: the shim cuts the MPI <-> slab conversions into ranges for several host threads.  Dense signed 96-bit a times
+    -3 x^5 (negacyclic): r_i = -3 a_{i-5}, with the sign flipped where the index wraps."""
+    res = subprocess.run([mpi_host, "polymulmono", "13"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    vals = _ints(res.stdout.split())
+    n, q = 1 << 13, 1 << 109
+    a, r = vals[:n], vals[n:]
+    assert len(r) == n and len(set(a)) > n - 4           # dense, (almost) all distinct
+    exp = [ref.centred_mod(-3 * a[i - 5] if i >= 5 else 3 * a[n + i - 5], q) for i in range(n)]
+    assert r == exp
+
+
 def test_crt_bridge_through_reference_signatures(mpi_host, oracle_ctx):
     """rns_decompose per limb, rns_reconstruct per coefficient and poly_rns2mpi with the signatures of src/rns.c:37,60 and
     src/poly.h:88, driven like tests/crt.c:76-109 but on the production 60-bit chain and with negative coefficients."""
