@@ -98,6 +98,7 @@ SIGNATURES = {
     "barrett_inv": (u64, [u64]),
     "gpq_dropin_set_logn": (None, [C.c_uint]),
     "gpq_dropin_reset": (None, []),
+    "gpq_mpi_shim_release": (None, []),
 }
 # by-value unsigned __int128 arguments cannot be expressed in ctypes; these two are
 # exercised from C (tests/c/dropin_host.c)

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <thread>
 #include <vector>
 
@@ -171,10 +172,22 @@ gpq_ctx *engine() {
   return g_engine;
 }
 
+// Device buffers of a call go back to a free list by size instead of hipFree: the same shapes come again with the next
+// he_mul / he_rs, and hipMalloc + hipFree of a few hundred MB per call cost more than the kernels.  gpq_mpi_shim_release()
+// gives the memory back.
+std::map<size_t, std::vector<void *>> g_pool;
+
 struct DevBuf {
   void *p = nullptr;
-  explicit DevBuf(size_t bytes) { if (gpq_malloc(&p, bytes ? bytes : 8) != GPQ_OK) die("device allocation failed"); }
-  ~DevBuf() { (void)gpq_free(p); }
+  size_t bytes;
+  explicit DevBuf(size_t b) : bytes(b ? b : 8) {
+    auto it = g_pool.find(bytes);
+    if (it != g_pool.end() && !it->second.empty()) { p = it->second.back(); it->second.pop_back(); return; }
+    if (gpq_malloc(&p, bytes) != GPQ_OK) die("device allocation failed");
+  }
+  ~DevBuf() { g_pool[bytes].push_back(p); }
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
   uint64_t *u64() const { return (uint64_t *)p; }
 };
 
@@ -401,6 +414,14 @@ static void automorphism(he_ct_t *ct, const he_evk_t *key, bool conj, unsigned r
 }
 void he_conj(he_ct_t *ct, const he_evk_t *ck) { automorphism(ct, ck, true, 0); }
 void he_rot(he_ct_t *ct, const int rot, const he_evk_t *rk) { automorphism(ct, &rk[rot], false, (unsigned)rot); }   // rk[rot], :110
+
+// frees the device buffers the MPI-typed calls keep between calls, and the engine context
+void gpq_mpi_shim_release(void) {
+  (void)gpq_stream_sync(nullptr);
+  for (auto &kv : g_pool) for (void *q : kv.second) (void)gpq_free(q);
+  g_pool.clear();
+  if (g_engine) { gpq_ctx_destroy(g_engine); g_engine = nullptr; }
+}
 
 void he_rs(struct he_ct *ct) { rescale_common(ct, true); }        // src/he-rescale.c:33-54
 void he_rescale(struct he_ct *ct) { rescale_common(ct, true); }

@@ -133,6 +133,8 @@ void he_rot(he_ct_t *ct, const int rot, const he_evk_t *rk);                    
 void gpq_dropin_set_logn(unsigned int logn);
 /* Releases the device tables the drop-in calls cached (per rns_ctx). */
 void gpq_dropin_reset(void);
+/* Releases the device buffers and the engine context the MPI-typed calls keep between calls. */
+void gpq_mpi_shim_release(void);
 
 #ifdef __cplusplus
 }
