@@ -59,18 +59,18 @@ __device__ __forceinline__ uint64_t fold_word(int64_t L, int64_t H, int64_t &car
 
 // ---------------------------------------------------------------------------
 // rns_decompose on the matrix cores.
-//   A[m][k]        = byte k of coefficient m, as s = u - 128 (top byte of the top word: signed as it is)
-//   B[k][8j + b]   = balanced digit b of T_jk = 256^k mod p_j
-//   C[m][8j + b]   = sum_k A B        |C| <= 8W * 2^14
-//   x mod p_j      = sum_b C[8j+b] 256^b + K_j,     K_j = 128 * sum_{k < 8W-1} 256^k mod p_j
-// One wave owns 64 consecutive coefficients (two 32-row tiles); the constant matrix sits in LDS.
-// Epilogue per (coefficient, prime): H = C7..C4, L = C3..C0 by Horner (46 bits each),
-//   V = H 2^32 + L,  H = Hh 2^27 + Hl  =>  V == Hl 2^32 + L - c Hh  (mod p),  + Kq_j, in (0, 3p) -> canonical.
+//   constants  T[8j + b][k] = balanced digit b of 256^k mod p_j            (A operand, rows = prime j's eight digits)
+//   data       X[k][m]      = byte k of coefficient m, as s = u - 128 (top byte of the top word: signed as it is)
+//   D[8j + b][m] = sum_k T X        |D| <= 8W * 2^14
+//   x mod p_j  = sum_b D[8j+b] 256^b + K_j,     K_j = 128 * sum_{k < 8W-1} 256^k mod p_j
+// One wave owns 64 consecutive coefficients (two 32-column tiles); the constant fragments sit in LDS.
+// Epilogue per (coefficient, prime): L = D3..D0 and H = D7..D4 by Horner (46 bits each), exchanged between the lane
+// halves,  V = H 2^32 + L,  H = Hh 2^27 + Hl  =>  V == Hl 2^32 + L - c Hh  (mod p),  + Kq_j, in (0, 3p) -> canonical.
 // ---------------------------------------------------------------------------
 struct DecomposeMfmaArgs {
   const uint64_t *big;       // [polys][W][n]
   uint64_t *slab;            // [polys][dim][n]
-  const v4i *bfrag;          // [NT][KS][64]: the B fragment of lane l for (column tile, k step)
+  const v4i *bfrag;          // [NT][KS][64]: the constant (A) fragment of lane l for (row tile, k step)
   const uint64_t *pk;        // [4 NT][3]: p_j, Kq_j = 2^50 + ((K_j - 2^50) mod p_j), c_j   (zeros for padding primes)
   unsigned W, dim, logn, NT;               // NT: row tiles of 4 primes
   unsigned groups_per_poly, total_groups;  // groups of 64 coefficients
@@ -148,10 +148,10 @@ __global__ __launch_bounds__(256, 2) void bridge_decompose_mfma(DecomposeMfmaArg
 // ---------------------------------------------------------------------------
 // poly_rns2mpi fast path (q = 2^logq, centred; see bridge_reconstruct_low) on the matrix cores.
 //   y_d = ahat_d * phat_invmp_d mod p_d                       VALU, by the lane that owns (row, limb) in the A layout
-//   A[m][8d + i]   = byte i of y_d, as s = u - 128
-//   B[8d + i][n]   = balanced digit n - i of phat_d mod 2^(64 WL)         columns 0 .. 8WL-1   (S)
-//                    balanced digit m - i of floor(2^104 / p_d)           columns 8WL + m, m < 14   (F)
-//   S = sum_n C[n] 256^n + Kc  (mod 2^(64 WL)),   F = sum_m C[8WL+m] 256^m + Kf
+//   data       X[8d + i][m] = byte i of y_d of coefficient m, as s = u - 128
+//   constants  T[n][8d + i] = balanced digit n - i of phat_d mod 2^(64 WL)         rows 0 .. 8WL-1   (S)
+//                             balanced digit m - i of floor(2^104 / p_d)           rows 8WL + m, m < 14   (F)
+//   S = sum_n D[n] 256^n + Kc  (mod 2^(64 WL)),   F = sum_m D[8WL+m] 256^m + Kf
 //   F underestimates 2^104 S/P by less than dim 2^60 < 2^66:  k = F >> 104, centred <=> bit 103,
 //   coefficients with frac(F) in [1/2 - 2^-38, 1/2) are flagged for the exact kernel (as bridge_reconstruct_low does
 //   with its 2^-61 window); result = S - (k + centred) P, masked and sign-extended at logq.
