@@ -153,6 +153,50 @@ def test_he_mul_by_one_is_identity_full_size(engine_ctx):
     assert torch.equal(o0, c0) and torch.equal(o1, c1)
 
 
+def test_he_swk_with_the_key_P_at_config5_size(engine_ctx):
+    """BASELINE configs[4] shape (n = 2^17, 44 limbs: q = 2^835 gives dimP/dimB = 15/44), size-independent property: with
+    swk.p0 = the constant polynomial P (its residues in every NTT slot; zero in the limbs of P itself) and swk.p1 = 0 the key
+    switch computes d1 * P, the division by P gives d1 back exactly, so he_swk returns (d0 + d1, 0) centred mod q.  Runs the
+    split-twiddle and the 7-mad butterflies in one transform (the chain's larger primes) and the matrix-core tail."""
+    torch = _torch()
+    logn, logq = 17, 835
+    g = engine_ctx(logn, 44)
+    dimP = (logq + 1 + logn) // 59 + 1
+    P = 1
+    for d in range(dimP):
+        P *= g.p[d]
+    dimB = (logq + 1 + P.bit_length() + logq + logn) // 59 + 1
+    assert (dimP, dimB) == (15, 44)
+    n, W = g.n, (logq + 64) // 64
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(17)
+
+    def centred(bits):
+        big = torch.randint(-(1 << 62), 1 << 62, (W, n), dtype=torch.int64, device="cuda", generator=gen)
+        top = bits - 64 * (W - 1)
+        big[W - 1] = torch.randint(-(1 << (top - 1)), 1 << (top - 1), (n,), dtype=torch.int64, device="cuda", generator=gen)
+        return big.reshape(-1).contiguous()
+
+    d0, d1 = centred(logq - 2), centred(logq - 2)            # |d0 + d1| < q/2: no wrap in the expected sum
+    swk0 = torch.cat([torch.full((n,), P % g.p[d], dtype=torch.int64, device="cuda") for d in range(dimB)])
+    swk1 = torch.zeros_like(swk0)
+    o0, o1 = torch.empty_like(d0), torch.empty_like(d0)
+    g.he_swk(o0, o1, d0, d1, swk0, swk1, W, logq, dimB, dimP)
+    host0, host1 = to_host(d0).reshape(W, n), to_host(d1).reshape(W, n)
+    exp = np.zeros((W, n), dtype=np.uint64)
+    carry = np.zeros(n, dtype=np.uint64)
+    for j in range(W):                                        # multiword d0 + d1 with numpy (two's complement)
+        a, b = host0[j].astype(np.uint64), host1[j].astype(np.uint64)
+        s1 = a + b
+        c1 = (s1 < a).astype(np.uint64)
+        s2 = s1 + carry
+        c2 = (s2 < s1).astype(np.uint64)
+        exp[j] = s2
+        carry = c1 + c2
+    assert np.array_equal(to_host(o0).reshape(W, n).astype(np.uint64), exp)
+    assert not to_host(o1).any()
+
+
 @pytest.mark.parametrize("logn,W", [(7, 2), (9, 14)])
 def test_poly_rot_and_conj_on_big_slabs(engine_ctx, logn, W):
     """src/poly.c:263-283 as signed permutations of big slabs (two polynomials per call)."""
