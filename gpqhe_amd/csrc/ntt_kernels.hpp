@@ -346,13 +346,17 @@ struct ContigBlock {       // per-workgroup addressing shared by the contiguous 
 // exactly once per limb), so one workgroup walks CONTIG_POLYS polynomials of
 // the same limb and tile with the 30 twiddles of a lane held in registers, and
 // fetches the next polynomial's coefficients while it works on the current one.
-constexpr int CONTIG_POLYS = 4;
+#ifndef GPQ_CONTIG_POLYS
+#define GPQ_CONTIG_POLYS 2   /* 2 polynomials per workgroup at 3 waves per SIMD beat 4 at 2 (split twiddles): -13 % on both passes */
+#endif
+constexpr int CONTIG_POLYS = GPQ_CONTIG_POLYS;
 
 #ifndef GPQ_CONTIG_MINWAVES
-#define GPQ_CONTIG_MINWAVES 2
+#define GPQ_CONTIG_MINWAVES 3
 #endif
+// (the plain-twiddle form keeps its 30 twiddles and a prefetched polynomial in registers: 2 waves per SIMD)
 template <bool INV, typename TW>
-__global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_CONTIG_MINWAVES) void contig_pass(PassArgs a, unsigned polys) {
+__global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTIG_MINWAVES)) void contig_pass(PassArgs a, unsigned polys) {
   using TT = TwTraits<TW>;
   __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
   const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
