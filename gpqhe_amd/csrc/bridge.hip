@@ -23,6 +23,21 @@ namespace {
 typedef unsigned __int128 u128h;
 typedef std::vector<uint64_t> Big;  // little-endian words, unsigned
 
+// Dynamic LDS above 64 KB needs the function attribute, once per (kernel, device).
+struct LdsRaised {
+  bool dev[64] = {};
+  int raise(const void *fn, int bytes) {
+    int d = 0;
+    HIP_TRY(hipGetDevice(&d));
+    if (d < 0 || d >= 64 || !dev[d]) {
+      HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      if (d >= 0 && d < 64) dev[d] = true;
+    }
+    return GPQ_OK;
+  }
+};
+
+
 void mul_small(Big &a, uint64_t m) {
   uint64_t carry = 0;
   for (auto &w : a) { u128h t = (u128h)w * m + carry; w = (uint64_t)t; carry = (uint64_t)(t >> 64); }
@@ -239,11 +254,8 @@ int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out
 
 template <int WL>
 int launch_low_mfma(const ReconMfmaArgs &a, size_t lds, hipStream_t s) {
-  static bool raised = false;
-  if (!raised) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&bridge_reconstruct_low_mfma<WL>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    raised = true;
-  }
+  static LdsRaised raised;
+  if (int rc = raised.raise(reinterpret_cast<const void *>(&bridge_reconstruct_low_mfma<WL>), 156 * 1024)) return rc;
   unsigned blocks = 256;                                   // one 8-wave workgroup per CU (LDS), persistent over the groups
   if (blocks > (a.total_groups + 7) / 8) blocks = (a.total_groups + 7) / 8;
   hipLaunchKernelGGL((bridge_reconstruct_low_mfma<WL>), dim3(blocks), dim3(512), lds, s, a);
@@ -381,11 +393,8 @@ int get_decomp_mfma(gpq_ctx *c, unsigned limb0, unsigned dim, unsigned W, gpq_de
 
 template <int KS>
 int launch_decompose_mfma_t(const DecomposeMfmaArgs &a, size_t lds, hipStream_t s) {
-  static bool raised = false;
-  if (!raised) {   // dynamic LDS above 64 KB needs the attribute once per kernel
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&bridge_decompose_mfma<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfmaLdsMax));
-    raised = true;
-  }
+  static LdsRaised raised;
+  if (int rc = raised.raise(reinterpret_cast<const void *>(&bridge_decompose_mfma<KS>), (int)kMfmaLdsMax)) return rc;
   unsigned per_cu = (unsigned)((160 * 1024) / lds);     // workgroups a CU's LDS holds; the registers allow 3
   if (per_cu > 4) per_cu = 4;
   if (per_cu < 1) per_cu = 1;
@@ -656,11 +665,8 @@ int get_relin_front(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables *
 
 template <int KS>
 int launch_relin_front_t(const RelinFrontArgs &a, size_t lds, hipStream_t s) {
-  static bool raised = false;
-  if (!raised) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&bridge_relin_front_mfma<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfmaLdsMax));
-    raised = true;
-  }
+  static LdsRaised raised;
+  if (int rc = raised.raise(reinterpret_cast<const void *>(&bridge_relin_front_mfma<KS>), (int)kMfmaLdsMax)) return rc;
   unsigned per_cu = (unsigned)((160 * 1024) / lds);
   if (per_cu > 3) per_cu = 3;
   if (per_cu < 1) per_cu = 1;
