@@ -1,0 +1,71 @@
+"""Parity sweep of the MPI-level chain at n = 64 (the smallest ring the matrix-core bridge takes) over modulus sizes up to
+the headline's: every limb count, word count and k-step count of the bridge kernels appears at least once, and the expected
+values come from the Python-integer restatement of src/he-mult.c / src/he-automorphism.c (oracle/bigint_ref.py)."""
+import random
+
+import numpy as np
+import pytest
+
+from gpqhe_amd import big_to_ints, ints_to_big, to_device, to_host
+from oracle import bigint_ref as ref
+
+pytestmark = pytest.mark.gpu
+LOGN = 6
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _centred(rng, logq, n):
+    half = 1 << (logq - 1)
+    edge = [half - 1, -half, 0, 1, -1]
+    return [edge[i] if i < len(edge) else rng.randrange(-half, half) for i in range(n)]
+
+
+@pytest.mark.parametrize("mfma", [True, False])
+@pytest.mark.parametrize("logqL,logql", [(300, 300), (300, 180), (438, 438), (438, 88), (610, 610), (610, 350), (850, 850), (850, 400), (1000, 1000)])
+def test_he_mul_and_he_swk_sweep(engine_ctx, oracle_ctx, logqL, logql, mfma):
+    torch = _torch()
+    probe = engine_ctx(LOGN, 20)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logqL, logql)
+    g, o = engine_ctx(LOGN, dimevk), oracle_ctx(LOGN, dimevk)
+    assert ref.he_dims(LOGN, o.p, logqL, logql) == (dimP, dimA, dimB, dimevk)
+    g.set_bridge_mfma(mfma)
+    try:
+        n, W = g.n, (logql + 64) // 64
+        rng = random.Random(logqL * 1000 + logql)
+        k0, k1 = o.gen(7000 + logqL, dimevk), o.gen(7001 + logqL, dimevk)
+        ct = [_centred(rng, logql, n) for _ in range(4)]
+        dev = [to_device(ints_to_big(v, W)) for v in ct]
+        o0, o1 = torch.empty_like(dev[0]), torch.empty_like(dev[0])
+        g.he_mul(o0, o1, dev[0], dev[1], dev[2], dev[3], to_device(k0), to_device(k1), W, logql, dimA, dimB, dimP)
+        e0, e1 = ref.he_mul(o, (ct[0], ct[1]), (ct[2], ct[3]), k0[: dimB * n], k1[: dimB * n], dimP, dimA, dimB, logql)
+        assert big_to_ints(to_host(o0), W, n)[0] == e0
+        assert big_to_ints(to_host(o1), W, n)[0] == e1
+        g.he_swk(o0, o1, dev[0], dev[1], to_device(k0), to_device(k1), W, logql, dimB, dimP)
+        s0, s1 = ref.he_swk(o, ct[0], ct[1], k0[: dimB * n], k1[: dimB * n], dimP, dimB, logql)
+        assert big_to_ints(to_host(o0), W, n)[0] == s0
+        assert big_to_ints(to_host(o1), W, n)[0] == s1
+    finally:
+        g.set_bridge_mfma(True)
+
+
+@pytest.mark.parametrize("dim,logq", [(4, 60), (5, 128), (8, 250), (11, 320), (16, 448), (20, 500), (23, 640), (31, 850), (37, 896), (44, 1000), (58, 1020)])
+def test_poly_mul_sweep(engine_ctx, oracle_ctx, dim, logq):
+    """poly_mul (src/poly.c:84-107) with q = 2^logq on `dim` limbs: decompose, NTT, product, INTT, CRT -- against the negacyclic
+    product of the centred inputs (inputs sized so that the product fits the basis, as the reference's callers guarantee)."""
+    torch = _torch()
+    g = engine_ctx(LOGN, max(dim, 12))
+    n = g.n
+    P = 1
+    for d in range(dim):
+        P *= g.p[d]
+    bits = min(logq, (P.bit_length() - LOGN - 3) // 2)       # |a*b| summed over n terms stays below P/2
+    W = (max(bits, logq) + 64) // 64
+    rng = random.Random(dim * 100 + logq)
+    a, b = _centred(rng, bits, n), _centred(rng, bits, n)
+    r = torch.empty(W * n, dtype=torch.int64, device="cuda")
+    g.poly_mul(r, to_device(ints_to_big(a, W)), to_device(ints_to_big(b, W)), W, dim, logq)
+    assert big_to_ints(to_host(r), W, n)[0] == [ref.centred_mod(v, 1 << logq) for v in ref.negacyclic_mul(a, b)]
