@@ -69,3 +69,25 @@ def test_poly_mul_sweep(engine_ctx, oracle_ctx, dim, logq):
     r = torch.empty(W * n, dtype=torch.int64, device="cuda")
     g.poly_mul(r, to_device(ints_to_big(a, W)), to_device(ints_to_big(b, W)), W, dim, logq)
     assert big_to_ints(to_host(r), W, n)[0] == [ref.centred_mod(v, 1 << logq) for v in ref.negacyclic_mul(a, b)]
+
+
+@pytest.mark.parametrize("logql,lognu", [(88, 30), (200, 40), (438, 50), (610, 50), (850, 50), (1000, 60)])
+def test_he_mulpt_and_he_rs_sweep(engine_ctx, oracle_ctx, logql, lognu):
+    """he_mulpt (src/he-mult.c:159-196; dim from log2(pt->nu) as :169) followed by he_rs (src/he-rescale.c:33-54)"""
+    torch = _torch()
+    dim = (logql + 1 + lognu + LOGN) // 59 + 1
+    g, o = engine_ctx(LOGN, max(dim, 20)), oracle_ctx(LOGN, max(dim, 20))
+    n, W = g.n, (logql + 64) // 64
+    rng = random.Random(logql + lognu)
+    ct = [_centred(rng, logql, n) for _ in range(2)]
+    m = [rng.randrange(-(1 << lognu), 1 << lognu) for _ in range(n)]
+    d0, d1, dm = (to_device(ints_to_big(v, W)) for v in (ct[0], ct[1], m))
+    o0, o1 = torch.empty_like(d0), torch.empty_like(d0)
+    g.he_mulpt(o0, o1, d0, d1, dm, W, logql, dim)
+    e0, e1 = ref.he_mulpt(o, ct, m, dim, logql)
+    assert big_to_ints(to_host(o0), W, n)[0] == e0 and big_to_ints(to_host(o1), W, n)[0] == e1
+    s = min(lognu, logql - 2)
+    g.he_rs(o0, o1, W, s, logql - s)                       # Delta = 2^s, q_{l-1} = 2^(logql - s)
+    r0 = [ref.mpi_smod(ref.mpi_rdiv(v, 1 << s), 1 << (logql - s)) for v in e0]
+    r1 = [ref.mpi_smod(ref.mpi_rdiv(v, 1 << s), 1 << (logql - s)) for v in e1]
+    assert big_to_ints(to_host(o0), W, n)[0] == r0 and big_to_ints(to_host(o1), W, n)[0] == r1
