@@ -91,3 +91,41 @@ def test_he_mulpt_and_he_rs_sweep(engine_ctx, oracle_ctx, logql, lognu):
     r0 = [ref.mpi_smod(ref.mpi_rdiv(v, 1 << s), 1 << (logql - s)) for v in e0]
     r1 = [ref.mpi_smod(ref.mpi_rdiv(v, 1 << s), 1 << (logql - s)) for v in e1]
     assert big_to_ints(to_host(o0), W, n)[0] == r0 and big_to_ints(to_host(o1), W, n)[0] == r1
+
+
+def test_bridge_random_shapes(engine_ctx):
+    """Seeded random (limbs, words, first limb) shapes at n = 64: matrix-core and VALU rns_decompose agree with each other and
+    with Python's floor mod; poly_rns2mpi of the result gives the centred value back."""
+    torch = _torch()
+    g = engine_ctx(LOGN, 58)
+    n = g.n
+    rng = random.Random(20261004)
+    for _ in range(24):
+        W = rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 13, 14, 16, 17, 24, 31, 32])
+        dim = rng.randrange(4, 59)
+        bits = rng.randrange(8, 64 * W)
+        vals = [rng.randrange(-(1 << (bits - 1)), 1 << (bits - 1)) for _ in range(n)]
+        vals[:4] = [0, -1, (1 << (bits - 1)) - 1, -(1 << (bits - 1))]
+        big = to_device(ints_to_big(vals, W))
+        outs = []
+        try:
+            for mfma in (True, False):
+                g.set_bridge_mfma(mfma)
+                slab = torch.empty(dim * n, dtype=torch.int64, device="cuda")
+                g.rns_decompose(slab, big, W, dim)
+                outs.append(slab)
+        finally:
+            g.set_bridge_mfma(True)
+        assert torch.equal(outs[0], outs[1]), (W, dim, bits)
+        host = to_host(outs[0]).reshape(dim, n)
+        for d in (0, dim // 2, dim - 1):
+            assert [int(x) for x in host[d]] == [v % g.p[d] for v in vals], (W, dim, d)
+        P = 1
+        for d in range(dim):
+            P *= g.p[d]
+        logq = bits + 1
+        if P.bit_length() >= 160 and 2 * logq < P.bit_length() and logq <= 1024:      # the values are below P/2: CRT returns them
+            Wq = (logq + 63) // 64
+            back = torch.empty(Wq * n, dtype=torch.int64, device="cuda")
+            g.rns_reconstruct(back, Wq, outs[0], dim, logq)
+            assert big_to_ints(to_host(back), Wq, n)[0] == vals, (W, dim, bits)
