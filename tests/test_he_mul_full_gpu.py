@@ -318,3 +318,49 @@ def test_he_mul_headline_dims_against_restated_reference(engine_ctx, oracle_ctx)
     ql = 1 << (logq - logDelta)
     assert big_to_ints(to_host(o0), W, n)[0] == [ref.mpi_smod(ref.mpi_rdiv(v, 1 << logDelta), ql) for v in e0]
     assert big_to_ints(to_host(o1), W, n)[0] == [ref.mpi_smod(ref.mpi_rdiv(v, 1 << logDelta), ql) for v in e1]
+
+
+def test_he_mul_is_graph_capturable_after_the_first_call(engine_ctx):
+    """After one warm-up call (tables are built on first use) gpq_he_mul is a pure sequence of kernel launches on the caller's
+    stream: it can be captured into a HIP graph and replayed on new inputs."""
+    torch = _torch()
+    logn, logq = 13, 438
+    probe = engine_ctx(logn, 20)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logq, logq)
+    g = engine_ctx(logn, dimevk)
+    n, W = g.n, (logq + 64) // 64
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(31)
+
+    def centred():
+        big = torch.randint(-(1 << 62), 1 << 62, (W, n), dtype=torch.int64, device="cuda", generator=gen)
+        big[W - 1] = torch.randint(-(1 << 20), 1 << 20, (n,), dtype=torch.int64, device="cuda", generator=gen)   # 438 - 6*64 = 54 bits
+        return big.reshape(-1).contiguous()
+
+    ins = [centred() for _ in range(4)]
+    rlk = [torch.cat([torch.randint(0, g.p[d], (n,), dtype=torch.int64, device="cuda", generator=gen) for d in range(dimB)]) for _ in range(2)]
+    o0, o1 = torch.empty_like(ins[0]), torch.empty_like(ins[0])
+    nbytes = g.lib.gpq_he_mul_workspace_bytes(g.h, W, dimA, dimB, dimP, 1)
+    ws = torch.empty(nbytes // 8 + 8, dtype=torch.int64, device="cuda")
+
+    def call():
+        from gpqhe_amd import _native
+        from gpqhe_amd.engine import _ptr, _stream
+        _native.check(g.lib.gpq_he_mul(g.h, _ptr(o0), _ptr(o1), *[_ptr(v) for v in ins], _ptr(rlk[0]), _ptr(rlk[1]), W, logq, dimA, dimB, dimP,
+                                       1, _ptr(ws), _stream()), "gpq_he_mul")
+
+    call()                                               # warm-up: builds the CRT / matrix tables
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call()
+    fresh = [centred() for _ in range(4)]
+    for dst, src in zip(ins, fresh):
+        dst.copy_(src)
+    graph.replay()
+    torch.cuda.synchronize()
+    r0, r1 = o0.clone(), o1.clone()
+    call()
+    torch.cuda.synchronize()
+    assert torch.equal(r0, o0) and torch.equal(r1, o1)
+    assert bool((r0 != 0).any())
