@@ -105,3 +105,76 @@ def test_add_sub_neg_and_evk_pack(engine_ctx, oracle_ctx):
     evk = torch.empty(dimevk * n, dtype=torch.int64, device="cuda")
     assert g.lib.gpq_evk_pack(g.h, P(evk), P(da), W, dimevk, 1, st) == 0
     assert np.array_equal(to_host(evk), _evk_slab(o, a, dimevk))
+
+
+def _sparse_negacyclic(dense, terms, n):
+    """dense * (sum of c x^k) mod x^n + 1, exactly, in O(len(terms) n)"""
+    out = [0] * n
+    for k, c in terms:
+        for i, v in enumerate(dense):
+            j = i + k
+            if j < n:
+                out[j] += c * v
+            else:
+                out[j - n] -= c * v
+    return out
+
+
+def _dense_of(terms, n):
+    out = [0] * n
+    for k, c in terms:
+        out[k] += c
+    return out
+
+
+@pytest.mark.parametrize("logn,logq,logDelta", [(13, 438, 40), (14, 438, 50)])
+def test_encrypt_mul_rescale_decrypt_at_two_pass_sizes(engine_ctx, oracle_ctx, logn, logq, logDelta):
+    """The same round trip at ring sizes that take the two-pass NTT kernels and the matrix-core bridge (the reference's own test
+    default is logn = 14, q = 2^438, tests/gpqhe.c:1349-1352).  Every host-side polynomial product has one sparse factor (secret,
+    key mask, encryption mask and the second message have a few terms), so the expected values stay exact Python integers."""
+    import torch
+    n, q, Delta = 1 << logn, 1 << logq, 1 << logDelta
+    probe = engine_ctx(logn, 20)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logq, logq)
+    g, o = engine_ctx(logn, dimevk), oracle_ctx(logn, dimevk)
+    rng = random.Random(77 + logn)
+    P = ref.RnsBasis(o.p[:dimP]).P
+    PqL = P * q
+    sparse = lambda cnt, draw: sorted({rng.randrange(n): draw() for _ in range(cnt)}.items())
+    err = lambda: [rng.randrange(-8, 9) for _ in range(n)]
+    s_terms = sparse(24, lambda: rng.choice((-1, 1)))
+    s = _dense_of(s_terms, n)
+    s2 = _sparse_negacyclic(s, s_terms, n)
+    p1_terms = sparse(6, lambda: rng.randrange(PqL))
+    p1 = _dense_of(p1_terms, n)
+    p1s = _sparse_negacyclic(s, p1_terms, n)                                 # p1 * s
+    e = err()
+    p0 = [ref.mpi_smod(-a + b + P * c, PqL) for a, b, c in zip(p1s, e, s2)]
+    rlk0, rlk1 = _evk_slab(o, p0, dimevk), _evk_slab(o, [ref.mpi_smod(v, PqL) for v in p1], dimevk)
+
+    def encrypt(m):
+        a_terms = sparse(6, lambda: rng.randrange(q))
+        a_s = _sparse_negacyclic(s, a_terms, n)
+        return [ref.centred_mod(-x + mm + ee, q) for x, mm, ee in zip(a_s, m, err())], [ref.centred_mod(v, q) for v in _dense_of(a_terms, n)]
+
+    def decrypt(c0, c1, ql):
+        return [ref.centred_mod(x + y, ql) for x, y in zip(c0, _sparse_negacyclic(c1, s_terms, n))]
+
+    m1 = [rng.randrange(-50, 51) * Delta for _ in range(n)]
+    m2_terms = sparse(5, lambda: rng.randrange(-50, 51) * Delta)
+    m2 = _dense_of(m2_terms, n)
+    ct1, ct2 = encrypt(m1), encrypt(m2)
+    W = logq // 64 + 1
+    dev = [to_device(ints_to_big(v, W)) for v in (ct1[0], ct1[1], ct2[0], ct2[1])]
+    o0, o1 = torch.empty_like(dev[0]), torch.empty_like(dev[0])
+    g.he_mul(o0, o1, *dev, to_device(rlk0), to_device(rlk1), W, logq, dimA, dimB, dimP)
+    c0, c1 = big_to_ints(to_host(o0), W, n)[0], big_to_ints(to_host(o1), W, n)[0]
+    want = [ref.centred_mod(v, q) for v in _sparse_negacyclic(m1, m2_terms, n)]
+    got = decrypt(c0, c1, q)
+    noise = max(abs(x - y) for x, y in zip(got, want))
+    assert noise < (max(abs(v) for v in want) >> 12), "relative error 2^%d" % (noise.bit_length() - max(abs(v) for v in want).bit_length())
+    g.he_rs(o0, o1, W, logDelta, logq - logDelta)
+    r0, r1 = big_to_ints(to_host(o0), W, n)[0], big_to_ints(to_host(o1), W, n)[0]
+    got_rs = decrypt(r0, r1, q >> logDelta)
+    want_rs = [ref.centred_mod(ref.mpi_rdiv(v, Delta), q >> logDelta) for v in want]
+    assert max(abs(x - y) for x, y in zip(got_rs, want_rs)) < 2**30
