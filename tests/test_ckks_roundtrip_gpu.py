@@ -127,7 +127,7 @@ def _dense_of(terms, n):
     return out
 
 
-@pytest.mark.parametrize("logn,logq,logDelta", [(13, 438, 40), (14, 438, 50)])
+@pytest.mark.parametrize("logn,logq,logDelta", [(13, 438, 40), (14, 438, 50), (16, 850, 50)])
 def test_encrypt_mul_rescale_decrypt_at_two_pass_sizes(engine_ctx, oracle_ctx, logn, logq, logDelta):
     """The same round trip at ring sizes that take the two-pass NTT kernels and the matrix-core bridge (the reference's own test
     default is logn = 14, q = 2^438, tests/gpqhe.c:1349-1352).  Every host-side polynomial product has one sparse factor (secret,
