@@ -178,3 +178,48 @@ def test_encrypt_mul_rescale_decrypt_at_two_pass_sizes(engine_ctx, oracle_ctx, l
     got_rs = decrypt(r0, r1, q >> logDelta)
     want_rs = [ref.centred_mod(ref.mpi_rdiv(v, Delta), q >> logDelta) for v in want]
     assert max(abs(x - y) for x, y in zip(got_rs, want_rs)) < 2**30
+
+
+@pytest.mark.parametrize("logn,logq,which", [(13, 438, "rot3"), (16, 850, "rot1"), (16, 850, "conj")])
+def test_rotate_and_conjugate_decrypt_to_the_permuted_message(engine_ctx, oracle_ctx, logn, logq, which):
+    """he_rot / he_conj (src/he-automorphism.c:87-115): permute both polynomials (src/poly.c:263-283), key-switch from the permuted
+    secret back to s with a key built as he_genswk does (src/he-kem.c:74-118).  The result must decrypt under s to the permuted
+    message.  Sparse secret and masks keep every host-side product exact and cheap, at the two-pass sizes up to the headline's."""
+    import torch
+    n, q = 1 << logn, 1 << logq
+    probe = engine_ctx(logn, 20)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logq, logq)
+    g, o = engine_ctx(logn, dimevk), oracle_ctx(logn, dimevk)
+    rng = random.Random(99 + logn)
+    P = ref.RnsBasis(o.p[:dimP]).P
+    PqL = P * q
+    perm = (lambda a: ref.poly_conj(a)) if which == "conj" else (lambda a: ref.poly_rot(a, int(which[3:])))
+    sparse = lambda cnt, draw: sorted({rng.randrange(n): draw() for _ in range(cnt)}.items())
+    terms_of = lambda dense: [(i, v) for i, v in enumerate(dense) if v]
+    err = lambda: [rng.randrange(-8, 9) for _ in range(n)]
+    s_terms = sparse(24, lambda: rng.choice((-1, 1)))
+    s = _dense_of(s_terms, n)
+    sp = perm(s)                                                             # the secret the permuted ciphertext is under
+    p1_terms = sparse(6, lambda: rng.randrange(PqL))
+    p1 = _dense_of(p1_terms, n)
+    p0 = [ref.mpi_smod(-a + b + P * c, PqL) for a, b, c in zip(_sparse_negacyclic(s, p1_terms, n), err(), sp)]
+    swk0, swk1 = _evk_slab(o, p0, dimevk), _evk_slab(o, [ref.mpi_smod(v, PqL) for v in p1], dimevk)
+    a_terms = sparse(6, lambda: rng.randrange(q))
+    m = [rng.randrange(-1000, 1001) << 40 for _ in range(n)]
+    c0 = [ref.centred_mod(-x + mm + ee, q) for x, mm, ee in zip(_sparse_negacyclic(s, a_terms, n), m, err())]
+    c1 = [ref.centred_mod(v, q) for v in _dense_of(a_terms, n)]
+    W = logq // 64 + 1
+    d0, d1 = to_device(ints_to_big(c0, W)), to_device(ints_to_big(c1, W))
+    r0, r1 = torch.empty_like(d0), torch.empty_like(d0)
+    if which == "conj":
+        g.poly_conj(r0, d0, W); g.poly_conj(r1, d1, W)
+    else:
+        g.poly_rot(r0, d0, W, int(which[3:])); g.poly_rot(r1, d1, W, int(which[3:]))
+    assert big_to_ints(to_host(r1), W, n)[0] == perm(c1)                    # the permutation itself, exactly
+    o0, o1 = torch.empty_like(d0), torch.empty_like(d0)
+    g.he_swk(o0, o1, r0, r1, to_device(swk0), to_device(swk1), W, logq, dimB, dimP)
+    k0, k1 = big_to_ints(to_host(o0), W, n)[0], big_to_ints(to_host(o1), W, n)[0]
+    got = [ref.centred_mod(x + y, q) for x, y in zip(k0, _sparse_negacyclic(k1, s_terms, n))]
+    want = perm(m)
+    assert max(abs(x - y) for x, y in zip(got, want)) < 1 << 30              # key-switching noise, far below the 2^40 scale
+    assert terms_of(sp) != s_terms
