@@ -223,3 +223,32 @@ def test_rotate_and_conjugate_decrypt_to_the_permuted_message(engine_ctx, oracle
     want = perm(m)
     assert max(abs(x - y) for x, y in zip(got, want)) < 1 << 30              # key-switching noise, far below the 2^40 scale
     assert terms_of(sp) != s_terms
+
+
+@pytest.mark.parametrize("logn,logq", [(13, 438), (16, 850)])
+def test_plaintext_multiplication_decrypts_to_the_product(engine_ctx, oracle_ctx, logn, logq):
+    """he_mulpt (src/he-mult.c:159-196): both ciphertext polynomials times the plaintext polynomial mod q_l.  The plaintext is
+    dense in the device call and has a few terms, so m * pt is exact on the host."""
+    import torch
+    n, q, lognu = 1 << logn, 1 << logq, 45
+    dim = (logq + 1 + lognu + logn) // 59 + 1                                # :169 with nu = 2^lognu
+    g = engine_ctx(logn, max(dim, 20))
+    rng = random.Random(5 + logn)
+    sparse = lambda cnt, draw: sorted({rng.randrange(n): draw() for _ in range(cnt)}.items())
+    s_terms = sparse(24, lambda: rng.choice((-1, 1)))
+    s = _dense_of(s_terms, n)
+    a_terms = sparse(6, lambda: rng.randrange(q))
+    m = [rng.randrange(-1000, 1001) << 40 for _ in range(n)]
+    c0 = [ref.centred_mod(-x + mm + rng.randrange(-8, 9), q) for x, mm in zip(_sparse_negacyclic(s, a_terms, n), m)]
+    c1 = [ref.centred_mod(v, q) for v in _dense_of(a_terms, n)]
+    pt_terms = sparse(7, lambda: rng.randrange(-(1 << lognu), 1 << lognu))
+    W = logq // 64 + 1
+    d0, d1, dp = (to_device(ints_to_big(v, W)) for v in (c0, c1, _dense_of(pt_terms, n)))
+    o0, o1 = torch.empty_like(d0), torch.empty_like(d0)
+    g.he_mulpt(o0, o1, d0, d1, dp, W, logq, dim)
+    k0, k1 = big_to_ints(to_host(o0), W, n)[0], big_to_ints(to_host(o1), W, n)[0]
+    assert k0 == [ref.centred_mod(v, q) for v in _sparse_negacyclic(c0, pt_terms, n)]       # exact, polynomial by polynomial
+    assert k1 == [ref.centred_mod(v, q) for v in _sparse_negacyclic(c1, pt_terms, n)]
+    got = [ref.centred_mod(x + y, q) for x, y in zip(k0, _sparse_negacyclic(k1, s_terms, n))]
+    want = [ref.centred_mod(v, q) for v in _sparse_negacyclic(m, pt_terms, n)]
+    assert max(abs(x - y) for x, y in zip(got, want)) < 1 << (lognu + 12)                    # noise: 7 terms * |e| * |pt|

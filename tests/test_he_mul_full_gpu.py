@@ -364,3 +364,50 @@ def test_he_mul_is_graph_capturable_after_the_first_call(engine_ctx):
     torch.cuda.synchronize()
     assert torch.equal(r0, o0) and torch.equal(r1, o1)
     assert bool((r0 != 0).any())
+
+
+def _sparse_mul(dense, terms, n):
+    out = [0] * n
+    for k, c in terms:
+        for i, v in enumerate(dense):
+            j = i + k
+            if j < n:
+                out[j] += c * v
+            else:
+                out[j - n] -= c * v
+    return out
+
+
+@pytest.mark.parametrize("logn,logq", [(13, 438), (16, 850)])
+def test_he_mul_bit_exact_at_full_size_through_sparse_operands(engine_ctx, oracle_ctx, logn, logq):
+    """Exact parity of the whole he_mul (src/he-mult.c:88-156) at the headline shape: the second ciphertext and the two key
+    polynomials have a few (full-size) coefficients each, so every polynomial product of the reference's formula is a dense-by-
+    sparse product Python integers do exactly:  d0 = c0 c0', d1 = c0 c1' + c1 c0', d2 = c1 c1' (smod q);
+    out_i = smod(d_i + rdiv(smod(d2 * rlk.p_i, P q_L), P), q)."""
+    torch = _torch()
+    n, q = 1 << logn, 1 << logq
+    probe = engine_ctx(logn, 20)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logq, logq)
+    g, o = engine_ctx(logn, dimevk), oracle_ctx(logn, dimevk)
+    P = ref.RnsBasis(o.p[:dimP]).P
+    PqL = P * q
+    rng = random.Random(4321 + logn)
+    sparse = lambda cnt, lim: sorted({rng.randrange(n): rng.randrange(-lim, lim) for _ in range(cnt)}.items())
+    dense_of = lambda terms: [dict(terms).get(i, 0) for i in range(n)]
+    c0 = [rng.randrange(-(q >> 1), q >> 1) for _ in range(n)]
+    c1 = [rng.randrange(-(q >> 1), q >> 1) for _ in range(n)]
+    t0, t1 = sparse(5, q >> 1), sparse(5, q >> 1)                            # ct2 = (c0', c1')
+    k0, k1 = sparse(6, PqL >> 1), sparse(6, PqL >> 1)                        # rlk.p0, rlk.p1 as polynomials
+    smod = ref.mpi_smod
+    d0 = [smod(v, q) for v in _sparse_mul(c0, t0, n)]
+    d2 = [smod(v, q) for v in _sparse_mul(c1, t1, n)]
+    d1 = [smod(x + y, q) for x, y in zip(_sparse_mul(c0, t1, n), _sparse_mul(c1, t0, n))]
+    exp0 = [smod(a + ref.mpi_rdiv(smod(b, PqL), P), q) for a, b in zip(d0, _sparse_mul(d2, k0, n))]
+    exp1 = [smod(a + ref.mpi_rdiv(smod(b, PqL), P), q) for a, b in zip(d1, _sparse_mul(d2, k1, n))]
+    slab = lambda poly: o.ntt_slab(np.array([v % o.p[d] for d in range(dimevk) for v in poly], dtype=np.uint64), dimevk)
+    W = logq // 64 + 1
+    dev = [to_device(ints_to_big(v, W)) for v in (c0, c1, dense_of(t0), dense_of(t1))]
+    o0, o1 = torch.empty_like(dev[0]), torch.empty_like(dev[0])
+    g.he_mul(o0, o1, *dev, to_device(slab(dense_of(k0))), to_device(slab(dense_of(k1))), W, logq, dimA, dimB, dimP)
+    assert big_to_ints(to_host(o0), W, n)[0] == exp0
+    assert big_to_ints(to_host(o1), W, n)[0] == exp1
