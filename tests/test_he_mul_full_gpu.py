@@ -411,3 +411,36 @@ def test_he_mul_bit_exact_at_full_size_through_sparse_operands(engine_ctx, oracl
     g.he_mul(o0, o1, *dev, to_device(slab(dense_of(k0))), to_device(slab(dense_of(k1))), W, logq, dimA, dimB, dimP)
     assert big_to_ints(to_host(o0), W, n)[0] == exp0
     assert big_to_ints(to_host(o1), W, n)[0] == exp1
+
+
+@pytest.mark.parametrize("logn,logq", [(14, 438), (17, 835)])
+def test_he_swk_bit_exact_at_full_size_through_sparse_keys(engine_ctx, oracle_ctx, logn, logq):
+    """Exact parity of he_swk (src/he-automorphism.c:40-85) up to BASELINE configs[4]'s shape (n = 2^17, 44 limbs): the key
+    polynomials have a few full-size coefficients, so out_0 = smod(d0 + rdiv(smod(d1 k0, P q_L), P), q) and
+    out_1 = smod(rdiv(smod(d1 k1, P q_L), P), q) are exact Python integers."""
+    torch = _torch()
+    n, q = 1 << logn, 1 << logq
+    dimP = (logq + 1 + logn) // 59 + 1
+    g0 = engine_ctx(logn, dimP)
+    P = 1
+    for d in range(dimP):
+        P *= g0.p[d]
+    PqL = P * q
+    dimB = (logq + 1 + PqL.bit_length() + logn) // 59 + 1
+    g, o = engine_ctx(logn, dimB), oracle_ctx(logn, dimB)
+    rng = random.Random(987 + logn)
+    sparse = lambda cnt, lim: sorted({rng.randrange(n): rng.randrange(-lim, lim) for _ in range(cnt)}.items())
+    dense_of = lambda terms: [dict(terms).get(i, 0) for i in range(n)]
+    d0 = [rng.randrange(-(q >> 1), q >> 1) for _ in range(n)]
+    d1 = [rng.randrange(-(q >> 1), q >> 1) for _ in range(n)]
+    k0, k1 = sparse(6, PqL >> 1), sparse(6, PqL >> 1)
+    smod = ref.mpi_smod
+    exp0 = [smod(a + ref.mpi_rdiv(smod(b, PqL), P), q) for a, b in zip(d0, _sparse_mul(d1, k0, n))]
+    exp1 = [smod(ref.mpi_rdiv(smod(b, PqL), P), q) for b in _sparse_mul(d1, k1, n)]
+    slab = lambda poly: o.ntt_slab(np.array([v % o.p[d] for d in range(dimB) for v in poly], dtype=np.uint64), dimB)
+    W = logq // 64 + 1
+    a0, a1 = to_device(ints_to_big(d0, W)), to_device(ints_to_big(d1, W))
+    o0, o1 = torch.empty_like(a0), torch.empty_like(a0)
+    g.he_swk(o0, o1, a0, a1, to_device(slab(dense_of(k0))), to_device(slab(dense_of(k1))), W, logq, dimB, dimP)
+    assert big_to_ints(to_host(o0), W, n)[0] == exp0
+    assert big_to_ints(to_host(o1), W, n)[0] == exp1
