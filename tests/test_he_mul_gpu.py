@@ -47,7 +47,8 @@ def test_golden_he_mul_core(golden, engine_ctx, oracle_ctx, logn):
     assert (fnv(c0), fnv(c1)) == (kat["c0"], kat["c1"])
 
 
-@pytest.mark.parametrize("logn,dim,batch,chunk", [(7, 5, 3, 4), (12, 2, 2, 4), (13, 2, 5, 2), (14, 3, 2, 4), (16, 2, 3, 2), (17, 2, 1, 4)])
+@pytest.mark.parametrize("logn,dim,batch,chunk", [(7, 5, 3, 4), (12, 2, 2, 4), (13, 2, 5, 2), (14, 3, 2, 4), (16, 2, 3, 2), (17, 2, 1, 4),
+                                                  (17, 44, 1, 4)])          # BASELINE configs[4]: every limb of the n = 2^17 shape
 def test_batched_core_matches_oracle(engine_ctx, oracle_ctx, logn, dim, batch, chunk):
     """Batches (including a batch that is not a multiple of the launch chunk) against the oracle."""
     o, g = oracle_ctx(logn, dim), engine_ctx(logn, dim)
