@@ -251,3 +251,34 @@ def test_poly_mul_general_modulus(engine_ctx, oracle_ctx, logn, dim, q):
     g.poly_mul_general(r, da, db, W, dim, q)
     exp = [mpi_smod(v, q) for v in negacyclic_mul(a, b)]   # |a*b| < n*3*q/2 < P/2 of the dim-limb basis
     assert big_to_ints(to_host(r), W, n)[0] == exp
+
+
+@pytest.mark.parametrize("logn", [13, 16])
+def test_poly_mul_general_modulus_exact_at_full_size(engine_ctx, logn):
+    """poly_mul with q = P q_L (odd, 1700+ bits) as he_genswk calls it (src/he-kem.c:95), n up to 2^16: dense uniform a times a
+    polynomial with a few small terms (the secret's shape), expected = smod(a * s, q) exactly."""
+    torch = _torch()
+    g = engine_ctx(logn, 45)
+    n = g.n
+    P = 1
+    for d in range(15):
+        P *= g.p[d]
+    q = P << 850
+    rng = random.Random(66 + logn)
+    a = [rng.randrange(-(q >> 1), q >> 1) for _ in range(n)]
+    terms = sorted({rng.randrange(n): rng.choice((-1, 1)) for _ in range(24)}.items())
+    s = [dict(terms).get(i, 0) for i in range(n)]
+    want = [0] * n
+    for k, c in terms:
+        for i, v in enumerate(a):
+            j = i + k
+            if j < n:
+                want[j] += c * v
+            else:
+                want[j - n] -= c * v
+    want = [mpi_smod(v, q) for v in want]
+    dim = (q.bit_length() + logn) // 59 + 1                  # src/he-kem.c:83
+    W = q.bit_length() // 64 + 1
+    r = torch.empty(W * n, dtype=torch.int64, device="cuda")
+    g.poly_mul_general(r, to_device(ints_to_big(a, W)), to_device(ints_to_big(s, W)), W, dim, q)
+    assert big_to_ints(to_host(r), W, n)[0] == want
