@@ -76,6 +76,8 @@ SIGNATURES = {
     "gpq_big_sub": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, vp]),
     "gpq_big_neg": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, vp]),
     "gpq_evk_pack": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, vp]),
+    "gpq_he_genswk_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint, C.c_uint]),
+    "gpq_he_genswk": (C.c_int, [vp] * 7 + [C.c_uint] * 4 + [vp, vp]),
     "gpq_he_swk_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
     "gpq_he_swk": (C.c_int, [vp] * 7 + [C.c_uint] * 5 + [vp, vp]),
     "gpq_profile_enable": (C.c_int, [vp, C.c_int]),

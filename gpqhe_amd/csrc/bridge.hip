@@ -1018,6 +1018,67 @@ extern "C" int gpq_evk_pack(gpq_ctx *c, uint64_t *evk, const uint64_t *big, unsi
   return rc ? rc : gpq_ntt(c, evk, dimevk, batch, stream);
 }
 
+// he_genswk, src/he-kem.c:74-118, from the polynomials the reference samples on the host (p1 uniform mod P q_L, the error e) and
+// the one the key hides (sp: s^2 for he_genrlk, the rotated / conjugated secret for he_genrk / he_genck):
+//   swk.p0 = smod(-p1 * sk + e + P * sp, P q_L),  swk.p1 = smod(p1, P q_L),  both stored as rns_decompose + ntt over dimevk limbs.
+// q_L = 2^logqL.  Big slabs of W words (W > bits(P q_L) / 64); one key per call.
+namespace {
+struct GenswkPlan { unsigned WPw, WF, dimmul, Lq; std::vector<uint64_t> PqL; size_t words; };
+int genswk_plan(gpq_ctx *c, unsigned W, unsigned dimP, unsigned logqL, GenswkPlan *p) {
+  gpq_bridge_basis *bp;
+  int rc = get_basis(c, 0, dimP, &bp);
+  if (rc) return rc;
+  Big q = bp->h_P;
+  const unsigned wsh = logqL / 64, bsh = logqL % 64;          // P << logqL
+  Big sh(q.size() + wsh + 1, 0);
+  for (size_t j = 0; j < q.size(); ++j) {
+    sh[j + wsh] |= q[j] << bsh;
+    if (bsh) sh[j + wsh + 1] |= q[j] >> (64 - bsh);
+  }
+  while (sh.size() > 1 && sh.back() == 0) sh.pop_back();
+  p->PqL = sh; p->Lq = (unsigned)sh.size();
+  p->WPw = (unsigned)bp->h_P.size();
+  p->WF = W + p->WPw + 1;
+  const unsigned nb = 64 * (p->Lq - 1) + (64 - __builtin_clzll(sh.back()));
+  p->dimmul = (nb + c->logn) / 59 + 1;                          // src/he-kem.c:83
+  if (W * 64 <= nb) return gpq_fail(GPQ_ERR_INVALID, "gpq_he_genswk: %u words cannot hold values mod P q_L (%u bits)", W, nb);
+  if (W > 32 || p->WPw > (unsigned)GENSWK_MAXP || p->dimmul > c->nprimes)
+    return gpq_fail(GPQ_ERR_UNSUPPORTED, "gpq_he_genswk: W=%u, P of %u words, %u limbs", W, p->WPw, p->dimmul);
+  p->words = ((size_t)(3 * W + p->WF) << c->logn) + (p->WPw + 7) / 8 * 8 + kModConstWords;
+  return GPQ_OK;
+}
+}  // namespace
+
+extern "C" size_t gpq_he_genswk_workspace_bytes(gpq_ctx *c, unsigned W, unsigned dimP, unsigned logqL) {
+  GenswkPlan p;
+  if (!c || genswk_plan(c, W, dimP, logqL, &p) != GPQ_OK) return 0;
+  return p.words * 8 + gpq_poly_mul_general_workspace_bytes(c, p.dimmul, 1);
+}
+
+extern "C" int gpq_he_genswk(gpq_ctx *c, uint64_t *evk0, uint64_t *evk1, const uint64_t *p1, const uint64_t *sk, const uint64_t *e,
+                             const uint64_t *sp, unsigned W, unsigned dimP, unsigned logqL, unsigned dimevk, void *workspace, void *stream) {
+  if (!c || !evk0 || !evk1 || !p1 || !sk || !e || !sp || !workspace || !logqL) return gpq_fail(GPQ_ERR_INVALID, "gpq_he_genswk: bad arguments");
+  int rc = check(c, dimevk, 1, "gpq_he_genswk");
+  if (rc) return rc;
+  GenswkPlan gp;
+  if ((rc = genswk_plan(c, W, dimP, logqL, &gp))) return rc;
+  gpq_bridge_basis *bp;
+  if ((rc = get_basis(c, 0, dimP, &bp))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = c->n;
+  uint64_t *t = (uint64_t *)workspace, *x = t + W * n, *p0 = x + gp.WF * n, *p1c = p0 + W * n, *dP = p1c + W * n,
+           *dconst = dP + (gp.WPw + 7) / 8 * 8;
+  void *wsmul = dconst + kModConstWords;
+  if ((rc = gpq_poly_mul_general(c, t, p1, sk, W, gp.dimmul, gp.PqL.data(), gp.Lq, 1, wsmul, stream))) return rc;      // :95
+  HIP_TRY(hipMemcpyAsync(dP, bp->h_P.data(), gp.WPw * 8, hipMemcpyHostToDevice, s));
+  GenswkArgs ga{t, e, sp, dP, x, W, gp.WPw, gp.WF, c->logn};
+  hipLaunchKernelGGL(bridge_genswk_combine, dim3((c->n + 63) / 64), dim3(64), 0, s, ga);                                 // :96-98
+  if ((rc = launch_smod_general(c, p0, W, x, gp.WF, gp.PqL.data(), gp.Lq, 1, dconst, s))) return rc;                    // :99
+  if ((rc = launch_smod_general(c, p1c, W, p1, W, gp.PqL.data(), gp.Lq, 1, dconst, s))) return rc;                      // :100
+  if ((rc = gpq_evk_pack(c, evk0, p0, W, dimevk, 1, stream)) || (rc = gpq_evk_pack(c, evk1, p1c, W, dimevk, 1, stream))) return rc;   // :103-110
+  return launched("gpq_he_genswk");
+}
+
 // ---------------------------------------------------------------------------
 // general q_l (any modulus, little-endian words) and Delta (any uint64_t): the same operations through the
 // Barrett kernel.  Slow-path quality (key generation / unusual parameter sets); results follow the same

@@ -377,6 +377,60 @@ __global__ __launch_bounds__(256) void bridge_roundfix(RoundFixArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// he_genswk's combination (src/he-kem.c:86-99) before the reduction mod P q_L:  x = -t + e + P * sp  per coefficient, with
+// t = swk.p1 * sk (already mod P q_L), e the error, sp the polynomial the key hides (s^2, or the rotated / conjugated s).
+// Full width (WF = W + WPw + 1 words, two's complement); mpi_smod by P q_L follows (bridge_smod_general).
+// Key-generation path: runtime word loops, per-thread arrays in scratch.
+// ---------------------------------------------------------------------------
+constexpr int GENSWK_MAXW = 48, GENSWK_MAXP = 32;
+
+struct GenswkArgs {
+  const uint64_t *t, *e, *sp;  // [W][n] each, two's complement
+  const uint64_t *P;           // [WPw]
+  uint64_t *x;                 // [WF][n]
+  unsigned W, WPw, WF, logn;
+};
+
+__global__ __launch_bounds__(64) void bridge_genswk_combine(GenswkArgs a) {
+  const unsigned i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= (1u << a.logn)) return;
+  uint64_t acc[GENSWK_MAXW + GENSWK_MAXP + 2], m[GENSWK_MAXW];
+  const unsigned W = a.W, WF = a.WF;
+  // acc = e - t, sign-extended to WF words
+  uint64_t borrow = 0;
+  for (unsigned j = 0; j < W; ++j) {
+    const u128 d = (u128)a.e[((size_t)j << a.logn) + i] - a.t[((size_t)j << a.logn) + i] - borrow;
+    acc[j] = (uint64_t)d; borrow = (uint64_t)(d >> 64) & 1;
+  }
+  const uint64_t es = (uint64_t)((int64_t)a.e[((size_t)(W - 1) << a.logn) + i] >> 63);
+  const uint64_t ts = (uint64_t)((int64_t)a.t[((size_t)(W - 1) << a.logn) + i] >> 63);
+  for (unsigned j = W; j < WF; ++j) {
+    const u128 d = (u128)es - ts - borrow;
+    acc[j] = (uint64_t)d; borrow = (uint64_t)(d >> 64) & 1;
+  }
+  // |sp| and its sign
+  const bool neg = a.sp[((size_t)(W - 1) << a.logn) + i] >> 63;
+  uint64_t carry = neg;
+  for (unsigned j = 0; j < W; ++j) {
+    uint64_t w = a.sp[((size_t)j << a.logn) + i];
+    if (neg) { w = ~w + carry; carry = carry && w == 0; }
+    m[j] = w;
+  }
+  // acc +/-= |sp| * P, row by row
+  for (unsigned j = 0; j < W; ++j) {
+    if (!m[j]) continue;
+    uint64_t c = 0, bw = 0;
+    for (unsigned k = 0; j + k < WF; ++k) {
+      const u128 pr = (u128)m[j] * (k < a.WPw ? a.P[k] : 0) + c;
+      c = (uint64_t)(pr >> 64);
+      if (neg) { const u128 d = (u128)acc[j + k] - (uint64_t)pr - bw; acc[j + k] = (uint64_t)d; bw = (uint64_t)(d >> 64) & 1; }
+      else { const u128 d = (u128)acc[j + k] + (uint64_t)pr + bw; acc[j + k] = (uint64_t)d; bw = (uint64_t)(d >> 64); }
+    }
+  }
+  for (unsigned j = 0; j < WF; ++j) a.x[((size_t)j << a.logn) + i] = acc[j];
+}
+
+// ---------------------------------------------------------------------------
 // mpi_smod(x, M, floor(M/2)) for an arbitrary modulus M of L words (src/types.c:108-113): the general
 // form of the second centring of poly_rns2mpi, needed when q is not a power of two (he_genswk calls
 // poly_mul with q = P*q_L, src/he-kem.c:95).  Multiword Barrett (HAC 14.42, base 2^64) on |x| with

@@ -199,6 +199,16 @@ class PolyContext:
         _native.check(self.lib.gpq_he_mulpt(self.h, _ptr(out_c0), _ptr(out_c1), _ptr(c0), _ptr(c1), _ptr(m), W, logql, dim, batch,
                                             _ptr(ws), _stream()), "gpq_he_mulpt")
 
+    def he_genswk(self, evk0, evk1, p1, sk, e, sp, W, dimP, logqL, dimevk):
+        """src/he-kem.c:74-118 from host-sampled p1 / e and the hidden polynomial sp; q_L = 2^logqL."""
+        torch = _torch()
+        nbytes = self.lib.gpq_he_genswk_workspace_bytes(self.h, W, dimP, logqL)
+        if not nbytes:
+            raise _native.GpqError("gpq_he_genswk_workspace_bytes: " + self.lib.gpq_last_error().decode())
+        ws = torch.empty(nbytes // 8 + 8, dtype=torch.int64, device="cuda")
+        _native.check(self.lib.gpq_he_genswk(self.h, _ptr(evk0), _ptr(evk1), _ptr(p1), _ptr(sk), _ptr(e), _ptr(sp), W, dimP, logqL, dimevk,
+                                             _ptr(ws), _stream()), "gpq_he_genswk")
+
     def poly_rot(self, r, a, W, rot):
         _native.check(self.lib.gpq_poly_rot(self.h, _ptr(r), _ptr(a), W, rot, a.numel() // (W * self.n), _stream()), "gpq_poly_rot")
         return r

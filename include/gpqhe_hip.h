@@ -250,6 +250,13 @@ int gpq_big_sub(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, const uint64_t *b,
 int gpq_big_neg(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, unsigned W, unsigned logql, unsigned batch, void *stream);
 /* The storage step of he_genswk (src/he-kem.c:103-110): a centred key polynomial (big slab) -> NTT-domain slab of dimevk limbs. */
 int gpq_evk_pack(gpq_ctx *ctx, uint64_t *evk, const uint64_t *big, unsigned W, unsigned dimevk, unsigned batch, void *stream);
+/* he_genswk, src/he-kem.c:74-118, from the polynomials the reference samples on the host: p1 (uniform mod P*q_L), e (error) and the
+ * polynomial the key hides (sp = s^2 for he_genrlk, the rotated / conjugated secret for he_genrk / he_genck), all big slabs of W words
+ * (64 W > bits of P*q_L), q_L = 2^logqL:  swk.p0 = smod(-p1*sk + e + P*sp, P*q_L), swk.p1 = smod(p1, P*q_L), each stored as
+ * rns_decompose + ntt over dimevk limbs (evk0, evk1: uint64_t[dimevk][n]). */
+size_t gpq_he_genswk_workspace_bytes(gpq_ctx *ctx, unsigned W, unsigned dimP, unsigned logqL);
+int gpq_he_genswk(gpq_ctx *ctx, uint64_t *evk0, uint64_t *evk1, const uint64_t *p1, const uint64_t *sk, const uint64_t *e,
+                  const uint64_t *sp, unsigned W, unsigned dimP, unsigned logqL, unsigned dimevk, void *workspace, void *stream);
 
 /* ---- per-kernel profile ----------------------------------------------------
  * When enabled every kernel launch of this context is bracketed by two HIP

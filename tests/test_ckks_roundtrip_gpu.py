@@ -252,3 +252,36 @@ def test_plaintext_multiplication_decrypts_to_the_product(engine_ctx, oracle_ctx
     got = [ref.centred_mod(x + y, q) for x, y in zip(k0, _sparse_negacyclic(k1, s_terms, n))]
     want = [ref.centred_mod(v, q) for v in _sparse_negacyclic(m, pt_terms, n)]
     assert max(abs(x - y) for x, y in zip(got, want)) < 1 << (lognu + 12)                    # noise: 7 terms * |e| * |pt|
+
+
+@pytest.mark.parametrize("logn,logq,sparse_s", [(7, 120, False), (8, 200, False), (13, 438, True), (16, 850, True)])
+def test_he_genswk_on_device_matches_the_reference_construction(engine_ctx, oracle_ctx, logn, logq, sparse_s):
+    """gpq_he_genswk (src/he-kem.c:74-118 with the sampling left to the caller): swk.p0 = smod(-p1 sk + e + P sp, P q_L),
+    swk.p1 = smod(p1, P q_L), stored as rns_decompose + ntt over dimevk limbs -- against Python integers and the oracle's NTT."""
+    import torch
+    n, q = 1 << logn, 1 << logq
+    probe = engine_ctx(logn, 20)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logq, logq)
+    g, o = engine_ctx(logn, dimevk), oracle_ctx(logn, dimevk)
+    rng = random.Random(31 + logn)
+    P = ref.RnsBasis(o.p[:dimP]).P
+    PqL = P * q
+    if sparse_s:
+        s_terms = sorted({rng.randrange(n): rng.choice((-1, 1)) for _ in range(24)}.items())
+        s = _dense_of(s_terms, n)
+        mul_s = lambda a: _sparse_negacyclic(a, s_terms, n)
+    else:
+        s = [rng.choice((-1, 0, 1)) for _ in range(n)]
+        mul_s = lambda a: ref.negacyclic_mul(a, s)
+    sp = mul_s(s)                                                            # he_genrlk: the key hides s^2
+    p1 = [rng.randrange(PqL) for _ in range(n)]                             # sample_uniform(&swkp1, PqL): [0, P q_L)
+    e = [rng.randrange(-8, 9) for _ in range(n)]
+    p0 = [ref.mpi_smod(-a + b + P * c, PqL) for a, b, c in zip(mul_s(p1), e, sp)]
+    want0, want1 = _evk_slab(o, p0, dimevk), _evk_slab(o, [ref.mpi_smod(v, PqL) for v in p1], dimevk)
+    W = PqL.bit_length() // 64 + 1
+    dev = [to_device(ints_to_big(v, W)) for v in (p1, s, e, sp)]
+    evk0 = torch.empty(dimevk * n, dtype=torch.int64, device="cuda")
+    evk1 = torch.empty_like(evk0)
+    g.he_genswk(evk0, evk1, *dev, W, dimP, logq, dimevk)
+    assert np.array_equal(to_host(evk0), want0)
+    assert np.array_equal(to_host(evk1), want1)
