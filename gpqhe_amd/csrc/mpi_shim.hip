@@ -23,6 +23,9 @@
 
 extern "C" struct poly_ctx polyctx __attribute__((weak));   // src/precomp.c:41
 extern "C" struct he_ctx hectx __attribute__((weak));       // src/precomp.c:47
+// the reference's samplers (src/sample.c; externs at src/he-kem.c:33-34): key generation draws from them in the reference's order
+extern "C" void sample_error(poly_mpi_t *r) __attribute__((weak));
+extern "C" void sample_uniform(poly_mpi_t *r, const gpq_MPI q) __attribute__((weak));
 
 namespace {
 
@@ -414,6 +417,95 @@ static void automorphism(he_ct_t *ct, const he_evk_t *key, bool conj, unsigned r
 }
 void he_conj(he_ct_t *ct, const he_evk_t *ck) { automorphism(ct, ck, true, 0); }
 void he_rot(he_ct_t *ct, const int rot, const he_evk_t *rk) { automorphism(ct, &rk[rot], false, (unsigned)rot); }   // rk[rot], :110
+
+// ---- key generation, src/he-kem.c:74-170 -----------------------------------------------------------------------------
+// he_genswk (static in the reference, :74-118) with the hidden polynomial given as a host big slab of W words.  The reference's
+// samplers are called in its order (error, then uniform mod P q_L), so a seeded RNG gives the reference's own keys.
+static void genswk(he_evk_t *swk, const std::vector<uint64_t> &sp, const std::vector<uint64_t> &hs, unsigned W) {
+  if (!sample_error || !sample_uniform) die("he_gen*k: the host program does not provide sample_error / sample_uniform (src/sample.c)");
+  gpq_ctx *c = engine();
+  const unsigned n = polyctx.n;
+  poly_mpi_t e, p1;
+  e.coeffs = (gpq_MPI *)malloc(n * sizeof(gpq_MPI));
+  p1.coeffs = (gpq_MPI *)malloc(n * sizeof(gpq_MPI));
+  for (unsigned i = 0; i < n; ++i) { e.coeffs[i] = G.mpi_new(0); p1.coeffs[i] = G.mpi_new(0); }
+  sample_error(&e);                                                                               // :87
+  sample_uniform(&p1, hectx.PqL);                                                                 // :94
+  const size_t big = (size_t)W * n, evk = (size_t)hectx.dimevk * n;
+  std::vector<uint64_t> he(big), hp(big);
+  to_slab(he.data(), &e, n, W);
+  to_slab(hp.data(), &p1, n, W);
+  for (unsigned i = 0; i < n; ++i) { G.mpi_release(e.coeffs[i]); G.mpi_release(p1.coeffs[i]); }
+  free(e.coeffs); free(p1.coeffs);
+  const unsigned logqL = G.mpi_get_nbits(hectx.q[hectx.L]) - 1;
+  if (!is_pow2(words_of(hectx.q[hectx.L], "he_gen*k: q_L must be positive"))) die("he_gen*k: q_L must be a power of two on this path");
+  DevBuf dp(big * 8), ds(big * 8), de(big * 8), dsp(big * 8), k0(evk * 8), k1(evk * 8), ws(gpq_he_genswk_workspace_bytes(c, W, hectx.dim, logqL));
+  up(dp, hp); up(ds, hs); up(de, he); up(dsp, sp);
+  if (gpq_he_genswk(c, k0.u64(), k1.u64(), dp.u64(), ds.u64(), de.u64(), dsp.u64(), W, hectx.dim, logqL, hectx.dimevk, ws.p, nullptr) != GPQ_OK)
+    die("he_genswk failed");
+  if (gpq_download(swk->p0.coeffs, k0.p, evk * 8, nullptr) != GPQ_OK || gpq_download(swk->p1.coeffs, k1.p, evk * 8, nullptr) != GPQ_OK ||
+      gpq_stream_sync(nullptr) != GPQ_OK) die("download failed");
+}
+
+static unsigned keygen_words() {
+  need_gcrypt();
+  if (&hectx == nullptr || !hectx.q) die("`hectx` is not initialised (hectx_init first)");
+  return G.mpi_get_nbits(hectx.PqL) / 64 + 1;
+}
+
+// a permutation of the secret as the hidden polynomial: poly_conj / poly_rot (src/poly.c:263-283) on the device
+static std::vector<uint64_t> permuted(const std::vector<uint64_t> &hs, unsigned W, bool conj, unsigned rot) {
+  gpq_ctx *c = engine();
+  const size_t big = (size_t)W * polyctx.n;
+  DevBuf a(big * 8), r(big * 8);
+  up(a, hs);
+  const int rc = conj ? gpq_poly_conj(c, r.u64(), a.u64(), W, 1, nullptr) : gpq_poly_rot(c, r.u64(), a.u64(), W, rot, 1, nullptr);
+  if (rc != GPQ_OK) die("poly_rot / poly_conj failed");
+  std::vector<uint64_t> out(big);
+  down(out, r);
+  return out;
+}
+
+void he_genrlk(he_evk_t *rlk, const poly_mpi_t *sk) {                                              // :120-137
+  const unsigned W = keygen_words(), n = polyctx.n;
+  gpq_ctx *c = engine();
+  printf("Generating rlk ... ");
+  fflush(stdout);
+  std::vector<uint64_t> hs((size_t)W * n), s2((size_t)W * n);
+  to_slab(hs.data(), sk, n, W);
+  const unsigned nbq = G.mpi_get_nbits(hectx.q[hectx.L]), dim = nbq / 59 + 1;                      // :131
+  const std::vector<uint64_t> qw = words_of(hectx.q[hectx.L], "he_genrlk: q_L must be positive");
+  {
+    DevBuf a(hs.size() * 8), r(hs.size() * 8), ws(gpq_poly_mul_general_workspace_bytes(c, dim, 1));
+    up(a, hs);
+    const int rc = is_pow2(qw) ? gpq_poly_mul(c, r.u64(), a.u64(), a.u64(), W, dim, nbq - 1, 1, ws.p, nullptr)
+                               : gpq_poly_mul_general(c, r.u64(), a.u64(), a.u64(), W, dim, qw.data(), (unsigned)qw.size(), 1, ws.p, nullptr);
+    if (rc != GPQ_OK) die("he_genrlk: poly_mul failed");
+    down(s2, r);
+  }
+  genswk(rlk, s2, hs, W);                                                                          // :132
+  printf("done.\n");
+}
+
+void he_genck(he_evk_t *ck, const poly_mpi_t *sk) {                                                // :140-154
+  const unsigned W = keygen_words(), n = polyctx.n;
+  printf("Generating ck ... ");
+  fflush(stdout);
+  std::vector<uint64_t> hs((size_t)W * n);
+  to_slab(hs.data(), sk, n, W);
+  genswk(ck, permuted(hs, W, true, 0), hs, W);
+  printf("done.\n");
+}
+
+void he_genrk(he_evk_t *rk, const poly_mpi_t *sk) {                                                // :156-170
+  const unsigned W = keygen_words(), n = polyctx.n;
+  printf("Generating rk ... ");
+  fflush(stdout);
+  std::vector<uint64_t> hs((size_t)W * n);
+  to_slab(hs.data(), sk, n, W);
+  for (unsigned rot = 0; rot < hectx.slots; ++rot) genswk(&rk[rot], permuted(hs, W, false, rot), hs, W);
+  printf("done.\n");
+}
 
 // frees the device buffers the MPI-typed calls keep between calls, and the engine context
 void gpq_mpi_shim_release(void) {

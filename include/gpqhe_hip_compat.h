@@ -127,6 +127,11 @@ void he_moddown(he_ct_t *ct);                                                   
 void he_mulpt(struct he_ct *dest, const struct he_ct *src, const struct he_pt *pt);     /* src/gpqhe.h:148  */
 void he_conj(he_ct_t *ct, const he_evk_t *ck);                                          /* src/gpqhe.h:151  */
 void he_rot(he_ct_t *ct, const int rot, const he_evk_t *rk);                            /* src/gpqhe.h:152  */
+/* Key generation, src/he-kem.c:120-170 (decl src/gpqhe.h:131-133).  The randomness comes from the host program's own
+ * sample_error / sample_uniform (src/sample.c), called in the reference's order; everything else runs on the device. */
+void he_genrlk(he_evk_t *rlk, const poly_mpi_t *sk);
+void he_genck(he_evk_t *ck, const poly_mpi_t *sk);
+void he_genrk(he_evk_t *rk, const poly_mpi_t *sk);
 
 /* When the host program has no `polyctx` symbol (the library references it
  * weakly), the ring degree for the drop-in calls is set here instead. */

@@ -6,6 +6,7 @@
  *   mpi_host polymul                     the two products of tests/polymul.c:59-76 (n = 128, 5 limbs, q = 2^61)
  *   mpi_host crt                         rns_decompose per limb, rns_reconstruct per coefficient, poly_rns2mpi (tests/crt.c:76-109)
  *   mpi_host polymulmono <logn>          poly_mul of a dense polynomial by -3 x^5 at a size that takes the threaded conversions
+ *   mpi_host keygen <logn> <logq>        he_genrlk / he_genck / he_genrk with deterministic stand-ins for the reference's samplers
  *   mpi_host hemultime <logn> <logq>     wall time of he_mul / he_rescale through the MPI-typed symbols (conversions and copies included)
  *   mpi_host hemul  <in.txt>             he_mul on ciphertexts read as hex, then he_rs, then he_moddown
  *
@@ -37,6 +38,7 @@ unsigned int gcry_mpi_get_nbits(MPI a);
 unsigned int gcry_mpi_scan(MPI *ret, int format, const void *buffer, size_t buflen, size_t *nscanned);
 unsigned int gcry_mpi_aprint(int format, unsigned char **buffer, size_t *nwritten, const MPI a);
 void gcry_free(void *p);
+void gcry_mpi_mod(MPI r, MPI dividend, MPI divisor);
 #define FMT_HEX 4
 
 struct poly_ctx polyctx; /* src/precomp.c:41 */
@@ -300,6 +302,67 @@ static int polymulmono(unsigned logn)
   return 0;
 }
 
+/* The reference's samplers (src/sample.c) as the key generation of libgpqhe_hip.so finds them in the host program: deterministic
+ * stand-ins here so that the test can restate the keys.  error: splitmix % 17 - 8; uniform: nbytes(q) + 8 splitmix bytes mod q. */
+static uint64_t err_state = 111, uni_state = 222;
+void sample_error(poly_mpi_t *r)
+{
+  for (unsigned i = 0; i < polyctx.n; i++) {
+    const long v = (long)(splitmix64(&err_state) % 17) - 8;
+    gcry_mpi_set_ui(r->coeffs[i], (unsigned long)(v < 0 ? -v : v));
+    if (v < 0) gcry_mpi_neg(r->coeffs[i], r->coeffs[i]);
+  }
+}
+void sample_uniform(poly_mpi_t *r, const MPI q)
+{
+  const unsigned nb = (gcry_mpi_get_nbits(q) + 7) / 8 + 8;
+  unsigned char *buf = malloc(nb + 8);
+  for (unsigned i = 0; i < polyctx.n; i++) {
+    for (unsigned b = 0; b < nb; b += 8) { const uint64_t v = splitmix64(&uni_state); memcpy(buf + b, &v, 8); }
+    MPI t = NULL;
+    gcry_mpi_scan(&t, 5, buf, nb, NULL);
+    gcry_mpi_mod(r->coeffs[i], t, q);
+    gcry_mpi_release(t);
+  }
+  free(buf);
+}
+
+static uint64_t fnv1a(const uint64_t *p, size_t words)
+{
+  uint64_t h = 0xcbf29ce484222325ull;
+  const unsigned char *b = (const unsigned char *)p;
+  for (size_t i = 0; i < words * 8; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
+  return h;
+}
+
+/* he_genrlk, he_genck, he_genrk through the reference's signatures (src/gpqhe.h:131-133) with the samplers above */
+static int keygen(unsigned logn, unsigned logq)
+{
+  MPI q = gcry_mpi_new(0);
+  gcry_mpi_set_ui(q, 1);
+  gcry_mpi_lshift(q, q, logq);
+  he_ctx_init(logn, q, 1ull << 30);
+  hectx.slots = 2;
+  poly_mpi_t sk;
+  poly_alloc(&sk);
+  uint64_t st = 333;
+  for (unsigned i = 0; i < polyctx.n; i++) {                 /* ternary secret */
+    const unsigned v = (unsigned)(splitmix64(&st) % 3);
+    gcry_mpi_set_ui(sk.coeffs[i], v == 2 ? 1 : v);
+    if (v == 2) gcry_mpi_neg(sk.coeffs[i], sk.coeffs[i]);
+  }
+  he_evk_t keys[4];                                          /* rlk, ck, rk[0], rk[1] */
+  const size_t words = (size_t)hectx.dimevk * polyctx.n;
+  for (int k = 0; k < 4; k++) { keys[k].p0.coeffs = malloc(words * 8); keys[k].p1.coeffs = malloc(words * 8); }
+  he_genrlk(&keys[0], &sk);
+  he_genck(&keys[1], &sk);
+  he_genrk(&keys[2], &sk);
+  printf("dims %u %u\n", hectx.dim, hectx.dimevk);
+  for (int k = 0; k < 4; k++)
+    printf("key %d %016llx %016llx\n", k, (unsigned long long)fnv1a(keys[k].p0.coeffs, words), (unsigned long long)fnv1a(keys[k].p1.coeffs, words));
+  return 0;
+}
+
 #include <time.h>
 static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 
@@ -352,6 +415,7 @@ int main(int argc, char **argv)
   if (argc >= 2 && !strcmp(argv[1], "crt")) return crt();
   if (argc >= 3 && !strcmp(argv[1], "hemul")) return hemul(argv[2]);
   if (argc >= 3 && !strcmp(argv[1], "polymulmono")) return polymulmono(atoi(argv[2]));
+  if (argc >= 4 && !strcmp(argv[1], "keygen")) return keygen(atoi(argv[2]), atoi(argv[3]));
   if (argc >= 4 && !strcmp(argv[1], "hemultime")) return hemultime(atoi(argv[2]), atoi(argv[3]));
   return 2;
 }

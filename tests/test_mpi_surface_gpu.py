@@ -185,3 +185,61 @@ def test_he_chain_with_real_mpis(mpi_host, oracle_ctx, tmp_path, logn, qL, Delta
     dim_pt = int((ql.bit_length() + 10.0 + logn) / 59 + 1)
     v0, v1 = ref.he_mulpt(o, (u0, u1), m, dim_pt, 0, ql=ql)
     assert _ints(lines[base + 1:base + 1 + n]) == v0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == v1
+
+
+def _splitmix(state):
+    state[0] = (state[0] + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = state[0]
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+@pytest.mark.parametrize("logn,logq", [(7, 120), (8, 200)])
+def test_key_generation_through_reference_signatures(mpi_host, oracle_ctx, logn, logq):
+    """he_genrlk / he_genck / he_genrk (src/gpqhe.h:131-133, src/he-kem.c:74-170): the library calls the host program's
+    sample_error / sample_uniform in the reference's order and does the rest on the device.  The C host's samplers are
+    deterministic, so the keys are restated here with Python integers and the oracle's NTT and compared by digest."""
+    import numpy as np
+    from oracle.oracle import fnv
+    res = subprocess.run([mpi_host, "keygen", str(logn), str(logq)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    lines = [ln.split() for ln in res.stdout.splitlines()]
+    dims = next(ln for ln in lines if ln and ln[0] == "dims")
+    got = {int(ln[1]): (int(ln[2], 16), int(ln[3], 16)) for ln in lines if ln and ln[0] == "key"}
+    n, q = 1 << logn, 1 << logq
+    dimP = (logq + 1 + logn) // 59 + 1
+    o = oracle_ctx(logn, 64 if logn > 7 else 5 + 40)
+    P = ref.RnsBasis(o.p[:dimP]).P
+    PqL = P * q
+    dimevk = (logq + 1 + PqL.bit_length() + logn) // 59 + 1
+    assert (int(dims[1]), int(dims[2])) == (dimP, dimevk)
+    st = [333]
+    s = [{0: 0, 1: 1, 2: -1}[_splitmix(st) % 3] for _ in range(n)]
+    es, us = [111], [222]
+    nb = (PqL.bit_length() + 7) // 8 + 8
+
+    def sample_error():
+        return [_splitmix(es) % 17 - 8 for _ in range(n)]
+
+    def sample_uniform():
+        out = []
+        for _ in range(n):
+            buf = b"".join(_splitmix(us).to_bytes(8, "little") for _ in range((nb + 7) // 8))
+            out.append(int.from_bytes(buf[:nb], "big") % PqL)
+        return out
+
+    def slab(poly):
+        return o.ntt_slab(np.array([v % o.p[d] for d in range(dimevk) for v in poly], dtype=np.uint64), dimevk)
+
+    def genswk(sp):
+        e = sample_error()
+        p1 = sample_uniform()
+        p0 = [ref.mpi_smod(-a + b + P * c, PqL) for a, b, c in zip(ref.negacyclic_mul(p1, s), e, sp)]
+        return int(fnv(slab(p0)), 16), int(fnv(slab([ref.mpi_smod(v, PqL) for v in p1])), 16)
+
+    s2 = [ref.centred_mod(v, q) for v in ref.negacyclic_mul(s, s)]
+    assert got[0] == genswk(s2)                               # he_genrlk
+    assert got[1] == genswk(ref.poly_conj(s))                 # he_genck
+    assert got[2] == genswk(ref.poly_rot(s, 0))               # he_genrk, rot = 0, 1
+    assert got[3] == genswk(ref.poly_rot(s, 1))
