@@ -162,6 +162,11 @@ static int upload_tables(gpq_ctx *c) {
   c->nsplit = 0;
   if (!(nosplit && nosplit[0] == '1'))
     while (c->nsplit < np && c->p[c->nsplit] - (1ull << 59) < GPQ_SPLIT_CMAX) ++c->nsplit;
+  // ... and among them the leading limbs whose forward stages may skip every other conditional subtraction (ct_bfly_wide)
+  const char *nowide = getenv("GPQHE_NO_WIDE");     // dev switch: A/B against one subtraction per stage
+  c->nwide = 0;
+  if (!(nowide && nowide[0] == '1'))
+    while (c->nwide < c->nsplit && c->p[c->nwide] - (1ull << 59) < GPQ_WIDE_CMAX) ++c->nwide;
   if (c->nsplit) {
     const size_t ns = c->nsplit;
     std::vector<TwS> ws(ns * n), wis(ns * n);
@@ -346,22 +351,26 @@ PassArgs make_args(const gpq_ctx *c, unsigned dim, unsigned nslab) {
   return a;
 }
 
-// A pass over the limbs 0..dim-1 of its slabs is launched once for the leading limbs that have
-// split-twiddle tables and once for the rest (none at n <= 2^16): f(twiddle type tag, args, limbs).
-template <typename F>
+// A pass over the limbs 0..dim-1 of its slabs is launched once per class of limbs present: wide-split (forward
+// kernels only: WIDE), split, plain (none at n <= 2^16): f(twiddle type tag, args, limbs).  The classes are
+// prefixes of the chain (c grows along it), so each is one contiguous range of limbs.
+template <bool WIDE, typename F>
 int for_limb_ranges(const gpq_ctx *c, PassArgs a, unsigned dim, const uint64_t **evk0, const uint64_t **evk1, F f) {
-  const unsigned first = a.limb0 < c->nsplit ? a.limb0 : c->nsplit;
-  const unsigned ns = c->nsplit - first < dim ? c->nsplit - first : dim;   // split limbs among limb0 .. limb0+dim-1
-  int rc;
-  if (ns && (rc = f(TwS{}, a, ns))) return rc;
-  if (dim > ns) {
-    const size_t shift = (size_t)ns << c->logn;
-    a.limb0 += ns;
+  const unsigned lo = a.limb0, hi = a.limb0 + dim;
+  auto upto = [&](unsigned bound) { return bound < lo ? lo : (bound > hi ? hi : bound); };
+  const unsigned e_wide = WIDE ? upto(c->nwide) : lo, e_split = upto(c->nsplit);
+  auto advance = [&](unsigned limbs) {
+    const size_t shift = (size_t)limbs << c->logn;
+    a.limb0 += limbs;
     for (int i = 0; i < GPQ_MAX_SLABS; ++i) { if (a.src[i]) a.src[i] += shift; if (a.dst[i]) a.dst[i] += shift; }
     if (evk0) *evk0 += shift;
     if (evk1) *evk1 += shift;
-    if ((rc = f(uint64_t{}, a, dim - ns))) return rc;
-  }
+  };
+  int rc;
+  if constexpr (WIDE)
+    if (e_wide > lo) { if ((rc = f(TwW{}, a, e_wide - lo))) return rc; advance(e_wide - lo); }
+  if (e_split > e_wide) { if ((rc = f(TwS{}, a, e_split - e_wide))) return rc; advance(e_split - e_wide); }
+  if (hi > e_split && (rc = f(uint64_t{}, a, hi - e_split))) return rc;
   return GPQ_OK;
 }
 
@@ -375,7 +384,7 @@ int launch_strided_t(const PassArgs &a, unsigned gy, unsigned gz, hipStream_t s)
 // strided pass over `polys` polynomials of each of a.nslab slabs, all `dim` limbs
 template <bool INV>
 int launch_strided(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigned polys, hipStream_t s) {
-  return for_limb_ranges(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
+  return for_limb_ranges<!INV>(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
     using TW = decltype(tag);
     ProfScope prof(c, INV ? GPQ_K_STRIDED_INV : GPQ_K_STRIDED_FWD, s);
     switch (c->logn) {
@@ -392,7 +401,7 @@ int launch_strided(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigne
 template <bool INV>
 int launch_contig(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigned polys, hipStream_t s) {
   if (args.nslab != 1) return gpq_fail(GPQ_ERR_INVALID, "contig_pass walks one slab");
-  return for_limb_ranges(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
+  return for_limb_ranges<!INV>(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
     using TW = decltype(tag);
     const dim3 grid(c->n >> 12, (polys + CONTIG_POLYS - 1) / CONTIG_POLYS, limbs);
     ProfScope prof(c, INV ? GPQ_K_CONTIG_INV : GPQ_K_CONTIG_FWD, s);
@@ -403,7 +412,7 @@ int launch_contig(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigned
 
 template <bool INV>
 int launch_small(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigned polys, hipStream_t s) {
-  return for_limb_ranges(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
+  return for_limb_ranges<false>(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
     using TW = decltype(tag);
     const dim3 grid(1, polys * a.nslab, limbs);
     ProfScope prof(c, GPQ_K_SMALL, s);
@@ -557,7 +566,7 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
     PassArgs m = make_args(c, dim, 1);
     for (int i = 0; i < 4; ++i) m.src[i] = f.dst[i];
     m.dst[0] = d0 + k0 * poly; m.dst[1] = d1 + k0 * poly; m.dst[2] = d2 + k0 * poly;
-    if ((rc = for_limb_ranges(c, m, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
+    if ((rc = for_limb_ranges<true>(c, m, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
           using TW = decltype(tag);
           ProfScope prof(c, GPQ_K_TENSOR_MID, s);
           hipLaunchKernelGGL((tensor_mid<TW>), dim3(c->n >> 12, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, a);
@@ -602,7 +611,7 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
     m.p = make_args(c, dim, 1);
     m.p.src[0] = ws; m.p.dst[0] = c0 + k0 * poly; m.p.dst[1] = c1 + k0 * poly;
     m.evk0 = evk0; m.evk1 = evk1;
-    if ((rc = for_limb_ranges(c, m.p, dim, &m.evk0, &m.evk1, [&](auto tag, const PassArgs &a, unsigned limbs) {
+    if ((rc = for_limb_ranges<true>(c, m.p, dim, &m.evk0, &m.evk1, [&](auto tag, const PassArgs &a, unsigned limbs) {
           using TW = decltype(tag);
           KeyswitchArgs ka{a, m.evk0, m.evk1};
           ProfScope prof(c, GPQ_K_KEYSWITCH_MID, s);

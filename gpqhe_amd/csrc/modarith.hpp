@@ -24,6 +24,8 @@
 #define GPQ_FOLD_CMAX 319000000u /* < 2^28.25 */
 // Split-twiddle multiply (below): one fold finishes when 3*2^30*c < 2^59, i.e. c <= floor(2^29/3).
 #define GPQ_SPLIT_CMAX 178956971u /* c < this: every prime of the n <= 2^16 chains, the first ones at n = 2^17 */
+// Forward butterflies that skip every other conditional subtraction (ct_bfly_wide below) need c < 2^27.
+#define GPQ_WIDE_CMAX 134217000u
 
 namespace gpq {
 
@@ -135,7 +137,11 @@ __device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, uint64_t w, co
 // ---------------------------------------------------------------------------
 typedef ulonglong2 TwS;   // .x = p - w, .y = p - (w*2^31 mod p)
 
-__device__ __forceinline__ uint64_t mulmod_split(uint64_t a, const TwS &w, const PrimeK &k) {
+// Same storage, other butterflies: the forward stages of limbs with c < GPQ_WIDE_CMAX (ct_bfly_wide).
+struct alignas(16) TwW { uint64_t x, y; };
+
+template <typename W>
+__device__ __forceinline__ uint64_t mulmod_split(uint64_t a, const W &w, const PrimeK &k) {
   const uint32_t al = (uint32_t)a & 0x7fffffffu;
   const uint32_t ah = __builtin_amdgcn_alignbit((uint32_t)(a >> 32), (uint32_t)a, 31);
   uint64_t t0 = mad_u64(al, (uint32_t)w.x, 0);
@@ -158,11 +164,32 @@ __device__ __forceinline__ void ct_bfly(uint64_t &x, uint64_t &y, const TwS &w, 
   y = xs + k.kys - t;
 }
 // Gentleman-Sande, split twiddle.  in: x,y < 2p ; out: x,y < 2p.
-__device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, const TwS &w, const PrimeK &k) {
+template <typename W>
+__device__ __forceinline__ void gs_bfly_split(uint64_t &x, uint64_t &y, const W &w, const PrimeK &k) {
   const uint64_t v = x + y;
   const uint64_t d = x + k.p2 - y;  // (0, 4p)
   x = v + (v >= k.p2 ? (uint64_t)0 - k.p2 : (uint64_t)0);
   y = mulmod_split(d, w, k) + k.c1;
+}
+__device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, const TwS &w, const PrimeK &k) { gs_bfly_split(x, y, w, k); }
+__device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, const TwW &w, const PrimeK &k) { gs_bfly_split(x, y, w, k); }
+
+// Cooley-Tukey, split twiddle, one conditional subtraction per TWO stages (c < GPQ_WIDE_CMAX <= 2^27).
+// The split multiply only needs th < 2^32, i.e. al + ah <= 2^32 - 2, which holds for every multiplicand
+// a <= 2^62 + 2^31 - 2 (above 2^62 the low part al is what exceeds 2^62: small), and then
+//   t = T' + (c+1) <= c (2^32 - 2) + 2^59 + c < 2p          for c <= 2^27.
+// Stage kinds alternate by the position s of the index bit a stage works on (len = 2^s):
+//   s odd  "A": no subtraction.   in: x, y < 6p          out: x' = x + t < 8p,  y' = x + 2p - t <= 8p - c - 2
+//   s even "B": subtract 4p.      in: x, y < 8p          out: x' = xr + t < 6p, y' = xr + 2p - t < 6p     (xr = csub(x, 4p) < 4p)
+// 8p - c - 2 = 2^62 + 7c - 2 is a legal multiplicand (7c < 2^31).  Two A stages never follow each other; the
+// last stage (s = 0) is B, so a finished forward transform is < 6p; canonical inputs may enter at either kind.
+// Measured (tools/bfly_lab): +8 % over a subtraction in every stage.
+template <bool CSUB>
+__device__ __forceinline__ void ct_bfly_wide(uint64_t &x, uint64_t &y, const TwW &w, const PrimeK &k) {
+  const uint64_t t = mulmod_split(y, w, k);
+  const uint64_t xs = x + (CSUB ? (x >= k.p4 ? k.kx1 : k.kx0) : k.kx0);
+  x = xs + t;
+  y = xs + k.kys - t;
 }
 
 // Exact a*b mod p for canonical a,b (poly_rns_mul, src/poly.c:77-82).

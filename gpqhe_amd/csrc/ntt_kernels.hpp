@@ -65,17 +65,24 @@ __device__ __forceinline__ void load_tw(TW (&tw)[tw_count(EL, BHI, BLO)], unsign
   load_tw_bits<EL, BHI, BHI, BLO, UNIFORM>(tw, ibase, rs, logn, w);
 }
 
-template <int EL, int BHI, int B, int BLO, int NTW, typename TW>
+// One forward butterfly of the stage on index bit S (len = 2^S).  Only the wide-split butterflies care about S.
+template <int S, typename TW>
+__device__ __forceinline__ void ct_stage(uint64_t &x, uint64_t &y, const TW &w, const PrimeK &k) { ct_bfly(x, y, w, k); }
+template <int S>
+__device__ __forceinline__ void ct_stage(uint64_t &x, uint64_t &y, const TwW &w, const PrimeK &k) { ct_bfly_wide<(S & 1) == 0>(x, y, w, k); }
+
+// RS = index bit that register bit 0 stands for.
+template <int EL, int BHI, int B, int BLO, int RS, int NTW, typename TW>
 __device__ __forceinline__ void ct_bits(uint64_t (&x)[1 << EL], const TW (&tw)[NTW], const PrimeK &k) {
 #pragma unroll
   for (int e = 0; e < (1 << EL); ++e)
-    if (!(e & (1 << B))) ct_bfly(x[e], x[e + (1 << B)], tw[tw_off(EL, BHI, B) + (e >> (B + 1))], k);
-  if constexpr (B > BLO) ct_bits<EL, BHI, B - 1, BLO>(x, tw, k);
+    if (!(e & (1 << B))) ct_stage<RS + B>(x[e], x[e + (1 << B)], tw[tw_off(EL, BHI, B) + (e >> (B + 1))], k);
+  if constexpr (B > BLO) ct_bits<EL, BHI, B - 1, BLO, RS>(x, tw, k);
 }
-template <int EL, int BHI, int BLO, typename TW>
+template <int EL, int BHI, int BLO, int RS, typename TW>
 __device__ __forceinline__ void ct_group(uint64_t (&x)[1 << EL], const TW (&tw)[tw_count(EL, BHI, BLO)],
                                          const PrimeK &k) {
-  ct_bits<EL, BHI, BHI, BLO>(x, tw, k);
+  ct_bits<EL, BHI, BHI, BLO, RS>(x, tw, k);
 }
 
 // Inverse: stages run from bit BLO up to BHI; tw[] is laid out as load_tw fills it (BHI first).
@@ -142,6 +149,24 @@ template <> struct TwTraits<TwS> {
   __device__ static __forceinline__ uint64_t right(uint64_t x, const PrimeK &) { return x; }
 };
 
+template <> struct LastK<TwW> : LastK<TwS> {      // (the inverse passes of wide limbs run as TwS; this only has to compile)
+  __device__ __forceinline__ explicit LastK(const LimbTab &t) : LastK<TwS>(t) {}
+};
+__device__ __forceinline__ void gs_last(uint64_t &x, uint64_t &y, const LastK<TwW> &t, const PrimeK &k) {
+  gs_last(x, y, static_cast<const LastK<TwS> &>(t), k);
+}
+// Wide-split limbs: forward data < 6p after a finished transform (< 8p inside one), inverse side exactly as TwS.
+template <> struct TwTraits<TwW> {
+  __device__ static __forceinline__ const TwW *table(const PassArgs &a, bool inv) { return reinterpret_cast<const TwW *>(inv ? a.winvs : a.ws); }
+  __device__ static __forceinline__ uint64_t canon_fwd(uint64_t x, const PrimeK &k) { return canon_fold(x, k.p, k.c); }
+  __device__ static __forceinline__ uint64_t canon_inv(uint64_t x, const PrimeK &k) { return csub(x, k.p); }
+  __device__ static __forceinline__ uint64_t inv_from4(uint64_t x, const PrimeK &k) { return csub(x, k.p2); }
+  __device__ static __forceinline__ uint64_t inv_from8(uint64_t x, const PrimeK &k) { return csub(csub(x, k.p4), k.p2); }
+  // products (mulmod_lazy wants a*b < 2^122.8): left < 4p, right < 6p as it comes: 24 p^2 = 2^122.6
+  __device__ static __forceinline__ uint64_t left(uint64_t x, const PrimeK &k) { return csub(x, k.p4); }
+  __device__ static __forceinline__ uint64_t right(uint64_t x, const PrimeK &) { return x; }
+};
+
 // ---------------------------------------------------------------------------
 // Strided pass: the M1 = logn-8 stages with len >= 256.
 // Tile = 2^M1 rows x 16 columns, T = 2^(M1+4-EL) threads, tid = col + 16*q.
@@ -151,6 +176,9 @@ template <> struct TwTraits<TwS> {
 // Forward runs A then B, inverse B then A.  Group A's twiddles are the same
 // for the whole grid (scalar loads); group B's are fetched at kernel entry.
 // ---------------------------------------------------------------------------
+#ifndef GPQ_LAB
+#define GPQ_LAB 0
+#endif
 #ifndef GPQ_STRIDED_CB
 #define GPQ_STRIDED_CB 4      /* log2 of the columns of a tile: 16 columns = 128-byte row segments */
 #endif
@@ -204,20 +232,37 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
 
   if (!INV) {
     TW twA[tw_count(EL, EL - 1, 0)];
+#if GPQ_LAB == 1   /* dev probe: no global data traffic */
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] = (uint64_t)(iA + e * strideA) * 0x9e3779b97f4a7c15ull >> 4;
+#else
 #pragma unroll
     for (int e = 0; e < E; ++e) x[e] = src[iA + e * strideA];
+#endif
     load_tw<EL, EL - 1, 0, true>(twA, iA, G::S2 + 8, logn, wt);
     if (G::S2 > 0) load_tw<EL, G::BB, 0, false>(twB, iB, 8, logn, wt);
-    ct_group<EL, EL - 1, 0>(x, twA, k);
+#if GPQ_LAB != 2   /* dev probe 2: no butterflies */
+    ct_group<EL, EL - 1, 0, G::S2 + 8>(x, twA, k);
+#endif
     if (G::S2 > 0) {
 #pragma unroll
       for (int e = 0; e < E; ++e) lds[G::pad(tid + e * G::T)] = x[e];
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = lds[G::pad((q << (EL + CB)) + (e << CB) + (tid & (G::C - 1)))];
-      ct_group<EL, G::BB, 0>(x, twB, k);
+#if GPQ_LAB != 2
+      ct_group<EL, G::BB, 0, 8>(x, twB, k);
+#else
+#pragma unroll
+      for (int e = 0; e < E; ++e) x[e] += *reinterpret_cast<const uint64_t *>(&twB[e % tw_count(EL, G::BB, 0)]) + *reinterpret_cast<const uint64_t *>(&twA[e % tw_count(EL, EL - 1, 0)]);
+#endif
+#if GPQ_LAB == 1
+#pragma unroll
+      for (int e = 0; e < E; ++e) if (x[e] == 0x123456789abcdefull) dst[iB + e * strideB] = x[e];
+#else
 #pragma unroll
       for (int e = 0; e < E; ++e) dst[iB + e * strideB] = CANON_OUT ? TwTraits<TW>::canon_fwd(x[e], k) : x[e];
+#endif
     } else {
 #pragma unroll
       for (int e = 0; e < E; ++e) dst[iA + e * strideA] = CANON_OUT ? TwTraits<TW>::canon_fwd(x[e], k) : x[e];
@@ -280,6 +325,9 @@ struct ContigLane {
   __device__ static __forceinline__ unsigned pad(unsigned l) { return l + (l >> 4); }
   // registers in H layout -> registers in L layout
   __device__ __forceinline__ void h_to_l(uint64_t (&x)[16]) const {
+#if GPQ_LAB == 5
+    return;
+#endif
 #pragma unroll
     for (int e = 0; e < 16; ++e) lds[pad(hbase + 16 * e)] = x[e];
     wave_lds_sync();
@@ -288,6 +336,9 @@ struct ContigLane {
     wave_lds_sync();
   }
   __device__ __forceinline__ void l_to_h(uint64_t (&x)[16]) const {
+#if GPQ_LAB == 5
+    return;
+#endif
 #pragma unroll
     for (int e = 0; e < 16; ++e) lds[pad(lbase + e)] = x[e];
     wave_lds_sync();
@@ -304,9 +355,17 @@ template <typename TW>
 struct ContigTw {
   TW t[15];
   __device__ __forceinline__ void load_h(const ContigLane &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
+#if GPQ_LAB == 6
+    for (int i = 0; i < 15; ++i) { uint64_t *q = reinterpret_cast<uint64_t *>(&t[i]); for (unsigned j = 0; j < sizeof(TW) / 8; ++j) q[j] = ((wave0 + ln.hbase + i + j) * 0x9e3779b97f4a7c15ull >> 5) + (uint64_t)w; }
+    return;
+#endif
     load_tw<4, 3, 0, false>(t, wave0 + ln.hbase, 4, logn, w);
   }
   __device__ __forceinline__ void load_l(const ContigLane &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
+#if GPQ_LAB == 6
+    for (int i = 0; i < 15; ++i) { uint64_t *q = reinterpret_cast<uint64_t *>(&t[i]); for (unsigned j = 0; j < sizeof(TW) / 8; ++j) q[j] = ((wave0 + ln.lbase + 3 * i + j) * 0x9e3779b97f4a7c15ull >> 5) + (uint64_t)w; }
+    return;
+#endif
     load_tw<4, 3, 0, false>(t, wave0 + ln.lbase, 0, logn, w);
   }
 };
@@ -383,9 +442,9 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTI
     for (unsigned i = 0; i < cnt; ++i) {
       if (i + 1 < cnt) load_h(nx, src + (size_t)(i + 1) * a.poly_stride, ln);
       if (!INV) {
-        ct_group<4, 3, 0>(x, twh.t, k);
+        ct_group<4, 3, 0, 4>(x, twh.t, k);
         ln.h_to_l(x);
-        ct_group<4, 3, 0>(x, twl.t, k);
+        ct_group<4, 3, 0, 0>(x, twl.t, k);
         ln.l_to_h(x);
 #pragma unroll
         for (int e = 0; e < 16; ++e) x[e] = TT::canon_fwd(x[e], k);
@@ -410,13 +469,13 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTI
     if (!INV) {
       tw.load_h(ln, wave0, a.logn, wt);
 #pragma unroll
-      for (int j = 0; j < CONTIG_POLYS; ++j) if (j < (int)cnt) ct_group<4, 3, 0>(x[j], tw.t, k);
+      for (int j = 0; j < CONTIG_POLYS; ++j) if (j < (int)cnt) ct_group<4, 3, 0, 4>(x[j], tw.t, k);
       tw.load_l(ln, wave0, a.logn, wt);
 #pragma unroll
       for (int j = 0; j < CONTIG_POLYS; ++j)
         if (j < (int)cnt) {
           ln.h_to_l(x[j]);
-          ct_group<4, 3, 0>(x[j], tw.t, k);
+          ct_group<4, 3, 0, 0>(x[j], tw.t, k);
           ln.l_to_h(x[j]);
 #pragma unroll
           for (int e = 0; e < 16; ++e) x[j][e] = TT::canon_fwd(x[j][e], k);
@@ -461,21 +520,39 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 2) void tensor_mid(PassArgs a) {
   const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
   uint64_t a0[16], a1[16], b0[16], b1[16];
   ContigTw<TW> tw;
-  load_h(a0, a.src[0] + cb.off, ln);
+#if GPQ_LAB == 4 || GPQ_LAB == 5 || GPQ_LAB == 6 || GPQ_LAB == 7  /* dev probe: no global data traffic (5: no LDS exchange either, 6: no twiddle loads either) */
+#define LAB_LOAD(x, p) for (int e_ = 0; e_ < 16; ++e_) x[e_] = (uint64_t)(cb.off + ln.hbase + 16 * e_ + (size_t)(p)) * 0x9e3779b97f4a7c15ull >> 4
+#define LAB_STORE(p, x) for (int e_ = 0; e_ < 16; ++e_) if (x[e_] == 0x123456789abcdefull) (p)[ln.hbase + 16 * e_] = x[e_]
+#else
+#define LAB_LOAD(x, p) load_h(x, p, ln)
+#define LAB_STORE(p, x) store_h(p, x, ln)
+#endif
+#if GPQ_LAB == 3   /* dev probe: no butterflies, no products */
+#define LAB_CT(x, rs) (void)0
+#define LAB_GS(x) (void)0
+#else
+#define LAB_CT(x, rs) ct_group<4, 3, 0, rs>(x, tw.t, k)
+#define LAB_GS(x) gs_group<4, 3, 0>(x, tw.t, k)
+#endif
+  LAB_LOAD(a0, a.src[0] + cb.off);
   tw.load_h(ln, cb.wave0, a.logn, wf);
-  load_h(b0, a.src[2] + cb.off, ln);
-  load_h(a1, a.src[1] + cb.off, ln);
-  load_h(b1, a.src[3] + cb.off, ln);
+  LAB_LOAD(b0, a.src[2] + cb.off);
+  LAB_LOAD(a1, a.src[1] + cb.off);
+  LAB_LOAD(b1, a.src[3] + cb.off);
   // forward, group H on all four, then group L on all four (15 twiddles live at a time)
-  ct_group<4, 3, 0>(a0, tw.t, k);
-  ct_group<4, 3, 0>(b0, tw.t, k);
-  ct_group<4, 3, 0>(a1, tw.t, k);
-  ct_group<4, 3, 0>(b1, tw.t, k);
+  LAB_CT(a0, 4);
+  LAB_CT(b0, 4);
+#if GPQ_LAB != 7
+  LAB_CT(a1, 4);
+  LAB_CT(b1, 4);
+#endif
   tw.load_l(ln, cb.wave0, a.logn, wf);
-  ln.h_to_l(a0); ct_group<4, 3, 0>(a0, tw.t, k);
-  ln.h_to_l(b0); ct_group<4, 3, 0>(b0, tw.t, k);
-  ln.h_to_l(a1); ct_group<4, 3, 0>(a1, tw.t, k);
-  ln.h_to_l(b1); ct_group<4, 3, 0>(b1, tw.t, k);
+  ln.h_to_l(a0); LAB_CT(a0, 0);
+  ln.h_to_l(b0); LAB_CT(b0, 0);
+#if GPQ_LAB != 7
+  ln.h_to_l(a1); LAB_CT(a1, 0);
+  ln.h_to_l(b1); LAB_CT(b1, 0);
+#endif
   tw.load_l(ln, cb.wave0, a.logn, wi);               // inverse twiddles arrive under the products
   // products: left operand < 2p, right operand < 4p  =>  a*b < 8p^2, as mulmod_lazy needs
   uint64_t d1[16];
@@ -483,21 +560,37 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 2) void tensor_mid(PassArgs a) {
   for (int e = 0; e < 16; ++e) {
     const uint64_t u0 = TT::left(a0[e], k), u1 = TT::left(a1[e], k);
     const uint64_t v0 = TT::right(b0[e], k), v1 = TT::right(b1[e], k);
+#if GPQ_LAB == 7
+    a0[e] = TT::inv_from4(mulmod_lazy(u0, v0, k), k); d1[e] = u1 ^ v1; a1[e] = v1;
+#elif GPQ_LAB == 3
+    a0[e] = u0 ^ v0; d1[e] = u0 + v1 + *reinterpret_cast<const uint64_t *>(&tw.t[e % 15]); a1[e] = u1 ^ v1 ^ v0;
+#else
     a0[e] = TT::inv_from4(mulmod_lazy(u0, v0, k), k);                                   // d0
     d1[e] = TT::inv_from8(mulmod_lazy(u0, v1, k) + mulmod_lazy(u1, v0, k), k);          // d1
     a1[e] = TT::inv_from4(mulmod_lazy(u1, v1, k), k);                                   // d2
+#endif
   }
-  gs_group<4, 3, 0>(a0, tw.t, k); ln.l_to_h(a0);
-  gs_group<4, 3, 0>(d1, tw.t, k); ln.l_to_h(d1);
-  gs_group<4, 3, 0>(a1, tw.t, k); ln.l_to_h(a1);
+  LAB_GS(a0); ln.l_to_h(a0);
+#if GPQ_LAB != 7
+  LAB_GS(d1); ln.l_to_h(d1);
+  LAB_GS(a1); ln.l_to_h(a1);
+#endif
   tw.load_h(ln, cb.wave0, a.logn, wi);
-  gs_group<4, 3, 0>(a0, tw.t, k);
-  store_h(a.dst[0] + cb.off, a0, ln);
-  gs_group<4, 3, 0>(d1, tw.t, k);
-  store_h(a.dst[1] + cb.off, d1, ln);
-  gs_group<4, 3, 0>(a1, tw.t, k);
-  store_h(a.dst[2] + cb.off, a1, ln);
+  LAB_GS(a0);
+  LAB_STORE(a.dst[0] + cb.off, a0);
+#if GPQ_LAB != 7
+  LAB_GS(d1);
+#endif
+  LAB_STORE(a.dst[1] + cb.off, d1);
+#if GPQ_LAB != 7
+  LAB_GS(a1);
+#endif
+  LAB_STORE(a.dst[2] + cb.off, a1);
 }
+#undef LAB_LOAD
+#undef LAB_STORE
+#undef LAB_CT
+#undef LAB_GS
 
 // ---------------------------------------------------------------------------
 // Fused middle of the key-switch inner product (src/he-mult.c:60-64 ==
@@ -522,10 +615,10 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid(KeyswitchA
   ContigTw<TW> tw;
   load_h(x, a.src[0] + cb.off, ln);
   tw.load_h(ln, cb.wave0, a.logn, wf);
-  ct_group<4, 3, 0>(x, tw.t, k);
+  ct_group<4, 3, 0, 4>(x, tw.t, k);
   tw.load_l(ln, cb.wave0, a.logn, wf);
   ln.h_to_l(x);
-  ct_group<4, 3, 0>(x, tw.t, k);
+  ct_group<4, 3, 0, 0>(x, tw.t, k);
   load_l(e0, ka.evk0 + koff, ln);   // measured faster than H-layout loads + two more LDS exchanges here
   load_l(e1, ka.evk1 + koff, ln);
   tw.load_l(ln, cb.wave0, a.logn, wi);

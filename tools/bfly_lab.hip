@@ -123,6 +123,17 @@ __device__ __forceinline__ void ct_split(uint64_t &x, uint64_t &y, uint64_t wn, 
   const uint64_t xs = x + (x >= k.p2 ? kx1 : kx0);
   x = xs + t; y = xs + ky - t;
 }
+// alternate-stage variant (wide split class, c < 2^27): stage A adds without the conditional subtract, stage B subtracts 4p
+__device__ __forceinline__ void ct_split_nocsub(uint64_t &x, uint64_t &y, uint64_t wn, uint64_t w2n, const PrimeK &k, uint64_t kx0, uint64_t ky) {
+  const uint64_t t = mulmod_split(y, wn, w2n, k);
+  const uint64_t xs = x + kx0;
+  x = xs + t; y = xs + ky - t;
+}
+__device__ __forceinline__ void ct_split_csub4(uint64_t &x, uint64_t &y, uint64_t wn, uint64_t w2n, const PrimeK &k, uint64_t kx0, uint64_t kx14, uint64_t ky) {
+  const uint64_t t = mulmod_split(y, wn, w2n, k);
+  const uint64_t xs = x + (x >= k.p4 ? kx14 : kx0);
+  x = xs + t; y = xs + ky - t;
+}
 // data in [0,2p)
 __device__ __forceinline__ void gs_split(uint64_t &x, uint64_t &y, uint64_t wn, uint64_t w2n, const PrimeK &k) {
   const uint64_t v = x + y;
@@ -137,15 +148,20 @@ __global__ __launch_bounds__(256) void probe(uint64_t *out, uint64_t seed, Prime
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = seed * (threadIdx.x + 1 + 64 * i) + blockIdx.x;
   const uint64_t p6 = 6 * k.p, ky3 = 3 * k.p - 2 * (uint64_t)k.c1, k60 = k.c1, k61 = (uint64_t)k.c1 - p6;
-  if (V == 10 || V == 11) {
+  if (V == 10 || V == 11 || V == 15 || V == 16) {
     for (int it = 0; it < ITER / 2; ++it) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] &= 0x3fffffffffffffffull;
+      for (int i = 0; i < 8; ++i) v[i] &= (V >= 15 ? 0x0fffffffffffffffull : 0x3fffffffffffffffull);
       // stage 1: pairs (0,2),(1,3),(4,6),(5,7); stage 2: pairs (0,1),(2,3),(4,5),(6,7)
 #pragma unroll
       for (int g = 0; g < 8; g += 4) {
         const uint64_t w = k.p - 3 - g;
-        if (V == 10) { ct_v6(v[g], v[g + 2], w, k); ct_v6(v[g + 1], v[g + 3], w, k); ct_v6(v[g], v[g + 1], w - 1, k); ct_v6(v[g + 2], v[g + 3], w - 2, k); }
+        const uint64_t w2 = w - 77 - seed, kx14 = (uint64_t)k.c1 - k.p4;
+        if (V == 15) { ct_split(v[g], v[g + 2], w, w2, k, k2.kx0, k2.kx1, k2.ky); ct_split(v[g + 1], v[g + 3], w, w2, k, k2.kx0, k2.kx1, k2.ky);
+                       ct_split(v[g], v[g + 1], w - 1, w2 - 1, k, k2.kx0, k2.kx1, k2.ky); ct_split(v[g + 2], v[g + 3], w - 2, w2 - 2, k, k2.kx0, k2.kx1, k2.ky); }
+        else if (V == 16) { ct_split_nocsub(v[g], v[g + 2], w, w2, k, k2.kx0, k2.ky); ct_split_nocsub(v[g + 1], v[g + 3], w, w2, k, k2.kx0, k2.ky);
+                            ct_split_csub4(v[g], v[g + 1], w - 1, w2 - 1, k, k2.kx0, kx14, k2.ky); ct_split_csub4(v[g + 2], v[g + 3], w - 2, w2 - 2, k, k2.kx0, kx14, k2.ky); }
+        else if (V == 10) { ct_v6(v[g], v[g + 2], w, k); ct_v6(v[g + 1], v[g + 3], w, k); ct_v6(v[g], v[g + 1], w - 1, k); ct_v6(v[g + 2], v[g + 3], w - 2, k); }
         else { ct_nocsub(v[g], v[g + 2], w, k, k60, ky3); ct_nocsub(v[g + 1], v[g + 3], w, k, k60, ky3);
                ct_csub6(v[g], v[g + 1], w - 1, k, p6, k61, k60, ky3); ct_csub6(v[g + 2], v[g + 3], w - 2, k, p6, k61, k60, ky3); }
       }
@@ -209,8 +225,9 @@ int main() {
                   run<3>("ct v3 (no csub)", d_out, k, 8); run<4>("mulmod only", d_out, k, 8); run<5>("4-mad product only", d_out, k, 8); run<6>("gs (current)", d_out, k, 8);
                   run<7>("ct v6 (pinned mid)", d_out, k, 8); run<8>("ct v7 (pinned + approx csub)", d_out, k, 8); run<9>("ct v8 (v7, y via ~t)", d_out, k, 8);
                   run<12>("ct split-twiddle (5 mads)", d_out, k, 8); run<13>("gs split-twiddle (5 mads)", d_out, k, 8); run<14>("mulmod split only", d_out, k, 8);
-                  run<10>("2 stages, csub(4p) each", d_out, k, 8); run<11>("2 stages, one csub(6p)", d_out, k, 8); }
-    if (w == 4) { run<0>("ct v0", d_out, k, 4); run<1>("ct v1", d_out, k, 4); }
+                  run<10>("2 stages, csub(4p) each", d_out, k, 8); run<11>("2 stages, one csub(6p)", d_out, k, 8);
+                  run<15>("split, 2 stages, csub(2p) each", d_out, k, 8); run<16>("split, 2 stages, one csub(4p)", d_out, k, 8); }
+    if (w == 4) { run<0>("ct v0", d_out, k, 4); run<1>("ct v1", d_out, k, 4); run<15>("split, 2 stages, csub(2p) each", d_out, k, 4); run<16>("split, 2 stages, one csub(4p)", d_out, k, 4); }
     if (w == 2) { run<0>("ct v0", d_out, k, 2); run<1>("ct v1", d_out, k, 2); }
   }
   return 0;
