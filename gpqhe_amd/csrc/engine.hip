@@ -163,6 +163,8 @@ static int upload_tables(gpq_ctx *c) {
   if (!(nosplit && nosplit[0] == '1'))
     while (c->nsplit < np && c->p[c->nsplit] - (1ull << 59) < GPQ_SPLIT_CMAX) ++c->nsplit;
   // ... and among them the leading limbs whose forward stages may skip every other conditional subtraction (ct_bfly_wide)
+  const char *mid8 = getenv("GPQHE_MID8");          // dev switch: 0 = tensor stage on the 16-coefficients-per-lane kernel
+  c->mid8 = !(mid8 && mid8[0] == '0');
   const char *nowide = getenv("GPQHE_NO_WIDE");     // dev switch: A/B against one subtraction per stage
   c->nwide = 0;
   if (!(nowide && nowide[0] == '1'))
@@ -569,7 +571,8 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
     if ((rc = for_limb_ranges<true>(c, m, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
           using TW = decltype(tag);
           ProfScope prof(c, GPQ_K_TENSOR_MID, s);
-          hipLaunchKernelGGL((tensor_mid<TW>), dim3(c->n >> 12, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, a);
+          if (c->mid8) hipLaunchKernelGGL((tensor_mid8<TW>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, a);
+          else hipLaunchKernelGGL((tensor_mid<TW>), dim3(c->n >> 12, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, a);
           return (int)GPQ_OK;
         }))) return rc;
     // 3. strided inverse pass in place on the three outputs

@@ -27,6 +27,10 @@
 // Forward butterflies that skip every other conditional subtraction (ct_bfly_wide below) need c < 2^27.
 #define GPQ_WIDE_CMAX 134217000u
 
+#ifndef GPQ_PIN_VOLATILE
+#define GPQ_PIN_VOLATILE volatile
+#endif
+
 namespace gpq {
 
 typedef unsigned __int128 u128;
@@ -59,7 +63,7 @@ __device__ __forceinline__ uint64_t mulmod_raw_t(uint64_t a, uint64_t w, const P
   uint64_t mid = mad_u64(a0, w1, (uint32_t)(m00 >> 32));
   // PIN keeps the carry inside the mad: stops hipcc re-associating it into a mad + 64-bit add.
   // Measured (profiles/r01): +5 % on forward butterflies, a loss on the inverse ones, hence per call site.
-  if (PIN) asm volatile("" : "+v"(mid));
+  if (PIN) asm GPQ_PIN_VOLATILE("" : "+v"(mid));
   mid = mad_u64(a1, w0, mid);                                   // < 2^60 + 2^62.1 : fits
   const uint64_t hi = mad_u64(a1, w1, (uint32_t)(mid >> 32));   // x >> 64
   const uint32_t midlo = (uint32_t)mid, hilo = (uint32_t)hi, hihi = (uint32_t)(hi >> 32);
@@ -146,9 +150,9 @@ __device__ __forceinline__ uint64_t mulmod_split(uint64_t a, const W &w, const P
   const uint32_t ah = __builtin_amdgcn_alignbit((uint32_t)(a >> 32), (uint32_t)a, 31);
   uint64_t t0 = mad_u64(al, (uint32_t)w.x, 0);
   t0 = mad_u64(ah, (uint32_t)w.y, t0);                         // < 2^63 + 2^62
-  asm volatile("" : "+v"(t0));                                 // keep the carries inside the mads (see mulmod_raw_t)
+  asm GPQ_PIN_VOLATILE("" : "+v"(t0));                                 // keep the carries inside the mads (see mulmod_raw_t)
   uint64_t t1 = mad_u64(al, (uint32_t)(w.x >> 32), (uint32_t)(t0 >> 32));
-  asm volatile("" : "+v"(t1));
+  asm GPQ_PIN_VOLATILE("" : "+v"(t1));
   t1 = mad_u64(ah, (uint32_t)(w.y >> 32), t1);                 // sum >> 32, < 0.75p
   const uint32_t t1lo = (uint32_t)t1, t1hi = (uint32_t)(t1 >> 32);
   const uint32_t th = __builtin_amdgcn_alignbit(t1hi, t1lo, 27);

@@ -176,9 +176,6 @@ template <> struct TwTraits<TwW> {
 // Forward runs A then B, inverse B then A.  Group A's twiddles are the same
 // for the whole grid (scalar loads); group B's are fetched at kernel entry.
 // ---------------------------------------------------------------------------
-#ifndef GPQ_LAB
-#define GPQ_LAB 0
-#endif
 #ifndef GPQ_STRIDED_CB
 #define GPQ_STRIDED_CB 4      /* log2 of the columns of a tile: 16 columns = 128-byte row segments */
 #endif
@@ -232,37 +229,20 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
 
   if (!INV) {
     TW twA[tw_count(EL, EL - 1, 0)];
-#if GPQ_LAB == 1   /* dev probe: no global data traffic */
-#pragma unroll
-    for (int e = 0; e < E; ++e) x[e] = (uint64_t)(iA + e * strideA) * 0x9e3779b97f4a7c15ull >> 4;
-#else
 #pragma unroll
     for (int e = 0; e < E; ++e) x[e] = src[iA + e * strideA];
-#endif
     load_tw<EL, EL - 1, 0, true>(twA, iA, G::S2 + 8, logn, wt);
     if (G::S2 > 0) load_tw<EL, G::BB, 0, false>(twB, iB, 8, logn, wt);
-#if GPQ_LAB != 2   /* dev probe 2: no butterflies */
     ct_group<EL, EL - 1, 0, G::S2 + 8>(x, twA, k);
-#endif
     if (G::S2 > 0) {
 #pragma unroll
       for (int e = 0; e < E; ++e) lds[G::pad(tid + e * G::T)] = x[e];
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = lds[G::pad((q << (EL + CB)) + (e << CB) + (tid & (G::C - 1)))];
-#if GPQ_LAB != 2
       ct_group<EL, G::BB, 0, 8>(x, twB, k);
-#else
-#pragma unroll
-      for (int e = 0; e < E; ++e) x[e] += *reinterpret_cast<const uint64_t *>(&twB[e % tw_count(EL, G::BB, 0)]) + *reinterpret_cast<const uint64_t *>(&twA[e % tw_count(EL, EL - 1, 0)]);
-#endif
-#if GPQ_LAB == 1
-#pragma unroll
-      for (int e = 0; e < E; ++e) if (x[e] == 0x123456789abcdefull) dst[iB + e * strideB] = x[e];
-#else
 #pragma unroll
       for (int e = 0; e < E; ++e) dst[iB + e * strideB] = CANON_OUT ? TwTraits<TW>::canon_fwd(x[e], k) : x[e];
-#endif
     } else {
 #pragma unroll
       for (int e = 0; e < E; ++e) dst[iA + e * strideA] = CANON_OUT ? TwTraits<TW>::canon_fwd(x[e], k) : x[e];
@@ -325,9 +305,6 @@ struct ContigLane {
   __device__ static __forceinline__ unsigned pad(unsigned l) { return l + (l >> 4); }
   // registers in H layout -> registers in L layout
   __device__ __forceinline__ void h_to_l(uint64_t (&x)[16]) const {
-#if GPQ_LAB == 5
-    return;
-#endif
 #pragma unroll
     for (int e = 0; e < 16; ++e) lds[pad(hbase + 16 * e)] = x[e];
     wave_lds_sync();
@@ -336,9 +313,6 @@ struct ContigLane {
     wave_lds_sync();
   }
   __device__ __forceinline__ void l_to_h(uint64_t (&x)[16]) const {
-#if GPQ_LAB == 5
-    return;
-#endif
 #pragma unroll
     for (int e = 0; e < 16; ++e) lds[pad(lbase + e)] = x[e];
     wave_lds_sync();
@@ -355,17 +329,9 @@ template <typename TW>
 struct ContigTw {
   TW t[15];
   __device__ __forceinline__ void load_h(const ContigLane &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
-#if GPQ_LAB == 6
-    for (int i = 0; i < 15; ++i) { uint64_t *q = reinterpret_cast<uint64_t *>(&t[i]); for (unsigned j = 0; j < sizeof(TW) / 8; ++j) q[j] = ((wave0 + ln.hbase + i + j) * 0x9e3779b97f4a7c15ull >> 5) + (uint64_t)w; }
-    return;
-#endif
     load_tw<4, 3, 0, false>(t, wave0 + ln.hbase, 4, logn, w);
   }
   __device__ __forceinline__ void load_l(const ContigLane &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
-#if GPQ_LAB == 6
-    for (int i = 0; i < 15; ++i) { uint64_t *q = reinterpret_cast<uint64_t *>(&t[i]); for (unsigned j = 0; j < sizeof(TW) / 8; ++j) q[j] = ((wave0 + ln.lbase + 3 * i + j) * 0x9e3779b97f4a7c15ull >> 5) + (uint64_t)w; }
-    return;
-#endif
     load_tw<4, 3, 0, false>(t, wave0 + ln.lbase, 0, logn, w);
   }
 };
@@ -520,39 +486,21 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 2) void tensor_mid(PassArgs a) {
   const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
   uint64_t a0[16], a1[16], b0[16], b1[16];
   ContigTw<TW> tw;
-#if GPQ_LAB == 4 || GPQ_LAB == 5 || GPQ_LAB == 6 || GPQ_LAB == 7  /* dev probe: no global data traffic (5: no LDS exchange either, 6: no twiddle loads either) */
-#define LAB_LOAD(x, p) for (int e_ = 0; e_ < 16; ++e_) x[e_] = (uint64_t)(cb.off + ln.hbase + 16 * e_ + (size_t)(p)) * 0x9e3779b97f4a7c15ull >> 4
-#define LAB_STORE(p, x) for (int e_ = 0; e_ < 16; ++e_) if (x[e_] == 0x123456789abcdefull) (p)[ln.hbase + 16 * e_] = x[e_]
-#else
-#define LAB_LOAD(x, p) load_h(x, p, ln)
-#define LAB_STORE(p, x) store_h(p, x, ln)
-#endif
-#if GPQ_LAB == 3   /* dev probe: no butterflies, no products */
-#define LAB_CT(x, rs) (void)0
-#define LAB_GS(x) (void)0
-#else
-#define LAB_CT(x, rs) ct_group<4, 3, 0, rs>(x, tw.t, k)
-#define LAB_GS(x) gs_group<4, 3, 0>(x, tw.t, k)
-#endif
-  LAB_LOAD(a0, a.src[0] + cb.off);
+  load_h(a0, a.src[0] + cb.off, ln);
   tw.load_h(ln, cb.wave0, a.logn, wf);
-  LAB_LOAD(b0, a.src[2] + cb.off);
-  LAB_LOAD(a1, a.src[1] + cb.off);
-  LAB_LOAD(b1, a.src[3] + cb.off);
+  load_h(b0, a.src[2] + cb.off, ln);
+  load_h(a1, a.src[1] + cb.off, ln);
+  load_h(b1, a.src[3] + cb.off, ln);
   // forward, group H on all four, then group L on all four (15 twiddles live at a time)
-  LAB_CT(a0, 4);
-  LAB_CT(b0, 4);
-#if GPQ_LAB != 7
-  LAB_CT(a1, 4);
-  LAB_CT(b1, 4);
-#endif
+  ct_group<4, 3, 0, 4>(a0, tw.t, k);
+  ct_group<4, 3, 0, 4>(b0, tw.t, k);
+  ct_group<4, 3, 0, 4>(a1, tw.t, k);
+  ct_group<4, 3, 0, 4>(b1, tw.t, k);
   tw.load_l(ln, cb.wave0, a.logn, wf);
-  ln.h_to_l(a0); LAB_CT(a0, 0);
-  ln.h_to_l(b0); LAB_CT(b0, 0);
-#if GPQ_LAB != 7
-  ln.h_to_l(a1); LAB_CT(a1, 0);
-  ln.h_to_l(b1); LAB_CT(b1, 0);
-#endif
+  ln.h_to_l(a0); ct_group<4, 3, 0, 0>(a0, tw.t, k);
+  ln.h_to_l(b0); ct_group<4, 3, 0, 0>(b0, tw.t, k);
+  ln.h_to_l(a1); ct_group<4, 3, 0, 0>(a1, tw.t, k);
+  ln.h_to_l(b1); ct_group<4, 3, 0, 0>(b1, tw.t, k);
   tw.load_l(ln, cb.wave0, a.logn, wi);               // inverse twiddles arrive under the products
   // products: left operand < 2p, right operand < 4p  =>  a*b < 8p^2, as mulmod_lazy needs
   uint64_t d1[16];
@@ -560,38 +508,21 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 2) void tensor_mid(PassArgs a) {
   for (int e = 0; e < 16; ++e) {
     const uint64_t u0 = TT::left(a0[e], k), u1 = TT::left(a1[e], k);
     const uint64_t v0 = TT::right(b0[e], k), v1 = TT::right(b1[e], k);
-#if GPQ_LAB == 7
-    a0[e] = TT::inv_from4(mulmod_lazy(u0, v0, k), k); d1[e] = u1 ^ v1; a1[e] = v1;
-#elif GPQ_LAB == 3
-    a0[e] = u0 ^ v0; d1[e] = u0 + v1 + *reinterpret_cast<const uint64_t *>(&tw.t[e % 15]); a1[e] = u1 ^ v1 ^ v0;
-#else
     a0[e] = TT::inv_from4(mulmod_lazy(u0, v0, k), k);                                   // d0
     d1[e] = TT::inv_from8(mulmod_lazy(u0, v1, k) + mulmod_lazy(u1, v0, k), k);          // d1
     a1[e] = TT::inv_from4(mulmod_lazy(u1, v1, k), k);                                   // d2
-#endif
   }
-  LAB_GS(a0); ln.l_to_h(a0);
-#if GPQ_LAB != 7
-  LAB_GS(d1); ln.l_to_h(d1);
-  LAB_GS(a1); ln.l_to_h(a1);
-#endif
+  gs_group<4, 3, 0>(a0, tw.t, k); ln.l_to_h(a0);
+  gs_group<4, 3, 0>(d1, tw.t, k); ln.l_to_h(d1);
+  gs_group<4, 3, 0>(a1, tw.t, k); ln.l_to_h(a1);
   tw.load_h(ln, cb.wave0, a.logn, wi);
-  LAB_GS(a0);
-  LAB_STORE(a.dst[0] + cb.off, a0);
-#if GPQ_LAB != 7
-  LAB_GS(d1);
-#endif
-  LAB_STORE(a.dst[1] + cb.off, d1);
-#if GPQ_LAB != 7
-  LAB_GS(a1);
-#endif
-  LAB_STORE(a.dst[2] + cb.off, a1);
+  gs_group<4, 3, 0>(a0, tw.t, k);
+  store_h(a.dst[0] + cb.off, a0, ln);
+  gs_group<4, 3, 0>(d1, tw.t, k);
+  store_h(a.dst[1] + cb.off, d1, ln);
+  gs_group<4, 3, 0>(a1, tw.t, k);
+  store_h(a.dst[2] + cb.off, a1, ln);
 }
-#undef LAB_LOAD
-#undef LAB_STORE
-#undef LAB_CT
-#undef LAB_GS
-
 // ---------------------------------------------------------------------------
 // Fused middle of the key-switch inner product (src/he-mult.c:60-64 ==
 // src/he-automorphism.c:61-65): src[0] = d2 after the strided forward pass,
@@ -635,6 +566,161 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid(KeyswitchA
   store_h(a.dst[0] + cb.off, e0, ln);
   gs_group<4, 3, 0>(e1, tw.t, k);
   store_h(a.dst[1] + cb.off, e1, ln);
+}
+
+// ---------------------------------------------------------------------------
+// The same two fused kernels with 8 coefficients per lane instead of 16.
+// The 16-per-lane forms hold 4 (3) polynomials x 16 coefficients x 2 VGPRs and run at 2 (3) waves per
+// SIMD, where the dependent instruction chain of a butterfly is not covered (profiles/r01: 4.75 cycles
+// per VALU instruction with arithmetic only, against 3.5 for the same mix at 8 waves).  Here a wave owns
+// 512 consecutive coefficients (2 blocks of 256), lane = j + 32*blk, and the 8 stages of a block run as
+// three register groups with two exchanges through the wave's own LDS region:
+//   H: k = j + 32 e                 index bits 7..5     (3 stages)
+//   M: k = 32 (j >> 2) + 4 e + (j & 3)   bits 4..2      (3 stages)
+//   L: k = 8 j + e                  index bits 1..0     (2 stages; bit 2 rides along)
+// Global accesses use the H layout (32 lanes = 256 contiguous bytes).
+// ---------------------------------------------------------------------------
+constexpr int LANE8_LDS_PER_WAVE = 576;     // 512 + padding (both paddings end below 576)
+
+struct Lane8 {
+  unsigned hk, mk, lk;      // index of x[0] inside the wave's 512 coefficients, per layout
+  uint64_t *lds;
+  __device__ __forceinline__ Lane8(uint64_t *wave_lds) {
+    const unsigned lane = threadIdx.x & 63, j = lane & 31, blk = lane >> 5;
+    hk = (blk << 8) + j;
+    mk = (blk << 8) + ((j >> 2) << 5) + (j & 3);
+    lk = (blk << 8) + (j << 3);
+    lds = wave_lds;
+  }
+  // H<->M exchange: 32-word rows padded by 4 (M reads walk 4 e + (j & 3) inside row j >> 2);
+  // M<->L exchange: one word per 8 (L reads are 9 j + e).  Both conflict-free per half-wave.
+  __device__ static __forceinline__ unsigned pad1(unsigned l) { return l + ((l >> 5) << 2); }
+  __device__ static __forceinline__ unsigned pad2(unsigned l) { return l + (l >> 3); }
+  __device__ __forceinline__ void h_to_m(uint64_t (&x)[8]) const {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds[pad1(hk + 32 * e)] = x[e];
+    wave_lds_sync();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = lds[pad1(mk + 4 * e)];
+    wave_lds_sync();
+  }
+  __device__ __forceinline__ void m_to_l(uint64_t (&x)[8]) const {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds[pad2(mk + 4 * e)] = x[e];
+    wave_lds_sync();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = lds[pad2(lk + e)];
+    wave_lds_sync();
+  }
+  __device__ __forceinline__ void l_to_m(uint64_t (&x)[8]) const {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds[pad2(lk + e)] = x[e];
+    wave_lds_sync();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = lds[pad2(mk + 4 * e)];
+    wave_lds_sync();
+  }
+  __device__ __forceinline__ void m_to_h(uint64_t (&x)[8]) const {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds[pad1(mk + 4 * e)] = x[e];
+    wave_lds_sync();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = lds[pad1(hk + 32 * e)];
+    wave_lds_sync();
+  }
+  __device__ __forceinline__ void load_h(uint64_t (&x)[8], const uint64_t *__restrict__ p) const {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = p[hk + 32 * e];
+  }
+  __device__ __forceinline__ void store_h(uint64_t *__restrict__ p, const uint64_t (&x)[8]) const {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) p[hk + 32 * e] = x[e];
+  }
+};
+
+// twiddles of one group of one direction: 7 for H and M, 6 for L
+template <typename TW>
+struct Tw8 {
+  TW t[7];
+  TW u[6];
+  __device__ __forceinline__ void load_h(const Lane8 &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
+    load_tw<3, 2, 0, false>(t, wave0 + ln.hk, 5, logn, w);
+  }
+  __device__ __forceinline__ void load_m(const Lane8 &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
+    load_tw<3, 2, 0, false>(t, wave0 + ln.mk, 2, logn, w);
+  }
+  __device__ __forceinline__ void load_l(const Lane8 &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
+    load_tw<3, 1, 0, false>(u, wave0 + ln.lk, 0, logn, w);
+  }
+};
+
+struct Block8 {             // per-workgroup addressing: 4 waves x 512 coefficients
+  unsigned wave0, limb;
+  size_t off, toff;
+  __device__ __forceinline__ Block8(const PassArgs &a) {
+    wave0 = (blockIdx.x * CONTIG_WAVES + (threadIdx.x >> 6)) << 9;
+    limb = a.limb0 + blockIdx.z;
+    off = (size_t)blockIdx.y * a.poly_stride + ((size_t)blockIdx.z << a.logn) + wave0;
+    toff = (size_t)limb << a.logn;
+  }
+};
+
+#ifndef GPQ_MID8_MINWAVES
+#define GPQ_MID8_MINWAVES 3
+#endif
+template <typename TW>
+__global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_MID8_MINWAVES) void tensor_mid8(PassArgs a) {
+  using TT = TwTraits<TW>;
+  __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
+  const Lane8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
+  const Block8 cb(a);
+  const PrimeK k = a.tabs[cb.limb].k;
+  const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
+  uint64_t a0[8], a1[8], b0[8], b1[8];
+  Tw8<TW> tw;
+  ln.load_h(a0, a.src[0] + cb.off);
+  tw.load_h(ln, cb.wave0, a.logn, wf);
+  ln.load_h(b0, a.src[2] + cb.off);
+  ln.load_h(a1, a.src[1] + cb.off);
+  ln.load_h(b1, a.src[3] + cb.off);
+  ct_group<3, 2, 0, 5>(a0, tw.t, k);
+  ct_group<3, 2, 0, 5>(b0, tw.t, k);
+  ct_group<3, 2, 0, 5>(a1, tw.t, k);
+  ct_group<3, 2, 0, 5>(b1, tw.t, k);
+  tw.load_m(ln, cb.wave0, a.logn, wf);
+  ln.h_to_m(a0); ct_group<3, 2, 0, 2>(a0, tw.t, k);
+  ln.h_to_m(b0); ct_group<3, 2, 0, 2>(b0, tw.t, k);
+  ln.h_to_m(a1); ct_group<3, 2, 0, 2>(a1, tw.t, k);
+  ln.h_to_m(b1); ct_group<3, 2, 0, 2>(b1, tw.t, k);
+  tw.load_l(ln, cb.wave0, a.logn, wf);
+  ln.m_to_l(a0); ct_group<3, 1, 0, 0>(a0, tw.u, k);
+  ln.m_to_l(b0); ct_group<3, 1, 0, 0>(b0, tw.u, k);
+  ln.m_to_l(a1); ct_group<3, 1, 0, 0>(a1, tw.u, k);
+  ln.m_to_l(b1); ct_group<3, 1, 0, 0>(b1, tw.u, k);
+  tw.load_l(ln, cb.wave0, a.logn, wi);               // inverse twiddles arrive under the products
+  uint64_t d1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {                      // operand ranges as in tensor_mid
+    const uint64_t u0 = TT::left(a0[e], k), u1 = TT::left(a1[e], k);
+    const uint64_t v0 = TT::right(b0[e], k), v1 = TT::right(b1[e], k);
+    a0[e] = TT::inv_from4(mulmod_lazy(u0, v0, k), k);                                   // d0
+    d1[e] = TT::inv_from8(mulmod_lazy(u0, v1, k) + mulmod_lazy(u1, v0, k), k);          // d1
+    a1[e] = TT::inv_from4(mulmod_lazy(u1, v1, k), k);                                   // d2
+  }
+  gs_group<3, 1, 0>(a0, tw.u, k); ln.l_to_m(a0);
+  gs_group<3, 1, 0>(d1, tw.u, k); ln.l_to_m(d1);
+  gs_group<3, 1, 0>(a1, tw.u, k); ln.l_to_m(a1);
+  tw.load_m(ln, cb.wave0, a.logn, wi);
+  gs_group<3, 2, 0>(a0, tw.t, k); ln.m_to_h(a0);
+  gs_group<3, 2, 0>(d1, tw.t, k); ln.m_to_h(d1);
+  gs_group<3, 2, 0>(a1, tw.t, k); ln.m_to_h(a1);
+  tw.load_h(ln, cb.wave0, a.logn, wi);
+  gs_group<3, 2, 0>(a0, tw.t, k);
+  ln.store_h(a.dst[0] + cb.off, a0);
+  gs_group<3, 2, 0>(d1, tw.t, k);
+  ln.store_h(a.dst[1] + cb.off, d1);
+  gs_group<3, 2, 0>(a1, tw.t, k);
+  ln.store_h(a.dst[2] + cb.off, a1);
 }
 
 // ---------------------------------------------------------------------------

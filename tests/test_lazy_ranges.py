@@ -1,0 +1,90 @@
+"""Integer model of the split-twiddle multiply and of the wide-split forward stages (gpqhe_amd/csrc/modarith.hpp):
+every intermediate fits the register it lives in and the lazy ranges close, for the largest c each class admits.
+CPU only; the kernels themselves are checked bit for bit on the GPU (tests/test_ntt_gpu.py)."""
+import random
+
+import pytest
+
+M64 = (1 << 64) - 1
+SPLIT_CMAX = 178956971   # GPQ_SPLIT_CMAX
+WIDE_CMAX = 134217000    # GPQ_WIDE_CMAX
+
+
+def mulmod_split(a, wx, wy, c):
+    """mulmod_split(): returns T' with a*w == T' + (c+1) (mod p); asserts what the device code relies on."""
+    al, ah = a & 0x7FFFFFFF, a >> 31
+    assert ah < (1 << 32)
+    t0 = al * (wx & 0xFFFFFFFF) + ah * (wy & 0xFFFFFFFF)
+    assert t0 <= M64
+    t1 = al * (wx >> 32) + (t0 >> 32) + ah * (wy >> 32)
+    assert t1 <= M64
+    th = t1 >> 27
+    assert th < (1 << 32)
+    ntl = ((~t0) & 0xFFFFFFFF) | (((~t1) & 0x7FFFFFF) << 32)
+    r = c * th + ntl
+    assert r <= M64
+    return r
+
+
+def pairs(p, w):
+    return p - w, p - ((w << 31) % p)
+
+
+@pytest.mark.parametrize("c", [4849665, 113508353, SPLIT_CMAX - 1])
+def test_split_multiply_below_2p_for_operands_below_4p(c):
+    p = (1 << 59) + c
+    rnd = random.Random(c)
+    for a in [0, 1, 4 * p - 1, 4 * p - 2, (1 << 61) - 1, 1 << 61] + [rnd.randrange(4 * p) for _ in range(3000)]:
+        for w in (1, p - 1, rnd.randrange(1, p)):
+            t = mulmod_split(a, *pairs(p, w), c) + c + 1
+            assert t < 2 * p and t % p == a * w % p
+    for wx in (p - 1, 1):
+        for wy in (p - 1, 1):
+            assert mulmod_split(4 * p - 1, wx, wy, c) + c + 1 < 2 * p
+
+
+@pytest.mark.parametrize("c", [4849665, 113508353, WIDE_CMAX - 1])
+def test_wide_split_stage_ranges_close(c):
+    """ct_bfly_wide: stage A (no subtraction) takes x, y < 6p to x' < 8p, y' <= 8p - c - 2; stage B (subtract 4p) takes
+    x, y < 8p back below 6p; every multiplicand that can occur keeps th in 32 bits and the product term below 2p."""
+    p = (1 << 59) + c
+    c1 = c + 1
+    kx0, kx1, kys = c1, (c1 - 4 * p) & M64, 2 * p - 2 * c1
+    rnd = random.Random(c)
+    edge = [0, 1, (1 << 62) - 1, 1 << 62, (1 << 62) + (1 << 31) - 2, 8 * p - c - 2, 6 * p - 1, 4 * p, 4 * p - 1]
+    for wx in (p - 1, 1, p // 2):
+        for wy in (p - 1, 1, p // 3):
+            for a in edge:
+                assert mulmod_split(a, wx, wy, c) + c1 < 2 * p
+    for _ in range(4000):
+        w = rnd.choice([1, 2, p - 1, rnd.randrange(1, p)])
+        wx, wy = pairs(p, w)
+        for kind, lim in (("A", 6 * p), ("B", 8 * p)):
+            x = rnd.choice(edge + [lim - 1, rnd.randrange(lim)]) % lim
+            y = min(rnd.choice(edge + [lim - 1, rnd.randrange(lim)]), lim - 1 if kind == "A" else 8 * p - c - 2)
+            T = mulmod_split(y, wx, wy, c)
+            assert (T + c1) % p == y * w % p and T + c1 < 2 * p
+            xs = (x + (kx1 if kind == "B" and x >= 4 * p else kx0)) & M64
+            x2, y2 = (xs + T) & M64, (xs + kys - T) & M64
+            assert x2 % p == (x + y * w) % p and y2 % p == (x - y * w) % p
+            if kind == "A":
+                assert x2 < 8 * p and y2 <= 8 * p - c - 2
+            else:
+                assert x2 < 6 * p and y2 < 6 * p
+
+
+def test_product_operands_of_the_wide_class_fit_the_general_multiply():
+    """tensor_mid: left operand < 4p, right operand < 6p for wide limbs: the 7-mad multiply's columns and folds stay in range."""
+    c = WIDE_CMAX - 1
+    p = (1 << 59) + c
+    a, w = 4 * p - 1, 6 * p - 1
+    a0, a1, w0, w1 = a & 0xFFFFFFFF, a >> 32, w & 0xFFFFFFFF, w >> 32
+    mid = a0 * w1 + ((a0 * w0) >> 32) + a1 * w0
+    assert mid <= M64
+    x = a * w
+    xh = x >> 59
+    assert xh <= M64
+    t = c * xh
+    assert (t >> 59) < (1 << 32)
+    tprime = (x & ((1 << 59) - 1)) + c * (t >> 59) + ((1 << 59) - 1 - (t & ((1 << 59) - 1)))
+    assert tprime + c + 1 < 4 * p and (tprime + c + 1) % p == x % p

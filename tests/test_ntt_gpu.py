@@ -162,23 +162,27 @@ def test_largest_c_of_the_supported_chains(engine_ctx, oracle_ctx):
     assert np.array_equal(to_host(outs[0]), e0) and np.array_equal(to_host(outs[1]), e1) and np.array_equal(to_host(outs[2]), e2)
 
 
+@pytest.mark.parametrize("switch,value", [("GPQHE_NO_SPLIT", "1"), ("GPQHE_NO_WIDE", "1"), ("GPQHE_MID8", "0")])
 @pytest.mark.parametrize("logn,dim", [(16, 58), (17, 57), (13, 20)])
-def test_split_twiddle_butterflies_equal_the_seven_mad_ones(logn, dim):
-    """The default contexts use the 5-mad split-twiddle multiply for every limb whose c allows it (all of them up to
-    n = 2^16, a prefix at n = 2^17: one transform then runs both kinds); GPQHE_NO_SPLIT=1 builds the tables for the 7-mad
-    butterflies only.  Same slabs through both, whole he_mul core included: bit-identical."""
+def test_kernel_families_agree_bit_for_bit(logn, dim, switch, value):
+    """The default contexts pick, per limb, the cheapest butterflies its c allows -- wide-split (c < 2^27: a conditional
+    subtraction every other forward stage), split (5-mad multiply), plain (7-mad) -- so one transform at n = 2^17 runs all
+    three, and run the tensor stage on the 8-coefficients-per-lane kernel.  Each development switch removes one of these
+    choices at context creation (GPQHE_NO_SPLIT=1: 7-mad butterflies only; GPQHE_NO_WIDE=1: a subtraction in every stage;
+    GPQHE_MID8=0: the 16-per-lane tensor kernel).  Same slabs through both contexts, whole he_mul core included: bit-identical."""
     import os
     import torch
     import gpqhe_amd
     gen = torch.Generator(device="cuda")
     gen.manual_seed(4242)
     outs = []
-    for nosplit in ("0", "1"):
-        os.environ["GPQHE_NO_SPLIT"] = nosplit
+    for setting in (None, value):
+        if setting is not None:
+            os.environ[switch] = setting
         try:
             g = gpqhe_amd.PolyContext(logn, dim)
         finally:
-            del os.environ["GPQHE_NO_SPLIT"]
+            os.environ.pop(switch, None)
         if not outs:
             batch = 2
             slabs = []
