@@ -900,15 +900,23 @@ constexpr size_t kModConstWords = 3 * 64;   // M, mu, floor(M/2) of a general mo
 
 // mpi_smod(x, q, floor(q/2)) of a big slab for an arbitrary q (host words): uploads the Barrett constants into
 // `dconst` (kModConstWords device words) and launches the kernel.  x and out may be the same slab.
+// What every entry point with a caller-supplied modulus checks before it launches anything: Wout = words of the result.
+int check_modulus(const uint64_t *q_words, unsigned Lq, unsigned Wout) {
+  if (!q_words || Lq < 1 || Lq > (unsigned)SMOD_MAXW / 2) return gpq_fail(GPQ_ERR_INVALID, "general modulus: bad word count %u", Lq);
+  unsigned L = Lq;
+  while (L > 1 && q_words[L - 1] == 0) --L;
+  if (L == 1 && q_words[0] == 0) return gpq_fail(GPQ_ERR_INVALID, "zero modulus");
+  if (Wout < L) return gpq_fail(GPQ_ERR_INVALID, "general modulus: %u words cannot hold a value mod q (%u words)", Wout, L);
+  return GPQ_OK;
+}
+
 int launch_smod_general(gpq_ctx *c, uint64_t *out, unsigned Wout, const uint64_t *x, unsigned Wx, const uint64_t *q_words, unsigned Lq,
                         unsigned batch, uint64_t *dconst, hipStream_t s) {
-  if (!q_words || Lq < 1 || Lq > (unsigned)SMOD_MAXW / 2) return gpq_fail(GPQ_ERR_INVALID, "general modulus: bad word count %u", Lq);
+  if (int rc = check_modulus(q_words, Lq, Wout)) return rc;
   Big M(q_words, q_words + Lq);
   while (M.size() > 1 && M.back() == 0) M.pop_back();
   const unsigned L = (unsigned)M.size();
-  if (L == 1 && M[0] == 0) return gpq_fail(GPQ_ERR_INVALID, "zero modulus");
   if (Wx > (unsigned)SMOD_MAXW) return gpq_fail(GPQ_ERR_UNSUPPORTED, "general modulus: value of %u words", Wx);
-  if (Wout < L) return gpq_fail(GPQ_ERR_INVALID, "general modulus: %u words cannot hold a value mod q (%u words)", Wout, L);
   Big mu = floor_pow2_div(128 * L, M), half = M;
   shr1(half);
   std::vector<uint64_t> consts(kModConstWords, 0);
@@ -927,6 +935,7 @@ extern "C" int gpq_rns_reconstruct_general(gpq_ctx *c, uint64_t *big, unsigned W
   int rc = check(c, dim, batch, "gpq_rns_reconstruct_general");
   if (rc) return rc;
   if (!big || !slab || !q_words || !scratch) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct_general: bad arguments");
+  if ((rc = check_modulus(q_words, Lq, Wout))) return rc;
   gpq_bridge_basis *b;
   if ((rc = get_basis(c, 0, dim, &b))) return rc;
   const unsigned Wx = b->WP + 1;
@@ -943,6 +952,7 @@ extern "C" int gpq_poly_mul_general(gpq_ctx *c, uint64_t *r, const uint64_t *a, 
   int rc = check(c, dim, batch, "gpq_poly_mul_general");
   if (rc) return rc;
   if (!r || !a || !b || !workspace) return gpq_fail(GPQ_ERR_INVALID, "gpq_poly_mul_general: bad arguments");
+  if ((rc = check_modulus(q_words, Lq, W))) return rc;
   const size_t poly = (size_t)dim << c->logn;
   uint64_t *sa = (uint64_t *)workspace, *sb = sa + batch * poly, *sr = sb + batch * poly, *scratch = sr + batch * poly;
   if ((rc = gpq_rns_decompose(c, sa, a, W, dim, batch, stream))) return rc;
@@ -1148,6 +1158,7 @@ extern "C" size_t gpq_he_general_workspace_bytes(gpq_ctx *c, unsigned W, unsigne
 extern "C" int gpq_he_rs_general(gpq_ctx *c, uint64_t *c0, uint64_t *c1, unsigned W, unsigned long long delta, const uint64_t *ql_words,
                                  unsigned Lq, unsigned batch, void *scratch, void *stream) {
   if (!c || !c0 || !c1 || !scratch || W < 1 || batch < 1 || !delta) return gpq_fail(GPQ_ERR_INVALID, "gpq_he_rs_general: bad arguments");
+  if (int rcm = check_modulus(ql_words, Lq, W)) return rcm;
   hipStream_t s = (hipStream_t)stream;
   int rc;
   for (uint64_t *p : {c0, c1}) {
@@ -1163,6 +1174,7 @@ extern "C" int gpq_relin_tail_general(gpq_ctx *c, uint64_t *out, const uint64_t 
   int rc = check(c, dimB, batch, "gpq_relin_tail_general");
   if (rc) return rc;
   if (!out || !chat || !workspace || !ql_words) return gpq_fail(GPQ_ERR_INVALID, "gpq_relin_tail_general: bad arguments");
+  if (int rcm = check_modulus(ql_words, Lq, W)) return rcm;
   return relin_tail_general(c, out, chat, d, W, dimP, dimB, ql_words, Lq, batch, workspace, (hipStream_t)stream);
 }
 
@@ -1175,6 +1187,7 @@ extern "C" int gpq_he_mul_general(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1
   if (rc || (rc = check(c, dimB, batch, "gpq_he_mul_general"))) return rc;
   if (!out_c0 || !out_c1 || !ct1c0 || !ct1c1 || !ct2c0 || !ct2c1 || !rlk0 || !rlk1 || !workspace || !ql_words)
     return gpq_fail(GPQ_ERR_INVALID, "gpq_he_mul_general: bad arguments");
+  if (int rcm = check_modulus(ql_words, Lq, W)) return rcm;
   hipStream_t s = (hipStream_t)stream;
   const size_t n = c->n, bigpoly = (size_t)W * n;
   const unsigned m = batch < c->chunk ? batch : c->chunk;
@@ -1221,6 +1234,7 @@ extern "C" int gpq_he_swk_general(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1
   int rc = check(c, dimB, batch, "gpq_he_swk_general");
   if (rc) return rc;
   if (!out_c0 || !out_c1 || !d0 || !d1 || !swk0 || !swk1 || !workspace || !ql_words) return gpq_fail(GPQ_ERR_INVALID, "gpq_he_swk_general: bad arguments");
+  if (int rcm = check_modulus(ql_words, Lq, W)) return rcm;
   hipStream_t s = (hipStream_t)stream;
   const size_t n = c->n, bigpoly = (size_t)W * n;
   const unsigned m = batch < c->chunk ? batch : c->chunk;
@@ -1246,6 +1260,7 @@ extern "C" int gpq_he_mulpt_general(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_
   int rc = check(c, dim, batch, "gpq_he_mulpt_general");
   if (rc) return rc;
   if (!out_c0 || !out_c1 || !c0 || !c1 || !m || !workspace || !ql_words) return gpq_fail(GPQ_ERR_INVALID, "gpq_he_mulpt_general: bad arguments");
+  if (int rcm = check_modulus(ql_words, Lq, W)) return rcm;
   const size_t poly = (size_t)dim << c->logn;
   uint64_t *s0 = (uint64_t *)workspace, *s1 = s0 + batch * poly, *sm = s1 + batch * poly, *scratch = sm + batch * poly;
   if ((rc = gpq_rns_decompose(c, sm, m, W, dim, batch, stream)) || (rc = gpq_rns_decompose(c, s0, c0, W, dim, batch, stream)) ||
