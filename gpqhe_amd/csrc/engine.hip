@@ -165,6 +165,8 @@ static int upload_tables(gpq_ctx *c) {
   // ... and among them the leading limbs whose forward stages may skip every other conditional subtraction (ct_bfly_wide)
   const char *mid8 = getenv("GPQHE_MID8");          // dev switch: 0 = tensor stage on the 16-coefficients-per-lane kernel
   c->mid8 = !(mid8 && mid8[0] == '0');
+  const char *low8 = getenv("GPQHE_N17_LOW8");      // dev switch: n = 2^17 as 9 strided + 8 low stages (512-row tiles)
+  c->low9 = c->logn == 17 && !(low8 && low8[0] == '1');
   const char *nowide = getenv("GPQHE_NO_WIDE");     // dev switch: A/B against one subtraction per stage
   c->nwide = 0;
   if (!(nowide && nowide[0] == '1'))
@@ -376,10 +378,10 @@ int for_limb_ranges(const gpq_ctx *c, PassArgs a, unsigned dim, const uint64_t *
   return GPQ_OK;
 }
 
-template <int M1, int EL, bool INV, bool CANON, typename TW>
+template <int M1, int EL, bool INV, bool CANON, typename TW, int CW = 8>
 int launch_strided_t(const PassArgs &a, unsigned gy, unsigned gz, hipStream_t s) {
   using G = StridedGeom<M1, EL>;
-  hipLaunchKernelGGL((strided_pass<M1, EL, INV, CANON, TW>), dim3(256 >> G::CB, gy, gz), dim3(G::T), 0, s, a);
+  hipLaunchKernelGGL((strided_pass<M1, EL, INV, CANON, TW, CW>), dim3((1u << CW) >> G::CB, gy, gz), dim3(G::T), 0, s, a);
   return GPQ_OK;
 }
 
@@ -394,7 +396,9 @@ int launch_strided(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigne
       case 14: return launch_strided_t<6, 4, INV, false, TW>(a, polys * a.nslab, limbs, s);
       case 15: return launch_strided_t<7, 4, INV, false, TW>(a, polys * a.nslab, limbs, s);
       case 16: return launch_strided_t<8, 4, INV, false, TW>(a, polys * a.nslab, limbs, s);
-      case 17: return launch_strided_t<9, 5, INV, false, TW>(a, polys * a.nslab, limbs, s);
+      case 17:   // 8 strided stages over 512-coefficient rows + 9 low stages, or (GPQHE_N17_LOW8=1) 9 + 8
+        if (c->low9) return launch_strided_t<8, 4, INV, false, TW, 9>(a, polys * a.nslab, limbs, s);
+        return launch_strided_t<9, 5, INV, false, TW>(a, polys * a.nslab, limbs, s);
     }
     return gpq_fail(GPQ_ERR_INVALID, "two-pass NTT needs 13 <= logn <= 17 (got %u)", c->logn);
   });
@@ -405,8 +409,13 @@ int launch_contig(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigned
   if (args.nslab != 1) return gpq_fail(GPQ_ERR_INVALID, "contig_pass walks one slab");
   return for_limb_ranges<!INV>(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
     using TW = decltype(tag);
-    const dim3 grid(c->n >> 12, (polys + CONTIG_POLYS - 1) / CONTIG_POLYS, limbs);
     ProfScope prof(c, INV ? GPQ_K_CONTIG_INV : GPQ_K_CONTIG_FWD, s);
+    if (c->low9) {
+      const dim3 grid9(c->n >> 11, (polys + CONTIG8_POLYS - 1) / CONTIG8_POLYS, limbs);
+      hipLaunchKernelGGL((contig_pass8<INV, TW, 9>), grid9, dim3(CONTIG_WAVES * 64), 0, s, a, polys);
+      return (int)GPQ_OK;
+    }
+    const dim3 grid(c->n >> 12, (polys + CONTIG_POLYS - 1) / CONTIG_POLYS, limbs);
     hipLaunchKernelGGL((contig_pass<INV, TW>), grid, dim3(CONTIG_WAVES * 64), 0, s, a, polys);
     return (int)GPQ_OK;
   });
@@ -571,7 +580,8 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
     if ((rc = for_limb_ranges<true>(c, m, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
           using TW = decltype(tag);
           ProfScope prof(c, GPQ_K_TENSOR_MID, s);
-          if (c->mid8) hipLaunchKernelGGL((tensor_mid8<TW>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, a);
+          if (c->low9) hipLaunchKernelGGL((tensor_mid8<TW, 9>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, a);
+          else if (c->mid8) hipLaunchKernelGGL((tensor_mid8<TW, 8>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, a);
           else hipLaunchKernelGGL((tensor_mid<TW>), dim3(c->n >> 12, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, a);
           return (int)GPQ_OK;
         }))) return rc;
@@ -618,7 +628,8 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
           using TW = decltype(tag);
           KeyswitchArgs ka{a, m.evk0, m.evk1};
           ProfScope prof(c, GPQ_K_KEYSWITCH_MID, s);
-          hipLaunchKernelGGL((keyswitch_mid<TW>), dim3(c->n >> 12, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, ka);
+          if (c->low9) hipLaunchKernelGGL((keyswitch_mid8<TW, 9>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, ka);
+          else hipLaunchKernelGGL((keyswitch_mid<TW>), dim3(c->n >> 12, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, ka);
           return (int)GPQ_OK;
         }))) return rc;
     PassArgs b = make_args(c, dim, 2);

@@ -191,11 +191,12 @@ struct StridedGeom {
   __device__ static __forceinline__ unsigned pad(unsigned l) { return l + ((l >> (EL + CB)) << CB); }
 };
 
-template <int M1, int EL, bool INV, bool CANON_OUT, typename TW>
+// CW = log2 of the row length the low kernels own: 8, or 9 for n = 2^17 (256-row tiles over 512-coefficient rows).
+template <int M1, int EL, bool INV, bool CANON_OUT, typename TW, int CW = 8>
 __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArgs a) {
   using G = StridedGeom<M1, EL>;
   constexpr int E = G::E;
-  constexpr unsigned logn = M1 + 8;
+  constexpr unsigned logn = M1 + CW;
   __shared__ uint64_t lds[G::S2 > 0 ? G::LDS_ELEMS : 1];
 
   // Workgroups go to the 8 XCDs round-robin by linear id.  The forward pass gives each XCD a
@@ -222,8 +223,8 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
   const unsigned col = (bx << CB) + (tid & (G::C - 1));
   const unsigned q = tid >> CB;
   // group A: element e at row q + (e << S2); group B: row (q << EL) + e
-  const unsigned iA = (q << 8) + col, iB = (q << (EL + 8)) + col;
-  constexpr unsigned strideA = 1u << (G::S2 + 8), strideB = 1u << 8;
+  const unsigned iA = (q << CW) + col, iB = (q << (EL + CW)) + col;
+  constexpr unsigned strideA = 1u << (G::S2 + CW), strideB = 1u << CW;
   uint64_t x[E];
   TW twB[tw_count(EL, G::BB, 0)];
 
@@ -231,16 +232,16 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
     TW twA[tw_count(EL, EL - 1, 0)];
 #pragma unroll
     for (int e = 0; e < E; ++e) x[e] = src[iA + e * strideA];
-    load_tw<EL, EL - 1, 0, true>(twA, iA, G::S2 + 8, logn, wt);
-    if (G::S2 > 0) load_tw<EL, G::BB, 0, false>(twB, iB, 8, logn, wt);
-    ct_group<EL, EL - 1, 0, G::S2 + 8>(x, twA, k);
+    load_tw<EL, EL - 1, 0, true>(twA, iA, G::S2 + CW, logn, wt);
+    if (G::S2 > 0) load_tw<EL, G::BB, 0, false>(twB, iB, CW, logn, wt);
+    ct_group<EL, EL - 1, 0, G::S2 + CW>(x, twA, k);
     if (G::S2 > 0) {
 #pragma unroll
       for (int e = 0; e < E; ++e) lds[G::pad(tid + e * G::T)] = x[e];
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = lds[G::pad((q << (EL + CB)) + (e << CB) + (tid & (G::C - 1)))];
-      ct_group<EL, G::BB, 0, 8>(x, twB, k);
+      ct_group<EL, G::BB, 0, CW>(x, twB, k);
 #pragma unroll
       for (int e = 0; e < E; ++e) dst[iB + e * strideB] = CANON_OUT ? TwTraits<TW>::canon_fwd(x[e], k) : x[e];
     } else {
@@ -253,8 +254,8 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
     if (G::S2 > 0) {
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = src[iB + e * strideB];
-      load_tw<EL, G::BB, 0, false>(twB, iB, 8, logn, wt);
-      if (EL > 1) load_tw<EL, (EL > 1 ? EL - 2 : 0), 0, true>(twA, iA, G::S2 + 8, logn, wt);
+      load_tw<EL, G::BB, 0, false>(twB, iB, CW, logn, wt);
+      if (EL > 1) load_tw<EL, (EL > 1 ? EL - 2 : 0), 0, true>(twA, iA, G::S2 + CW, logn, wt);
       gs_group<EL, G::BB, 0>(x, twB, k);
 #pragma unroll
       for (int e = 0; e < E; ++e) lds[G::pad((q << (EL + CB)) + (e << CB) + (tid & (G::C - 1)))] = x[e];
@@ -264,7 +265,7 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
     } else {
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = src[iA + e * strideA];
-      if (EL > 1) load_tw<EL, (EL > 1 ? EL - 2 : 0), 0, true>(twA, iA, G::S2 + 8, logn, wt);
+      if (EL > 1) load_tw<EL, (EL > 1 ? EL - 2 : 0), 0, true>(twA, iA, G::S2 + CW, logn, wt);
     }
     if (EL > 1) gs_group<EL, (EL > 1 ? EL - 2 : 0), 0>(x, twA, k);
 #pragma unroll
@@ -569,44 +570,51 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid(KeyswitchA
 }
 
 // ---------------------------------------------------------------------------
-// The same two fused kernels with 8 coefficients per lane instead of 16.
+// The low stages with 8 coefficients per lane instead of 16.
 // The 16-per-lane forms hold 4 (3) polynomials x 16 coefficients x 2 VGPRs and run at 2 (3) waves per
 // SIMD, where the dependent instruction chain of a butterfly is not covered (profiles/r01: 4.75 cycles
 // per VALU instruction with arithmetic only, against 3.5 for the same mix at 8 waves).  Here a wave owns
-// 512 consecutive coefficients (2 blocks of 256), lane = j + 32*blk, and the 8 stages of a block run as
-// three register groups with two exchanges through the wave's own LDS region:
-//   H: k = j + 32 e                 index bits 7..5     (3 stages)
-//   M: k = 32 (j >> 2) + 4 e + (j & 3)   bits 4..2      (3 stages)
-//   L: k = 8 j + e                  index bits 1..0     (2 stages; bit 2 rides along)
-// Global accesses use the H layout (32 lanes = 256 contiguous bytes).
+// 512 consecutive coefficients and the LOW = 8 or 9 low stages run as three register groups with two
+// exchanges through the wave's own LDS region.  LOW = 8 (blocks of 256, two per wave; lane = j + 32 blk):
+//   H: k = j + 32 e                      index bits 7..5     (3 stages)
+//   M: k = 32 (j >> 2) + 4 e + (j & 3)   bits 4..2           (3 stages)
+//   L: k = 8 j + e                       bits 1..0           (2 stages; bit 2 rides along)
+// LOW = 9 (one block of 512 per wave; j = lane): H: k = j + 64 e (bits 8..6), M: k = 64 (j >> 3) + 8 e + (j & 7)
+// (bits 5..3), L: k = 8 j + e (bits 2..0): three full groups.  With LOW = 9 the strided passes of n = 2^17 keep
+// the 256-row tiles of n = 2^16 (512-coefficient rows) instead of 512-row tiles at 2 waves per SIMD.
+// Global accesses use the H layout (32 or 64 lanes = 256 or 512 contiguous bytes).
 // ---------------------------------------------------------------------------
 constexpr int LANE8_LDS_PER_WAVE = 576;     // 512 + padding (both paddings end below 576)
 
+template <int LOW>
 struct Lane8 {
+  static constexpr int JB = LOW - 3;        // log2 lanes per block = log2 of the H stride
+  static constexpr int MB = LOW - 6;        // log2 of the M stride
+  static constexpr int LHI = LOW - 7;       // highest register bit the L group works on
   unsigned hk, mk, lk;      // index of x[0] inside the wave's 512 coefficients, per layout
   uint64_t *lds;
   __device__ __forceinline__ Lane8(uint64_t *wave_lds) {
-    const unsigned lane = threadIdx.x & 63, j = lane & 31, blk = lane >> 5;
-    hk = (blk << 8) + j;
-    mk = (blk << 8) + ((j >> 2) << 5) + (j & 3);
-    lk = (blk << 8) + (j << 3);
+    const unsigned lane = threadIdx.x & 63, j = lane & ((1u << JB) - 1), blk = lane >> JB;
+    hk = (blk << LOW) + j;
+    mk = (blk << LOW) + ((j >> MB) << JB) + (j & ((1u << MB) - 1));
+    lk = (blk << LOW) + (j << 3);
     lds = wave_lds;
   }
-  // H<->M exchange: 32-word rows padded by 4 (M reads walk 4 e + (j & 3) inside row j >> 2);
-  // M<->L exchange: one word per 8 (L reads are 9 j + e).  Both conflict-free per half-wave.
-  __device__ static __forceinline__ unsigned pad1(unsigned l) { return l + ((l >> 5) << 2); }
+  // H<->M exchange: rows of 2^JB words padded by 2^MB (M reads walk 2^MB e + (j mod 2^MB) inside row j >> MB);
+  // M<->L exchange: one word per 8 (L reads are 9 j + e).  Both conflict-free per half-wave (0 measured).
+  __device__ static __forceinline__ unsigned pad1(unsigned l) { return l + ((l >> JB) << MB); }
   __device__ static __forceinline__ unsigned pad2(unsigned l) { return l + (l >> 3); }
   __device__ __forceinline__ void h_to_m(uint64_t (&x)[8]) const {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) lds[pad1(hk + 32 * e)] = x[e];
+    for (int e = 0; e < 8; ++e) lds[pad1(hk + (e << JB))] = x[e];
     wave_lds_sync();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = lds[pad1(mk + 4 * e)];
+    for (int e = 0; e < 8; ++e) x[e] = lds[pad1(mk + (e << MB))];
     wave_lds_sync();
   }
   __device__ __forceinline__ void m_to_l(uint64_t (&x)[8]) const {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) lds[pad2(mk + 4 * e)] = x[e];
+    for (int e = 0; e < 8; ++e) lds[pad2(mk + (e << MB))] = x[e];
     wave_lds_sync();
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = lds[pad2(lk + e)];
@@ -617,40 +625,70 @@ struct Lane8 {
     for (int e = 0; e < 8; ++e) lds[pad2(lk + e)] = x[e];
     wave_lds_sync();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = lds[pad2(mk + 4 * e)];
+    for (int e = 0; e < 8; ++e) x[e] = lds[pad2(mk + (e << MB))];
     wave_lds_sync();
   }
   __device__ __forceinline__ void m_to_h(uint64_t (&x)[8]) const {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) lds[pad1(mk + 4 * e)] = x[e];
+    for (int e = 0; e < 8; ++e) lds[pad1(mk + (e << MB))] = x[e];
     wave_lds_sync();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = lds[pad1(hk + 32 * e)];
+    for (int e = 0; e < 8; ++e) x[e] = lds[pad1(hk + (e << JB))];
+    wave_lds_sync();
+  }
+  // direct L<->H for the standalone passes (global accesses stay in the H layout): padding 2, where a few lanes of the
+  // H side share a bank pair with another one
+  __device__ __forceinline__ void l_to_h(uint64_t (&x)[8]) const {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds[pad2(lk + e)] = x[e];
+    wave_lds_sync();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = lds[pad2(hk + (e << JB))];
+    wave_lds_sync();
+  }
+  __device__ __forceinline__ void h_to_l(uint64_t (&x)[8]) const {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds[pad2(hk + (e << JB))] = x[e];
+    wave_lds_sync();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = lds[pad2(lk + e)];
     wave_lds_sync();
   }
   __device__ __forceinline__ void load_h(uint64_t (&x)[8], const uint64_t *__restrict__ p) const {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = p[hk + 32 * e];
+    for (int e = 0; e < 8; ++e) x[e] = p[hk + (e << JB)];
   }
   __device__ __forceinline__ void store_h(uint64_t *__restrict__ p, const uint64_t (&x)[8]) const {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) p[hk + 32 * e] = x[e];
+    for (int e = 0; e < 8; ++e) p[hk + (e << JB)] = x[e];
   }
+  __device__ __forceinline__ void load_l(uint64_t (&x)[8], const uint64_t *__restrict__ p) const {
+    const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(p + lk);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ulonglong2 t = v[e]; x[2 * e] = t.x; x[2 * e + 1] = t.y; }
+  }
+  // the stages of the three groups (forward: H, M, L; inverse: L, M, H)
+  template <typename TW> __device__ static __forceinline__ void ct_h(uint64_t (&x)[8], const TW (&t)[7], const PrimeK &k) { ct_group<3, 2, 0, LOW - 3>(x, t, k); }
+  template <typename TW> __device__ static __forceinline__ void ct_m(uint64_t (&x)[8], const TW (&t)[7], const PrimeK &k) { ct_group<3, 2, 0, LOW - 6>(x, t, k); }
+  template <typename TW> __device__ static __forceinline__ void ct_l(uint64_t (&x)[8], const TW (&u)[tw_count(3, LHI, 0)], const PrimeK &k) { ct_group<3, LHI, 0, 0>(x, u, k); }
+  template <typename TW> __device__ static __forceinline__ void gs_hm(uint64_t (&x)[8], const TW (&t)[7], const PrimeK &k) { gs_group<3, 2, 0>(x, t, k); }
+  template <typename TW> __device__ static __forceinline__ void gs_l(uint64_t (&x)[8], const TW (&u)[tw_count(3, LHI, 0)], const PrimeK &k) { gs_group<3, LHI, 0>(x, u, k); }
 };
 
-// twiddles of one group of one direction: 7 for H and M, 6 for L
-template <typename TW>
+// twiddles of one group of one direction: 7 for H and M, 6 or 7 for L
+template <typename TW, int LOW>
 struct Tw8 {
+  using L8 = Lane8<LOW>;
   TW t[7];
-  TW u[6];
-  __device__ __forceinline__ void load_h(const Lane8 &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
-    load_tw<3, 2, 0, false>(t, wave0 + ln.hk, 5, logn, w);
+  TW u[tw_count(3, L8::LHI, 0)];
+  __device__ __forceinline__ void load_h(const L8 &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
+    load_tw<3, 2, 0, false>(t, wave0 + ln.hk, LOW - 3, logn, w);
   }
-  __device__ __forceinline__ void load_m(const Lane8 &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
-    load_tw<3, 2, 0, false>(t, wave0 + ln.mk, 2, logn, w);
+  __device__ __forceinline__ void load_m(const L8 &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
+    load_tw<3, 2, 0, false>(t, wave0 + ln.mk, LOW - 6, logn, w);
   }
-  __device__ __forceinline__ void load_l(const Lane8 &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
-    load_tw<3, 1, 0, false>(u, wave0 + ln.lk, 0, logn, w);
+  __device__ __forceinline__ void load_l(const L8 &ln, unsigned wave0, unsigned logn, const TW *__restrict__ w) {
+    load_tw<3, L8::LHI, 0, false>(u, wave0 + ln.lk, 0, logn, w);
   }
 };
 
@@ -668,35 +706,36 @@ struct Block8 {             // per-workgroup addressing: 4 waves x 512 coefficie
 #ifndef GPQ_MID8_MINWAVES
 #define GPQ_MID8_MINWAVES 3
 #endif
-template <typename TW>
+template <typename TW, int LOW>
 __global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_MID8_MINWAVES) void tensor_mid8(PassArgs a) {
   using TT = TwTraits<TW>;
+  using L8 = Lane8<LOW>;
   __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
-  const Lane8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
+  const L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
   const Block8 cb(a);
   const PrimeK k = a.tabs[cb.limb].k;
   const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
   uint64_t a0[8], a1[8], b0[8], b1[8];
-  Tw8<TW> tw;
+  Tw8<TW, LOW> tw;
   ln.load_h(a0, a.src[0] + cb.off);
   tw.load_h(ln, cb.wave0, a.logn, wf);
   ln.load_h(b0, a.src[2] + cb.off);
   ln.load_h(a1, a.src[1] + cb.off);
   ln.load_h(b1, a.src[3] + cb.off);
-  ct_group<3, 2, 0, 5>(a0, tw.t, k);
-  ct_group<3, 2, 0, 5>(b0, tw.t, k);
-  ct_group<3, 2, 0, 5>(a1, tw.t, k);
-  ct_group<3, 2, 0, 5>(b1, tw.t, k);
+  L8::ct_h(a0, tw.t, k);
+  L8::ct_h(b0, tw.t, k);
+  L8::ct_h(a1, tw.t, k);
+  L8::ct_h(b1, tw.t, k);
   tw.load_m(ln, cb.wave0, a.logn, wf);
-  ln.h_to_m(a0); ct_group<3, 2, 0, 2>(a0, tw.t, k);
-  ln.h_to_m(b0); ct_group<3, 2, 0, 2>(b0, tw.t, k);
-  ln.h_to_m(a1); ct_group<3, 2, 0, 2>(a1, tw.t, k);
-  ln.h_to_m(b1); ct_group<3, 2, 0, 2>(b1, tw.t, k);
+  ln.h_to_m(a0); L8::ct_m(a0, tw.t, k);
+  ln.h_to_m(b0); L8::ct_m(b0, tw.t, k);
+  ln.h_to_m(a1); L8::ct_m(a1, tw.t, k);
+  ln.h_to_m(b1); L8::ct_m(b1, tw.t, k);
   tw.load_l(ln, cb.wave0, a.logn, wf);
-  ln.m_to_l(a0); ct_group<3, 1, 0, 0>(a0, tw.u, k);
-  ln.m_to_l(b0); ct_group<3, 1, 0, 0>(b0, tw.u, k);
-  ln.m_to_l(a1); ct_group<3, 1, 0, 0>(a1, tw.u, k);
-  ln.m_to_l(b1); ct_group<3, 1, 0, 0>(b1, tw.u, k);
+  ln.m_to_l(a0); L8::ct_l(a0, tw.u, k);
+  ln.m_to_l(b0); L8::ct_l(b0, tw.u, k);
+  ln.m_to_l(a1); L8::ct_l(a1, tw.u, k);
+  ln.m_to_l(b1); L8::ct_l(b1, tw.u, k);
   tw.load_l(ln, cb.wave0, a.logn, wi);               // inverse twiddles arrive under the products
   uint64_t d1[8];
 #pragma unroll
@@ -707,20 +746,122 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_MID8_MINWAVES) void tensor_m
     d1[e] = TT::inv_from8(mulmod_lazy(u0, v1, k) + mulmod_lazy(u1, v0, k), k);          // d1
     a1[e] = TT::inv_from4(mulmod_lazy(u1, v1, k), k);                                   // d2
   }
-  gs_group<3, 1, 0>(a0, tw.u, k); ln.l_to_m(a0);
-  gs_group<3, 1, 0>(d1, tw.u, k); ln.l_to_m(d1);
-  gs_group<3, 1, 0>(a1, tw.u, k); ln.l_to_m(a1);
+  L8::gs_l(a0, tw.u, k); ln.l_to_m(a0);
+  L8::gs_l(d1, tw.u, k); ln.l_to_m(d1);
+  L8::gs_l(a1, tw.u, k); ln.l_to_m(a1);
   tw.load_m(ln, cb.wave0, a.logn, wi);
-  gs_group<3, 2, 0>(a0, tw.t, k); ln.m_to_h(a0);
-  gs_group<3, 2, 0>(d1, tw.t, k); ln.m_to_h(d1);
-  gs_group<3, 2, 0>(a1, tw.t, k); ln.m_to_h(a1);
+  L8::gs_hm(a0, tw.t, k); ln.m_to_h(a0);
+  L8::gs_hm(d1, tw.t, k); ln.m_to_h(d1);
+  L8::gs_hm(a1, tw.t, k); ln.m_to_h(a1);
   tw.load_h(ln, cb.wave0, a.logn, wi);
-  gs_group<3, 2, 0>(a0, tw.t, k);
+  L8::gs_hm(a0, tw.t, k);
   ln.store_h(a.dst[0] + cb.off, a0);
-  gs_group<3, 2, 0>(d1, tw.t, k);
+  L8::gs_hm(d1, tw.t, k);
   ln.store_h(a.dst[1] + cb.off, d1);
-  gs_group<3, 2, 0>(a1, tw.t, k);
+  L8::gs_hm(a1, tw.t, k);
   ln.store_h(a.dst[2] + cb.off, a1);
+}
+
+// keyswitch_mid in the 8-per-lane geometry (used for n = 2^17: LOW = 9; at n = 2^16 the 16-per-lane form is faster)
+template <typename TW, int LOW>
+__global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid8(KeyswitchArgs ka) {
+  using TT = TwTraits<TW>;
+  using L8 = Lane8<LOW>;
+  __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
+  const PassArgs &a = ka.p;
+  const L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
+  const Block8 cb(a);
+  const PrimeK k = a.tabs[cb.limb].k;
+  const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
+  const size_t koff = ((size_t)blockIdx.z << a.logn) + cb.wave0;
+  uint64_t x[8], e0[8], e1[8];
+  Tw8<TW, LOW> tw;
+  ln.load_h(x, a.src[0] + cb.off);
+  tw.load_h(ln, cb.wave0, a.logn, wf);
+  L8::ct_h(x, tw.t, k);
+  tw.load_m(ln, cb.wave0, a.logn, wf);
+  ln.h_to_m(x);
+  L8::ct_m(x, tw.t, k);
+  tw.load_l(ln, cb.wave0, a.logn, wf);
+  ln.m_to_l(x);
+  L8::ct_l(x, tw.u, k);
+  ln.load_l(e0, ka.evk0 + koff);
+  ln.load_l(e1, ka.evk1 + koff);
+  tw.load_l(ln, cb.wave0, a.logn, wi);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const uint64_t u = TT::right(x[e], k);
+    e0[e] = TT::inv_from4(mulmod_lazy(u, e0[e], k), k);
+    e1[e] = TT::inv_from4(mulmod_lazy(u, e1[e], k), k);
+  }
+  L8::gs_l(e0, tw.u, k); ln.l_to_m(e0);
+  L8::gs_l(e1, tw.u, k); ln.l_to_m(e1);
+  tw.load_m(ln, cb.wave0, a.logn, wi);
+  L8::gs_hm(e0, tw.t, k); ln.m_to_h(e0);
+  L8::gs_hm(e1, tw.t, k); ln.m_to_h(e1);
+  tw.load_h(ln, cb.wave0, a.logn, wi);
+  L8::gs_hm(e0, tw.t, k);
+  ln.store_h(a.dst[0] + cb.off, e0);
+  L8::gs_hm(e1, tw.t, k);
+  ln.store_h(a.dst[1] + cb.off, e1);
+}
+
+// contig_pass in the 8-per-lane geometry (n = 2^17): CONTIG8_POLYS polynomials of the same limb and tile share each twiddle group.
+constexpr int CONTIG8_POLYS = 2;
+template <bool INV, typename TW, int LOW>
+__global__ __launch_bounds__(CONTIG_WAVES * 64, 4) void contig_pass8(PassArgs a, unsigned polys) {
+  using TT = TwTraits<TW>;
+  using L8 = Lane8<LOW>;
+  __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
+  const L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
+  const unsigned wave0 = (blockIdx.x * CONTIG_WAVES + (threadIdx.x >> 6)) << 9;
+  const unsigned limb = a.limb0 + blockIdx.z;
+  const PrimeK k = a.tabs[limb].k;
+  const unsigned p0 = blockIdx.y * CONTIG8_POLYS;
+  const unsigned cnt = polys - p0 < CONTIG8_POLYS ? polys - p0 : CONTIG8_POLYS;
+  const size_t off = (size_t)p0 * a.poly_stride + ((size_t)blockIdx.z << a.logn) + wave0;
+  const uint64_t *__restrict__ src = a.src[0] + off;
+  uint64_t *__restrict__ dst = a.dst[0] + off;
+  const TW *__restrict__ wt = TT::table(a, INV) + ((size_t)limb << a.logn);
+  uint64_t x[CONTIG8_POLYS][8];
+  Tw8<TW, LOW> tw;
+#pragma unroll
+  for (int j = 0; j < CONTIG8_POLYS; ++j)
+    if (j < (int)cnt) ln.load_h(x[j], src + (size_t)j * a.poly_stride);
+  if (!INV) {
+    tw.load_h(ln, wave0, a.logn, wt);
+#pragma unroll
+    for (int j = 0; j < CONTIG8_POLYS; ++j) if (j < (int)cnt) L8::ct_h(x[j], tw.t, k);
+    tw.load_m(ln, wave0, a.logn, wt);
+#pragma unroll
+    for (int j = 0; j < CONTIG8_POLYS; ++j) if (j < (int)cnt) { ln.h_to_m(x[j]); L8::ct_m(x[j], tw.t, k); }
+    tw.load_l(ln, wave0, a.logn, wt);
+#pragma unroll
+    for (int j = 0; j < CONTIG8_POLYS; ++j)
+      if (j < (int)cnt) {
+        ln.m_to_l(x[j]);
+        L8::ct_l(x[j], tw.u, k);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[j][e] = TT::canon_fwd(x[j][e], k);
+        ln.l_to_h(x[j]);
+        ln.store_h(dst + (size_t)j * a.poly_stride, x[j]);
+      }
+  } else {
+    tw.load_l(ln, wave0, a.logn, wt);
+#pragma unroll
+    for (int j = 0; j < CONTIG8_POLYS; ++j) if (j < (int)cnt) { ln.h_to_l(x[j]); L8::gs_l(x[j], tw.u, k); }
+    tw.load_m(ln, wave0, a.logn, wt);
+#pragma unroll
+    for (int j = 0; j < CONTIG8_POLYS; ++j) if (j < (int)cnt) { ln.l_to_m(x[j]); L8::gs_hm(x[j], tw.t, k); }
+    tw.load_h(ln, wave0, a.logn, wt);
+#pragma unroll
+    for (int j = 0; j < CONTIG8_POLYS; ++j)
+      if (j < (int)cnt) {
+        ln.m_to_h(x[j]);
+        L8::gs_hm(x[j], tw.t, k);
+        ln.store_h(dst + (size_t)j * a.poly_stride, x[j]);
+      }
+  }
 }
 
 // ---------------------------------------------------------------------------
