@@ -36,6 +36,7 @@ SIGNATURES = {
     "gpq_rns_mul": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, vp]),
     "gpq_rns_add": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, vp]),
     "gpq_poly_mul_rns": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, vp]),
+    "gpq_mulpt_rns": (C.c_int, [vp] * 6 + [C.c_uint, C.c_uint, vp]),
     "gpq_set_chunk": (C.c_int, [vp, C.c_uint]),
     "gpq_tensor_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
     "gpq_keyswitch_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),

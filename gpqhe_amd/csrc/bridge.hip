@@ -980,9 +980,7 @@ extern "C" int gpq_he_mulpt(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, cons
   if ((rc = gpq_rns_decompose(c, sm, m, W, dim, batch, stream))) return rc;       // :176
   if ((rc = gpq_rns_decompose(c, s0, c0, W, dim, batch, stream))) return rc;      // :177
   if ((rc = gpq_rns_decompose(c, s1, c1, W, dim, batch, stream))) return rc;      // :178
-  if ((rc = gpq_ntt(c, sm, dim, batch, stream)) || (rc = gpq_ntt(c, s0, dim, batch, stream)) || (rc = gpq_ntt(c, s1, dim, batch, stream))) return rc;  // :179-181
-  if ((rc = gpq_rns_mul(c, s0, s0, sm, dim, batch, stream)) || (rc = gpq_invntt(c, s0, dim, batch, stream))) return rc;   // :182-183
-  if ((rc = gpq_rns_mul(c, s1, s1, sm, dim, batch, stream)) || (rc = gpq_invntt(c, s1, dim, batch, stream))) return rc;   // :184-185
+  if ((rc = gpq_mulpt_rns(c, s0, s1, sm, s0, s1, dim, batch, stream))) return rc;                                          // :179-185
   if ((rc = gpq_rns_reconstruct(c, out_c0, W, s0, dim, batch, logql, stream))) return rc;                                 // :188
   return gpq_rns_reconstruct(c, out_c1, W, s1, dim, batch, logql, stream);                                                // :189
 }
@@ -1265,9 +1263,7 @@ extern "C" int gpq_he_mulpt_general(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_
   uint64_t *s0 = (uint64_t *)workspace, *s1 = s0 + batch * poly, *sm = s1 + batch * poly, *scratch = sm + batch * poly;
   if ((rc = gpq_rns_decompose(c, sm, m, W, dim, batch, stream)) || (rc = gpq_rns_decompose(c, s0, c0, W, dim, batch, stream)) ||
       (rc = gpq_rns_decompose(c, s1, c1, W, dim, batch, stream))) return rc;
-  if ((rc = gpq_ntt(c, sm, dim, batch, stream)) || (rc = gpq_ntt(c, s0, dim, batch, stream)) || (rc = gpq_ntt(c, s1, dim, batch, stream))) return rc;
-  if ((rc = gpq_rns_mul(c, s0, s0, sm, dim, batch, stream)) || (rc = gpq_invntt(c, s0, dim, batch, stream))) return rc;
-  if ((rc = gpq_rns_mul(c, s1, s1, sm, dim, batch, stream)) || (rc = gpq_invntt(c, s1, dim, batch, stream))) return rc;
+  if ((rc = gpq_mulpt_rns(c, s0, s1, sm, s0, s1, dim, batch, stream))) return rc;
   if ((rc = gpq_rns_reconstruct_general(c, out_c0, W, s0, dim, batch, ql_words, Lq, scratch, stream))) return rc;
   return gpq_rns_reconstruct_general(c, out_c1, W, s1, dim, batch, ql_words, Lq, scratch, stream);
 }

@@ -37,6 +37,8 @@ extern "C" const char *gpq_last_error(void) { return g_err; }
 // ---------------------------------------------------------------------------
 // host number theory (64-bit), own implementation of what precomp.c needs
 // ---------------------------------------------------------------------------
+constexpr unsigned kMaxPolysPerLaunch = 16384;   // gridDim.y <= 65535 with up to 4 slabs per launch
+
 namespace {
 
 typedef unsigned __int128 u128h;
@@ -167,6 +169,8 @@ static int upload_tables(gpq_ctx *c) {
   c->mid8 = !(mid8 && mid8[0] == '0');
   const char *low8 = getenv("GPQHE_N17_LOW8");      // dev switch: n = 2^17 as 9 strided + 8 low stages (512-row tiles)
   c->low9 = c->logn == 17 && !(low8 && low8[0] == '1');
+  const char *nofuse = getenv("GPQHE_NO_FUSED_POLYMUL");   // dev switch: poly_mul's limb loop as ntt, ntt, mul, invntt
+  c->fused_polymul = !(nofuse && nofuse[0] == '1');
   const char *nowide = getenv("GPQHE_NO_WIDE");     // dev switch: A/B against one subtraction per stage
   c->nwide = 0;
   if (!(nowide && nowide[0] == '1'))
@@ -459,7 +463,6 @@ int inverse_slabs(const gpq_ctx *c, PassArgs a, unsigned dim, unsigned polys, hi
 
 }  // namespace
 
-constexpr unsigned kMaxPolysPerLaunch = 16384;   // gridDim.y <= 65535 with up to 4 slabs per launch
 
 extern "C" int gpq_ntt(gpq_ctx *c, uint64_t *slab, unsigned dim, unsigned batch, void *stream) {
   int rc = check_shape(c, dim, batch, "gpq_ntt");
@@ -513,11 +516,74 @@ extern "C" int gpq_rns_add(gpq_ctx *c, uint64_t *r, const uint64_t *a, const uin
 }
 
 extern "C" int gpq_poly_mul_rns(gpq_ctx *c, uint64_t *r, uint64_t *a, uint64_t *b, unsigned dim, unsigned batch, void *stream) {
-  int rc;
-  if ((rc = gpq_ntt(c, a, dim, batch, stream))) return rc;
-  if ((rc = gpq_ntt(c, b, dim, batch, stream))) return rc;
-  if ((rc = gpq_rns_mul(c, r, a, b, dim, batch, stream))) return rc;
-  return gpq_invntt(c, r, dim, batch, stream);
+  int rc = check_shape(c, dim, batch, "gpq_poly_mul_rns");
+  if (rc) return rc;
+  if (!r || !a || !b) return gpq_fail(GPQ_ERR_INVALID, "gpq_poly_mul_rns: null slab");
+  if (!two_pass(c) || !c->fused_polymul) {
+    if ((rc = gpq_ntt(c, a, dim, batch, stream))) return rc;
+    if ((rc = gpq_ntt(c, b, dim, batch, stream))) return rc;
+    if ((rc = gpq_rns_mul(c, r, a, b, dim, batch, stream))) return rc;
+    return gpq_invntt(c, r, dim, batch, stream);
+  }
+  // three kernels instead of seven: strided forward pass on both operands in place, fused middle, strided inverse pass on r
+  hipStream_t s = (hipStream_t)stream;
+  const size_t poly = (size_t)dim << c->logn;
+  for (unsigned k0 = 0; k0 < batch; k0 += kMaxPolysPerLaunch / 2) {
+    const unsigned polys = batch - k0 < kMaxPolysPerLaunch / 2 ? batch - k0 : kMaxPolysPerLaunch / 2;
+    PassArgs f = make_args(c, dim, 2);
+    f.src[0] = f.dst[0] = a + k0 * poly; f.src[1] = f.dst[1] = b + k0 * poly;
+    if ((rc = launch_strided<false>(c, f, dim, polys, s))) return rc;
+    PassArgs m = make_args(c, dim, 1);
+    m.src[0] = f.dst[0]; m.src[1] = f.dst[1]; m.dst[0] = r + k0 * poly;
+    if ((rc = for_limb_ranges<true>(c, m, dim, nullptr, nullptr, [&](auto tag, const PassArgs &p, unsigned limbs) {
+          using TW = decltype(tag);
+          ProfScope prof(c, GPQ_K_CONTIG_FWD, s);
+          if (c->low9) hipLaunchKernelGGL((polymul_mid8<TW, 9>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, p);
+          else hipLaunchKernelGGL((polymul_mid8<TW, 8>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, p);
+          return (int)GPQ_OK;
+        }))) return rc;
+    PassArgs b2 = make_args(c, dim, 1);
+    b2.src[0] = b2.dst[0] = m.dst[0];
+    if ((rc = launch_strided<true>(c, b2, dim, polys, s))) return rc;
+  }
+  return after_launch("gpq_poly_mul_rns");
+}
+
+// Limb loop of he_mulpt, src/he-mult.c:179-185: r0 = m (*) x0, r1 = m (*) x1 (negacyclic, per limb); m, x0, x1 are
+// overwritten; r0 / r1 may be x0 / x1.
+extern "C" int gpq_mulpt_rns(gpq_ctx *c, uint64_t *r0, uint64_t *r1, uint64_t *m, uint64_t *x0, uint64_t *x1, unsigned dim, unsigned batch,
+                             void *stream) {
+  int rc = check_shape(c, dim, batch, "gpq_mulpt_rns");
+  if (rc) return rc;
+  if (!r0 || !r1 || !m || !x0 || !x1) return gpq_fail(GPQ_ERR_INVALID, "gpq_mulpt_rns: null slab");
+  if (!two_pass(c) || !c->fused_polymul) {
+    if ((rc = gpq_ntt(c, m, dim, batch, stream)) || (rc = gpq_ntt(c, x0, dim, batch, stream)) || (rc = gpq_ntt(c, x1, dim, batch, stream))) return rc;
+    if ((rc = gpq_rns_mul(c, r0, x0, m, dim, batch, stream)) || (rc = gpq_invntt(c, r0, dim, batch, stream))) return rc;
+    if ((rc = gpq_rns_mul(c, r1, x1, m, dim, batch, stream))) return rc;
+    return gpq_invntt(c, r1, dim, batch, stream);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const size_t poly = (size_t)dim << c->logn;
+  for (unsigned k0 = 0; k0 < batch; k0 += kMaxPolysPerLaunch / 4) {
+    const unsigned polys = batch - k0 < kMaxPolysPerLaunch / 4 ? batch - k0 : kMaxPolysPerLaunch / 4;
+    PassArgs f = make_args(c, dim, 3);
+    f.src[0] = f.dst[0] = m + k0 * poly; f.src[1] = f.dst[1] = x0 + k0 * poly; f.src[2] = f.dst[2] = x1 + k0 * poly;
+    if ((rc = launch_strided<false>(c, f, dim, polys, s))) return rc;
+    PassArgs p = make_args(c, dim, 1);
+    for (int i = 0; i < 3; ++i) p.src[i] = f.dst[i];
+    p.dst[0] = r0 + k0 * poly; p.dst[1] = r1 + k0 * poly;
+    if ((rc = for_limb_ranges<true>(c, p, dim, nullptr, nullptr, [&](auto tag, const PassArgs &q, unsigned limbs) {
+          using TW = decltype(tag);
+          ProfScope prof(c, GPQ_K_CONTIG_FWD, s);
+          if (c->low9) hipLaunchKernelGGL((mulpt_mid8<TW, 9>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, q);
+          else hipLaunchKernelGGL((mulpt_mid8<TW, 8>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, q);
+          return (int)GPQ_OK;
+        }))) return rc;
+    PassArgs b2 = make_args(c, dim, 2);
+    b2.src[0] = b2.dst[0] = p.dst[0]; b2.src[1] = b2.dst[1] = p.dst[1];
+    if ((rc = launch_strided<true>(c, b2, dim, polys, s))) return rc;
+  }
+  return after_launch("gpq_mulpt_rns");
 }
 
 // ---------------------------------------------------------------------------

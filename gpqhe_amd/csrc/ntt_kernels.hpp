@@ -762,6 +762,89 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_MID8_MINWAVES) void tensor_m
   ln.store_h(a.dst[2] + cb.off, a1);
 }
 
+// Middle of poly_mul's limb loop (src/poly.c:96-103): low forward stages of a and b, a (*) b, low inverse stages.
+// src[0], src[1] = a, b after the strided forward pass; dst[0] = r before the strided inverse pass (r may be a or b: a
+// workgroup reads its 2048 coefficients of both before it writes them).
+template <typename TW, int LOW>
+__global__ __launch_bounds__(CONTIG_WAVES * 64, 4) void polymul_mid8(PassArgs a) {
+  using TT = TwTraits<TW>;
+  using L8 = Lane8<LOW>;
+  __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
+  const L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
+  const Block8 cb(a);
+  const PrimeK k = a.tabs[cb.limb].k;
+  const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
+  uint64_t x[8], y[8];
+  Tw8<TW, LOW> tw;
+  ln.load_h(x, a.src[0] + cb.off);
+  tw.load_h(ln, cb.wave0, a.logn, wf);
+  ln.load_h(y, a.src[1] + cb.off);
+  L8::ct_h(x, tw.t, k);
+  L8::ct_h(y, tw.t, k);
+  tw.load_m(ln, cb.wave0, a.logn, wf);
+  ln.h_to_m(x); L8::ct_m(x, tw.t, k);
+  ln.h_to_m(y); L8::ct_m(y, tw.t, k);
+  tw.load_l(ln, cb.wave0, a.logn, wf);
+  ln.m_to_l(x); L8::ct_l(x, tw.u, k);
+  ln.m_to_l(y); L8::ct_l(y, tw.u, k);
+  tw.load_l(ln, cb.wave0, a.logn, wi);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = TT::inv_from4(mulmod_lazy(TT::left(x[e], k), TT::right(y[e], k), k), k);
+  L8::gs_l(x, tw.u, k); ln.l_to_m(x);
+  tw.load_m(ln, cb.wave0, a.logn, wi);
+  L8::gs_hm(x, tw.t, k); ln.m_to_h(x);
+  tw.load_h(ln, cb.wave0, a.logn, wi);
+  L8::gs_hm(x, tw.t, k);
+  ln.store_h(a.dst[0] + cb.off, x);
+}
+
+// Middle of he_mulpt's limb loop (src/he-mult.c:179-185): low forward stages of m, c0, c1, then m (*) c0 and m (*) c1,
+// low inverse stages of both.  src[0..2] = m, c0, c1 after the strided forward pass; dst[0..1] may be c0, c1.
+template <typename TW, int LOW>
+__global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void mulpt_mid8(PassArgs a) {
+  using TT = TwTraits<TW>;
+  using L8 = Lane8<LOW>;
+  __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
+  const L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
+  const Block8 cb(a);
+  const PrimeK k = a.tabs[cb.limb].k;
+  const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
+  uint64_t m[8], x[8], y[8];
+  Tw8<TW, LOW> tw;
+  ln.load_h(m, a.src[0] + cb.off);
+  tw.load_h(ln, cb.wave0, a.logn, wf);
+  ln.load_h(x, a.src[1] + cb.off);
+  ln.load_h(y, a.src[2] + cb.off);
+  L8::ct_h(m, tw.t, k);
+  L8::ct_h(x, tw.t, k);
+  L8::ct_h(y, tw.t, k);
+  tw.load_m(ln, cb.wave0, a.logn, wf);
+  ln.h_to_m(m); L8::ct_m(m, tw.t, k);
+  ln.h_to_m(x); L8::ct_m(x, tw.t, k);
+  ln.h_to_m(y); L8::ct_m(y, tw.t, k);
+  tw.load_l(ln, cb.wave0, a.logn, wf);
+  ln.m_to_l(m); L8::ct_l(m, tw.u, k);
+  ln.m_to_l(x); L8::ct_l(x, tw.u, k);
+  ln.m_to_l(y); L8::ct_l(y, tw.u, k);
+  tw.load_l(ln, cb.wave0, a.logn, wi);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const uint64_t u = TT::left(m[e], k);
+    x[e] = TT::inv_from4(mulmod_lazy(u, TT::right(x[e], k), k), k);
+    y[e] = TT::inv_from4(mulmod_lazy(u, TT::right(y[e], k), k), k);
+  }
+  L8::gs_l(x, tw.u, k); ln.l_to_m(x);
+  L8::gs_l(y, tw.u, k); ln.l_to_m(y);
+  tw.load_m(ln, cb.wave0, a.logn, wi);
+  L8::gs_hm(x, tw.t, k); ln.m_to_h(x);
+  L8::gs_hm(y, tw.t, k); ln.m_to_h(y);
+  tw.load_h(ln, cb.wave0, a.logn, wi);
+  L8::gs_hm(x, tw.t, k);
+  ln.store_h(a.dst[0] + cb.off, x);
+  L8::gs_hm(y, tw.t, k);
+  ln.store_h(a.dst[1] + cb.off, y);
+}
+
 // keyswitch_mid in the 8-per-lane geometry (used for n = 2^17: LOW = 9; at n = 2^16 the 16-per-lane form is faster)
 template <typename TW, int LOW>
 __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid8(KeyswitchArgs ka) {

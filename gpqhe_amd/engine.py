@@ -261,6 +261,11 @@ class PolyContext:
                       "gpq_poly_mul_rns")
         return r
 
+    def mulpt_rns(self, r0, r1, m, x0, x1, dim):
+        _native.check(self.lib.gpq_mulpt_rns(self.h, _ptr(r0), _ptr(r1), _ptr(m), _ptr(x0), _ptr(x1), dim, self._shape(m, dim), _stream()),
+                      "gpq_mulpt_rns")
+        return r0, r1
+
     # --- he_mul RNS core ---
     def tensor_workspace(self, dim, batch):
         torch = _torch()

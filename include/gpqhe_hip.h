@@ -103,8 +103,14 @@ int gpq_rns_mul(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, const uint64_t *b,
 int gpq_rns_add(gpq_ctx *ctx, uint64_t *r, const uint64_t *a, const uint64_t *b, unsigned dim, unsigned batch, void *stream);
 
 /* Limb loop of poly_mul, src/poly.c:96-103 (without rns_decompose):
- * r = invntt(ntt(a) (*) ntt(b)).  a and b are overwritten (NTT domain). */
+ * r = invntt(ntt(a) (*) ntt(b)).  a and b are distinct slabs and are overwritten (scratch: for n >= 2^13 the loop runs
+ * as three kernels -- strided pass, fused low stages + product, strided pass -- and leaves them half transformed);
+ * r may be a or b. */
 int gpq_poly_mul_rns(gpq_ctx *ctx, uint64_t *r, uint64_t *a, uint64_t *b, unsigned dim, unsigned batch, void *stream);
+/* Limb loop of he_mulpt, src/he-mult.c:179-185: r0 = invntt(ntt(m) (*) ntt(x0)), r1 = invntt(ntt(m) (*) ntt(x1)).
+ * m, x0, x1 are distinct slabs and are overwritten; r0 / r1 may be x0 / x1. */
+int gpq_mulpt_rns(gpq_ctx *ctx, uint64_t *r0, uint64_t *r1, uint64_t *m, uint64_t *x0, uint64_t *x1, unsigned dim, unsigned batch,
+                  void *stream);
 
 /* The fused operations process the batch in groups of `chunk` polynomials so
  * that the scratch stays bounded (default 32; larger groups amortise launch tails). */

@@ -71,15 +71,35 @@ def test_batched_core_matches_oracle(engine_ctx, oracle_ctx, logn, dim, batch, c
     g.set_chunk(4)
 
 
-@pytest.mark.parametrize("logn,dim", [(7, 5), (13, 2)])
-def test_poly_mul_limb_loop(engine_ctx, oracle_ctx, logn, dim):
-    """src/poly.c:96-103 without rns_decompose."""
+@pytest.mark.parametrize("logn,dim,batch", [(7, 5, 1), (13, 2, 3), (14, 3, 2), (16, 4, 2), (17, 33, 1)])
+def test_poly_mul_limb_loop(engine_ctx, oracle_ctx, logn, dim, batch):
+    """src/poly.c:96-103 without rns_decompose (small rings: four transforms; n >= 2^13: strided pass, fused middle, strided pass;
+    (17, 33) crosses the three twiddle classes), also with the result written over an operand."""
     o, g = oracle_ctx(logn, dim), engine_ctx(logn, dim)
-    a, b = o.gen(41, dim), o.gen(42, dim)
+    a = np.concatenate([o.gen(41 + 2 * k, dim) for k in range(batch)])
+    b = np.concatenate([o.gen(42 + 2 * k, dim) for k in range(batch)])
+    per = dim << logn
+    want = np.concatenate([o.poly_mul_rns(a[k * per:(k + 1) * per], b[k * per:(k + 1) * per], dim) for k in range(batch)])
     da, db = to_device(a), to_device(b)
     r = _empty_like(da)
     g.poly_mul_rns(r, da, db, dim)
-    assert np.array_equal(to_host(r), o.poly_mul_rns(a, b, dim))
+    assert np.array_equal(to_host(r), want)
+    da, db = to_device(a), to_device(b)
+    g.poly_mul_rns(db, da, db, dim)
+    assert np.array_equal(to_host(db), want)
+
+
+@pytest.mark.parametrize("logn,dim,batch", [(7, 5, 2), (13, 2, 3), (16, 4, 1), (17, 33, 1)])
+def test_mulpt_limb_loop(engine_ctx, oracle_ctx, logn, dim, batch):
+    """src/he-mult.c:179-185: both ciphertext polynomials times the plaintext polynomial, in place on the operands."""
+    o, g = oracle_ctx(logn, dim), engine_ctx(logn, dim)
+    per = dim << logn
+    m, x0, x1 = (np.concatenate([o.gen(s + 3 * k, dim) for k in range(batch)]) for s in (51, 52, 53))
+    want0 = np.concatenate([o.poly_mul_rns(m[k * per:(k + 1) * per], x0[k * per:(k + 1) * per], dim) for k in range(batch)])
+    want1 = np.concatenate([o.poly_mul_rns(m[k * per:(k + 1) * per], x1[k * per:(k + 1) * per], dim) for k in range(batch)])
+    dm, d0, d1 = to_device(m), to_device(x0), to_device(x1)
+    g.mulpt_rns(d0, d1, dm, d0, d1, dim)
+    assert np.array_equal(to_host(d0), want0) and np.array_equal(to_host(d1), want1)
 
 
 def test_linearity_full_size(engine_ctx, oracle_ctx):

@@ -162,14 +162,16 @@ def test_largest_c_of_the_supported_chains(engine_ctx, oracle_ctx):
     assert np.array_equal(to_host(outs[0]), e0) and np.array_equal(to_host(outs[1]), e1) and np.array_equal(to_host(outs[2]), e2)
 
 
-@pytest.mark.parametrize("switch,value", [("GPQHE_NO_SPLIT", "1"), ("GPQHE_NO_WIDE", "1"), ("GPQHE_MID8", "0"), ("GPQHE_N17_LOW8", "1")])
+@pytest.mark.parametrize("switch,value", [("GPQHE_NO_SPLIT", "1"), ("GPQHE_NO_WIDE", "1"), ("GPQHE_MID8", "0"), ("GPQHE_N17_LOW8", "1"),
+                                          ("GPQHE_NO_FUSED_POLYMUL", "1")])
 @pytest.mark.parametrize("logn,dim", [(16, 58), (17, 57), (13, 20)])
 def test_kernel_families_agree_bit_for_bit(logn, dim, switch, value):
     """The default contexts pick, per limb, the cheapest butterflies its c allows -- wide-split (c < 2^27: a conditional
     subtraction every other forward stage), split (5-mad multiply), plain (7-mad) -- so one transform at n = 2^17 runs all
     three, and run the tensor stage on the 8-coefficients-per-lane kernel.  Each development switch removes one of these
     choices at context creation (GPQHE_NO_SPLIT=1: 7-mad butterflies only; GPQHE_NO_WIDE=1: a subtraction in every stage;
-    GPQHE_MID8=0: the 16-per-lane tensor kernel; GPQHE_N17_LOW8=1: n = 2^17 as 9 strided + 8 low stages instead of 8 + 9).  Same slabs
+    GPQHE_MID8=0: the 16-per-lane tensor kernel; GPQHE_N17_LOW8=1: n = 2^17 as 9 strided + 8 low stages instead of 8 + 9;
+    GPQHE_NO_FUSED_POLYMUL=1: poly_mul's limb loop as four separate transforms and a pointwise product).  Same slabs
     through both contexts, whole he_mul core included: bit-identical."""
     import os
     import torch
@@ -204,7 +206,9 @@ def test_kernel_families_agree_bit_for_bit(logn, dim, switch, value):
         g.he_mul_tensor(d0, d1, d2, slabs[0], slabs[1], slabs[2], slabs[3], dim, g.tensor_workspace(dim, batch))
         c0, c1 = torch.empty_like(f), torch.empty_like(f)
         g.he_keyswitch(c0, c1, slabs[4], e0, e1, dim, g.keyswitch_workspace(dim, batch))
-        outs.append([f, i, d0, d1, d2, c0, c1])
+        pa, pb, pr = slabs[0].clone(), slabs[2].clone(), torch.empty_like(f)
+        g.poly_mul_rns(pr, pa, pb, dim)
+        outs.append([f, i, d0, d1, d2, c0, c1, pr])
         g.close()
     for a, b in zip(*outs):
         assert torch.equal(a, b)
