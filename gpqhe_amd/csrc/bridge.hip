@@ -808,9 +808,8 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
       if ((rc = launch_decompose(c, h[i], in[i] + k0 * bigpoly, W, 0, dimA, polys, s))) return rc;
     if ((rc = gpq_he_mul_tensor(c, d0h, d1h, d2h, h[0], h[1], h[2], h[3], dimA, polys, wsT, stream))) return rc;  // :121-136
     uint64_t *d0 = dbig, *d1 = dbig + polys * bigpoly, *d2 = dbig + 2 * polys * bigpoly;
-    if ((rc = launch_reconstruct(c, bA, d0, W, d0h, dimA, 0, polys, logql, true, nullptr, s))) return rc;          // :139
-    if ((rc = launch_reconstruct(c, bA, d2, W, d2h, dimA, 0, polys, logql, true, nullptr, s))) return rc;          // :140
-    if ((rc = launch_reconstruct(c, bA, d1, W, d1h, dimA, 0, polys, logql, true, nullptr, s))) return rc;          // :141
+    // poly_rns2mpi of d0, d2, d1 (:139-141): the three slabs are adjacent on both sides, one launch
+    if ((rc = launch_reconstruct(c, bA, d0, W, d0h, dimA, 0, 3 * polys, logql, true, nullptr, s))) return rc;
     // he_relin, :40-85
     uint64_t *d2hat = sB, *c0hat = sB + pb, *c1hat = sB + 2 * pb;
     if ((rc = launch_decompose(c, d2hat, d2, W, 0, dimB, polys, s))) return rc;                                    // :59
