@@ -345,7 +345,8 @@ def main():
             out["ntt"] = [ntt_rate(torch, gpqhe_amd, 16, DIM_A, B), ntt_rate(torch, gpqhe_amd, 15, 10, 64)]
             del a0, a1, b0, b1, x, d0, d1, d2, c0, c1, wsA, wsB
             torch.cuda.empty_cache()
-            out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, 16)
+            out["ntt"].append(ntt_rate(torch, gpqhe_amd, 16, DIM_A, 4 * B))   # launch size matters: 4 GiB slab
+            out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, B, iters=3)   # BASELINE configs[2]: he_mul + he_rescale, batch 64
             out["keyswitch_n17"] = keyswitch_n17_rate(torch, gpqhe_amd)
         print(json.dumps(out))
     if dist is not None:
