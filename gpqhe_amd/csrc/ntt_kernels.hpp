@@ -12,6 +12,12 @@
 //                    a workgroup owns 2^M1 rows x 16 columns (M1 = logn-8)
 //   contiguous pass  stages with len <= 128: inside 256-element blocks;
 //                    a wave owns 4 consecutive blocks, no workgroup barrier
+//   (n = 2^17: len >= 512 / len <= 256, rows of 512 and blocks of 512: same
+//   256-row tiles, 9 low stages in the 8-per-lane kernels further down)
+// The low stages are fused with what surrounds them wherever a limb loop of
+// the reference allows it: tensor_mid / tensor_mid8 (he_mul tensor stage),
+// keyswitch_mid / keyswitch_mid8 (he_relin, he_swk), polymul_mid8 (poly_mul),
+// mulpt_mid8 (he_mulpt).
 //
 // Inside a pass a thread keeps 2^EL coefficients in registers and runs EL
 // (or fewer) stages on them before exchanging through LDS (padded, conflict
