@@ -61,7 +61,7 @@ def pmc_traffic(kernel, chunk):
     return None
 
 
-def ntt_rate(torch, gpqhe_amd, logn, dim, batch, iters=5):
+def ntt_rate(torch, gpqhe_amd, logn, dim, batch, iters=20):
     """Second half of BASELINE's metric: NTT GB/s = 16*n bytes per limb per direction
     (read + write once) over a forward+inverse pair, HIP-event timed."""
     ctx = gpqhe_amd.PolyContext(logn, dim)
@@ -70,8 +70,11 @@ def ntt_rate(torch, gpqhe_amd, logn, dim, batch, iters=5):
     slab = rand_slab(torch, ctx, dim, batch, gen)
     ref = slab.clone()
     ctx.poly_ntt(slab, dim)
-    ctx.poly_invntt(slab, dim)          # warm-up, and the round trip must be the identity
+    ctx.poly_invntt(slab, dim)          # the round trip must be the identity
     ok = bool(torch.equal(slab, ref))
+    for _ in range(3):                  # warm-up: the first pairs after a synchronisation run ~10 % slower
+        ctx.poly_ntt(slab, dim)
+        ctx.poly_invntt(slab, dim)
     t = gpqhe_amd.StreamTimer()
     t.start()
     for _ in range(iters):
