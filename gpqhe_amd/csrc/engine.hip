@@ -171,6 +171,8 @@ static int upload_tables(gpq_ctx *c) {
   c->low9 = c->logn == 17 && !(low8 && low8[0] == '1');
   const char *nofuse = getenv("GPQHE_NO_FUSED_POLYMUL");   // dev switch: poly_mul's limb loop as ntt, ntt, mul, invntt
   c->fused_polymul = !(nofuse && nofuse[0] == '1');
+  const char *ksp = getenv("GPQHE_KS_PAIRS");       // dev switch: 0 = key switch one polynomial per workgroup (keyswitch_mid / keyswitch_mid8)
+  c->ks_pairs = !(ksp && ksp[0] == '0');
   const char *nowide = getenv("GPQHE_NO_WIDE");     // dev switch: A/B against one subtraction per stage
   c->nwide = 0;
   if (!(nowide && nowide[0] == '1'))
@@ -694,7 +696,9 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
           using TW = decltype(tag);
           KeyswitchArgs ka{a, m.evk0, m.evk1};
           ProfScope prof(c, GPQ_K_KEYSWITCH_MID, s);
-          if (c->low9) hipLaunchKernelGGL((keyswitch_mid8<TW, 9>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, ka);
+          if (c->ks_pairs && c->low9) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 9>), dim3(c->n >> 11, (polys + 1) / 2, limbs), dim3(CONTIG_WAVES * 64), 0, s, ka, polys);
+          else if (c->ks_pairs) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 8>), dim3(c->n >> 11, (polys + 1) / 2, limbs), dim3(CONTIG_WAVES * 64), 0, s, ka, polys);
+          else if (c->low9) hipLaunchKernelGGL((keyswitch_mid8<TW, 9>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, ka);
           else hipLaunchKernelGGL((keyswitch_mid<TW>), dim3(c->n >> 12, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, ka);
           return (int)GPQ_OK;
         }))) return rc;

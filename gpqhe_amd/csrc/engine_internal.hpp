@@ -62,6 +62,7 @@ struct gpq_ctx {
   unsigned nsplit = 0;                            // leading limbs with c < GPQ_SPLIT_CMAX
   bool low9 = false;                              // n = 2^17: strided passes over 512-coefficient rows, 9 low stages (Lane8<9>)
   bool fused_polymul = true;                      // gpq_poly_mul_rns as strided pass, polymul_mid8, strided pass
+  bool ks_pairs = true;                           // key switch on keyswitch_mid8x2 (two polynomials per workgroup)
   bool mid8 = true;                               // tensor stage on tensor_mid8 (8 coefficients per lane, 3 waves per SIMD)
   unsigned nwide = 0;                             // leading limbs with c < GPQ_WIDE_CMAX (<= nsplit): forward stages as ct_bfly_wide
   gpq::LimbTab *d_tabs = nullptr;

@@ -163,7 +163,7 @@ def test_largest_c_of_the_supported_chains(engine_ctx, oracle_ctx):
 
 
 @pytest.mark.parametrize("switch,value", [("GPQHE_NO_SPLIT", "1"), ("GPQHE_NO_WIDE", "1"), ("GPQHE_MID8", "0"), ("GPQHE_N17_LOW8", "1"),
-                                          ("GPQHE_NO_FUSED_POLYMUL", "1")])
+                                          ("GPQHE_NO_FUSED_POLYMUL", "1"), ("GPQHE_KS_PAIRS", "0")])
 @pytest.mark.parametrize("logn,dim", [(16, 58), (17, 57), (13, 20)])
 def test_kernel_families_agree_bit_for_bit(logn, dim, switch, value):
     """The default contexts pick, per limb, the cheapest butterflies its c allows -- wide-split (c < 2^27: a conditional
@@ -171,7 +171,8 @@ def test_kernel_families_agree_bit_for_bit(logn, dim, switch, value):
     three, and run the tensor stage on the 8-coefficients-per-lane kernel.  Each development switch removes one of these
     choices at context creation (GPQHE_NO_SPLIT=1: 7-mad butterflies only; GPQHE_NO_WIDE=1: a subtraction in every stage;
     GPQHE_MID8=0: the 16-per-lane tensor kernel; GPQHE_N17_LOW8=1: n = 2^17 as 9 strided + 8 low stages instead of 8 + 9;
-    GPQHE_NO_FUSED_POLYMUL=1: poly_mul's limb loop as four separate transforms and a pointwise product).  Same slabs
+    GPQHE_NO_FUSED_POLYMUL=1: poly_mul's limb loop as four separate transforms and a pointwise product; GPQHE_KS_PAIRS=0: the key
+    switch one polynomial per workgroup instead of two).  Same slabs
     through both contexts, whole he_mul core included: bit-identical."""
     import os
     import torch
@@ -187,7 +188,7 @@ def test_kernel_families_agree_bit_for_bit(logn, dim, switch, value):
         finally:
             os.environ.pop(switch, None)
         if not outs:
-            batch = 2
+            batch = 3
             slabs = []
             for _ in range(5):
                 s = torch.empty((batch, dim, g.n), dtype=torch.int64, device="cuda")
