@@ -578,8 +578,8 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid(KeyswitchA
 // ---------------------------------------------------------------------------
 // The low stages with 8 coefficients per lane instead of 16.
 // The 16-per-lane forms hold 4 (3) polynomials x 16 coefficients x 2 VGPRs and run at 2 (3) waves per
-// SIMD, where the dependent instruction chain of a butterfly is not covered (profiles/r01: 4.75 cycles
-// per VALU instruction with arithmetic only, against 3.5 for the same mix at 8 waves).  Here a wave owns
+// SIMD, where the dependent instruction chain of a butterfly is not covered (profiles/r01: 20 % more cycles
+// per VALU instruction with arithmetic only than the same mix at 8 waves).  Here a wave owns
 // 512 consecutive coefficients and the LOW = 8 or 9 low stages run as three register groups with two
 // exchanges through the wave's own LDS region.  LOW = 8 (blocks of 256, two per wave; lane = j + 32 blk):
 //   H: k = j + 32 e                      index bits 7..5     (3 stages)

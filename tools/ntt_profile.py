@@ -11,7 +11,7 @@ for logn, dim, batch in ((16, 30, 64), (15, 10, 64), (17, 44, 8)):
         ctx.poly_ntt(slab, dim); ctx.poly_invntt(slab, dim)
     torch.cuda.synchronize()
     ctx.profile(True)
-    for _ in range(5):
+    for _ in range(int(os.environ.get('ITERS', '5'))):
         ctx.poly_ntt(slab, dim); ctx.poly_invntt(slab, dim)
     torch.cuda.synchronize()
     prof = ctx.profile_collect()
