@@ -48,7 +48,11 @@ def pmc_traffic(kernel, chunk):
     being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section).  The PMC run
     used launch groups of `pmc_chunk` polynomials; traffic scales with the group size."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json")))
+    import re
+    def order(path):   # profiles/rNN/vMM_pmc_summary.json: by round, then by version number (v10 after v9)
+        m = re.search(r"r(\d+)[/\\]v(\d+)_", path)
+        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json")), key=order)
     if not files:
         return None
     try:

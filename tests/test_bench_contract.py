@@ -29,3 +29,17 @@ def test_pmc_traffic_reads_the_committed_summary():
         assert t is not None and 1.0 <= t / algo < 1.15
     for k in ("strided_fwd", "strided_inv", "keyswitch_mid"):
         assert b.pmc_traffic(k, 32) is not None
+
+
+def test_pmc_traffic_takes_the_latest_summary_by_number():
+    """v10 comes after v9: the summary used must be the one with the highest (round, version), i.e. the current kernels."""
+    import glob
+    import json
+    import re
+    b = _bench()
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json"))
+    latest = max(files, key=lambda p: tuple(int(v) for v in re.search(r"r(\d+)[/\\]v(\d+)_", p).groups()))
+    data = json.load(open(latest))
+    name = next(k for k in data if "tensor_mid" in k)
+    want = int((2 * data[name]["FETCH_SIZE"] + data[name]["WRITE_SIZE"]) * 1024 * 32 / data.get("_chunk", 4))
+    assert b.pmc_traffic("tensor_mid", 32) == want
