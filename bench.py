@@ -65,6 +65,35 @@ def pmc_traffic(kernel, chunk):
     return None
 
 
+def power_state(torch, step, seconds=2.5):
+    """Shader clock and package power while the hot loop runs (rocm-smi polled during an extra, untimed stretch of steps):
+    on this part the loop sits at the package power cap, which is what sets its clock.  None if rocm-smi is unavailable."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("rocm-smi") is None:
+        return None
+    try:
+        dev = torch.cuda.current_device()
+        t0, clk, pw = time.perf_counter(), [], []
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(8):
+                step()                                   # asynchronous: about as much work as one poll takes
+            out = subprocess.run(["rocm-smi", "-d", str(dev), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+            m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+            w = re.search(r"Power \(W\): ([0-9.]+)", out)
+            if m and w:
+                clk.append(int(m.group(1))); pw.append(float(w.group(1)))
+        torch.cuda.synchronize()
+        if len(clk) < 2:
+            return None
+        clk, pw = sorted(clk[1:]), sorted(pw[1:])       # the first sample may precede the ramp
+        return {"sclk_MHz": clk[len(clk) // 2], "package_W": pw[len(pw) // 2], "samples": len(clk),
+                "how": "rocm-smi polled during an extra untimed stretch of the same steps"}
+    except Exception:
+        return None
+
+
 def ntt_rate(torch, gpqhe_amd, logn, dim, batch, iters=20):
     """Second half of BASELINE's metric: NTT GB/s = 16*n bytes per limb per direction
     (read + write once) over a forward+inverse pair, HIP-event timed."""
@@ -348,6 +377,9 @@ def main():
                       [gpqhe_amd.to_host(v[: s * DIM_B * ctx.n]) for v in (c0, c1)]
             out["cpu_baseline"] = cpu_baseline(ctx, host_in, gpu_out, s)
         if world == 1 and not args.no_ntt:
+            pw = power_state(torch, step)
+            if pw is not None:
+                out["power"] = pw
             # NTT GB/s at the headline ring (n=2^16, 30 limbs) and at BASELINE configs[1] (n=2^15, 10 limbs)
             out["ntt"] = [ntt_rate(torch, gpqhe_amd, 16, DIM_A, B), ntt_rate(torch, gpqhe_amd, 15, 10, 64)]
             del a0, a1, b0, b1, x, d0, d1, d2, c0, c1, wsA, wsB
