@@ -77,7 +77,7 @@ def power_state(torch, step, seconds=2.5):
         dev = torch.cuda.current_device()
         t0, clk, pw = time.perf_counter(), [], []
         while time.perf_counter() - t0 < seconds:
-            for _ in range(8):
+            for _ in range(11):
                 step()                                   # asynchronous: about as much work as one poll takes
             out = subprocess.run(["rocm-smi", "-d", str(dev), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
             m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
