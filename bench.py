@@ -9,8 +9,18 @@ form and resident in HBM.  One "step" = the whole batch once.  he_rescale has
 no RNS-domain work in the reference (src/he-rescale.c:33-54 is big-integer
 only), so it is not part of the timed RNS core.
 
-Multi-GPU: independent ciphertexts, one shard per rank, no data-path collective
-(weak scaling); the only collectives are the timing barrier and a MAX.
+Multi-GPU: independent ciphertexts, one shard per rank, no data-path collective;
+the only collectives of the timed region are the barrier and a MAX.  One process per
+GPU over RCCL.  Either start the ranks yourself
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+or run `python bench.py --gpus N ...` alone: with WORLD_SIZE unset the parent (which never
+touches a GPU) starts the N rank processes itself and exits with their status.
+  --batch B         ciphertexts per GPU (weak scaling, the default: 64 per GPU)
+  --total-batch T   T ciphertexts block-partitioned over the ranks (strong scaling;
+                    BASELINE configs[3] = --total-batch 512 at N = 2/4/8)
+With N > 1 the line also carries `with_scatter_gather`: the same shards with the input
+slabs sent from rank 0 and the results returned to it inside the timed region.
 
 Prints ONE JSON line (rank 0).
 """
@@ -46,7 +56,10 @@ def pmc_traffic(kernel, chunk):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/, separate
     rocprofv3 --pmc runs of this same command): 2*FETCH_SIZE + WRITE_SIZE in KiB, the factor 2
     being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section).  The PMC run
-    used launch groups of `pmc_chunk` polynomials; traffic scales with the group size."""
+    used launch groups of `_chunk` polynomials; traffic scales with the group size.
+    Returns (bytes or None, provenance): the counters are NOT collected by the run that prints
+    them (gpurun refuses counter collection next to other tracing), so the line says which
+    committed summary the figure comes from and which commit that summary profiled."""
     import glob
     import re
     def order(path):   # profiles/rNN/vMM_pmc_summary.json: by round, then by version number (v10 after v9)
@@ -54,15 +67,22 @@ def pmc_traffic(kernel, chunk):
         return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json")), key=order)
     if not files:
-        return None
+        return None, "no profiles/r*/*pmc_summary.json in the tree"
+    rel = os.path.relpath(files[-1], ROOT)
     try:
         data = json.load(open(files[-1]))
-        for name, v in data.items():
-            if kernel in name.replace("strided_pass<8, 4, false", "strided_fwd").replace("strided_pass<8, 4, true", "strided_inv"):
-                return int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 * chunk / data.get("_chunk", 4))
-    except Exception:
-        return None
-    return None
+    except (OSError, ValueError) as exc:
+        return None, "%s unreadable: %s" % (rel, exc)
+    src = {"file": rel, "profiled_head": data.get("_head"), "profiled_chunk": data.get("_chunk", 4),
+           "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, scaled by chunk/profiled_chunk"}
+    for name, v in data.items():
+        if name.startswith("_"):
+            continue
+        if kernel in name.replace("strided_pass<8, 4, false", "strided_fwd").replace("strided_pass<8, 4, true", "strided_inv"):
+            src["kernel"] = name
+            return int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 * chunk / data.get("_chunk", 4)), src
+    src["error"] = "no kernel matching %r in the summary" % kernel
+    return None, src
 
 
 def power_state(torch, step, seconds=2.5):
@@ -217,34 +237,92 @@ def cpu_baseline(ctx, host_inputs, gpu_outputs, sample):
     return out
 
 
-def main():
+ROCPROF_NAMES = {   # how rocprofv3 names the kernels of the default n = 2^16 path (every limb wide-split)
+    "tensor_mid": "gpq::tensor_mid8<gpq::TwW, 8>",
+    "keyswitch_mid": "gpq::keyswitch_mid8x2<gpq::TwW, 8>",
+    "strided_fwd": "gpq::strided_pass<8, 4, false, false, gpq::TwW, 8>",
+    "strided_inv": "gpq::strided_pass<8, 4, true, false, HIP_vector_type<unsigned long long, 2u>, 8>",
+}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="ciphertext multiplications per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="ciphertext multiplications per GPU per step (weak scaling)")
+    ap.add_argument("--total-batch", type=int, default=0, help="ciphertext multiplications per step over ALL GPUs, block-partitioned "
+                    "(strong scaling; BASELINE configs[3] = 512); overrides --batch")
     ap.add_argument("--chunk", type=int, default=0, help="polynomials per fused launch group (0 = library default)")
+    ap.add_argument("--limb-block", type=int, default=0, help="limbs per launch group (0 = library default: all)")
     ap.add_argument("--cpu-sample", type=int, default=2, help="ciphertexts the CPU baseline replays (0 = skip)")
     ap.add_argument("--no-ntt", action="store_true", help="skip the secondary legs run after the timed region (NTT GB/s, MPI-level he_mul, n=2^17 key switch)")
     ap.add_argument("--streams", type=int, default=1, help="2: tensor stage and key-switch stage on separate HIP streams")
-    ap.add_argument("--scatter-gather", action="store_true", help="N>1 only: also time a step with the input slabs scattered from rank 0 "
-                    "and the outputs gathered back (grouped isend/irecv = one RCCL group over xGMI); SURVEY.md 8d config 4")
+    ap.add_argument("--no-scatter-gather", action="store_true", help="N>1: skip the extra step that has the input slabs scattered from "
+                    "rank 0 and the outputs gathered back inside the timed region (SURVEY.md 8d config 4)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path with several ranks on one GPU)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import torch
-    import gpqhe_amd
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: this parent makes no torch / HIP call at all and starts the N rank
+    processes as children (a process that has touched the GPU must never exec another program on this pool), one per GPU,
+    rendezvous on 127.0.0.1.  Returns the first non-zero exit status of a rank (0 if all succeed)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print("bench.py: rank %d exited with status %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                for o in alive:
+                    procs[o].terminate()                           # exactly the children started above
+        time.sleep(0.05)
+    return rc
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:      # never run another rank count than the one asked for and report it as if it were
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+
+    import torch
+    import gpqhe_amd
+    from gpqhe_amd.dist import shard_range
+
     dist = None
+    ndev = torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        ndev = torch.cuda.device_count()
         if args.backend == "nccl":
+            if local >= ndev:
+                sys.exit("bench.py: rank %d needs cuda:%d but this node shows %d device(s); one rank per GPU over RCCL "
+                         "(--backend gloo rehearses several ranks on one GPU)" % (rank, local, ndev))
             torch.cuda.set_device(local)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
@@ -252,14 +330,21 @@ def main():
             dist.init_process_group(backend=args.backend)
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world:
-        if rank == 0 and world > 1:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    dev_index = torch.cuda.current_device()
+
+    if args.total_batch:
+        if args.total_batch < world:
+            sys.exit("bench.py: --total-batch %d is smaller than the %d ranks" % (args.total_batch, world))
+        lo, hi = shard_range(args.total_batch, world, rank)
+        B, total_batch, scaling = hi - lo, args.total_batch, "strong"
+    else:
+        B, total_batch, scaling = args.batch, args.batch * world, "weak"
 
     ctx = gpqhe_amd.PolyContext(LOGN, DIM_B)
     if args.chunk:
         ctx.set_chunk(args.chunk)
-    B = args.batch
+    if args.limb_block:
+        ctx.set_limb_block(args.limb_block)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1000 + rank)
     a0, a1, b0, b1 = (rand_slab(torch, ctx, DIM_A, B, gen) for _ in range(4))
@@ -299,48 +384,36 @@ def main():
     dt = time.perf_counter() - t0
     ctx.profile(False)
     prof = ctx.profile_collect()
+    ranks_seen, devices = 1, ["cuda:%d" % dev_index]
     if dist is not None:
         from gpqhe_amd.dist import max_over_ranks
         dt = max_over_ranks(dt)
+        ranks_seen = dist.get_world_size()
+        devices = [None] * ranks_seen
+        dist.all_gather_object(devices, "cuda:%d" % dev_index)
 
     sg = None
-    if dist is not None and args.scatter_gather:
+    if dist is not None and not args.no_scatter_gather:
         # BASELINE configs[3] with the transfers inside the timed region: rank 0 owns the whole batch, every rank works on its
-        # shard, results return to rank 0.  A root-GPU scatter is bound by one xGMI link per peer.
-        from gpqhe_amd.dist import scatter_slab, gather_slab, max_over_ranks
-        Bs = min(B, 16)
-        dev = torch.device("cuda", torch.cuda.current_device())
-        per_a, per_b = DIM_A * ctx.n, DIM_B * ctx.n
-        full_in = [torch.cat([v[: Bs * per_a]] * world) if rank == 0 else None for v in (a0, a1, b0, b1)]
-        full_x = torch.cat([x[: Bs * per_b]] * world) if rank == 0 else None
-        barrier()
-        t1 = time.perf_counter()
-        sa = [scatter_slab(f, per_a, Bs * world, 0, dev) for f in full_in]
-        sx = scatter_slab(full_x, per_b, Bs * world, 0, dev)
-        torch.cuda.synchronize()
-        o = [torch.empty_like(sa[0]) for _ in range(3)] + [torch.empty_like(sx) for _ in range(2)]
-        ctx.he_mul_tensor(o[0], o[1], o[2], sa[0], sa[1], sa[2], sa[3], DIM_A, wsA)
-        ctx.he_keyswitch(o[3], o[4], sx, e0, e1, DIM_B, wsB)
-        torch.cuda.synchronize()      # the results must exist before a backend without stream semantics (gloo rehearsal) reads them
-        back = [gather_slab(o[i], per_a if i < 3 else per_b, Bs * world, 0) for i in range(5)]
-        barrier()
-        dsg = max_over_ranks(time.perf_counter() - t1)
-        moved = (4 * per_a + per_b + 3 * per_a + 2 * per_b) * 8 * Bs * (world - 1)
-        sg = {"batch_per_gpu": Bs, "he_mul_per_s": round(Bs * world / dsg, 1), "ms": round(dsg * 1e3, 2), "bytes_over_links": moved,
-              "GBps_root": round(moved / dsg / 1e9, 1)}
-        if rank == 0:   # the shards are copies of the first ciphertexts: every shard's result equals rank 0's own
-            assert all(torch.equal(back[i][: o[i].numel()], back[i][o[i].numel(): 2 * o[i].numel()]) for i in range(5))
-        del full_in, full_x, sa, sx, o, back
+        # shard, results return to rank 0.  A root-GPU scatter is bound by one xGMI link per peer.  A failure of
+        # this secondary leg is reported in the line, it does not void the compute-only headline.
+        try:
+            sg = scatter_gather_step(torch, dist, ctx, (a0, a1, b0, b1), x, (e0, e1), (wsA, wsB), min(total_batch // world, 16), world, rank, barrier)
+        except Exception as exc:           # noqa: BLE001
+            sg = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     if rank == 0:
-        total_he_mul = world * B * args.steps
+        total_he_mul = total_batch * args.steps
         value = total_he_mul / dt
         # dominant kernel by accumulated device time
         kname, (kms, kcnt) = max(prof.items(), key=lambda kv: kv[1][0])
         # strided kernels run for both stages: average units per launch from the launch mix
         chunk = min(B, args.chunk or 32)
-        units = {"tensor_mid": DIM_A * chunk, "keyswitch_mid": DIM_B * chunk,
-                 "strided_fwd": (4 * DIM_A + 1 * DIM_B) * chunk / 2.0, "strided_inv": (3 * DIM_A + 2 * DIM_B) * chunk / 2.0}
+        lb = args.limb_block or 0
+        la, lbb = (min(lb, DIM_A), min(lb, DIM_B)) if lb else (DIM_A, DIM_B)
+        units = {"tensor_mid": la * chunk, "keyswitch_mid": lbb * chunk,
+                 "strided_fwd": (4 * DIM_A + 1 * DIM_B) * chunk / (DIM_A / la + DIM_B / lbb),
+                 "strided_inv": (3 * DIM_A + 2 * DIM_B) * chunk / (DIM_A / la + DIM_B / lbb)}
         kernels = {}
         for name, (ms, cnt) in prof.items():
             avg_ms = ms / cnt
@@ -350,17 +423,23 @@ def main():
         kavg = kms / kcnt
         kbytes = KERNEL_LIMB_PASSES[kname] * units[kname] * (8 << LOGN)
         achieved = kbytes / (kavg * 1e-3) / 1e9
-        traffic = pmc_traffic(kname, chunk)
+        traffic, traffic_source = pmc_traffic(kname, chunk)
         out = {
             "metric": "ciphertext he_mul/sec (RNS core: tensor 30 limbs + key-switch 45 limbs), N=2^16",
-            "value": round(value, 2), "unit": "he_mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "value": round(value, 2), "unit": "he_mul/s", "n_gpus": world, "ranks_seen": ranks_seen, "devices": devices,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "he_mul RNS core, n=2^16, dimA=30, dimB=45, batch=%d ciphertexts per GPU (BASELINE configs[2]); "
-                                   "he_rescale has no RNS-domain work in the reference" % B,
-                       "batch_per_gpu": B, "chunk": chunk, "parallelism": "ciphertext-per-GPU x%d, no data-path collective" % world},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "config": {"workload": "he_mul RNS core, n=2^16, dimA=30, dimB=45, %s; he_rescale has no RNS-domain work in the reference"
+                                   % ("batch=%d ciphertexts per GPU (BASELINE configs[2])" % B if scaling == "weak" else
+                                      "batch=%d ciphertexts block-partitioned over %d GPU(s) (BASELINE configs[3])" % (total_batch, world)),
+                       "batch_per_gpu": B, "total_batch": total_batch, "chunk": chunk,
+                       "parallelism": "ciphertext-per-GPU x%d, no data-path collective" % world,
+                       "launcher": "torchrun / external" if os.environ.get("TORCHELASTIC_RUN_ID") else ("self-launched ranks" if world > 1 else "single process"),
+                       "backend": args.backend if world > 1 else None},
+            "roofline": {"bound": "hbm", "kernel": kname, "kernel_rocprof": ROCPROF_NAMES.get(kname, kname),
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_launch": int(kbytes), "avg_launch_ms": round(kavg, 4)},
             "he_mul_e2e": {"algo_bytes_per_he_mul": ALGO_BYTES_PER_HE_MUL,
                            "achieved_GBps_per_gpu": round(ALGO_BYTES_PER_HE_MUL * value / world / 1e9, 1),
@@ -370,7 +449,7 @@ def main():
         if sg is not None:
             out["with_scatter_gather"] = sg
         if world == 1 and args.cpu_sample > 0:
-            s = args.cpu_sample
+            s = min(args.cpu_sample, B)
             host_in = [gpqhe_amd.to_host(v[: s * DIM_A * ctx.n]) for v in (a0, a1, b0, b1)] + \
                       [gpqhe_amd.to_host(x[: s * DIM_B * ctx.n]), gpqhe_amd.to_host(e0), gpqhe_amd.to_host(e1)]
             gpu_out = [gpqhe_amd.to_host(v[: s * DIM_A * ctx.n]) for v in (d0, d1, d2)] + \
@@ -387,10 +466,38 @@ def main():
             out["ntt"].append(ntt_rate(torch, gpqhe_amd, 16, DIM_A, 4 * B))   # launch size matters: 4 GiB slab
             out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, B, iters=3)   # BASELINE configs[2]: he_mul + he_rescale, batch 64
             out["keyswitch_n17"] = keyswitch_n17_rate(torch, gpqhe_amd)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def scatter_gather_step(torch, dist, ctx, ins, x, evk, wss, Bs, world, rank, barrier):
+    """One step over Bs ciphertexts per rank with the transfers timed: rank 0 holds the Bs*world inputs, every rank receives
+    its shard (grouped isend/irecv = one RCCL group over xGMI), computes, and returns its five output slabs to rank 0."""
+    from gpqhe_amd.dist import scatter_slab, gather_slab, max_over_ranks
+    a0, a1, b0, b1 = ins
+    dev = torch.device("cuda", torch.cuda.current_device())
+    per_a, per_b = DIM_A * ctx.n, DIM_B * ctx.n
+    full_in = [torch.cat([v[: Bs * per_a]] * world) if rank == 0 else None for v in (a0, a1, b0, b1)]
+    full_x = torch.cat([x[: Bs * per_b]] * world) if rank == 0 else None
+    barrier()
+    t1 = time.perf_counter()
+    sa = [scatter_slab(f, per_a, Bs * world, 0, dev) for f in full_in]
+    sx = scatter_slab(full_x, per_b, Bs * world, 0, dev)
+    o = [torch.empty_like(sa[0]) for _ in range(3)] + [torch.empty_like(sx) for _ in range(2)]
+    ctx.he_mul_tensor(o[0], o[1], o[2], sa[0], sa[1], sa[2], sa[3], DIM_A, wss[0])
+    ctx.he_keyswitch(o[3], o[4], sx, evk[0], evk[1], DIM_B, wss[1])
+    back = [gather_slab(o[i], per_a if i < 3 else per_b, Bs * world, 0) for i in range(5)]
+    barrier()
+    dsg = max_over_ranks(time.perf_counter() - t1)
+    moved = (4 * per_a + per_b + 3 * per_a + 2 * per_b) * 8 * Bs * (world - 1)
+    sg = {"batch_per_gpu": Bs, "he_mul_per_s": round(Bs * world / dsg, 1), "ms": round(dsg * 1e3, 2), "bytes_over_links": moved,
+          "GBps_root": round(moved / dsg / 1e9, 1)}
+    if rank == 0:   # the shards are copies of the first ciphertexts: every shard's result equals rank 0's own
+        sg["shards_identical"] = bool(all(torch.equal(back[i][: o[i].numel()], back[i][r * o[i].numel(): (r + 1) * o[i].numel()])
+                                          for i in range(5) for r in range(1, world)))
+    return sg
 
 
 if __name__ == "__main__":

@@ -117,7 +117,7 @@ int get_basis(gpq_ctx *c, unsigned first, unsigned dim, gpq_bridge_basis **out) 
   put(phalf, 0, h, WP + 1);
   Big m = P;
   for (int k = 5; k >= 0; --k) { put(pmult, (size_t)k * (WP + 1), m, WP + 1); mul_small(m, 2); }  // P,2P,..,32P at rows 5..0
-  HIP_TRY(hipSetDevice(c->device));
+  DeviceScope on_device(c->device);
   HIP_TRY(hipMalloc((void **)&b.d_phat, phat.size() * 8));
   HIP_TRY(hipMalloc((void **)&b.d_phat_inv, pinv.size() * 8));
   HIP_TRY(hipMalloc((void **)&b.d_pmult, pmult.size() * 8));
@@ -238,7 +238,7 @@ int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out
       }
       mP = nxt;
     }
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceScope on_device(c->device);
     HIP_TRY(hipMalloc(&t.d_bfrag, bf.size()));
     HIP_TRY(hipMalloc((void **)&t.d_lk, lk.size() * 8));
     HIP_TRY(hipMalloc((void **)&t.d_kc, kc.size() * 8));
@@ -287,8 +287,16 @@ int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, uns
   if (fast) {
     const size_t flags = (size_t)batch << logn;
     if (flags > c->redo_cap) {
-      if (c->d_redo) HIP_TRY(hipFree(c->d_redo));
-      HIP_TRY(hipMalloc((void **)&c->d_redo, flags));
+      // Growing inside a stream capture would put hipMalloc into the graph; and a graph captured earlier keeps the old
+      // pointer, so outgrown buffers are retired (freed with the context), never freed here.
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return gpq_fail(GPQ_ERR_INVALID, "the first call at a new batch size allocates scratch: run it once outside stream capture");
+      DeviceScope on_device(c->device);
+      unsigned char *grown = nullptr;
+      HIP_TRY(hipMalloc((void **)&grown, flags));
+      if (c->d_redo) c->retired.push_back(c->d_redo);
+      c->d_redo = grown;
       c->redo_cap = flags;
     }
     bool done = false;
@@ -381,7 +389,7 @@ int get_decomp_mfma(gpq_ctx *c, unsigned limb0, unsigned dim, unsigned W, gpq_de
         }
       }
     }
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceScope on_device(c->device);
     HIP_TRY(hipMalloc(&t.d_bfrag, bf.size()));
     HIP_TRY(hipMalloc((void **)&t.d_pk, pk.size() * 8));
     HIP_TRY(hipMemcpy(t.d_bfrag, bf.data(), bf.size(), hipMemcpyHostToDevice));
@@ -457,6 +465,8 @@ void gpq_bridge_release(gpq_ctx *c) {
   }
   if (c->d_redo) (void)hipFree(c->d_redo);
   c->d_redo = nullptr; c->redo_cap = 0;
+  for (void *old : c->retired) (void)hipFree(old);
+  c->retired.clear();
   c->bases.clear();
   for (auto &kv : c->relins) {
     (void)hipFree(kv.second.d_pinv);
@@ -517,7 +527,7 @@ extern "C" int gpq_rns_reconstruct_one(gpq_ctx *c, uint64_t *words, unsigned Wou
   if (Wout * 64 < b->pbits + 1) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct_one: %u words cannot hold a value mod P (%u bits)", Wout, b->pbits);
   for (unsigned d = 0; d < dim; ++d)
     if (residues[d] >= c->p[d]) return gpq_fail(GPQ_ERR_INVALID, "gpq_rns_reconstruct_one: residue %u is not reduced", d);
-  HIP_TRY(hipSetDevice(c->device));
+  DeviceScope on_device(c->device);
   uint64_t *dev = nullptr;
   HIP_TRY(hipMalloc((void **)&dev, (size_t)(dim + Wout) * 8));
   hipError_t e = hipMemcpy(dev, residues, (size_t)dim * 8, hipMemcpyHostToDevice);
@@ -648,7 +658,7 @@ int get_relin_front(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables *
     pk[3 * (size_t)j + 2] = (uint64_t)((u128h)Pinv * bq->h_phat_inv[j] % pj);
     for (unsigned k = 0; k < 64; ++k) tkp[(size_t)j * 64 + k] = (pj - (uint64_t)((u128h)k * Pm % pj)) % pj;
   }
-  HIP_TRY(hipSetDevice(c->device));
+  DeviceScope on_device(c->device);
   HIP_TRY(hipMalloc(&rt->d_bfrag, bf.size()));
   HIP_TRY(hipMalloc((void **)&rt->d_lk, lk.size() * 8));
   HIP_TRY(hipMalloc((void **)&rt->d_pk, pk.size() * 8));

@@ -128,7 +128,10 @@ uint64_t inv_mod_2_64(uint64_t q) {  // Newton; equals the 64-step product of sr
 // ---------------------------------------------------------------------------
 static int upload_tables(gpq_ctx *c) {
   const size_t n = c->n, np = c->nprimes;
-  HIP_TRY(hipSetDevice(c->device));
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (c->device < 0 || c->device >= ndev) return gpq_fail(GPQ_ERR_INVALID, "device %d outside 0..%d", c->device, ndev - 1);
+  DeviceScope on_device(c->device);
   HIP_TRY(hipMalloc((void **)&c->d_w, np * n * sizeof(uint64_t)));
   HIP_TRY(hipMalloc((void **)&c->d_winv, np * n * sizeof(uint64_t)));
   HIP_TRY(hipMalloc((void **)&c->d_tabs, np * sizeof(LimbTab)));
@@ -594,6 +597,9 @@ extern "C" int gpq_mulpt_rns(gpq_ctx *c, uint64_t *r0, uint64_t *r1, uint64_t *m
 static unsigned tensor_chunk(const gpq_ctx *c, unsigned batch) {
   return batch < c->chunk ? batch : c->chunk;
 }
+static unsigned limb_block(const gpq_ctx *c, unsigned dim) {
+  return (c->limb_block && c->limb_block < dim) ? c->limb_block : dim;
+}
 
 extern "C" size_t gpq_tensor_workspace_bytes(const gpq_ctx *c, unsigned dim, unsigned batch) {
   if (!two_pass(c)) return 4ull * batch * ((size_t)dim << c->logn) * 8;
@@ -635,28 +641,38 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
   }
 
   const unsigned chunk = tensor_chunk(c, batch);
+  const unsigned lblock = limb_block(c, dim);
   for (unsigned k0 = 0; k0 < batch; k0 += chunk) {
     const unsigned polys = (batch - k0 < chunk) ? batch - k0 : chunk;
-    // 1. strided forward pass, inputs -> workspace
-    PassArgs f = make_args(c, dim, 4);
-    for (int i = 0; i < 4; ++i) { f.src[i] = in[i] + k0 * poly; f.dst[i] = ws + (size_t)i * chunk * poly; }
-    if ((rc = launch_strided<false>(c, f, dim, polys, s))) return rc;
-    // 2. low forward stages, products, low inverse stages -> outputs
-    PassArgs m = make_args(c, dim, 1);
-    for (int i = 0; i < 4; ++i) m.src[i] = f.dst[i];
-    m.dst[0] = d0 + k0 * poly; m.dst[1] = d1 + k0 * poly; m.dst[2] = d2 + k0 * poly;
-    if ((rc = for_limb_ranges<true>(c, m, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
-          using TW = decltype(tag);
-          ProfScope prof(c, GPQ_K_TENSOR_MID, s);
-          if (c->low9) hipLaunchKernelGGL((tensor_mid8<TW, 9>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, a);
-          else if (c->mid8) hipLaunchKernelGGL((tensor_mid8<TW, 8>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, a);
-          else hipLaunchKernelGGL((tensor_mid<TW>), dim3(c->n >> 12, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, a);
-          return (int)GPQ_OK;
-        }))) return rc;
-    // 3. strided inverse pass in place on the three outputs
-    PassArgs b = make_args(c, dim, 3);
-    for (int i = 0; i < 3; ++i) { b.src[i] = m.dst[i]; b.dst[i] = m.dst[i]; }
-    if ((rc = launch_strided<true>(c, b, dim, polys, s))) return rc;
+    // A launch group = `polys` polynomials x `limbs` limbs of every slab: its three kernels run back to back so that
+    // what one writes the next one reads while it is still in the Infinity Cache (gpq_set_limb_block).
+    for (unsigned l0 = 0; l0 < dim; l0 += lblock) {
+      const unsigned limbs = dim - l0 < lblock ? dim - l0 : lblock;
+      const size_t loff = (size_t)l0 << c->logn;
+      // 1. strided forward pass, inputs -> workspace
+      PassArgs f = make_args(c, dim, 4);
+      f.limb0 = l0;
+      for (int i = 0; i < 4; ++i) { f.src[i] = in[i] + k0 * poly + loff; f.dst[i] = ws + (size_t)i * chunk * poly + loff; }
+      if ((rc = launch_strided<false>(c, f, limbs, polys, s))) return rc;
+      // 2. low forward stages, products, low inverse stages -> outputs
+      PassArgs m = make_args(c, dim, 1);
+      m.limb0 = l0;
+      for (int i = 0; i < 4; ++i) m.src[i] = f.dst[i];
+      m.dst[0] = d0 + k0 * poly + loff; m.dst[1] = d1 + k0 * poly + loff; m.dst[2] = d2 + k0 * poly + loff;
+      if ((rc = for_limb_ranges<true>(c, m, limbs, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned nl) {
+            using TW = decltype(tag);
+            ProfScope prof(c, GPQ_K_TENSOR_MID, s);
+            if (c->low9) hipLaunchKernelGGL((tensor_mid8<TW, 9>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
+            else if (c->mid8) hipLaunchKernelGGL((tensor_mid8<TW, 8>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
+            else hipLaunchKernelGGL((tensor_mid<TW>), dim3(c->n >> 12, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
+            return (int)GPQ_OK;
+          }))) return rc;
+      // 3. strided inverse pass in place on the three outputs
+      PassArgs b = make_args(c, dim, 3);
+      b.limb0 = l0;
+      for (int i = 0; i < 3; ++i) { b.src[i] = m.dst[i]; b.dst[i] = m.dst[i]; }
+      if ((rc = launch_strided<true>(c, b, limbs, polys, s))) return rc;
+    }
   }
   return after_launch("gpq_he_mul_tensor");
 }
@@ -683,30 +699,44 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
   }
 
   const unsigned chunk = tensor_chunk(c, batch);
+  const unsigned lblock = limb_block(c, dim);
   for (unsigned k0 = 0; k0 < batch; k0 += chunk) {
     const unsigned polys = (batch - k0 < chunk) ? batch - k0 : chunk;
-    PassArgs f = make_args(c, dim, 1);
-    f.src[0] = x + k0 * poly; f.dst[0] = ws;
-    if ((rc = launch_strided<false>(c, f, dim, polys, s))) return rc;
-    KeyswitchArgs m;
-    m.p = make_args(c, dim, 1);
-    m.p.src[0] = ws; m.p.dst[0] = c0 + k0 * poly; m.p.dst[1] = c1 + k0 * poly;
-    m.evk0 = evk0; m.evk1 = evk1;
-    if ((rc = for_limb_ranges<true>(c, m.p, dim, &m.evk0, &m.evk1, [&](auto tag, const PassArgs &a, unsigned limbs) {
-          using TW = decltype(tag);
-          KeyswitchArgs ka{a, m.evk0, m.evk1};
-          ProfScope prof(c, GPQ_K_KEYSWITCH_MID, s);
-          if (c->ks_pairs && c->low9) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 9>), dim3(c->n >> 11, (polys + 1) / 2, limbs), dim3(CONTIG_WAVES * 64), 0, s, ka, polys);
-          else if (c->ks_pairs) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 8>), dim3(c->n >> 11, (polys + 1) / 2, limbs), dim3(CONTIG_WAVES * 64), 0, s, ka, polys);
-          else if (c->low9) hipLaunchKernelGGL((keyswitch_mid8<TW, 9>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, ka);
-          else hipLaunchKernelGGL((keyswitch_mid<TW>), dim3(c->n >> 12, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, ka);
-          return (int)GPQ_OK;
-        }))) return rc;
-    PassArgs b = make_args(c, dim, 2);
-    for (int i = 0; i < 2; ++i) { b.src[i] = m.p.dst[i]; b.dst[i] = m.p.dst[i]; }
-    if ((rc = launch_strided<true>(c, b, dim, polys, s))) return rc;
+    for (unsigned l0 = 0; l0 < dim; l0 += lblock) {       // launch groups as in gpq_he_mul_tensor
+      const unsigned limbs = dim - l0 < lblock ? dim - l0 : lblock;
+      const size_t loff = (size_t)l0 << c->logn;
+      PassArgs f = make_args(c, dim, 1);
+      f.limb0 = l0;
+      f.src[0] = x + k0 * poly + loff; f.dst[0] = ws + loff;
+      if ((rc = launch_strided<false>(c, f, limbs, polys, s))) return rc;
+      KeyswitchArgs m;
+      m.p = make_args(c, dim, 1);
+      m.p.limb0 = l0;
+      m.p.src[0] = f.dst[0]; m.p.dst[0] = c0 + k0 * poly + loff; m.p.dst[1] = c1 + k0 * poly + loff;
+      m.evk0 = evk0 + loff; m.evk1 = evk1 + loff;
+      if ((rc = for_limb_ranges<true>(c, m.p, limbs, &m.evk0, &m.evk1, [&](auto tag, const PassArgs &a, unsigned nl) {
+            using TW = decltype(tag);
+            KeyswitchArgs ka{a, m.evk0, m.evk1};
+            ProfScope prof(c, GPQ_K_KEYSWITCH_MID, s);
+            if (c->ks_pairs && c->low9) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 9>), dim3(c->n >> 11, (polys + 1) / 2, nl), dim3(CONTIG_WAVES * 64), 0, s, ka, polys);
+            else if (c->ks_pairs) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 8>), dim3(c->n >> 11, (polys + 1) / 2, nl), dim3(CONTIG_WAVES * 64), 0, s, ka, polys);
+            else if (c->low9) hipLaunchKernelGGL((keyswitch_mid8<TW, 9>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, ka);
+            else hipLaunchKernelGGL((keyswitch_mid<TW>), dim3(c->n >> 12, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, ka);
+            return (int)GPQ_OK;
+          }))) return rc;
+      PassArgs b = make_args(c, dim, 2);
+      b.limb0 = l0;
+      for (int i = 0; i < 2; ++i) { b.src[i] = m.p.dst[i]; b.dst[i] = m.p.dst[i]; }
+      if ((rc = launch_strided<true>(c, b, limbs, polys, s))) return rc;
+    }
   }
   return after_launch("gpq_keyswitch");
+}
+
+extern "C" int gpq_set_limb_block(gpq_ctx *c, unsigned limbs) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_limb_block: null context");
+  c->limb_block = limbs;
+  return GPQ_OK;
 }
 
 extern "C" int gpq_set_chunk(gpq_ctx *c, unsigned chunk) {

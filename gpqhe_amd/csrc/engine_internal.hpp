@@ -53,6 +53,7 @@ struct gpq_ctx {
   int device = 0;
   unsigned logn = 0, n = 0, nprimes = 0;
   unsigned chunk = 32; // polynomials per fused launch group (measured: larger groups amortise launch tails; profiles/r01/v9_sweep_chunk.txt)
+  unsigned limb_block = 0; // limbs per fused launch group (0 = all limbs of the slab); gpq_set_limb_block
   // host copies in the reference's own representation (struct rns_ctx, src/poly.h:28-41)
   std::vector<uint64_t> p, pinv_mont, pinv_barr, ninv_mont, psi;
   std::vector<uint64_t> zetas, zetas_inv;  // [nprimes][n], Montgomery form, bit-reversed index
@@ -72,11 +73,20 @@ struct gpq_ctx {
   bool bridge_mfma = true;            // matrix-core decompose (GPQHE_NO_MFMA=1 or gpq_set_bridge_mfma(ctx, 0): VALU kernels)
   unsigned char *d_redo = nullptr;    // per-coefficient "redo exactly" flags of the fast CRT path
   size_t redo_cap = 0;
+  std::vector<void *> retired;        // outgrown d_redo buffers: a HIP graph captured earlier may still write them, so they live as long as the context
   bool exact_crt = false;             // force the exact CRT kernel (tests)
   // profiling
   bool prof_on = false;
   std::vector<gpq_prof_rec> prof;     // launches recorded since the last reset
   std::vector<hipEvent_t> prof_pool;  // recycled events
+};
+
+// Makes `device` current for a scope and puts the caller's device back afterwards (context creation must not leave
+// the calling thread on another GPU).
+struct DeviceScope {
+  int prev = -1;
+  explicit DeviceScope(int device) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(device); }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
 int gpq_fail(int code, const char *fmt, ...);

@@ -19,16 +19,26 @@ def shard_range(batch, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _wire_device(device):
+    """Where a slab sits while it is on the wire: RCCL moves device memory; gloo (CPU tests, and the
+    rehearsal of several ranks on one GPU) moves host memory, so device slabs are staged through the host."""
+    return device if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
 def scatter_slab(full, per_ct, batch, src=0, device=None):
     """Rank `src` holds `full` = int64[batch*per_ct] (others pass None); every rank
-    gets its own shard int64[(hi-lo)*per_ct].  Ragged shards are allowed."""
+    gets its own shard int64[(hi-lo)*per_ct] on `device` (default: where `full` lives).
+    Ragged shards are allowed."""
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = shard_range(batch, world, rank)
     device = full.device if full is not None else (device or _default_device())
-    mine = torch.empty((hi - lo) * per_ct, dtype=torch.int64, device=device)
     if world == 1:
-        mine.copy_(full)
-        return mine
+        return full.to(device, copy=True)
+    wire = _wire_device(device)
+    if wire != device:
+        staged = scatter_slab(full.to(wire) if full is not None else None, per_ct, batch, src, wire)
+        return staged.to(device)
+    mine = torch.empty((hi - lo) * per_ct, dtype=torch.int64, device=device)
     ops = []
     if rank == src:
         for r in range(world):
@@ -51,6 +61,10 @@ def gather_slab(mine, per_ct, batch, dst=0):
     world, rank = dist.get_world_size(), dist.get_rank()
     if world == 1:
         return mine.clone()
+    wire = _wire_device(mine.device)
+    if wire != mine.device:
+        full = gather_slab(mine.to(wire), per_ct, batch, dst)       # .to() waits for the kernels that produced `mine`
+        return full.to(mine.device) if full is not None else None
     ops = []
     full = None
     if rank == dst:

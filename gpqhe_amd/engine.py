@@ -57,11 +57,21 @@ class PolyContext:
         if not torch.cuda.is_available():
             raise _native.GpqError("gpqhe_amd needs a HIP device; there is no CPU path")
         self.device = torch.cuda.current_device() if device is None else int(device)
+        self._dev = torch.device("cuda", self.device)     # workspaces and streams belong to the context's device, not the current one
         h = C.c_void_p()
         _native.check(self.lib.gpq_ctx_create(C.byref(h), logn, nprimes, self.device), "gpq_ctx_create")
         self.h = h
         self.logn, self.n, self.nprimes = logn, 1 << logn, nprimes
         self.p = [self.lib.gpq_ctx_const(h, d, 0) for d in range(nprimes)]
+
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _ptr(self, t):
+        """device pointer of a slab, which must live on this context's device"""
+        if not t.is_cuda or t.device.index != self.device:
+            raise ValueError("slab on %s, context on cuda:%d" % (t.device, self.device))
+        return C.c_void_p(t.data_ptr())
 
     def close(self):
         if getattr(self, "h", None):
@@ -81,17 +91,20 @@ class PolyContext:
     def set_chunk(self, chunk):
         _native.check(self.lib.gpq_set_chunk(self.h, chunk), "gpq_set_chunk")
 
+    def set_limb_block(self, limbs):
+        _native.check(self.lib.gpq_set_limb_block(self.h, limbs), "gpq_set_limb_block")
+
     # --- MPI <-> RNS bridge on big slabs uint64[batch][W][n] ---
     def rns_decompose(self, slab, big, W, dim):
         """src/rns.c:37-48 for all limbs."""
         batch = big.numel() // (W * self.n)
-        _native.check(self.lib.gpq_rns_decompose(self.h, _ptr(slab), _ptr(big), W, dim, batch, _stream()), "gpq_rns_decompose")
+        _native.check(self.lib.gpq_rns_decompose(self.h, self._ptr(slab), self._ptr(big), W, dim, batch, self._stream()), "gpq_rns_decompose")
         return slab
 
     def rns_reconstruct(self, big, Wout, slab, dim, logq):
         """src/poly.c:109-120 with q = 2^logq (0: centre mod P only)."""
         batch = self._shape(slab, dim)
-        _native.check(self.lib.gpq_rns_reconstruct(self.h, _ptr(big), Wout, _ptr(slab), dim, batch, logq, _stream()), "gpq_rns_reconstruct")
+        _native.check(self.lib.gpq_rns_reconstruct(self.h, self._ptr(big), Wout, self._ptr(slab), dim, batch, logq, self._stream()), "gpq_rns_reconstruct")
         return big
 
     def set_bridge_mfma(self, on):
@@ -105,8 +118,8 @@ class PolyContext:
         """src/poly.c:84-107 on big slabs, q = 2^logq."""
         torch = _torch()
         batch = a.numel() // (W * self.n)
-        ws = torch.empty(self.lib.gpq_poly_mul_workspace_bytes(self.h, dim, batch) // 8, dtype=torch.int64, device="cuda")
-        _native.check(self.lib.gpq_poly_mul(self.h, _ptr(r), _ptr(a), _ptr(b), W, dim, logq, batch, _ptr(ws), _stream()), "gpq_poly_mul")
+        ws = torch.empty(self.lib.gpq_poly_mul_workspace_bytes(self.h, dim, batch) // 8, dtype=torch.int64, device=self._dev)
+        _native.check(self.lib.gpq_poly_mul(self.h, self._ptr(r), self._ptr(a), self._ptr(b), W, dim, logq, batch, self._ptr(ws), self._stream()), "gpq_poly_mul")
         return r
 
     def poly_mul_general(self, r, a, b, W, dim, q):
@@ -115,15 +128,15 @@ class PolyContext:
         batch = a.numel() // (W * self.n)
         Lq = (q.bit_length() + 63) // 64
         qw = (_native.u64 * Lq)(*[(q >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(Lq)])
-        ws = torch.empty(self.lib.gpq_poly_mul_general_workspace_bytes(self.h, dim, batch) // 8 + 8, dtype=torch.int64, device="cuda")
-        _native.check(self.lib.gpq_poly_mul_general(self.h, _ptr(r), _ptr(a), _ptr(b), W, dim, qw, Lq, batch, _ptr(ws), _stream()),
+        ws = torch.empty(self.lib.gpq_poly_mul_general_workspace_bytes(self.h, dim, batch) // 8 + 8, dtype=torch.int64, device=self._dev)
+        _native.check(self.lib.gpq_poly_mul_general(self.h, self._ptr(r), self._ptr(a), self._ptr(b), W, dim, qw, Lq, batch, self._ptr(ws), self._stream()),
                       "gpq_poly_mul_general")
         return r
 
     def he_rs(self, c0, c1, W, logDelta, logql):
         """src/he-rescale.c:33-54 with Delta = 2^logDelta, q_l = 2^logql, in place."""
         batch = c0.numel() // (W * self.n)
-        _native.check(self.lib.gpq_he_rs(self.h, _ptr(c0), _ptr(c1), W, logDelta, logql, batch, _stream()), "gpq_he_rs")
+        _native.check(self.lib.gpq_he_rs(self.h, self._ptr(c0), self._ptr(c1), W, logDelta, logql, batch, self._stream()), "gpq_he_rs")
 
     def he_dims(self, logqL, logql):
         """(dimP, dimA, dimB, dimevk) as src/precomp.c:401,407 and src/he-mult.c:99,51 compute them."""
@@ -136,18 +149,18 @@ class PolyContext:
         torch = _torch()
         batch = ct1c0.numel() // (W * self.n)
         nbytes = self.lib.gpq_he_mul_workspace_bytes(self.h, W, dimA, dimB, dimP, batch)
-        ws = torch.empty(nbytes // 8 + 8, dtype=torch.int64, device="cuda")
-        _native.check(self.lib.gpq_he_mul(self.h, _ptr(out_c0), _ptr(out_c1), _ptr(ct1c0), _ptr(ct1c1), _ptr(ct2c0), _ptr(ct2c1),
-                                          _ptr(rlk0), _ptr(rlk1), W, logql, dimA, dimB, dimP, batch, _ptr(ws), _stream()), "gpq_he_mul")
+        ws = torch.empty(nbytes // 8 + 8, dtype=torch.int64, device=self._dev)
+        _native.check(self.lib.gpq_he_mul(self.h, self._ptr(out_c0), self._ptr(out_c1), self._ptr(ct1c0), self._ptr(ct1c1), self._ptr(ct2c0), self._ptr(ct2c1),
+                                          self._ptr(rlk0), self._ptr(rlk1), W, logql, dimA, dimB, dimP, batch, self._ptr(ws), self._stream()), "gpq_he_mul")
         return ws
 
     def relin_tail(self, out, chat, d, W, logql, dimB, dimP):
         """src/he-mult.c:67-77 alone (d = None: nothing added)."""
         torch = _torch()
         batch = self._shape(chat, dimB)
-        ws = torch.empty(self.lib.gpq_relin_tail_workspace_bytes(self.h, W, dimB, dimP, batch) // 8 + 8, dtype=torch.int64, device="cuda")
-        _native.check(self.lib.gpq_relin_tail(self.h, _ptr(out), _ptr(chat), _ptr(d) if d is not None else None, W, logql, dimB, dimP,
-                                              batch, _ptr(ws), _stream()), "gpq_relin_tail")
+        ws = torch.empty(self.lib.gpq_relin_tail_workspace_bytes(self.h, W, dimB, dimP, batch) // 8 + 8, dtype=torch.int64, device=self._dev)
+        _native.check(self.lib.gpq_relin_tail(self.h, self._ptr(out), self._ptr(chat), self._ptr(d) if d is not None else None, W, logql, dimB, dimP,
+                                              batch, self._ptr(ws), self._stream()), "gpq_relin_tail")
         return out
 
     def he_swk(self, out_c0, out_c1, d0, d1, swk0, swk1, W, logql, dimB, dimP):
@@ -155,9 +168,9 @@ class PolyContext:
         torch = _torch()
         batch = d0.numel() // (W * self.n)
         nbytes = self.lib.gpq_he_swk_workspace_bytes(self.h, W, dimB, dimP, batch)
-        ws = torch.empty(nbytes // 8 + 8, dtype=torch.int64, device="cuda")
-        _native.check(self.lib.gpq_he_swk(self.h, _ptr(out_c0), _ptr(out_c1), _ptr(d0), _ptr(d1), _ptr(swk0), _ptr(swk1),
-                                          W, logql, dimB, dimP, batch, _ptr(ws), _stream()), "gpq_he_swk")
+        ws = torch.empty(nbytes // 8 + 8, dtype=torch.int64, device=self._dev)
+        _native.check(self.lib.gpq_he_swk(self.h, self._ptr(out_c0), self._ptr(out_c1), self._ptr(d0), self._ptr(d1), self._ptr(swk0), self._ptr(swk1),
+                                          W, logql, dimB, dimP, batch, self._ptr(ws), self._stream()), "gpq_he_swk")
         return ws
 
     @staticmethod
@@ -170,34 +183,34 @@ class PolyContext:
         torch = _torch()
         batch = ct1c0.numel() // (W * self.n)
         qw, L = self._words(ql)
-        ws = torch.empty(self.lib.gpq_he_general_workspace_bytes(self.h, W, dimA, dimB, dimP, batch) // 8 + 8, dtype=torch.int64, device="cuda")
-        _native.check(self.lib.gpq_he_mul_general(self.h, _ptr(out_c0), _ptr(out_c1), _ptr(ct1c0), _ptr(ct1c1), _ptr(ct2c0), _ptr(ct2c1),
-                                                  _ptr(rlk0), _ptr(rlk1), W, qw, L, dimA, dimB, dimP, batch, _ptr(ws), _stream()),
+        ws = torch.empty(self.lib.gpq_he_general_workspace_bytes(self.h, W, dimA, dimB, dimP, batch) // 8 + 8, dtype=torch.int64, device=self._dev)
+        _native.check(self.lib.gpq_he_mul_general(self.h, self._ptr(out_c0), self._ptr(out_c1), self._ptr(ct1c0), self._ptr(ct1c1), self._ptr(ct2c0), self._ptr(ct2c1),
+                                                  self._ptr(rlk0), self._ptr(rlk1), W, qw, L, dimA, dimB, dimP, batch, self._ptr(ws), self._stream()),
                       "gpq_he_mul_general")
 
     def he_swk_general(self, out_c0, out_c1, d0, d1, swk0, swk1, W, ql, dimB, dimP):
         torch = _torch()
         batch = d0.numel() // (W * self.n)
         qw, L = self._words(ql)
-        ws = torch.empty(self.lib.gpq_he_general_workspace_bytes(self.h, W, 0, dimB, dimP, batch) // 8 + 8, dtype=torch.int64, device="cuda")
-        _native.check(self.lib.gpq_he_swk_general(self.h, _ptr(out_c0), _ptr(out_c1), _ptr(d0), _ptr(d1), _ptr(swk0), _ptr(swk1),
-                                                  W, qw, L, dimB, dimP, batch, _ptr(ws), _stream()), "gpq_he_swk_general")
+        ws = torch.empty(self.lib.gpq_he_general_workspace_bytes(self.h, W, 0, dimB, dimP, batch) // 8 + 8, dtype=torch.int64, device=self._dev)
+        _native.check(self.lib.gpq_he_swk_general(self.h, self._ptr(out_c0), self._ptr(out_c1), self._ptr(d0), self._ptr(d1), self._ptr(swk0), self._ptr(swk1),
+                                                  W, qw, L, dimB, dimP, batch, self._ptr(ws), self._stream()), "gpq_he_swk_general")
 
     def he_rs_general(self, c0, c1, W, delta, ql):
         """src/he-rescale.c:33-54 for any Delta (< 2^64) and any q_l."""
         torch = _torch()
         batch = c0.numel() // (W * self.n)
         qw, L = self._words(ql)
-        scratch = torch.empty(192, dtype=torch.int64, device="cuda")
-        _native.check(self.lib.gpq_he_rs_general(self.h, _ptr(c0), _ptr(c1), W, delta, qw, L, batch, _ptr(scratch), _stream()), "gpq_he_rs_general")
+        scratch = torch.empty(192, dtype=torch.int64, device=self._dev)
+        _native.check(self.lib.gpq_he_rs_general(self.h, self._ptr(c0), self._ptr(c1), W, delta, qw, L, batch, self._ptr(scratch), self._stream()), "gpq_he_rs_general")
 
     def he_mulpt(self, out_c0, out_c1, c0, c1, m, W, logql, dim):
         """src/he-mult.c:159-196 on big slabs."""
         torch = _torch()
         batch = c0.numel() // (W * self.n)
-        ws = torch.empty(self.lib.gpq_he_mulpt_workspace_bytes(self.h, dim, batch) // 8 + 8, dtype=torch.int64, device="cuda")
-        _native.check(self.lib.gpq_he_mulpt(self.h, _ptr(out_c0), _ptr(out_c1), _ptr(c0), _ptr(c1), _ptr(m), W, logql, dim, batch,
-                                            _ptr(ws), _stream()), "gpq_he_mulpt")
+        ws = torch.empty(self.lib.gpq_he_mulpt_workspace_bytes(self.h, dim, batch) // 8 + 8, dtype=torch.int64, device=self._dev)
+        _native.check(self.lib.gpq_he_mulpt(self.h, self._ptr(out_c0), self._ptr(out_c1), self._ptr(c0), self._ptr(c1), self._ptr(m), W, logql, dim, batch,
+                                            self._ptr(ws), self._stream()), "gpq_he_mulpt")
 
     def he_genswk(self, evk0, evk1, p1, sk, e, sp, W, dimP, logqL, dimevk):
         """src/he-kem.c:74-118 from host-sampled p1 / e and the hidden polynomial sp; q_L = 2^logqL."""
@@ -205,16 +218,16 @@ class PolyContext:
         nbytes = self.lib.gpq_he_genswk_workspace_bytes(self.h, W, dimP, logqL)
         if not nbytes:
             raise _native.GpqError("gpq_he_genswk_workspace_bytes: " + self.lib.gpq_last_error().decode())
-        ws = torch.empty(nbytes // 8 + 8, dtype=torch.int64, device="cuda")
-        _native.check(self.lib.gpq_he_genswk(self.h, _ptr(evk0), _ptr(evk1), _ptr(p1), _ptr(sk), _ptr(e), _ptr(sp), W, dimP, logqL, dimevk,
-                                             _ptr(ws), _stream()), "gpq_he_genswk")
+        ws = torch.empty(nbytes // 8 + 8, dtype=torch.int64, device=self._dev)
+        _native.check(self.lib.gpq_he_genswk(self.h, self._ptr(evk0), self._ptr(evk1), self._ptr(p1), self._ptr(sk), self._ptr(e), self._ptr(sp), W, dimP, logqL, dimevk,
+                                             self._ptr(ws), self._stream()), "gpq_he_genswk")
 
     def poly_rot(self, r, a, W, rot):
-        _native.check(self.lib.gpq_poly_rot(self.h, _ptr(r), _ptr(a), W, rot, a.numel() // (W * self.n), _stream()), "gpq_poly_rot")
+        _native.check(self.lib.gpq_poly_rot(self.h, self._ptr(r), self._ptr(a), W, rot, a.numel() // (W * self.n), self._stream()), "gpq_poly_rot")
         return r
 
     def poly_conj(self, r, a, W):
-        _native.check(self.lib.gpq_poly_conj(self.h, _ptr(r), _ptr(a), W, a.numel() // (W * self.n), _stream()), "gpq_poly_conj")
+        _native.check(self.lib.gpq_poly_conj(self.h, self._ptr(r), self._ptr(a), W, a.numel() // (W * self.n), self._stream()), "gpq_poly_conj")
         return r
 
     def phat_invmp(self, dim):
@@ -239,30 +252,30 @@ class PolyContext:
 
     # --- src/ntt.c:37,54 over slabs, in place ---
     def poly_ntt(self, slab, dim):
-        _native.check(self.lib.gpq_ntt(self.h, _ptr(slab), dim, self._shape(slab, dim), _stream()), "gpq_ntt")
+        _native.check(self.lib.gpq_ntt(self.h, self._ptr(slab), dim, self._shape(slab, dim), self._stream()), "gpq_ntt")
         return slab
 
     def poly_invntt(self, slab, dim):
-        _native.check(self.lib.gpq_invntt(self.h, _ptr(slab), dim, self._shape(slab, dim), _stream()), "gpq_invntt")
+        _native.check(self.lib.gpq_invntt(self.h, self._ptr(slab), dim, self._shape(slab, dim), self._stream()), "gpq_invntt")
         return slab
 
     # --- src/poly.c:71-82 over slabs ---
     def poly_rns_mul(self, r, a, b, dim):
-        _native.check(self.lib.gpq_rns_mul(self.h, _ptr(r), _ptr(a), _ptr(b), dim, self._shape(a, dim), _stream()), "gpq_rns_mul")
+        _native.check(self.lib.gpq_rns_mul(self.h, self._ptr(r), self._ptr(a), self._ptr(b), dim, self._shape(a, dim), self._stream()), "gpq_rns_mul")
         return r
 
     def poly_rns_add(self, r, a, b, dim):
-        _native.check(self.lib.gpq_rns_add(self.h, _ptr(r), _ptr(a), _ptr(b), dim, self._shape(a, dim), _stream()), "gpq_rns_add")
+        _native.check(self.lib.gpq_rns_add(self.h, self._ptr(r), self._ptr(a), self._ptr(b), dim, self._shape(a, dim), self._stream()), "gpq_rns_add")
         return r
 
     # --- limb loop of poly_mul, src/poly.c:96-103 ---
     def poly_mul_rns(self, r, a, b, dim):
-        _native.check(self.lib.gpq_poly_mul_rns(self.h, _ptr(r), _ptr(a), _ptr(b), dim, self._shape(a, dim), _stream()),
+        _native.check(self.lib.gpq_poly_mul_rns(self.h, self._ptr(r), self._ptr(a), self._ptr(b), dim, self._shape(a, dim), self._stream()),
                       "gpq_poly_mul_rns")
         return r
 
     def mulpt_rns(self, r0, r1, m, x0, x1, dim):
-        _native.check(self.lib.gpq_mulpt_rns(self.h, _ptr(r0), _ptr(r1), _ptr(m), _ptr(x0), _ptr(x1), dim, self._shape(m, dim), _stream()),
+        _native.check(self.lib.gpq_mulpt_rns(self.h, self._ptr(r0), self._ptr(r1), self._ptr(m), self._ptr(x0), self._ptr(x1), dim, self._shape(m, dim), self._stream()),
                       "gpq_mulpt_rns")
         return r0, r1
 
@@ -270,27 +283,27 @@ class PolyContext:
     def tensor_workspace(self, dim, batch):
         torch = _torch()
         nbytes = self.lib.gpq_tensor_workspace_bytes(self.h, dim, batch)
-        return torch.empty(nbytes // 8, dtype=torch.int64, device="cuda")
+        return torch.empty(nbytes // 8, dtype=torch.int64, device=self._dev)
 
     def keyswitch_workspace(self, dim, batch):
         torch = _torch()
         nbytes = self.lib.gpq_keyswitch_workspace_bytes(self.h, dim, batch)
-        return torch.empty(nbytes // 8, dtype=torch.int64, device="cuda")
+        return torch.empty(nbytes // 8, dtype=torch.int64, device=self._dev)
 
     def he_mul_tensor(self, d0, d1, d2, a0, a1, b0, b1, dim, workspace=None):
         """src/he-mult.c:116-138 on decomposed inputs: d0=a0*b0, d1=a0*b1+a1*b0, d2=a1*b1."""
         batch = self._shape(a0, dim)
         ws = workspace if workspace is not None else self.tensor_workspace(dim, batch)
-        _native.check(self.lib.gpq_he_mul_tensor(self.h, _ptr(d0), _ptr(d1), _ptr(d2), _ptr(a0), _ptr(a1), _ptr(b0), _ptr(b1),
-                                                 dim, batch, _ptr(ws), _stream()), "gpq_he_mul_tensor")
+        _native.check(self.lib.gpq_he_mul_tensor(self.h, self._ptr(d0), self._ptr(d1), self._ptr(d2), self._ptr(a0), self._ptr(a1), self._ptr(b0), self._ptr(b1),
+                                                 dim, batch, self._ptr(ws), self._stream()), "gpq_he_mul_tensor")
         return d0, d1, d2
 
     def he_keyswitch(self, c0, c1, x, evk0, evk1, dim, workspace=None):
         """src/he-mult.c:58-66 / src/he-automorphism.c:59-67 on a decomposed input."""
         batch = self._shape(x, dim)
         ws = workspace if workspace is not None else self.keyswitch_workspace(dim, batch)
-        _native.check(self.lib.gpq_keyswitch(self.h, _ptr(c0), _ptr(c1), _ptr(x), _ptr(evk0), _ptr(evk1),
-                                             dim, batch, _ptr(ws), _stream()), "gpq_keyswitch")
+        _native.check(self.lib.gpq_keyswitch(self.h, self._ptr(c0), self._ptr(c1), self._ptr(x), self._ptr(evk0), self._ptr(evk1),
+                                             dim, batch, self._ptr(ws), self._stream()), "gpq_keyswitch")
         return c0, c1
 
 

@@ -115,6 +115,10 @@ int gpq_mulpt_rns(gpq_ctx *ctx, uint64_t *r0, uint64_t *r1, uint64_t *m, uint64_
 /* The fused operations process the batch in groups of `chunk` polynomials so
  * that the scratch stays bounded (default 32; larger groups amortise launch tails). */
 int gpq_set_chunk(gpq_ctx *ctx, unsigned chunk);
+/* ... and, inside a group of polynomials, in blocks of `limbs` limbs (0 = all limbs at once, the default): the three
+ * kernels of a block run back to back, so a block of chunk x limbs x 7 slabs x n x 8 bytes that fits the 256 MiB
+ * Infinity Cache is re-read from there instead of from HBM.  Results do not depend on either setting. */
+int gpq_set_limb_block(gpq_ctx *ctx, unsigned limbs);
 
 /* Bytes of scratch the two fused operations below need for this shape. */
 size_t gpq_tensor_workspace_bytes(const gpq_ctx *ctx, unsigned dim, unsigned batch);

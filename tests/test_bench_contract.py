@@ -25,10 +25,13 @@ def test_pmc_traffic_reads_the_committed_summary():
     b = _bench()
     for chunk in (16, 32):
         algo = 7 * 30 * chunk * (8 << 16)
-        t = b.pmc_traffic("tensor_mid", chunk)
+        t, src = b.pmc_traffic("tensor_mid", chunk)
         assert t is not None and 1.0 <= t / algo < 1.15
+        assert src["file"].startswith("profiles/r") and "tensor_mid" in src["kernel"]      # the line says where the figure comes from
     for k in ("strided_fwd", "strided_inv", "keyswitch_mid"):
-        assert b.pmc_traffic(k, 32) is not None
+        assert b.pmc_traffic(k, 32)[0] is not None
+    t, src = b.pmc_traffic("no_such_kernel", 32)
+    assert t is None and "error" in src
 
 
 def test_pmc_traffic_takes_the_latest_summary_by_number():
@@ -42,4 +45,26 @@ def test_pmc_traffic_takes_the_latest_summary_by_number():
     data = json.load(open(latest))
     name = next(k for k in data if "tensor_mid" in k)
     want = int((2 * data[name]["FETCH_SIZE"] + data[name]["WRITE_SIZE"]) * 1024 * 32 / data.get("_chunk", 4))
-    assert b.pmc_traffic("tensor_mid", 32) == want
+    assert b.pmc_traffic("tensor_mid", 32)[0] == want
+
+
+def test_gpus_flag_never_silently_runs_another_rank_count():
+    """--gpus N with a launcher that started another WORLD_SIZE is an error (exit status != 0) before any GPU work; with
+    WORLD_SIZE unset the parent starts N children itself and hands back their status."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    b = _bench()
+    assert b.launch_ranks(2, ["--gpus", "0"]) == 1          # both children refuse --gpus 0; the first failure is the status
+    assert b.launch_ranks(2, ["--help"]) == 0
+
+
+def test_total_batch_partition_is_configs3():
+    """BASELINE configs[3]: 512 ciphertexts over 2/4/8 GPUs = 256/128/64 per GPU (block partition of gpqhe_amd/dist.py)."""
+    from gpqhe_amd.dist import shard_range
+    for world, per in ((2, 256), (4, 128), (8, 64)):
+        assert [shard_range(512, world, r)[1] - shard_range(512, world, r)[0] for r in range(world)] == [per] * world
+    a = _bench().parse_args(["--gpus", "8", "--total-batch", "512"])
+    assert a.total_batch == 512 and a.gpus == 8 and not a.no_scatter_gather

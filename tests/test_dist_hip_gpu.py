@@ -1,0 +1,113 @@
+"""The N>1 path with the HIP kernels: two ranks share the one GPU of the box over gloo (RCCL wants one device per
+rank; the partition, the transfers and the kernels are the same).  Rank 0 owns a ragged batch of independent
+ciphertext multiplications (src/he-mult.c:116-138 + :58-66 carry no cross-ciphertext state), scatters the input
+slabs, every rank runs gpq_he_mul_tensor + gpq_keyswitch on its shard through the C ABI, the outputs are gathered and
+every ciphertext is compared bit for bit with the oracle.  Also: `bench.py --gpus 2` must start two ranks by itself."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, logn, dim_a, dim_b, batch, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gpqhe_amd
+        from gpqhe_amd.dist import gather_slab, scatter_slab, shard_range
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        g = gpqhe_amd.PolyContext(logn, dim_b)
+        n = g.n
+        per_a, per_b = dim_a * n, dim_b * n
+        full, o = None, None
+        if rank == 0:
+            from oracle.oracle import OracleCtx
+            o = OracleCtx(logn, dim_b)
+            assert o.p == g.p
+            full = [torch.from_numpy(np.concatenate([o.gen(100 * s + k, dim_a) for k in range(batch)]).view(np.int64)) for s in range(4)]
+            full.append(torch.from_numpy(np.concatenate([o.gen(900 + k, dim_b) for k in range(batch)]).view(np.int64)))
+            evk = [o.gen(7000, dim_b), o.gen(7001, dim_b)]
+            ev = [torch.from_numpy(e.view(np.int64)).clone() for e in evk]
+        else:
+            ev = [torch.empty(per_b, dtype=torch.int64) for _ in range(2)]
+        for e in ev:                                   # the key is replicated, not sharded
+            dist.broadcast(e, 0)
+        ev = [e.to(dev) for e in ev]
+        mine = [scatter_slab(full[s] if rank == 0 else None, per_a, batch, 0, dev) for s in range(4)]
+        x = scatter_slab(full[4] if rank == 0 else None, per_b, batch, 0, dev)
+        lo, hi = shard_range(batch, world, rank)
+        assert all(m.is_cuda and m.numel() == (hi - lo) * per_a for m in mine) and x.numel() == (hi - lo) * per_b
+        d = [torch.empty_like(mine[0]) for _ in range(3)]
+        c = [torch.empty_like(x) for _ in range(2)]
+        g.he_mul_tensor(d[0], d[1], d[2], *mine, dim_a)            # HIP kernels through the C ABI
+        g.he_keyswitch(c[0], c[1], x, ev[0], ev[1], dim_b)
+        back = [gather_slab(v, per_a, batch, 0) for v in d] + [gather_slab(v, per_b, batch, 0) for v in c]
+        if rank == 0:
+            bad = []
+            got = [b.cpu().numpy().view(np.uint64) for b in back]
+            host = [f.numpy().view(np.uint64) for f in full]
+            for k in range(batch):
+                sa, sb = slice(k * per_a, (k + 1) * per_a), slice(k * per_b, (k + 1) * per_b)
+                exp = list(o.he_mul_tensor(*[np.ascontiguousarray(h[sa]) for h in host[:4]], dim_a))
+                exp += list(o.keyswitch(np.ascontiguousarray(host[4][sb]), evk[0], evk[1], dim_b))
+                for name, gv, ev_, sl in zip(("d0", "d1", "d2", "c0", "c1"), got, exp, (sa, sa, sa, sb, sb)):
+                    if not np.array_equal(gv[sl], ev_):
+                        bad.append((k, name))
+            q.put(bad)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("logn,dim_a,dim_b,batch", [(13, 3, 4, 5), (16, 30, 45, 3)])
+def test_two_ranks_run_the_hip_core_on_their_shards(logn, dim_a, dim_b, batch):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, logn, dim_a, dim_b, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        bad = q.get(timeout=540)
+    finally:
+        for p in procs:
+            p.join(60)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert bad == [], "ciphertexts whose gathered result differs from the oracle: %r" % bad
+
+
+@pytest.mark.timeout(900)
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: the parent spawns two ranks (gloo: both on the one GPU here),
+    the line says n_gpus = ranks_seen = 2 and carries the scatter/gather leg; --total-batch shards 5 as 3 + 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--total-batch", "5",
+           "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--no-ntt"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=840, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["devices"] == ["cuda:0", "cuda:0"]
+    assert out["scaling"] == "strong" and out["config"]["total_batch"] == 5 and out["config"]["batch_per_gpu"] == 3
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
+    sg = out["with_scatter_gather"]
+    assert "error" not in sg and sg["shards_identical"] is True and sg["he_mul_per_s"] > 0

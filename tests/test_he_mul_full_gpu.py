@@ -365,6 +365,18 @@ def test_he_mul_is_graph_capturable_after_the_first_call(engine_ctx):
     assert torch.equal(r0, o0) and torch.equal(r1, o1)
     assert bool((r0 != 0).any())
 
+    # A later eager call at a LARGER batch grows the context's CRT flag scratch.  The graph captured above still holds the
+    # old buffer: it is retired, not freed, so the replay stays valid and exact.
+    big_ins = [torch.cat([v, v, v]) for v in ins]
+    bo0, bo1 = torch.empty_like(big_ins[0]), torch.empty_like(big_ins[0])
+    g.he_mul(bo0, bo1, *big_ins, rlk[0], rlk[1], W, logq, dimA, dimB, dimP)
+    torch.cuda.synchronize()
+    assert torch.equal(bo0[: o0.numel()], r0) and torch.equal(bo0[2 * o0.numel():], r0) and torch.equal(bo1[o1.numel(): 2 * o1.numel()], r1)
+    o0.zero_(); o1.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(r0, o0) and torch.equal(r1, o1)
+
 
 def _sparse_mul(dense, terms, n):
     out = [0] * n
