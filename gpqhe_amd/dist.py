@@ -31,7 +31,9 @@ def scatter_slab(full, per_ct, batch, src=0, device=None):
     Ragged shards are allowed."""
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = shard_range(batch, world, rank)
-    device = full.device if full is not None else (device or _default_device())
+    if device is None:
+        device = full.device if full is not None else _default_device()
+    device = torch.device(device)
     if world == 1:
         return full.to(device, copy=True)
     wire = _wire_device(device)

@@ -43,7 +43,9 @@ def _worker(rank, world, port, q):
         full = None
         if rank == 0:
             full = [torch.from_numpy(np.concatenate([o.gen(10 * s + k, DIM) for k in range(BATCH)]).view(np.int64)) for s in range(4)]
-        mine = [scatter_slab(full[s] if rank == 0 else None, per, BATCH) for s in range(4)]
+        # the shard lands on the device asked for, on the source rank too (here: the host; on the GPU box: cuda)
+        mine = [scatter_slab(full[s] if rank == 0 else None, per, BATCH, 0, torch.device("cpu") if s % 2 else None) for s in range(4)]
+        assert all(m.device.type == "cpu" for m in mine)
         lo, hi = shard_range(BATCH, world, rank)
         outs = [np.empty((hi - lo) * per, dtype=np.uint64) for _ in range(3)]
         for k in range(hi - lo):

@@ -24,55 +24,65 @@ def _free_port():
 
 
 def _worker(rank, world, port, logn, dim_a, dim_b, batch, q):
+    import datetime
+    import traceback
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a rank that dies must not leave its peer waiting for long: short collective timeout, and every failure is reported
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
-        import gpqhe_amd
-        from gpqhe_amd.dist import gather_slab, scatter_slab, shard_range
-        torch.cuda.set_device(0)
-        dev = torch.device("cuda", 0)
-        g = gpqhe_amd.PolyContext(logn, dim_b)
-        n = g.n
-        per_a, per_b = dim_a * n, dim_b * n
-        full, o = None, None
-        if rank == 0:
-            from oracle.oracle import OracleCtx
-            o = OracleCtx(logn, dim_b)
-            assert o.p == g.p
-            full = [torch.from_numpy(np.concatenate([o.gen(100 * s + k, dim_a) for k in range(batch)]).view(np.int64)) for s in range(4)]
-            full.append(torch.from_numpy(np.concatenate([o.gen(900 + k, dim_b) for k in range(batch)]).view(np.int64)))
-            evk = [o.gen(7000, dim_b), o.gen(7001, dim_b)]
-            ev = [torch.from_numpy(e.view(np.int64)).clone() for e in evk]
-        else:
-            ev = [torch.empty(per_b, dtype=torch.int64) for _ in range(2)]
-        for e in ev:                                   # the key is replicated, not sharded
-            dist.broadcast(e, 0)
-        ev = [e.to(dev) for e in ev]
-        mine = [scatter_slab(full[s] if rank == 0 else None, per_a, batch, 0, dev) for s in range(4)]
-        x = scatter_slab(full[4] if rank == 0 else None, per_b, batch, 0, dev)
-        lo, hi = shard_range(batch, world, rank)
-        assert all(m.is_cuda and m.numel() == (hi - lo) * per_a for m in mine) and x.numel() == (hi - lo) * per_b
-        d = [torch.empty_like(mine[0]) for _ in range(3)]
-        c = [torch.empty_like(x) for _ in range(2)]
-        g.he_mul_tensor(d[0], d[1], d[2], *mine, dim_a)            # HIP kernels through the C ABI
-        g.he_keyswitch(c[0], c[1], x, ev[0], ev[1], dim_b)
-        back = [gather_slab(v, per_a, batch, 0) for v in d] + [gather_slab(v, per_b, batch, 0) for v in c]
-        if rank == 0:
-            bad = []
-            got = [b.cpu().numpy().view(np.uint64) for b in back]
-            host = [f.numpy().view(np.uint64) for f in full]
-            for k in range(batch):
-                sa, sb = slice(k * per_a, (k + 1) * per_a), slice(k * per_b, (k + 1) * per_b)
-                exp = list(o.he_mul_tensor(*[np.ascontiguousarray(h[sa]) for h in host[:4]], dim_a))
-                exp += list(o.keyswitch(np.ascontiguousarray(host[4][sb]), evk[0], evk[1], dim_b))
-                for name, gv, ev_, sl in zip(("d0", "d1", "d2", "c0", "c1"), got, exp, (sa, sa, sa, sb, sb)):
-                    if not np.array_equal(gv[sl], ev_):
-                        bad.append((k, name))
-            q.put(bad)
+        _run_rank(rank, world, logn, dim_a, dim_b, batch, q, torch, dist)
+    except BaseException:
+        q.put(("error", rank, traceback.format_exc()))
+        raise
     finally:
         dist.destroy_process_group()
+
+
+def _run_rank(rank, world, logn, dim_a, dim_b, batch, q, torch, dist):
+    import gpqhe_amd
+    from gpqhe_amd.dist import gather_slab, scatter_slab, shard_range
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    g = gpqhe_amd.PolyContext(logn, dim_b)
+    n = g.n
+    per_a, per_b = dim_a * n, dim_b * n
+    full, o = None, None
+    if rank == 0:
+        from oracle.oracle import OracleCtx
+        o = OracleCtx(logn, dim_b)
+        assert o.p == g.p
+        full = [torch.from_numpy(np.concatenate([o.gen(100 * s + k, dim_a) for k in range(batch)]).view(np.int64)) for s in range(4)]
+        full.append(torch.from_numpy(np.concatenate([o.gen(900 + k, dim_b) for k in range(batch)]).view(np.int64)))
+        evk = [o.gen(7000, dim_b), o.gen(7001, dim_b)]
+        ev = [torch.from_numpy(e.view(np.int64)).clone() for e in evk]
+    else:
+        ev = [torch.empty(per_b, dtype=torch.int64) for _ in range(2)]
+    for e in ev:                                   # the key is replicated, not sharded
+        dist.broadcast(e, 0)
+    ev = [e.to(dev) for e in ev]
+    mine = [scatter_slab(full[s] if rank == 0 else None, per_a, batch, 0, dev) for s in range(4)]
+    x = scatter_slab(full[4] if rank == 0 else None, per_b, batch, 0, dev)
+    lo, hi = shard_range(batch, world, rank)
+    assert all(m.is_cuda and m.numel() == (hi - lo) * per_a for m in mine) and x.numel() == (hi - lo) * per_b
+    d = [torch.empty_like(mine[0]) for _ in range(3)]
+    c = [torch.empty_like(x) for _ in range(2)]
+    g.he_mul_tensor(d[0], d[1], d[2], *mine, dim_a)            # HIP kernels through the C ABI
+    g.he_keyswitch(c[0], c[1], x, ev[0], ev[1], dim_b)
+    back = [gather_slab(v, per_a, batch, 0) for v in d] + [gather_slab(v, per_b, batch, 0) for v in c]
+    if rank == 0:
+        bad = []
+        got = [b.cpu().numpy().view(np.uint64) for b in back]
+        host = [f.numpy().view(np.uint64) for f in full]
+        for k in range(batch):
+            sa, sb = slice(k * per_a, (k + 1) * per_a), slice(k * per_b, (k + 1) * per_b)
+            exp = list(o.he_mul_tensor(*[np.ascontiguousarray(h[sa]) for h in host[:4]], dim_a))
+            exp += list(o.keyswitch(np.ascontiguousarray(host[4][sb]), evk[0], evk[1], dim_b))
+            for name, gv, ev_, sl in zip(("d0", "d1", "d2", "c0", "c1"), got, exp, (sa, sa, sa, sb, sb)):
+                if not np.array_equal(gv[sl], ev_):
+                    bad.append((k, name))
+        q.put(("done", 0, bad))
 
 
 @pytest.mark.timeout(600)
@@ -86,12 +96,15 @@ def test_two_ranks_run_the_hip_core_on_their_shards(logn, dim_a, dim_b, batch):
     for p in procs:
         p.start()
     try:
-        bad = q.get(timeout=540)
+        kind, who, what = q.get(timeout=300)
     finally:
         for p in procs:
-            p.join(60)
+            p.join(150)
+            if p.is_alive():
+                p.terminate()
+    assert kind == "done", "rank %d failed:\n%s" % (who, what)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    assert bad == [], "ciphertexts whose gathered result differs from the oracle: %r" % bad
+    assert what == [], "ciphertexts whose gathered result differs from the oracle: %r" % what
 
 
 @pytest.mark.timeout(900)

@@ -85,23 +85,42 @@ def test_reduce_edge_cases(oracle_ctx):
 
 def test_golden_fixture_is_a_faithful_transcription_of_the_survey(golden):
     """tests/golden/survey_8c.json carries the values SURVEY.md section 8c recorded from the compiled reference
-    (the reference cannot be rebuilt here: no <gcrypt.h>).  Every number and digest in the fixture must occur
-    verbatim in SURVEY.md, so the pin is the survey's capture and not something re-derived from our own code."""
+    (the reference cannot be rebuilt here: no <gcrypt.h>).  The fixture names, per entry, the SURVEY.md line its values
+    were taken from (`_survey_rows`); every number and digest must stand ON that line -- location, not mere occurrence --
+    so the pin is the survey's capture of the reference's output and not something re-derived from our own code."""
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    text = open(os.path.join(root, "SURVEY.md")).read()
-    missing = []
+    lines = open(os.path.join(root, "SURVEY.md")).read().split("\n")
+    rows = golden["_survey_rows"]
+    wrong, checked = [], 0
 
-    def walk(v):
+    def leaves(v):
         if isinstance(v, dict):
             for k, x in v.items():
                 if not k.startswith("_"):
-                    walk(x)
+                    yield from leaves(x)
         elif isinstance(v, list):
             for x in v:
-                walk(x)
-        elif isinstance(v, str) and len(v) >= 8 and v not in text:
-            missing.append(v)
+                yield from leaves(x)
+        elif isinstance(v, str):
+            yield v
 
-    walk({k: v for k, v in golden.items() if k != "context_dims"})
-    assert not missing, missing
+    for group in ("prime_chain", "p0_constants", "ntt_kat_seed1_limb0", "he_mul_core_kat"):
+        for key, rec in golden[group].items():
+            if key.startswith("_"):
+                continue
+            line = lines[rows["%s/%s" % (group, key)] - 1]
+            assert line.lstrip().startswith("| %s " % key) or line.lstrip().startswith("| **%s" % key), line[:40]   # the row of that logn
+            for v in leaves(rec):
+                checked += 1
+                if v not in line:
+                    wrong.append((group, key, v))
+    for i, rec in enumerate(golden["phat_invmp_logn7"]):
+        if i:
+            for v in rec:
+                checked += 1
+                if v not in lines[rows["phat_invmp_logn7/%d" % i] - 1]:
+                    wrong.append(("phat_invmp_logn7", i, v))
+    assert not wrong, wrong
+    assert checked >= 125
+    assert "section 8c" in golden["_survey_rows"]["_what"] and lines[rows["prime_chain/7"] - 3].startswith("| logn | p_0")

@@ -2,7 +2,8 @@
 # round 2, first call: GPU suite (incl. the two-rank HIP test), bench line, Infinity-Cache probe, limb-block A/B
 set -o pipefail
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q 2>&1 | tee gpurun_out/pytest_gpu.txt | tail -8 || exit 1
+timeout -k 10 400 python -m pytest tests/test_dist_hip_gpu.py -m gpu -x -q 2>&1 | tee gpurun_out/pytest_dist.txt || exit 1
+timeout -k 10 600 python -m pytest tests -m gpu -x -q --deselect tests/test_dist_hip_gpu.py 2>&1 | tee gpurun_out/pytest_gpu.txt || exit 1
 timeout -k 10 500 python bench.py 2>gpurun_out/bench.err | tee gpurun_out/bench.json | cut -c1-600 || { tail -20 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python tools/mall_probe.py 48 2>gpurun_out/mall.err | tee gpurun_out/mall_probe.txt || { tail -20 gpurun_out/mall.err; exit 1; }
 for r in 1 2; do for lb in 0 1 2 3 5 8 15; do
