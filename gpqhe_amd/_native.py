@@ -103,12 +103,18 @@ SIGNATURES = {
     "gpq_dropin_set_logn": (None, [C.c_uint]),
     "gpq_dropin_reset": (None, []),
     "gpq_mpi_shim_release": (None, []),
+    "gpq_fill_rns_chain": (C.c_int, [vp, C.c_uint, vp, C.c_int]),
+    "gpq_release_rns_chain": (None, [vp]),
+    "poly_rns_alloc": (None, [vp, C.c_uint]),
+    "poly_rns_free": (None, [vp]),
 }
 # by-value unsigned __int128 arguments cannot be expressed in ctypes; these two are
 # exercised from C (tests/c/dropin_host.c)
 EXPORTED_ONLY = ["montgomery_reduce", "barrett_reduce",
                  # MPI-typed surface: driven from C with real libgcrypt MPIs (tests/c/mpi_host.c)
-                 "rns_decompose", "rns_reconstruct", "poly_rns2mpi", "poly_mul", "he_mul", "he_rs", "he_rescale", "he_moddown", "he_mulpt", "he_conj", "he_rot", "he_genrlk", "he_genck", "he_genrk"]
+                 "rns_decompose", "rns_reconstruct", "poly_rns2mpi", "poly_mul", "he_mul", "he_rs", "he_rescale", "he_moddown", "he_mulpt", "he_conj", "he_rot", "he_genrlk", "he_genck", "he_genrk",
+                 # context construction / MPI storage (weak definitions, need libgcrypt MPIs: driven from C) and the data symbols
+                 "polyctx_init", "polyctx_exit", "hectx_init", "hectx_exit", "poly_mpi_alloc", "poly_mpi_free", "polyctx", "hectx", "GPQHE_TWO"]
 
 _lib = None
 

@@ -41,6 +41,8 @@ struct Gcry {
   int (*mpi_test_bit)(MPI, unsigned);
   unsigned (*mpi_print)(int, unsigned char *, size_t, size_t *, MPI);
   unsigned (*mpi_scan)(MPI *, int, const void *, size_t, size_t *);
+  void *(*xmalloc)(size_t);
+  void (*xfree)(void *);
   bool ok = false;
 } G;
 const int FMT_USG = 5;  // GCRYMPI_FMT_USG: unsigned big-endian magnitude
@@ -69,6 +71,8 @@ void need_gcrypt() {
   G.mpi_test_bit = (int (*)(MPI, unsigned))get("gcry_mpi_test_bit");
   G.mpi_print = (unsigned (*)(int, unsigned char *, size_t, size_t *, MPI))get("gcry_mpi_print");
   G.mpi_scan = (unsigned (*)(MPI *, int, const void *, size_t, size_t *))get("gcry_mpi_scan");
+  G.xmalloc = (void *(*)(size_t))get("gcry_malloc");
+  G.xfree = (void (*)(void *))get("gcry_free");
   G.ok = true;
 }
 
@@ -129,6 +133,7 @@ void to_slab_range(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W, u
   }
 }
 void to_slab(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W) {
+  if (W < 1 || W > 32) die("coefficients wider than 2047 bits");      // the device kernels hold at most 32 words; w[64] below is sized for that
   for_ranges(n, [=](unsigned lo, unsigned hi) { to_slab_range(dst, a, n, W, lo, hi); });
 }
 
@@ -156,6 +161,7 @@ void from_slab_range(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W,
   }
 }
 void from_slab(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W) {
+  if (W < 1 || W > 64) die("big slab wider than 64 words");
   for_ranges(n, [=](unsigned lo, unsigned hi) { from_slab_range(r, src, n, W, lo, hi); });
 }
 
@@ -518,5 +524,285 @@ void gpq_mpi_shim_release(void) {
 void he_rs(struct he_ct *ct) { rescale_common(ct, true); }        // src/he-rescale.c:33-54
 void he_rescale(struct he_ct *ct) { rescale_common(ct, true); }
 void he_moddown(he_ct_t *ct) { rescale_common(ct, false); }       // src/he-rescale.c:56-70
+
+}  // extern "C"
+
+// ======================================================================================================================
+// Context construction and polynomial storage with the reference's names (exports a replacement provides).
+//
+//   gpq_fill_rns_chain           the per-prime chain `struct rns_ctx` (src/poly.h:28-41) out of an engine context
+//   polyctx_init / polyctx_exit  src/precomp.c:328-384, :463-487        hectx_init / hectx_exit  src/precomp.c:386-450, :489-503
+//   poly_mpi_alloc/free, poly_rns_alloc/free                            src/poly.c:46-69
+//   data symbols polyctx, hectx, GPQHE_TWO                              src/precomp.c:37-47
+// All of them are WEAK definitions: a program that links GPQHE's own precomp.o / poly.o keeps GPQHE's (strong) ones and this
+// library reads them; a host that is not GPQHE (tests/c/*.c) gets a complete context from here without restating precomp.c.
+// kemctx / bootstrapctx belong to the KEM and the bootstrapping skeleton (out of scope) and are not defined.
+// ======================================================================================================================
+namespace {
+
+typedef std::vector<uint64_t> Words;   // non-negative integer, little-endian 64-bit words, no leading zero word (0 = empty)
+typedef unsigned __int128 u128s;
+
+void trim(Words &a) { while (!a.empty() && a.back() == 0) a.pop_back(); }
+void mul_word(Words &a, uint64_t m) {
+  uint64_t carry = 0;
+  for (uint64_t &w : a) { const u128s t = (u128s)w * m + carry; w = (uint64_t)t; carry = (uint64_t)(t >> 64); }
+  if (carry) a.push_back(carry);
+  trim(a);
+}
+uint64_t divmod_word(Words &a, uint64_t d) {      // a <- floor(a / d), returns a mod d
+  uint64_t rem = 0;
+  for (size_t i = a.size(); i-- > 0;) { const u128s t = ((u128s)rem << 64) | a[i]; a[i] = (uint64_t)(t / d); rem = (uint64_t)(t % d); }
+  trim(a);
+  return rem;
+}
+Words mul_words(const Words &a, const Words &b) {
+  Words r(a.size() + b.size() + 1, 0);
+  for (size_t i = 0; i < a.size(); ++i) {
+    uint64_t carry = 0;
+    for (size_t j = 0; j < b.size(); ++j) { const u128s t = (u128s)a[i] * b[j] + r[i + j] + carry; r[i + j] = (uint64_t)t; carry = (uint64_t)(t >> 64); }
+    r[i + b.size()] += carry;
+  }
+  trim(r);
+  return r;
+}
+unsigned bits_of(const Words &a) { return a.empty() ? 0 : 64 * (unsigned)(a.size() - 1) + (64 - (unsigned)__builtin_clzll(a.back())); }
+void shr1(Words &a) { for (size_t i = 0; i < a.size(); ++i) a[i] = (a[i] >> 1) | (i + 1 < a.size() ? a[i + 1] << 63 : 0); trim(a); }
+
+MPI mpi_of(const Words &w) {                       // a fresh libgcrypt integer with this value
+  MPI r = G.mpi_new(0);
+  if (w.empty()) { G.mpi_set_ui(r, 0); return r; }
+  poly_mpi_t one{&r};
+  from_slab(&one, w.data(), 1, (unsigned)w.size() + 1);   // one more (zero) word: the value is non-negative
+  return r;
+}
+uint64_t powm64(uint64_t b, uint64_t e, uint64_t m) {
+  uint64_t r = 1;
+  for (b %= m; e; e >>= 1) { if (e & 1) r = (uint64_t)((u128s)r * b % m); b = (uint64_t)((u128s)b * b % m); }
+  return r;
+}
+
+// logqub of the homomorphic-encryption standard for 128-bit classical security (the reference's build: GPQHE_CQ 'C',
+// GPQHE_SEC_LEVEL 128, src/params.h:39-46; table src/precomp.c:53-64); 0 outside 10..15
+unsigned std_logqub(unsigned logn) {
+  static const unsigned tab[6] = {27, 54, 109, 218, 438, 881};
+  return (logn >= 10 && logn <= 15) ? tab[logn - 10] : 0;
+}
+
+struct ChainOwner { struct rns_ctx *nodes; unsigned count; bool mpi; };
+std::vector<ChainOwner> g_chains;        // what gpq_fill_rns_chain allocated, for gpq_release_rns_chain
+bool g_own_polyctx = false, g_own_hectx = false;
+
+}  // namespace
+
+extern "C" {
+
+__attribute__((weak)) struct poly_ctx polyctx;      // src/precomp.c:41
+__attribute__((weak)) struct he_ctx hectx;          // src/precomp.c:47
+__attribute__((weak)) gpq_MPI GPQHE_TWO;            // src/precomp.c:37
+
+// Fills nodes[0..count) -- an array the caller owns -- like polyctx_init's loop does (src/precomp.c:359-380): node d
+// describes the prefix of d + 1 primes; dim, p, pinv_mont, pinv_barr, ninv as src/precomp.c:246-248; zetas / zetas_inv
+// point into the engine context's host tables (Montgomery form, bit-reversed: src/precomp.c:255-263; valid while `ctx`
+// lives); phat_invmp as src/precomp.c:287-290 (malloc'ed here).  with_mpi != 0 also builds the libgcrypt integers
+// P, P_2, phat[] (src/precomp.c:268-286) -- needs libgcrypt in the process; with 0 they stay NULL (the RNS-level symbols
+// ntt / invntt / poly_rns_* never read them).  gpq_release_rns_chain frees what this call allocated.
+int gpq_fill_rns_chain(struct rns_ctx *nodes, unsigned count, const gpq_ctx *ctx, int with_mpi) {
+  if (!nodes || !ctx || count < 1 || count > gpq_ctx_nprimes(ctx)) return GPQ_ERR_INVALID;
+  if (with_mpi) need_gcrypt();
+  Words P;
+  std::vector<uint64_t> primes(count);
+  for (unsigned d = 0; d < count; ++d) {
+    struct rns_ctx &r = nodes[d];
+    primes[d] = gpq_ctx_const(ctx, d, 0);
+    r.dim = d + 1;
+    r.p = primes[d];
+    r.pinv_mont = gpq_ctx_const(ctx, d, 1);
+    r.pinv_barr = gpq_ctx_const(ctx, d, 2);
+    r.ninv = gpq_ctx_const(ctx, d, 3);
+    r.zetas = const_cast<uint64_t *>(gpq_ctx_zetas(ctx, d, 0));
+    r.zetas_inv = const_cast<uint64_t *>(gpq_ctx_zetas(ctx, d, 1));
+    r.next = d + 1 < count ? &nodes[d + 1] : nullptr;
+    if (d == 0) P.assign(1, primes[0]); else mul_word(P, primes[d]);
+    r.phat_invmp = (uint64_t *)malloc((size_t)(d + 1) * sizeof(uint64_t));
+    r.P = r.P_2 = nullptr;
+    r.phat = nullptr;
+    if (with_mpi) {
+      r.P = mpi_of(P);
+      Words half = P;
+      shr1(half);
+      r.P_2 = mpi_of(half);
+      r.phat = (gpq_MPI *)G.xmalloc((size_t)(d + 1) * sizeof(gpq_MPI));
+    }
+    for (unsigned k = 0; k <= d; ++k) {
+      Words phat = P;
+      (void)divmod_word(phat, primes[k]);                      // P / p_k, exact
+      Words t = phat;
+      const uint64_t res = divmod_word(t, primes[k]);          // (P / p_k) mod p_k
+      r.phat_invmp[k] = powm64(res, primes[k] - 2, primes[k]);
+      if (with_mpi) r.phat[k] = mpi_of(phat);
+    }
+  }
+  g_chains.push_back(ChainOwner{nodes, count, with_mpi != 0});
+  return GPQ_OK;
+}
+
+void gpq_release_rns_chain(struct rns_ctx *nodes) {
+  for (size_t i = 0; i < g_chains.size(); ++i) {
+    if (g_chains[i].nodes != nodes) continue;
+    for (unsigned d = 0; d < g_chains[i].count; ++d) {
+      struct rns_ctx &r = nodes[d];
+      free(r.phat_invmp);
+      if (g_chains[i].mpi) {
+        G.mpi_release(r.P); G.mpi_release(r.P_2);
+        for (unsigned k = 0; k <= d; ++k) G.mpi_release(r.phat[k]);
+        G.xfree(r.phat);
+      }
+      r.phat_invmp = nullptr; r.P = r.P_2 = nullptr; r.phat = nullptr; r.zetas = r.zetas_inv = nullptr;
+    }
+    g_chains.erase(g_chains.begin() + i);
+    return;
+  }
+}
+
+// src/precomp.c:328-384.  The chain is built by the engine (same primes, constants and tables: tests/test_ntt_gpu.py pins them
+// to SURVEY.md 8c) and handed out in the reference's representation; the ring part (src/precomp.c:295-326) is the encoder's.
+__attribute__((weak)) void polyctx_init(unsigned int logn, gpq_MPI q) {
+  need_gcrypt();
+  if (logn < 1 || logn > 17) die("polyctx_init: 1 <= logn <= 17");
+  memset(&polyctx, 0, sizeof polyctx);
+  GPQHE_TWO = G.mpi_set_ui(G.mpi_new(0), 2);
+  polyctx.logn = logn; polyctx.n = 1u << logn; polyctx.m = 2 * polyctx.n;
+  polyctx.logq = G.mpi_get_nbits(q) - 1;
+  polyctx.logqub = std_logqub(logn);
+  if (logn < 10 || logn > 15) polyctx.logqub = polyctx.logq;                     // :339-340
+  if (polyctx.logq > polyctx.logqub) {                                           // :343-350
+    errno = EINVAL;
+    fprintf(stderr, "\033[1m\033[31merror:\033[0m \033[1m%s\033[0m. The input modulus q is too large. Must guarantee log(q)<=log(qub).\n", strerror(errno));
+    abort();
+  }
+  polyctx.q = G.mpi_set(G.mpi_new(0), q);
+  polyctx.logR = 64; polyctx.R = (gpq_u128)1 << 64; polyctx.Rsub1 = polyctx.R - 1;
+  polyctx.dimub = (1 + logn + 4 * polyctx.logqub) / 59 + 1;                      // :357
+  polyctx.rns = (struct rns_ctx *)calloc(polyctx.dimub, sizeof(struct rns_ctx));
+  // engine() builds the context for (logn, dimub) -- it needs n and dimub, and compares primes only once rns is set
+  struct rns_ctx *nodes = polyctx.rns;
+  polyctx.rns = nullptr;
+  gpq_ctx *c = engine();
+  if (gpq_fill_rns_chain(nodes, polyctx.dimub, c, 1) != GPQ_OK) die("polyctx_init: cannot build the prime chain");
+  polyctx.rns = nodes;
+  // ring_init, src/precomp.c:295-311: the rotation group 5^i mod m and the m-th roots of unity the encoder reads
+  const unsigned nh = polyctx.n / 2, m = polyctx.m;
+  polyctx.ring.cyc_group = (unsigned int *)malloc((nh ? nh : 1) * sizeof(unsigned int));
+  polyctx.ring.cyc_group[0] = 1;
+  for (unsigned i = 1; i < nh; ++i) polyctx.ring.cyc_group[i] = (unsigned)((5ull * polyctx.ring.cyc_group[i - 1]) % m);
+  double *z = (double *)malloc((size_t)(m + 1) * 2 * sizeof(double));           // _Complex double = (re, im)
+  for (unsigned i = 0; i < m; ++i) {
+    const double theta = 2 * 3.141592653589793238462643383279502884 * i / m;
+    z[2 * i] = cos(theta); z[2 * i + 1] = sin(theta);
+  }
+  z[2 * m] = z[0]; z[2 * m + 1] = z[1];
+  polyctx.ring.zetas = (_Complex double *)z;
+  g_own_polyctx = true;
+}
+
+__attribute__((weak)) void polyctx_exit(void) {                                  // src/precomp.c:463-487
+  if (!g_own_polyctx) return;
+  G.mpi_release(GPQHE_TWO);
+  G.mpi_release(polyctx.q);
+  gpq_release_rns_chain(polyctx.rns);
+  free(polyctx.rns);
+  free(polyctx.ring.cyc_group);
+  free(polyctx.ring.zetas);
+  memset(&polyctx, 0, sizeof polyctx);
+  g_own_polyctx = false;
+  gpq_mpi_shim_release();
+}
+
+// src/precomp.c:386-450: qtable_init (q[l] = floor(q[l+1] / Delta), P = first hectx.dim primes, P q_L, dimevk), bounds_init
+// (the noise bounds of the CKKS paper, host doubles) and the argument checks.
+__attribute__((weak)) void hectx_init(unsigned int logn, gpq_MPI q, unsigned int slots, uint64_t Delta) {
+  polyctx_init(logn, q);
+  if (slots & (slots - 1)) { errno = EINVAL; fprintf(stderr, "\033[1m\033[31merror:\033[0m \033[1m%s\033[0m. The slots must be the power of 2.\n", strerror(errno)); abort(); }
+  if (slots > polyctx.n / 2) { errno = EINVAL; fprintf(stderr, "\033[1m\033[31merror:\033[0m \033[1m%s\033[0m. Must guarantee slots<=(n/2).\n", strerror(errno)); abort(); }
+  if (Delta < 2) die("hectx_init: Delta must be at least 2");
+  memset(&hectx, 0, sizeof hectx);
+  hectx.slots = slots;
+  hectx.Delta = (double)Delta;
+  hectx.p = G.mpi_set_ui(G.mpi_new(0), Delta);
+  const unsigned logq = polyctx.logq, logDelta = 63 - (unsigned)__builtin_clzll(Delta);
+  hectx.L = logq / logDelta;                                                     // "ceil" of an integer quotient, :391
+  hectx.q = (gpq_MPI *)G.xmalloc((hectx.L + 1) * sizeof(gpq_MPI));
+  hectx.qh = (gpq_MPI *)G.xmalloc((hectx.L + 1) * sizeof(gpq_MPI));
+  Words cur = words_of(q, "hectx_init: q must be positive");
+  const Words qL = cur;
+  Words q0;
+  for (int l = (int)hectx.L; l >= 0; --l) {                                      // :394-400
+    hectx.q[l] = mpi_of(cur);
+    Words h = cur;
+    shr1(h);
+    hectx.qh[l] = mpi_of(h);
+    if (l == 0) q0 = cur;
+    (void)divmod_word(cur, Delta);
+  }
+  hectx.dim = (bits_of(qL) + logn) / 59 + 1;                                     // :401
+  if (hectx.dim > polyctx.dimub) die("hectx_init: the chain is shorter than hectx.dim");
+  Words P(1, 1);
+  const struct rns_ctx *r = polyctx.rns;
+  for (unsigned d = 0; d < hectx.dim; ++d, r = r->next) mul_word(P, r->p);
+  hectx.P = mpi_of(P);                                                           // :402-404
+  const Words PqL = mul_words(P, qL);
+  hectx.PqL = mpi_of(PqL);                                                       // :405-406
+  hectx.dimevk = (bits_of(qL) + bits_of(PqL) + logn) / 59 + 1;                   // :407
+  // bounds_init, :411-432
+  const double n = polyctx.n, h = 64 /* GPQHE_BLKSIZ */, sigma = 3.1915382432114616 /* GPQHE_SIGMA */;
+  hectx.bnd.Bclean = 8 * sqrt(2) * sigma * n + 6 * sigma * sqrt(n) + 16 * sigma * sqrt(h * n);
+  hectx.bnd.Brs = sqrt(n / 3.) * (3 + 8 * sqrt(h));
+  hectx.bnd.Bks = 8 * sigma * n / sqrt(3);
+  hectx.bnd.Bmult = (double *)malloc((hectx.L + 1) * sizeof(double));
+  long double Pinv = 1;
+  for (r = polyctx.rns; r; r = r->next) Pinv *= 1. / r->p;
+  long double Pinvql = Pinv * (q0.empty() ? 0 : q0[0]);                          // mpi_to_u64(q[0])
+  hectx.bnd.Bmult[0] = (double)(Pinvql * hectx.bnd.Bks + hectx.bnd.Brs);
+  for (unsigned l = 1; l <= hectx.L; ++l) {
+    Pinvql *= hectx.Delta;
+    hectx.bnd.Bmult[l] = (double)(Pinvql * hectx.bnd.Bks + hectx.bnd.Brs);
+  }
+  if (!((double)Delta > polyctx.n + 2 * hectx.bnd.Bclean)) die("hectx_init: Delta <= n + 2 Bclean (assert at src/precomp.c:449)");
+  g_own_hectx = true;
+}
+
+__attribute__((weak)) void hectx_exit(void) {                                    // src/precomp.c:489-503
+  if (g_own_hectx) {
+    for (unsigned l = 0; l <= hectx.L; ++l) { G.mpi_release(hectx.q[l]); G.mpi_release(hectx.qh[l]); }
+    G.xfree(hectx.q); G.xfree(hectx.qh);
+    G.mpi_release(hectx.p); G.mpi_release(hectx.P); G.mpi_release(hectx.PqL);
+    free(hectx.bnd.Bmult);
+    memset(&hectx, 0, sizeof hectx);
+    g_own_hectx = false;
+  }
+  polyctx_exit();
+}
+
+// src/poly.c:46-69.  poly_rns_alloc: the reference clears only the first 8 bytes; contents are indeterminate
+// until written either way, so this one clears nothing.
+__attribute__((weak)) void poly_mpi_alloc(poly_mpi_t *a) {
+  need_gcrypt();
+  a->coeffs = (gpq_MPI *)G.xmalloc((size_t)polyctx.n * sizeof(gpq_MPI));
+  for (unsigned i = 0; i < polyctx.n; ++i) a->coeffs[i] = G.mpi_new(0);
+}
+__attribute__((weak)) void poly_mpi_free(poly_mpi_t *a) {
+  need_gcrypt();
+  for (unsigned i = 0; i < polyctx.n; ++i) G.mpi_release(a->coeffs[i]);
+  G.xfree(a->coeffs);
+  a->coeffs = nullptr;
+}
+__attribute__((weak)) void poly_rns_alloc(poly_rns_t *a, const unsigned int dim) {
+  a->coeffs = (uint64_t *)malloc((size_t)dim * polyctx.n * sizeof(uint64_t));
+}
+__attribute__((weak)) void poly_rns_free(poly_rns_t *a) {
+  free(a->coeffs);
+  a->coeffs = nullptr;
+}
 
 }  // extern "C"

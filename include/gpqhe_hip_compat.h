@@ -133,6 +133,29 @@ void he_genrlk(he_evk_t *rlk, const poly_mpi_t *sk);
 void he_genck(he_evk_t *ck, const poly_mpi_t *sk);
 void he_genrk(he_evk_t *rk, const poly_mpi_t *sk);
 
+/* ---- context construction and polynomial storage (weak definitions) ---------------------------------
+ * A program that links GPQHE's own precomp.o / poly.o keeps GPQHE's definitions (put libgpqhe / its objects BEFORE
+ * -lgpqhe_hip on the link line) and this library only reads `polyctx` / `hectx`.  A host that is not GPQHE gets the
+ * same context from here: the prime chain, constants and tables come from the engine (bit-identical with
+ * src/precomp.c:244-293, pinned in tests/), the MPI fields are built through libgcrypt's runtime ABI. */
+struct gpq_ctx;
+extern struct poly_ctx polyctx;                                                          /* src/precomp.c:41 */
+extern struct he_ctx hectx;                                                              /* src/precomp.c:47 */
+extern gpq_MPI GPQHE_TWO;                                                                /* src/precomp.c:37 */
+void polyctx_init(unsigned int logn, gpq_MPI q);                                        /* src/poly.h:94  */
+void polyctx_exit(void);                                                                /* src/poly.h:95  */
+void hectx_init(unsigned int logn, gpq_MPI q, unsigned int slots, uint64_t Delta);      /* src/gpqhe.h:100 */
+void hectx_exit(void);                                                                  /* src/gpqhe.h:101 */
+void poly_mpi_alloc(poly_mpi_t *a);                                                     /* src/poly.h:80  */
+void poly_mpi_free(poly_mpi_t *a);                                                      /* src/poly.h:81  */
+void poly_rns_alloc(poly_rns_t *a, const unsigned int dim);                             /* src/poly.h:82  */
+void poly_rns_free(poly_rns_t *a);                                                      /* src/poly.h:83  */
+/* The chain of `struct rns_ctx` nodes (src/poly.h:28-41) for the first `count` primes of an engine context, in a
+ * caller-owned array: scalars and table pointers always (tables stay owned by `ctx`), phat_invmp malloc'ed, and with
+ * with_mpi != 0 the libgcrypt integers P, P_2, phat[] (src/precomp.c:266-293).  Returns GPQ_OK or GPQ_ERR_INVALID. */
+int gpq_fill_rns_chain(struct rns_ctx *nodes, unsigned count, const struct gpq_ctx *ctx, int with_mpi);
+void gpq_release_rns_chain(struct rns_ctx *nodes);
+
 /* When the host program has no `polyctx` symbol (the library references it
  * weakly), the ring degree for the drop-in calls is set here instead. */
 void gpq_dropin_set_logn(unsigned int logn);

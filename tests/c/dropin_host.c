@@ -17,7 +17,7 @@
 #include "gpqhe_hip.h"
 #include "gpqhe_hip_compat.h"
 
-struct poly_ctx polyctx; /* the reference's global, src/precomp.c:41 */
+struct poly_ctx polyctx; /* the reference's global, src/precomp.c:41: a strong definition, like GPQHE's own, in front of the library's weak one */
 
 static uint64_t splitmix64(uint64_t *s)
 {
@@ -52,16 +52,8 @@ int main(int argc, char **argv)
   gpq_ctx *ctx = NULL;
   if (gpq_ctx_create(&ctx, logn, dim, 0) != GPQ_OK) { fprintf(stderr, "%s\n", gpq_last_error()); return 1; }
   struct rns_ctx *nodes = calloc(dim, sizeof *nodes);
-  for (unsigned d = 0; d < dim; d++) {
-    nodes[d].dim = d + 1;
-    nodes[d].p = gpq_ctx_const(ctx, d, 0);
-    nodes[d].pinv_mont = gpq_ctx_const(ctx, d, 1);
-    nodes[d].pinv_barr = gpq_ctx_const(ctx, d, 2);
-    nodes[d].ninv = gpq_ctx_const(ctx, d, 3);
-    nodes[d].zetas = (uint64_t *)gpq_ctx_zetas(ctx, d, 0);
-    nodes[d].zetas_inv = (uint64_t *)gpq_ctx_zetas(ctx, d, 1);
-    nodes[d].next = d + 1 < dim ? &nodes[d + 1] : NULL;
-  }
+  if (gpq_fill_rns_chain(nodes, dim, ctx, 0) != GPQ_OK) { fprintf(stderr, "gpq_fill_rns_chain failed\n"); return 1; }   /* no libgcrypt here: MPI fields stay NULL */
+  if (nodes[dim - 1].dim != dim || nodes[dim - 1].next || nodes[0].P || !nodes[0].phat_invmp || nodes[0].phat_invmp[0] != 1) { fprintf(stderr, "bad chain\n"); return 1; }
   polyctx.rns = nodes;
 
   /* scalar helpers of src/reduce.c on the first prime */
@@ -103,6 +95,7 @@ int main(int argc, char **argv)
   printf("ntt_b %016llx\nmul %016llx\nadd %016llx\nalias %016llx\n", (unsigned long long)fnv(b, dim * n),
          (unsigned long long)fnv(r, dim * n), (unsigned long long)fnv(s, dim * n), (unsigned long long)fnv(a, dim * n));
   gpq_dropin_reset();
+  gpq_release_rns_chain(nodes);
   gpq_ctx_destroy(ctx);
   free(nodes); free(a); free(b); free(r); free(s);
   return 0;

@@ -9,9 +9,10 @@
  *   mpi_host keygen <logn> <logq>        he_genrlk / he_genck / he_genrk with deterministic stand-ins for the reference's samplers
  *   mpi_host hemultime <logn> <logq>     wall time of he_mul / he_rescale through the MPI-typed symbols (conversions and copies included)
  *   mpi_host hemul  <in.txt>             he_mul on ciphertexts read as hex, then he_rs, then he_moddown
+ *   mpi_host ctxcheck <logn> <logq> <Delta>   every field hectx_init / polyctx_init fill, for comparison with the restated formulas
  *
- * It owns `polyctx` and `hectx` (as src/precomp.c:41,47 do) and fills the fields the hot path reads,
- * following polyctx_init / qtable_init (src/precomp.c:328-409) with libgcrypt arithmetic.
+ * `polyctx`, `hectx`, polyctx_init, hectx_init and the poly_*_alloc functions are the library's (weak) definitions of the
+ * reference's symbols (src/poly.h:80-83,94-95, src/gpqhe.h:100-101), so this host restates nothing of src/precomp.c.
  * libgcrypt's public functions are declared here by hand: the image has the runtime library only.
  */
 #include <stdio.h>
@@ -41,8 +42,8 @@ void gcry_free(void *p);
 void gcry_mpi_mod(MPI r, MPI dividend, MPI divisor);
 #define FMT_HEX 4
 
-struct poly_ctx polyctx; /* src/precomp.c:41 */
-struct he_ctx hectx;     /* src/precomp.c:47 */
+/* `polyctx`, `hectx`, polyctx_init, hectx_init, poly_mpi_alloc come from libgpqhe_hip.so (weak definitions, gpqhe_hip_compat.h):
+ * this host is not GPQHE, so nothing here restates src/precomp.c. */
 
 static void print_mpi(MPI a)
 {
@@ -52,34 +53,25 @@ static void print_mpi(MPI a)
   gcry_free(s);
 }
 
-static void poly_alloc(poly_mpi_t *a)                      /* poly_mpi_alloc, src/poly.c:46-51 */
+static void poly_alloc(poly_mpi_t *a) { poly_mpi_alloc(a); }   /* src/poly.c:46-51 */
+
+static MPI pow2(unsigned logq)
 {
-  a->coeffs = malloc(polyctx.n * sizeof(MPI));
-  for (unsigned i = 0; i < polyctx.n; i++) a->coeffs[i] = gcry_mpi_new(0);
+  MPI q = gcry_mpi_new(0);
+  gcry_mpi_set_ui(q, 1);
+  gcry_mpi_lshift(q, q, logq);
+  return q;
 }
 
-static gpq_ctx *tables;
-
-static void ctx_init(unsigned logn, unsigned logq)         /* the RNS part of polyctx_init, src/precomp.c:328-383 */
+static void ctx_init(unsigned logn, unsigned logq)         /* polyctx_init(logn, 2^logq), src/precomp.c:328-384 */
 {
-  memset(&polyctx, 0, sizeof polyctx);
-  polyctx.logn = logn; polyctx.n = 1u << logn; polyctx.m = 2 * polyctx.n;
-  polyctx.logq = logq; polyctx.logqub = logq;
-  polyctx.logR = 64; polyctx.R = (gpq_u128)1 << 64; polyctx.Rsub1 = polyctx.R - 1;
-  polyctx.dimub = gpq_dimub(logn, logq);
-  if (gpq_ctx_create(&tables, logn, polyctx.dimub, 0) != GPQ_OK) { fprintf(stderr, "%s\n", gpq_last_error()); exit(1); }
-  struct rns_ctx *nodes = calloc(polyctx.dimub, sizeof *nodes);
-  for (unsigned d = 0; d < polyctx.dimub; d++) {
-    nodes[d].dim = d + 1;
-    nodes[d].p = gpq_ctx_const(tables, d, 0);
-    nodes[d].pinv_mont = gpq_ctx_const(tables, d, 1);
-    nodes[d].pinv_barr = gpq_ctx_const(tables, d, 2);
-    nodes[d].ninv = gpq_ctx_const(tables, d, 3);
-    nodes[d].zetas = (uint64_t *)gpq_ctx_zetas(tables, d, 0);
-    nodes[d].zetas_inv = (uint64_t *)gpq_ctx_zetas(tables, d, 1);
-    nodes[d].next = d + 1 < polyctx.dimub ? &nodes[d + 1] : NULL;
+  MPI q = pow2(logq);
+  polyctx_init(logn, q);
+  gcry_mpi_release(q);
+  if (polyctx.dimub != gpq_dimub(logn, logq) || !polyctx.rns || polyctx.rns->dim != 1 || !polyctx.rns->P || !polyctx.ring.cyc_group) {
+    fprintf(stderr, "polyctx_init left an incomplete context\n");
+    exit(1);
   }
-  polyctx.rns = nodes;
 }
 
 static int polymul(int odd_modulus)
@@ -89,7 +81,6 @@ static int polymul(int odd_modulus)
   gcry_mpi_set_ui(q, odd_modulus ? 3 : 1);
   gcry_mpi_lshift(q, q, 61);
   if (odd_modulus) { MPI seven = gcry_mpi_new(0); gcry_mpi_set_ui(seven, 7); gcry_mpi_add(q, q, seven); }   /* q = 3*2^61 + 7 */
-  polyctx.q = q;
   poly_mpi_t a, b, r;
   poly_alloc(&a); poly_alloc(&b); poly_alloc(&r);
   for (int t = 0; t < 2; t++) {
@@ -97,7 +88,7 @@ static int polymul(int odd_modulus)
       if (t == 0) { gcry_mpi_set_ui(a.coeffs[i], i + 2); gcry_mpi_set_ui(b.coeffs[i], i + 3); }             /* :60-63 */
       else { gcry_mpi_set_ui(a.coeffs[i], polyctx.rns->p - i - 1); gcry_mpi_set_ui(b.coeffs[i], polyctx.rns->next->p - i - 1); } /* :69-74 */
     }
-    poly_mul(&r, &a, &b, polyctx.dimub, polyctx.q);         /* :64, :75 */
+    poly_mul(&r, &a, &b, polyctx.dimub, q);                 /* :64, :75 */
     for (unsigned i = 0; i < polyctx.n; i++) print_mpi(r.coeffs[i]);
   }
   return 0;
@@ -165,30 +156,11 @@ static void read_poly(FILE *f, poly_mpi_t *a)
   free(line);
 }
 
-static void he_ctx_init(unsigned logn, MPI q, unsigned long long Delta)   /* hectx_init, src/precomp.c:386-409 */
+static void he_ctx_init(unsigned logn, MPI q, unsigned long long Delta)   /* hectx_init, src/precomp.c:434-450 */
 {
-  const unsigned logq = gcry_mpi_get_nbits(q) - 1;           /* polyctx.logq, src/precomp.c:337 */
-  ctx_init(logn, logq);
-  /* qtable_init, src/precomp.c:386-409: q[l] = floor(q[l+1] / Delta), L = floor(logq / logDelta) */
-  polyctx.q = q;
-  hectx.p = gcry_mpi_new(0);
-  gcry_mpi_set_ui(hectx.p, Delta);
-  hectx.Delta = (double)Delta;
-  hectx.L = logq / (gcry_mpi_get_nbits(hectx.p) - 1);
-  hectx.q = malloc((hectx.L + 1) * sizeof(MPI)); hectx.qh = malloc((hectx.L + 1) * sizeof(MPI));
-  MPI cur = gcry_mpi_copy(q);
-  for (int l = (int)hectx.L; l >= 0; l--) {
-    hectx.q[l] = gcry_mpi_copy(cur);
-    hectx.qh[l] = gcry_mpi_new(0); gcry_mpi_rshift(hectx.qh[l], cur, 1);
-    gcry_mpi_div(cur, NULL, cur, hectx.p, 0);                /* positive operands: unaffected by libgcrypt 1.9's floor bug */
-  }
-  hectx.dim = (gcry_mpi_get_nbits(hectx.q[hectx.L]) + logn) / 59 + 1;
-  hectx.P = gcry_mpi_new(0); gcry_mpi_set_ui(hectx.P, 1);
-  struct rns_ctx *r = polyctx.rns;
-  for (unsigned d = 0; d < hectx.dim; d++, r = r->next) gcry_mpi_mul_ui(hectx.P, hectx.P, r->p);
-  hectx.PqL = gcry_mpi_new(0); gcry_mpi_mul(hectx.PqL, hectx.P, q);
-  hectx.dimevk = (gcry_mpi_get_nbits(hectx.q[hectx.L]) + gcry_mpi_get_nbits(hectx.PqL) + logn) / 59 + 1;
-  hectx.bnd.Brs = 11.5; hectx.bnd.Bmult = malloc((hectx.L + 1) * sizeof(double));
+  hectx_init(logn, q, 2, Delta);
+  /* the noise bookkeeping of he_mul / he_rs reads these two; fixed values make the expected nu / B of the tests exact */
+  hectx.bnd.Brs = 11.5;
   for (unsigned l = 0; l <= hectx.L; l++) hectx.bnd.Bmult[l] = 100.0 + l;
 }
 
@@ -281,7 +253,6 @@ static int polymulmono(unsigned logn)
   MPI q = gcry_mpi_new(0);
   gcry_mpi_set_ui(q, 1);
   gcry_mpi_lshift(q, q, 109);
-  polyctx.q = q;
   poly_mpi_t a, b, r;
   poly_alloc(&a); poly_alloc(&b); poly_alloc(&r);
   uint64_t st = 4096;
@@ -296,7 +267,7 @@ static int polymulmono(unsigned logn)
     gcry_mpi_set_ui(b.coeffs[i], i == 5 ? 3 : 0);
   }
   gcry_mpi_neg(b.coeffs[5], b.coeffs[5]);
-  poly_mul(&r, &a, &b, polyctx.dimub, polyctx.q);
+  poly_mul(&r, &a, &b, polyctx.dimub, q);
   for (unsigned i = 0; i < polyctx.n; i++) print_mpi(a.coeffs[i]);
   for (unsigned i = 0; i < polyctx.n; i++) print_mpi(r.coeffs[i]);
   return 0;
@@ -342,7 +313,6 @@ static int keygen(unsigned logn, unsigned logq)
   gcry_mpi_set_ui(q, 1);
   gcry_mpi_lshift(q, q, logq);
   he_ctx_init(logn, q, 1ull << 30);
-  hectx.slots = 2;
   poly_mpi_t sk;
   poly_alloc(&sk);
   uint64_t st = 333;
@@ -408,8 +378,50 @@ static int hemultime(unsigned logn, unsigned logq)
   return 0;
 }
 
+/* hectx_init / polyctx_init / poly_*_alloc of the library (weak definitions), printed field by field for the Python side to compare
+ * with the restated formulas (src/precomp.c:266-293, :328-450) and with the dims SURVEY.md 8c captured from the reference */
+static int ctxcheck(unsigned logn, unsigned logq, unsigned long long Delta)
+{
+  MPI q = pow2(logq);
+  hectx_init(logn, q, 2, Delta);
+  printf("poly %u %u %u %u %u %u\n", polyctx.logn, polyctx.n, polyctx.m, polyctx.logq, polyctx.logqub, polyctx.dimub);
+  printf("two "); print_mpi(GPQHE_TWO);
+  printf("q "); print_mpi(polyctx.q);
+  unsigned count = 0;
+  for (struct rns_ctx *r = polyctx.rns; r; r = r->next, count++) {
+    printf("node %u %llu %llu %llu %llu %llu %llu\n", r->dim, (unsigned long long)r->p, (unsigned long long)r->pinv_mont,
+           (unsigned long long)r->pinv_barr, (unsigned long long)r->ninv, (unsigned long long)r->zetas[1], (unsigned long long)r->zetas_inv[polyctx.n / 2]);
+    if (r->dim <= 5 || !r->next) {                           /* the big integers of a few prefixes */
+      printf("P "); print_mpi(r->P);
+      printf("P_2 "); print_mpi(r->P_2);
+      for (unsigned d = 0; d < r->dim; d++) { printf("phat %u %llu ", d, (unsigned long long)r->phat_invmp[d]); print_mpi(r->phat[d]); }
+    }
+  }
+  printf("count %u\n", count);
+  printf("ring %u %u %.17g %.17g\n", polyctx.ring.cyc_group[1], polyctx.ring.cyc_group[polyctx.n / 2 - 1],
+         __real__ polyctx.ring.zetas[1], __imag__ polyctx.ring.zetas[polyctx.m]);
+  printf("he %u %u %u %u %u %u %.17g\n", hectx.L, hectx.dim, hectx.dimevk, gcry_mpi_get_nbits(hectx.P), gcry_mpi_get_nbits(hectx.PqL), hectx.slots, hectx.Delta);
+  for (unsigned l = 0; l <= hectx.L; l++) { printf("q %u ", l); print_mpi(hectx.q[l]); printf("qh %u ", l); print_mpi(hectx.qh[l]); }
+  printf("bnd %.17g %.17g %.17g %.17g %.17g\n", hectx.bnd.Bclean, hectx.bnd.Brs, hectx.bnd.Bks, hectx.bnd.Bmult[0], hectx.bnd.Bmult[hectx.L]);
+  poly_mpi_t a;
+  poly_rns_t h;
+  poly_mpi_alloc(&a);                                       /* src/poly.c:46-51: n fresh MPIs (value 0) */
+  poly_rns_alloc(&h, hectx.dimevk);                         /* src/poly.c:60-64 */
+  for (unsigned i = 0; i < hectx.dimevk * polyctx.n; i++) h.coeffs[i] = i;
+  printf("alloc %u %llu\n", gcry_mpi_get_nbits(a.coeffs[polyctx.n - 1]), (unsigned long long)h.coeffs[hectx.dimevk * polyctx.n - 1]);
+  poly_rns_free(&h);
+  poly_mpi_free(&a);
+  hectx_exit();
+  printf("exit %d %d\n", polyctx.rns == NULL, hectx.q == NULL);
+  hectx_init(logn, q, 2, Delta);                            /* a context can be built again after hectx_exit */
+  printf("again %u %u\n", polyctx.dimub, hectx.dimevk);
+  hectx_exit();
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
+  if (argc >= 5 && !strcmp(argv[1], "ctxcheck")) return ctxcheck(atoi(argv[2]), atoi(argv[3]), strtoull(argv[4], NULL, 10));
   if (argc >= 2 && !strcmp(argv[1], "polymul")) return polymul(0);
   if (argc >= 2 && !strcmp(argv[1], "polymulodd")) return polymul(1);
   if (argc >= 2 && !strcmp(argv[1], "crt")) return crt();

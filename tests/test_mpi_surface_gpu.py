@@ -243,3 +243,77 @@ def test_key_generation_through_reference_signatures(mpi_host, oracle_ctx, logn,
     assert got[1] == genswk(ref.poly_conj(s))                 # he_genck
     assert got[2] == genswk(ref.poly_rot(s, 0))               # he_genrk, rot = 0, 1
     assert got[3] == genswk(ref.poly_rot(s, 1))
+
+
+@pytest.mark.parametrize("logn,logq,Delta", [(7, 61, 1 << 30), (14, 438, 1 << 50), (16, 850, 1 << 50)])
+def test_context_symbols_of_the_library(mpi_host, oracle_ctx, golden, logn, logq, Delta):
+    """polyctx_init / hectx_init / poly_mpi_alloc / poly_rns_alloc and the data symbols polyctx, hectx, GPQHE_TWO as the library
+    defines them (weak; src/poly.h:80-83,94-95, src/gpqhe.h:100-101): every field against the restated formulas of
+    src/precomp.c:266-293 and :328-450, the per-prime constants against the oracle, and L / dim / dimevk / dimub / nbits(P) /
+    nbits(P q_L) against the values SURVEY.md 8c captured from the reference's own hectx_init."""
+    import math
+    res = subprocess.run([mpi_host, "ctxcheck", str(logn), str(logq), str(Delta)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    lines = res.stdout.split("\n")
+    it = iter(lines)
+    n = 1 << logn
+    logqub = {10: 27, 11: 54, 12: 109, 13: 218, 14: 438, 15: 881}.get(logn, logq)       # src/precomp.c:53-64, :338-340
+    dimub = (1 + logn + 4 * logqub) // 59 + 1                                             # :357
+    assert next(it).split() == ["poly", str(logn), str(n), str(2 * n), str(logq), str(logqub), str(dimub)]
+    assert next(it).split() == ["two", "02"]
+    assert int(next(it).split()[1], 16) == 1 << logq
+    o = oracle_ctx(logn, dimub)
+    for d in range(dimub):
+        f = next(it).split()
+        z, zi = o.zetas(d), o.zetas(d, inverse=True)
+        assert f == ["node", str(d + 1), str(o.p[d]), str(o.const("pinv_mont", d)), str(o.const("pinv_barr", d)), str(o.const("ninv", d)),
+                     str(z[1]), str(zi[n // 2])]
+        if d + 1 <= 5 or d + 1 == dimub:
+            basis = ref.RnsBasis(o.p[: d + 1])
+            assert int(next(it).split()[1], 16) == basis.P
+            assert int(next(it).split()[1], 16) == basis.P // 2
+            for k in range(d + 1):
+                g = next(it).split()
+                assert g[:3] == ["phat", str(k), str(basis.phat_invmp[k])] and int(g[3], 16) == basis.phat[k]
+            if logn == 7:
+                assert [str(v) for v in basis.phat_invmp] == golden["phat_invmp_logn7"][d]       # the reference's own printout
+    assert next(it).split() == ["count", str(dimub)]
+    f = next(it).split()
+    assert f[:3] == ["ring", "5", str(pow(5, n // 2 - 1, 2 * n))]                                # src/precomp.c:300-303
+    assert float(f[3]) == math.cos(2 * 3.141592653589793238462643383279502884 / (2 * n)) and abs(float(f[4])) == 0.0
+    # qtable_init, src/precomp.c:386-409
+    logDelta = Delta.bit_length() - 1
+    L = logq // logDelta
+    qL = 1 << logq
+    dimP = (qL.bit_length() + logn) // 59 + 1
+    P = ref.RnsBasis(o.p[:dimP]).P
+    dimevk = (qL.bit_length() + (P * qL).bit_length() + logn) // 59 + 1
+    f = next(it).split()
+    assert f[:7] == ["he", str(L), str(dimP), str(dimevk), str(P.bit_length()), str((P * qL).bit_length()), "2"] and float(f[7]) == float(Delta)
+    key = "%d_%d_%d" % (logn, logq, logDelta)
+    if key in golden["context_dims"]:                                                           # the reference's own numbers
+        c = golden["context_dims"][key]
+        assert (L, dimP, dimevk, dimub) == (c["L"], c["dim"], c["dimevk"], c["dimub"])
+        if "nbits_P" in c:
+            assert (P.bit_length(), (P * qL).bit_length()) == (c["nbits_P"], c["nbits_PqL"])
+    cur = qL
+    qs = {}
+    for l in range(L, -1, -1):
+        qs[l] = cur
+        cur //= Delta
+    for l in range(L + 1):
+        a, b = next(it).split(), next(it).split()
+        assert a[:2] == ["q", str(l)] and int(a[2], 16) == qs[l] and b[:2] == ["qh", str(l)] and int(b[2], 16) == qs[l] // 2
+    # bounds_init, src/precomp.c:411-432 (doubles: same formulas, compared to a few ulps)
+    sigma, h = 3.1915382432114616, 64
+    Bclean = 8 * math.sqrt(2) * sigma * n + 6 * sigma * math.sqrt(n) + 16 * sigma * math.sqrt(h * n)
+    Brs, Bks = math.sqrt(n / 3.0) * (3 + 8 * math.sqrt(h)), 8 * sigma * n / math.sqrt(3)
+    f = [float(v) for v in next(it).split()[1:]]
+    assert f[0] == pytest.approx(Bclean, rel=1e-14) and f[1] == pytest.approx(Brs, rel=1e-14) and f[2] == pytest.approx(Bks, rel=1e-14)
+    pinv = 1.0
+    for p in o.p:
+        pinv /= p
+    assert f[3] == pytest.approx(pinv * qs[0] * Bks + Brs, rel=1e-9) and f[4] == pytest.approx(pinv * qs[0] * float(Delta) ** L * Bks + Brs, rel=1e-9)
+    assert next(it).split() == ["alloc", "0", str(dimevk * n - 1)]
+    assert next(it).split() == ["exit", "1", "1"]
+    assert next(it).split() == ["again", str(dimub), str(dimevk)]
