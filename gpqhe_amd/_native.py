@@ -39,6 +39,7 @@ SIGNATURES = {
     "gpq_mulpt_rns": (C.c_int, [vp] * 6 + [C.c_uint, C.c_uint, vp]),
     "gpq_set_chunk": (C.c_int, [vp, C.c_uint]),
     "gpq_set_limb_block": (C.c_int, [vp, C.c_uint]),
+    "gpq_set_limb_classes": (C.c_int, [vp, C.c_uint, C.c_uint]),
     "gpq_tensor_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
     "gpq_keyswitch_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
     "gpq_he_mul_tensor": (C.c_int, [vp] * 8 + [C.c_uint, C.c_uint, vp, vp]),

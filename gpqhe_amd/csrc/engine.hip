@@ -160,26 +160,14 @@ static int upload_tables(gpq_ctx *c) {
     t.winv1_ninv = n >= 2 ? mulm(wistd[d * n + 1], t.ninv, p) : t.ninv;
     t.ninv_s = t.winv1_ninv_s = TwS{0, 0};
   }
-  // split-twiddle pairs (p - w, p - w*2^31 mod p) for the leading limbs whose c allows the single fold
-  const char *nomfma = getenv("GPQHE_NO_MFMA");     // dev switch: bridge on the VALU kernels
-  c->bridge_mfma = !(nomfma && nomfma[0] == '1');
-  const char *nosplit = getenv("GPQHE_NO_SPLIT");   // dev switch: A/B against the 7-mad butterflies
+  // split-twiddle pairs (p - w, p - w*2^31 mod p) for the leading limbs whose c allows the single fold ...
   c->nsplit = 0;
-  if (!(nosplit && nosplit[0] == '1'))
-    while (c->nsplit < np && c->p[c->nsplit] - (1ull << 59) < GPQ_SPLIT_CMAX) ++c->nsplit;
+  while (c->nsplit < np && c->p[c->nsplit] - (1ull << 59) < GPQ_SPLIT_CMAX) ++c->nsplit;
   // ... and among them the leading limbs whose forward stages may skip every other conditional subtraction (ct_bfly_wide)
-  const char *mid8 = getenv("GPQHE_MID8");          // dev switch: 0 = tensor stage on the 16-coefficients-per-lane kernel
-  c->mid8 = !(mid8 && mid8[0] == '0');
-  const char *low8 = getenv("GPQHE_N17_LOW8");      // dev switch: n = 2^17 as 9 strided + 8 low stages (512-row tiles)
-  c->low9 = c->logn == 17 && !(low8 && low8[0] == '1');
-  const char *nofuse = getenv("GPQHE_NO_FUSED_POLYMUL");   // dev switch: poly_mul's limb loop as ntt, ntt, mul, invntt
-  c->fused_polymul = !(nofuse && nofuse[0] == '1');
-  const char *ksp = getenv("GPQHE_KS_PAIRS");       // dev switch: 0 = key switch one polynomial per workgroup (keyswitch_mid / keyswitch_mid8)
-  c->ks_pairs = !(ksp && ksp[0] == '0');
-  const char *nowide = getenv("GPQHE_NO_WIDE");     // dev switch: A/B against one subtraction per stage
   c->nwide = 0;
-  if (!(nowide && nowide[0] == '1'))
-    while (c->nwide < c->nsplit && c->p[c->nwide] - (1ull << 59) < GPQ_WIDE_CMAX) ++c->nwide;
+  while (c->nwide < c->nsplit && c->p[c->nwide] - (1ull << 59) < GPQ_WIDE_CMAX) ++c->nwide;
+  c->nsplit_tables = c->nsplit; c->nwide_max = c->nwide;
+  c->low9 = c->logn == 17;            // n = 2^17: 8 strided stages over 512-coefficient rows + 9 low stages
   if (c->nsplit) {
     const size_t ns = c->nsplit;
     std::vector<TwS> ws(ns * n), wis(ns * n);
@@ -405,9 +393,8 @@ int launch_strided(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigne
       case 14: return launch_strided_t<6, 4, INV, false, TW>(a, polys * a.nslab, limbs, s);
       case 15: return launch_strided_t<7, 4, INV, false, TW>(a, polys * a.nslab, limbs, s);
       case 16: return launch_strided_t<8, 4, INV, false, TW>(a, polys * a.nslab, limbs, s);
-      case 17:   // 8 strided stages over 512-coefficient rows + 9 low stages, or (GPQHE_N17_LOW8=1) 9 + 8
-        if (c->low9) return launch_strided_t<8, 4, INV, false, TW, 9>(a, polys * a.nslab, limbs, s);
-        return launch_strided_t<9, 5, INV, false, TW>(a, polys * a.nslab, limbs, s);
+      case 17:   // 8 strided stages over 512-coefficient rows (the 256-row tiles of n = 2^16) + 9 low stages
+        return launch_strided_t<8, 4, INV, false, TW, 9>(a, polys * a.nslab, limbs, s);
     }
     return gpq_fail(GPQ_ERR_INVALID, "two-pass NTT needs 13 <= logn <= 17 (got %u)", c->logn);
   });
@@ -524,7 +511,7 @@ extern "C" int gpq_poly_mul_rns(gpq_ctx *c, uint64_t *r, uint64_t *a, uint64_t *
   int rc = check_shape(c, dim, batch, "gpq_poly_mul_rns");
   if (rc) return rc;
   if (!r || !a || !b) return gpq_fail(GPQ_ERR_INVALID, "gpq_poly_mul_rns: null slab");
-  if (!two_pass(c) || !c->fused_polymul) {
+  if (!two_pass(c)) {
     if ((rc = gpq_ntt(c, a, dim, batch, stream))) return rc;
     if ((rc = gpq_ntt(c, b, dim, batch, stream))) return rc;
     if ((rc = gpq_rns_mul(c, r, a, b, dim, batch, stream))) return rc;
@@ -561,7 +548,7 @@ extern "C" int gpq_mulpt_rns(gpq_ctx *c, uint64_t *r0, uint64_t *r1, uint64_t *m
   int rc = check_shape(c, dim, batch, "gpq_mulpt_rns");
   if (rc) return rc;
   if (!r0 || !r1 || !m || !x0 || !x1) return gpq_fail(GPQ_ERR_INVALID, "gpq_mulpt_rns: null slab");
-  if (!two_pass(c) || !c->fused_polymul) {
+  if (!two_pass(c)) {
     if ((rc = gpq_ntt(c, m, dim, batch, stream)) || (rc = gpq_ntt(c, x0, dim, batch, stream)) || (rc = gpq_ntt(c, x1, dim, batch, stream))) return rc;
     if ((rc = gpq_rns_mul(c, r0, x0, m, dim, batch, stream)) || (rc = gpq_invntt(c, r0, dim, batch, stream))) return rc;
     if ((rc = gpq_rns_mul(c, r1, x1, m, dim, batch, stream))) return rc;
@@ -663,8 +650,7 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
             using TW = decltype(tag);
             ProfScope prof(c, GPQ_K_TENSOR_MID, s);
             if (c->low9) hipLaunchKernelGGL((tensor_mid8<TW, 9>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
-            else if (c->mid8) hipLaunchKernelGGL((tensor_mid8<TW, 8>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
-            else hipLaunchKernelGGL((tensor_mid<TW>), dim3(c->n >> 12, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
+            else hipLaunchKernelGGL((tensor_mid8<TW, 8>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
             return (int)GPQ_OK;
           }))) return rc;
       // 3. strided inverse pass in place on the three outputs
@@ -718,10 +704,8 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
             using TW = decltype(tag);
             KeyswitchArgs ka{a, m.evk0, m.evk1};
             ProfScope prof(c, GPQ_K_KEYSWITCH_MID, s);
-            if (c->ks_pairs && c->low9) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 9>), dim3(c->n >> 11, (polys + 1) / 2, nl), dim3(CONTIG_WAVES * 64), 0, s, ka, polys);
-            else if (c->ks_pairs) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 8>), dim3(c->n >> 11, (polys + 1) / 2, nl), dim3(CONTIG_WAVES * 64), 0, s, ka, polys);
-            else if (c->low9) hipLaunchKernelGGL((keyswitch_mid8<TW, 9>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, ka);
-            else hipLaunchKernelGGL((keyswitch_mid<TW>), dim3(c->n >> 12, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, ka);
+            if (c->low9) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 9>), dim3(c->n >> 11, (polys + 1) / 2, nl), dim3(CONTIG_WAVES * 64), 0, s, ka, polys);
+            else hipLaunchKernelGGL((keyswitch_mid8x2<TW, 8>), dim3(c->n >> 11, (polys + 1) / 2, nl), dim3(CONTIG_WAVES * 64), 0, s, ka, polys);
             return (int)GPQ_OK;
           }))) return rc;
       PassArgs b = make_args(c, dim, 2);
@@ -731,6 +715,18 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
     }
   }
   return after_launch("gpq_keyswitch");
+}
+
+// Which butterflies a limb runs is decided by its c = p - 2^59 (modarith.hpp): the first `wide` limbs the wide-split ones, the
+// limbs up to `split` the split-twiddle ones, the rest the 7-mad ones.  The context picks the cheapest class each limb
+// admits; this call can only move limbs towards the more general (slower) classes -- what the tests use to run every class on
+// every limb and compare bit for bit.  Values above what the chain admits are clamped.
+extern "C" int gpq_set_limb_classes(gpq_ctx *c, unsigned wide, unsigned split) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_limb_classes: null context");
+  c->nsplit = split < c->nsplit_tables ? split : c->nsplit_tables;
+  c->nwide = wide < c->nwide_max ? wide : c->nwide_max;
+  if (c->nwide > c->nsplit) c->nwide = c->nsplit;
+  return GPQ_OK;
 }
 
 extern "C" int gpq_set_limb_block(gpq_ctx *c, unsigned limbs) {

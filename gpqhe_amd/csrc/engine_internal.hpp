@@ -60,17 +60,15 @@ struct gpq_ctx {
   // device tables (standard form)
   uint64_t *d_w = nullptr, *d_winv = nullptr;
   gpq::TwS *d_ws = nullptr, *d_winvs = nullptr;   // split-twiddle pairs for the first nsplit limbs (modarith.hpp)
-  unsigned nsplit = 0;                            // leading limbs with c < GPQ_SPLIT_CMAX
+  unsigned nsplit = 0;                            // leading limbs that run the split-twiddle butterflies (c < GPQ_SPLIT_CMAX)
+  unsigned nsplit_tables = 0;                     // ... and for how many limbs the pair tables exist (gpq_set_limb_classes can only lower nsplit)
   bool low9 = false;                              // n = 2^17: strided passes over 512-coefficient rows, 9 low stages (Lane8<9>)
-  bool fused_polymul = true;                      // gpq_poly_mul_rns as strided pass, polymul_mid8, strided pass
-  bool ks_pairs = true;                           // key switch on keyswitch_mid8x2 (two polynomials per workgroup)
-  bool mid8 = true;                               // tensor stage on tensor_mid8 (8 coefficients per lane, 3 waves per SIMD)
-  unsigned nwide = 0;                             // leading limbs with c < GPQ_WIDE_CMAX (<= nsplit): forward stages as ct_bfly_wide
+  unsigned nwide = 0, nwide_max = 0;              // leading limbs with c < GPQ_WIDE_CMAX (<= nsplit): forward stages as ct_bfly_wide
   gpq::LimbTab *d_tabs = nullptr;
   std::map<std::pair<unsigned, unsigned>, gpq_bridge_basis> bases;   // by (first limb, count), built on first use
   std::map<std::pair<unsigned, unsigned>, gpq_relin_tables> relins;  // by (dimP, dimB)
   std::map<std::pair<std::pair<unsigned, unsigned>, unsigned>, gpq_decomp_mfma> decomps;  // by ((first limb, limbs), W)
-  bool bridge_mfma = true;            // matrix-core decompose (GPQHE_NO_MFMA=1 or gpq_set_bridge_mfma(ctx, 0): VALU kernels)
+  bool bridge_mfma = true;            // matrix-core decompose / CRT (gpq_set_bridge_mfma(ctx, 0): the integer-VALU kernels)
   unsigned char *d_redo = nullptr;    // per-coefficient "redo exactly" flags of the fast CRT path
   size_t redo_cap = 0;
   std::vector<void *> retired;        // outgrown d_redo buffers: a HIP graph captured earlier may still write them, so they live as long as the context

@@ -17,7 +17,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -100,19 +103,72 @@ unsigned max_bits(const poly_mpi_t *a, unsigned n) {
 
 // The conversions are per coefficient and independent (gcry_mpi_print only reads its MPI, gcry_mpi_scan / gcry_mpi_set write
 // the caller's own, distinct MPIs), so large polynomials are cut into ranges for a few host threads: at n = 2^16 the MPI <-> slab
-// conversions are 40 ms of a 42 ms he_mul call on one thread.
+// conversions are 40 ms of a 42 ms he_mul call on one thread.  The threads are started once and kept (starting 16 threads four
+// times per call cost more than the device work of the call).
+class Workers {
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable wake_, idle_;
+  const std::function<void(unsigned)> *job_ = nullptr;
+  unsigned tasks_ = 0, next_ = 0, open_ = 0;
+  uint64_t round_ = 0;
+
+  void drain(std::unique_lock<std::mutex> &lk) {       // run tasks of the current round until none is left to take
+    while (next_ < tasks_) {
+      const unsigned t = next_++;
+      const std::function<void(unsigned)> *job = job_;
+      lk.unlock();
+      (*job)(t);
+      lk.lock();
+      if (--open_ == 0) idle_.notify_all();
+    }
+  }
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu_);
+    uint64_t seen = 0;
+    for (;;) {
+      wake_.wait(lk, [&] { return round_ != seen; });
+      seen = round_;
+      drain(lk);
+    }
+  }
+
+ public:
+  explicit Workers(unsigned helpers) {
+    for (unsigned i = 0; i < helpers; ++i) { th_.emplace_back([this] { loop(); }); th_.back().detach(); }
+  }
+  unsigned width() const { return (unsigned)th_.size() + 1; }
+  void run(unsigned tasks, const std::function<void(unsigned)> &f) {     // the caller works too; returns when every task is done
+    std::unique_lock<std::mutex> lk(mu_);
+    job_ = &f; tasks_ = tasks; next_ = 0; open_ = tasks; ++round_;
+    wake_.notify_all();
+    drain(lk);
+    idle_.wait(lk, [&] { return open_ == 0; });
+    job_ = nullptr; tasks_ = 0;
+  }
+};
+Workers &workers() {       // never destroyed: its threads wait detached and vanish with the process
+  static Workers *w = [] {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 1) nt = 1;
+    return new Workers(nt - 1);
+  }();
+  return *w;
+}
+int g_dev = 0;             // device of the engine context: HIP's current device is per thread, the workers set it for their copies
+
+// f(task, lo, hi) over [0, n) cut into ranges; small polynomials stay on the calling thread
 template <typename F>
 void for_ranges(unsigned n, F f) {
-  unsigned nt = n >= 4096 ? std::thread::hardware_concurrency() : 1;
-  if (nt > 16) nt = 16;
+  const unsigned nt = n >= 4096 ? workers().width() : 1;
   if (nt < 2) { f(0u, n); return; }
-  std::vector<std::thread> th;
   const unsigned per = (n + nt - 1) / nt;
-  for (unsigned t = 0; t < nt; ++t) {
+  const std::function<void(unsigned)> job = [&](unsigned t) {
     const unsigned lo = t * per, hi = lo + per < n ? lo + per : n;
-    if (lo < hi) th.emplace_back([=] { f(lo, hi); });
-  }
-  for (auto &x : th) x.join();
+    if (lo < hi) f(lo, hi);
+  };
+  workers().run(nt, job);
 }
 
 // MPI coefficients -> host big slab [W][n], two's complement
@@ -174,6 +230,7 @@ gpq_ctx *engine() {
   if (g_engine) gpq_ctx_destroy(g_engine);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) die("no HIP device");
+  g_dev = dev;
   if (gpq_ctx_create(&g_engine, polyctx.logn, polyctx.dimub, dev) != GPQ_OK) die("cannot build the engine context");
   unsigned d = 0;
   for (const struct rns_ctx *r = polyctx.rns; r && d < polyctx.dimub; r = r->next, ++d)
@@ -203,6 +260,113 @@ struct DevBuf {
 void up(const DevBuf &d, const std::vector<uint64_t> &h) { if (gpq_upload(d.p, h.data(), h.size() * 8, nullptr) != GPQ_OK) die("upload failed"); }
 void down(std::vector<uint64_t> &h, const DevBuf &d) {
   if (gpq_download(h.data(), d.p, h.size() * 8, nullptr) != GPQ_OK || gpq_stream_sync(nullptr) != GPQ_OK) die("download failed");
+}
+
+// Page-locked staging memory for the big slabs, kept by size like the device buffers: copies from / to it are true DMA and run
+// while the host threads convert the next range.
+std::map<size_t, std::vector<void *>> g_pinned;
+struct HostBuf {
+  void *p = nullptr;
+  size_t bytes;
+  explicit HostBuf(size_t b) : bytes(b ? b : 8) {
+    auto it = g_pinned.find(bytes);
+    if (it != g_pinned.end() && !it->second.empty()) { p = it->second.back(); it->second.pop_back(); return; }
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) die("page-locked allocation failed");
+  }
+  ~HostBuf() { g_pinned[bytes].push_back(p); }
+  HostBuf(const HostBuf &) = delete;
+  HostBuf &operator=(const HostBuf &) = delete;
+  uint64_t *u64() const { return (uint64_t *)p; }
+};
+std::vector<hipEvent_t> g_events;
+hipEvent_t event_at(size_t i) {
+  while (g_events.size() <= i) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) die("hipEventCreate failed");
+    g_events.push_back(e);
+  }
+  return g_events[i];
+}
+
+// words [lo, hi) of every row of a big slab [W][n]: one strided DMA
+void copy_range(void *dst, const void *src, unsigned n, unsigned W, unsigned lo, unsigned hi, hipMemcpyKind kind) {
+  const size_t pitch = (size_t)n * 8;
+  if (hipMemcpy2DAsync((char *)dst + (size_t)lo * 8, pitch, (const char *)src + (size_t)lo * 8, pitch, (size_t)(hi - lo) * 8, W, kind, nullptr) != hipSuccess)
+    die("slab copy failed");
+}
+
+// MPI polynomials -> device big slabs: every host thread converts its range of a polynomial into page-locked memory and sends
+// that range off at once, so conversion of the next range / polynomial overlaps the DMA of the previous one.
+void upload_polys(const DevBuf *const dst[], const HostBuf *const stage[], const poly_mpi_t *const src[], int count, unsigned n, unsigned W) {
+  if (W < 1 || W > 32) die("coefficients wider than 2047 bits");
+  for_ranges(n, [=](unsigned lo, unsigned hi) {
+    (void)hipSetDevice(g_dev);
+    for (int i = 0; i < count; ++i) {
+      to_slab_range(stage[i]->u64(), src[i], n, W, lo, hi);
+      copy_range(dst[i]->p, stage[i]->p, n, W, lo, hi, hipMemcpyHostToDevice);
+    }
+  });
+}
+
+// device big slabs -> the caller's MPIs: the ranges come back one DMA each, in order, an event behind every one; a host thread
+// converts its range as soon as that range has landed while the later ones are still in flight.
+void download_polys(poly_mpi_t *const dst[], const HostBuf *const stage[], const DevBuf *const src[], int count, unsigned n, unsigned W) {
+  if (W < 1 || W > 64) die("big slab wider than 64 words");
+  const unsigned nt = n >= 4096 ? workers().width() : 1, per = (n + nt - 1) / nt;
+  const unsigned ranges = (n + per - 1) / per;            // the non-empty ones: [t per, min(n, (t + 1) per)), t < ranges <= nt
+  for (int i = 0; i < count; ++i)
+    for (unsigned t = 0; t < ranges; ++t) {
+      const unsigned lo = t * per, hi = lo + per < n ? lo + per : n;
+      copy_range(stage[i]->p, src[i]->p, n, W, lo, hi, hipMemcpyDeviceToHost);
+      if (hipEventRecord(event_at((size_t)i * ranges + t), nullptr) != hipSuccess) die("hipEventRecord failed");
+    }
+  const std::function<void(unsigned)> job = [&](unsigned t) {
+    (void)hipSetDevice(g_dev);
+    const unsigned lo = t * per, hi = lo + per < n ? lo + per : n;
+    for (int i = 0; i < count; ++i) {
+      if (hipEventSynchronize(g_events[(size_t)i * ranges + t]) != hipSuccess) die("download failed");
+      from_slab_range(dst[i], stage[i]->u64(), n, W, lo, hi);
+    }
+  };
+  if (ranges < 2) job(0); else workers().run(ranges, job);
+}
+
+// Evaluation keys are 2 x dim x n words (47 MB at the headline shape) and the same key multiplies many ciphertexts: the device
+// copy is kept, identified by the caller's two pointers, the length and a fingerprint of sampled words (a key rewritten in
+// place at the same address is uploaded again).  A handful of keys (rlk, ck, the rotation keys in use) stay resident.
+struct KeySlot { const uint64_t *h0, *h1; size_t words; uint64_t print; void *d0, *d1; uint64_t used; };
+std::vector<KeySlot> g_keys;
+uint64_t g_key_clock = 0;
+uint64_t key_print(const uint64_t *a, const uint64_t *b, size_t words) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  auto mix = [&](uint64_t v) { h = (h ^ v) * 0x100000001b3ull; h ^= h >> 29; };
+  const size_t step = words > 512 ? words / 509 : 1;     // ~512 samples of each polynomial, plus both ends
+  for (size_t i = 0; i < words; i += step) { mix(a[i]); mix(b[i]); }
+  for (size_t i = 0; i < 8 && i < words; ++i) { mix(a[i]); mix(b[i]); mix(a[words - 1 - i]); mix(b[words - 1 - i]); }
+  return h;
+}
+void key_on_device(const he_evk_t *key, size_t words, uint64_t **d0, uint64_t **d1) {
+  const uint64_t *h0 = key->p0.coeffs, *h1 = key->p1.coeffs;
+  const uint64_t print = key_print(h0, h1, words);
+  for (KeySlot &k : g_keys)
+    if (k.h0 == h0 && k.h1 == h1 && k.words == words && k.print == print) { k.used = ++g_key_clock; *d0 = (uint64_t *)k.d0; *d1 = (uint64_t *)k.d1; return; }
+  KeySlot slot{h0, h1, words, print, nullptr, nullptr, ++g_key_clock};
+  size_t victim = g_keys.size();
+  for (size_t i = 0; i < g_keys.size(); ++i)               // same host key at another state / length, else the least recently used of 6
+    if (g_keys[i].h0 == h0 && g_keys[i].h1 == h1 && g_keys[i].words == words) victim = i;
+  if (victim == g_keys.size() && g_keys.size() >= 6) {
+    victim = 0;
+    for (size_t i = 1; i < g_keys.size(); ++i) if (g_keys[i].used < g_keys[victim].used) victim = i;
+  }
+  if (victim < g_keys.size()) {
+    if (g_keys[victim].words == words) { slot.d0 = g_keys[victim].d0; slot.d1 = g_keys[victim].d1; }
+    else { (void)gpq_stream_sync(nullptr); (void)gpq_free(g_keys[victim].d0); (void)gpq_free(g_keys[victim].d1); }
+    g_keys.erase(g_keys.begin() + victim);
+  }
+  if (!slot.d0 && (gpq_malloc(&slot.d0, words * 8) != GPQ_OK || gpq_malloc(&slot.d1, words * 8) != GPQ_OK)) die("device allocation failed");
+  if (gpq_upload(slot.d0, h0, words * 8, nullptr) != GPQ_OK || gpq_upload(slot.d1, h1, words * 8, nullptr) != GPQ_OK) die("upload failed");
+  g_keys.push_back(slot);
+  *d0 = (uint64_t *)slot.d0; *d1 = (uint64_t *)slot.d1;
 }
 
 }  // namespace
@@ -282,16 +446,18 @@ void poly_mul(poly_mpi_t *r, const poly_mpi_t *a, const poly_mpi_t *b, const uns
   if (nbq > bits) bits = nbq;
   const unsigned W = bits / 64 + 1;
   if (W > 32) die("poly_mul: coefficients wider than 2047 bits");
-  std::vector<uint64_t> ha((size_t)W * n), hb((size_t)W * n), hr((size_t)W * n);
-  to_slab(ha.data(), a, n, W);
-  to_slab(hb.data(), b, n, W);
-  DevBuf da(ha.size() * 8), db(hb.size() * 8), dr(hr.size() * 8), ws(gpq_poly_mul_general_workspace_bytes(c, dim, 1));
-  up(da, ha); up(db, hb);
+  const size_t big = (size_t)W * n;
+  HostBuf s0(big * 8), s1(big * 8);
+  DevBuf da(big * 8), db(big * 8), dr(big * 8), ws(gpq_poly_mul_general_workspace_bytes(c, dim, 1));
+  const DevBuf *dd[2] = {&da, &db}, *oo[1] = {&dr};
+  const HostBuf *ss[2] = {&s0, &s1};
+  const poly_mpi_t *in[2] = {a, b};
+  upload_polys(dd, ss, in, 2, n, W);
   const int rc = is_pow2(qw) ? gpq_poly_mul(c, dr.u64(), da.u64(), db.u64(), W, dim, nbq - 1, 1, ws.p, nullptr)
                              : gpq_poly_mul_general(c, dr.u64(), da.u64(), db.u64(), W, dim, qw.data(), (unsigned)qw.size(), 1, ws.p, nullptr);
   if (rc != GPQ_OK) die("poly_mul failed");   // q = P*q_L in he_genswk (src/he-kem.c:95) takes the general path
-  down(hr, dr);
-  from_slab(r, hr.data(), n, W);
+  poly_mpi_t *out[1] = {r};
+  download_polys(out, ss, oo, 1, n, W);
 }
 
 // src/he-mult.c:88-156
@@ -312,21 +478,22 @@ void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t 
   if (gpq_ctx_pbits(c, dimP) != G.mpi_get_nbits(hectx.P)) die("he_mul: hectx.P is not the product of the first hectx.dim primes");
   const unsigned W = logql / 64 + 1;
   const size_t big = (size_t)W * n, evk = (size_t)dimB * n;
-  std::vector<uint64_t> h[4] = {std::vector<uint64_t>(big), std::vector<uint64_t>(big), std::vector<uint64_t>(big), std::vector<uint64_t>(big)};
   const poly_mpi_t *in[4] = {&ct1->c0, &ct1->c1, &ct2->c0, &ct2->c1};
-  for (int i = 0; i < 4; ++i) to_slab(h[i].data(), in[i], n, W);
-  DevBuf d0(big * 8), d1(big * 8), d2(big * 8), d3(big * 8), o0(big * 8), o1(big * 8), k0(evk * 8), k1(evk * 8),
+  HostBuf s0(big * 8), s1(big * 8), s2(big * 8), s3(big * 8);
+  DevBuf d0(big * 8), d1(big * 8), d2(big * 8), d3(big * 8), o0(big * 8), o1(big * 8),
       ws(pow2 ? gpq_he_mul_workspace_bytes(c, W, dimA, dimB, dimP, 1) : gpq_he_general_workspace_bytes(c, W, dimA, dimB, dimP, 1));
-  up(d0, h[0]); up(d1, h[1]); up(d2, h[2]); up(d3, h[3]);
-  if (gpq_upload(k0.p, rlk->p0.coeffs, evk * 8, nullptr) != GPQ_OK || gpq_upload(k1.p, rlk->p1.coeffs, evk * 8, nullptr) != GPQ_OK) die("upload failed");
-  const int rc = pow2 ? gpq_he_mul(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), d2.u64(), d3.u64(), k0.u64(), k1.u64(), W, logql, dimA, dimB, dimP,
+  const DevBuf *dd[4] = {&d0, &d1, &d2, &d3}, *oo[2] = {&o0, &o1};
+  const HostBuf *ss[4] = {&s0, &s1, &s2, &s3};
+  upload_polys(dd, ss, in, 4, n, W);
+  uint64_t *k0, *k1;
+  key_on_device(rlk, evk, &k0, &k1);
+  const int rc = pow2 ? gpq_he_mul(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), d2.u64(), d3.u64(), k0, k1, W, logql, dimA, dimB, dimP,
                                    1, ws.p, nullptr)
-                      : gpq_he_mul_general(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), d2.u64(), d3.u64(), k0.u64(), k1.u64(), W, qw.data(),
+                      : gpq_he_mul_general(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), d2.u64(), d3.u64(), k0, k1, W, qw.data(),
                                            (unsigned)qw.size(), dimA, dimB, dimP, 1, ws.p, nullptr);
   if (rc != GPQ_OK) die("he_mul failed");
-  down(h[0], o0); down(h[1], o1);
-  from_slab(&ct->c0, h[0].data(), n, W);
-  from_slab(&ct->c1, h[1].data(), n, W);
+  poly_mpi_t *out[2] = {&ct->c0, &ct->c1};
+  download_polys(out, ss, oo, 2, n, W);
   ct->l = l; ct->nu = nu; ct->B = B;                                                           // :92-95
 }
 
@@ -347,18 +514,18 @@ static void rescale_common(he_ct_t *ct, bool divide) {
   if (b1 > bits) bits = b1;
   if (logql + 1 > bits) bits = logql + 1;
   const unsigned W = bits / 64 + 1;
-  std::vector<uint64_t> h0((size_t)W * n), h1((size_t)W * n);
-  to_slab(h0.data(), &ct->c0, n, W);
-  to_slab(h1.data(), &ct->c1, n, W);
-  DevBuf d0(h0.size() * 8), d1(h1.size() * 8);
-  up(d0, h0); up(d1, h1);
-  DevBuf scratch(192 * 8);
+  const size_t big = (size_t)W * n;
+  HostBuf s0(big * 8), s1(big * 8);
+  DevBuf d0(big * 8), d1(big * 8), scratch(192 * 8);
+  const DevBuf *dd[2] = {&d0, &d1};
+  const HostBuf *ss[2] = {&s0, &s1};
+  const poly_mpi_t *in[2] = {&ct->c0, &ct->c1};
+  upload_polys(dd, ss, in, 2, n, W);
   const int rc = pow2 ? gpq_he_rs(c, d0.u64(), d1.u64(), W, s, logql, 1, nullptr)                                  // :45-48 / :64-65
                       : gpq_he_rs_general(c, d0.u64(), d1.u64(), W, divide ? dw[0] : 1ull, qw.data(), (unsigned)qw.size(), 1, scratch.p, nullptr);
   if (rc != GPQ_OK) die("he_rs failed");
-  down(h0, d0); down(h1, d1);
-  from_slab(&ct->c0, h0.data(), n, W);
-  from_slab(&ct->c1, h1.data(), n, W);
+  poly_mpi_t *out[2] = {&ct->c0, &ct->c1};
+  download_polys(out, ss, dd, 2, n, W);
   ct->l = lnew;
   if (divide) { ct->nu /= hectx.Delta; ct->B = ct->B / hectx.Delta + hectx.bnd.Brs; }             // :37-38
 }
@@ -378,17 +545,18 @@ void he_mulpt(struct he_ct *dest, const struct he_ct *src, const struct he_pt *p
   if (logql + 1 > bits) bits = logql + 1;
   const unsigned W = bits / 64 + 1;
   const size_t big = (size_t)W * n;
-  std::vector<uint64_t> h0(big), h1(big), hm(big);
-  to_slab(h0.data(), &src->c0, n, W); to_slab(h1.data(), &src->c1, n, W); to_slab(hm.data(), &pt->m, n, W);
+  HostBuf s0(big * 8), s1(big * 8), s2(big * 8);
   DevBuf d0(big * 8), d1(big * 8), dm(big * 8), o0(big * 8), o1(big * 8),
       ws(gpq_he_mulpt_workspace_bytes(c, dim, 1) + gpq_poly_mul_general_workspace_bytes(c, dim, 1));
-  up(d0, h0); up(d1, h1); up(dm, hm);
+  const DevBuf *dd[3] = {&d0, &d1, &dm}, *oo[2] = {&o0, &o1};
+  const HostBuf *ss[3] = {&s0, &s1, &s2};
+  const poly_mpi_t *in[3] = {&src->c0, &src->c1, &pt->m};
+  upload_polys(dd, ss, in, 3, n, W);
   const int rc = pow2 ? gpq_he_mulpt(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), dm.u64(), W, logql, dim, 1, ws.p, nullptr)
                       : gpq_he_mulpt_general(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), dm.u64(), W, qw.data(), (unsigned)qw.size(), dim, 1, ws.p, nullptr);
   if (rc != GPQ_OK) die("he_mulpt failed");
-  down(h0, o0); down(h1, o1);
-  from_slab(&dest->c0, h0.data(), n, W);
-  from_slab(&dest->c1, h1.data(), n, W);
+  poly_mpi_t *out[2] = {&dest->c0, &dest->c1};
+  download_polys(out, ss, oo, 2, n, W);
   dest->l = l; dest->nu = nu; dest->B = B;                                                      // :162-164
 }
 
@@ -404,22 +572,24 @@ static void automorphism(he_ct_t *ct, const he_evk_t *key, bool conj, unsigned r
   const unsigned dimB = (nbq + nbPqL + polyctx.logn) / 59 + 1, dimP = hectx.dim;                // src/he-automorphism.c:52
   const unsigned W = logql / 64 + 1;
   const size_t big = (size_t)W * n, evk = (size_t)dimB * n;
-  std::vector<uint64_t> h0(big), h1(big);
-  to_slab(h0.data(), &ct->c0, n, W); to_slab(h1.data(), &ct->c1, n, W);
-  DevBuf a0(big * 8), a1(big * 8), r0(big * 8), r1(big * 8), o0(big * 8), o1(big * 8), k0(evk * 8), k1(evk * 8),
+  HostBuf s0(big * 8), s1(big * 8);
+  DevBuf a0(big * 8), a1(big * 8), r0(big * 8), r1(big * 8), o0(big * 8), o1(big * 8),
       ws(pow2 ? gpq_he_swk_workspace_bytes(c, W, dimB, dimP, 1) : gpq_he_general_workspace_bytes(c, W, 0, dimB, dimP, 1));
-  up(a0, h0); up(a1, h1);
-  if (gpq_upload(k0.p, key->p0.coeffs, evk * 8, nullptr) != GPQ_OK || gpq_upload(k1.p, key->p1.coeffs, evk * 8, nullptr) != GPQ_OK) die("upload failed");
+  const DevBuf *dd[2] = {&a0, &a1}, *oo[2] = {&o0, &o1};
+  const HostBuf *ss[2] = {&s0, &s1};
+  const poly_mpi_t *in[2] = {&ct->c0, &ct->c1};
+  upload_polys(dd, ss, in, 2, n, W);
+  uint64_t *k0, *k1;
+  key_on_device(key, evk, &k0, &k1);
   int rc = conj ? gpq_poly_conj(c, r0.u64(), a0.u64(), W, 1, nullptr) : gpq_poly_rot(c, r0.u64(), a0.u64(), W, rot, 1, nullptr);      // :95-96 / :108-109
   if (rc == GPQ_OK) rc = conj ? gpq_poly_conj(c, r1.u64(), a1.u64(), W, 1, nullptr) : gpq_poly_rot(c, r1.u64(), a1.u64(), W, rot, 1, nullptr);
   if (rc == GPQ_OK)                                                                                                                       // :97 / :110
-    rc = pow2 ? gpq_he_swk(c, o0.u64(), o1.u64(), r0.u64(), r1.u64(), k0.u64(), k1.u64(), W, logql, dimB, dimP, 1, ws.p, nullptr)
-              : gpq_he_swk_general(c, o0.u64(), o1.u64(), r0.u64(), r1.u64(), k0.u64(), k1.u64(), W, qw.data(), (unsigned)qw.size(), dimB, dimP, 1,
+    rc = pow2 ? gpq_he_swk(c, o0.u64(), o1.u64(), r0.u64(), r1.u64(), k0, k1, W, logql, dimB, dimP, 1, ws.p, nullptr)
+              : gpq_he_swk_general(c, o0.u64(), o1.u64(), r0.u64(), r1.u64(), k0, k1, W, qw.data(), (unsigned)qw.size(), dimB, dimP, 1,
                                    ws.p, nullptr);
   if (rc != GPQ_OK) die("he_rot/he_conj failed");
-  down(h0, o0); down(h1, o1);
-  from_slab(&ct->c0, h0.data(), n, W);
-  from_slab(&ct->c1, h1.data(), n, W);
+  poly_mpi_t *out[2] = {&ct->c0, &ct->c1};
+  download_polys(out, ss, oo, 2, n, W);
 }
 void he_conj(he_ct_t *ct, const he_evk_t *ck) { automorphism(ct, ck, true, 0); }
 void he_rot(he_ct_t *ct, const int rot, const he_evk_t *rk) { automorphism(ct, &rk[rot], false, (unsigned)rot); }   // rk[rot], :110
@@ -518,6 +688,12 @@ void gpq_mpi_shim_release(void) {
   (void)gpq_stream_sync(nullptr);
   for (auto &kv : g_pool) for (void *q : kv.second) (void)gpq_free(q);
   g_pool.clear();
+  for (auto &kv : g_pinned) for (void *q : kv.second) (void)hipHostFree(q);
+  g_pinned.clear();
+  for (KeySlot &k : g_keys) { (void)gpq_free(k.d0); (void)gpq_free(k.d1); }
+  g_keys.clear();
+  for (hipEvent_t e : g_events) (void)hipEventDestroy(e);
+  g_events.clear();
   if (g_engine) { gpq_ctx_destroy(g_engine); g_engine = nullptr; }
 }
 

@@ -15,8 +15,8 @@
 //   (n = 2^17: len >= 512 / len <= 256, rows of 512 and blocks of 512: same
 //   256-row tiles, 9 low stages in the 8-per-lane kernels further down)
 // The low stages are fused with what surrounds them wherever a limb loop of
-// the reference allows it: tensor_mid / tensor_mid8 (he_mul tensor stage),
-// keyswitch_mid / keyswitch_mid8 (he_relin, he_swk), polymul_mid8 (poly_mul),
+// the reference allows it: tensor_mid8 (he_mul tensor stage),
+// keyswitch_mid8x2 (he_relin, he_swk), polymul_mid8 (poly_mul),
 // mulpt_mid8 (he_mulpt).
 //
 // Inside a pass a thread keeps 2^EL coefficients in registers and runs EL
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTI
     }
   } else {
     // split pairs are 4 VGPRs each: the CONTIG_POLYS polynomials are held together and one twiddle
-    // group (15 pairs) at a time runs over all of them, as in tensor_mid
+    // group (15 pairs) at a time runs over all of them, as in tensor_mid8
     uint64_t x[CONTIG_POLYS][16];
     ContigTw<TW> tw;
 #pragma unroll
@@ -480,56 +480,8 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTI
 //   d0 = c0*c0', d2 = c1*c1', d1 = c0*c1' + c1*c0'   (the add moved in front
 //   of the inverse transform: INTT is linear, canonical results are identical)
 //   low 8 inverse stages of d0, d1, d2
-// src[0..3] = a0,a1,b0,b1 after the strided forward pass; dst[0..2] = d0,d1,d2.
+// src[0..3] = a0,a1,b0,b1 after the strided forward pass; dst[0..2] = d0,d1,d2.  Kernel: tensor_mid8 below.
 // ---------------------------------------------------------------------------
-template <typename TW>
-__global__ __launch_bounds__(CONTIG_WAVES * 64, 2) void tensor_mid(PassArgs a) {
-  using TT = TwTraits<TW>;
-  __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
-  const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
-  const ContigBlock cb(a);           // nslab == 1 here: blockIdx.y = poly
-  const LimbTab &tab = a.tabs[cb.limb];
-  const PrimeK k = tab.k;
-  const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
-  uint64_t a0[16], a1[16], b0[16], b1[16];
-  ContigTw<TW> tw;
-  load_h(a0, a.src[0] + cb.off, ln);
-  tw.load_h(ln, cb.wave0, a.logn, wf);
-  load_h(b0, a.src[2] + cb.off, ln);
-  load_h(a1, a.src[1] + cb.off, ln);
-  load_h(b1, a.src[3] + cb.off, ln);
-  // forward, group H on all four, then group L on all four (15 twiddles live at a time)
-  ct_group<4, 3, 0, 4>(a0, tw.t, k);
-  ct_group<4, 3, 0, 4>(b0, tw.t, k);
-  ct_group<4, 3, 0, 4>(a1, tw.t, k);
-  ct_group<4, 3, 0, 4>(b1, tw.t, k);
-  tw.load_l(ln, cb.wave0, a.logn, wf);
-  ln.h_to_l(a0); ct_group<4, 3, 0, 0>(a0, tw.t, k);
-  ln.h_to_l(b0); ct_group<4, 3, 0, 0>(b0, tw.t, k);
-  ln.h_to_l(a1); ct_group<4, 3, 0, 0>(a1, tw.t, k);
-  ln.h_to_l(b1); ct_group<4, 3, 0, 0>(b1, tw.t, k);
-  tw.load_l(ln, cb.wave0, a.logn, wi);               // inverse twiddles arrive under the products
-  // products: left operand < 2p, right operand < 4p  =>  a*b < 8p^2, as mulmod_lazy needs
-  uint64_t d1[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const uint64_t u0 = TT::left(a0[e], k), u1 = TT::left(a1[e], k);
-    const uint64_t v0 = TT::right(b0[e], k), v1 = TT::right(b1[e], k);
-    a0[e] = TT::inv_from4(mulmod_lazy(u0, v0, k), k);                                   // d0
-    d1[e] = TT::inv_from8(mulmod_lazy(u0, v1, k) + mulmod_lazy(u1, v0, k), k);          // d1
-    a1[e] = TT::inv_from4(mulmod_lazy(u1, v1, k), k);                                   // d2
-  }
-  gs_group<4, 3, 0>(a0, tw.t, k); ln.l_to_h(a0);
-  gs_group<4, 3, 0>(d1, tw.t, k); ln.l_to_h(d1);
-  gs_group<4, 3, 0>(a1, tw.t, k); ln.l_to_h(a1);
-  tw.load_h(ln, cb.wave0, a.logn, wi);
-  gs_group<4, 3, 0>(a0, tw.t, k);
-  store_h(a.dst[0] + cb.off, a0, ln);
-  gs_group<4, 3, 0>(d1, tw.t, k);
-  store_h(a.dst[1] + cb.off, d1, ln);
-  gs_group<4, 3, 0>(a1, tw.t, k);
-  store_h(a.dst[2] + cb.off, a1, ln);
-}
 // ---------------------------------------------------------------------------
 // Fused middle of the key-switch inner product (src/he-mult.c:60-64 ==
 // src/he-automorphism.c:61-65): src[0] = d2 after the strided forward pass,
@@ -537,43 +489,6 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 2) void tensor_mid(PassArgs a) {
 // stride), dst[0..1] = low inverse stages of d2*evk.p0 and d2*evk.p1.
 // ---------------------------------------------------------------------------
 struct KeyswitchArgs { PassArgs p; const uint64_t *evk0; const uint64_t *evk1; };
-
-template <typename TW>
-__global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid(KeyswitchArgs ka) {
-  using TT = TwTraits<TW>;
-  __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
-  const PassArgs &a = ka.p;
-  const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
-  const ContigBlock cb(a);
-  const LimbTab &tab = a.tabs[cb.limb];
-  const PrimeK k = tab.k;
-  const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
-  const size_t koff = ((size_t)blockIdx.z << a.logn) + cb.wave0;
-  uint64_t x[16], e0[16], e1[16];
-  ContigTw<TW> tw;
-  load_h(x, a.src[0] + cb.off, ln);
-  tw.load_h(ln, cb.wave0, a.logn, wf);
-  ct_group<4, 3, 0, 4>(x, tw.t, k);
-  tw.load_l(ln, cb.wave0, a.logn, wf);
-  ln.h_to_l(x);
-  ct_group<4, 3, 0, 0>(x, tw.t, k);
-  load_l(e0, ka.evk0 + koff, ln);   // measured faster than H-layout loads + two more LDS exchanges here
-  load_l(e1, ka.evk1 + koff, ln);
-  tw.load_l(ln, cb.wave0, a.logn, wi);
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const uint64_t u = TT::right(x[e], k);         // < 4p ; evk limbs are canonical (< p)
-    e0[e] = TT::inv_from4(mulmod_lazy(u, e0[e], k), k);
-    e1[e] = TT::inv_from4(mulmod_lazy(u, e1[e], k), k);
-  }
-  gs_group<4, 3, 0>(e0, tw.t, k); ln.l_to_h(e0);
-  gs_group<4, 3, 0>(e1, tw.t, k); ln.l_to_h(e1);
-  tw.load_h(ln, cb.wave0, a.logn, wi);
-  gs_group<4, 3, 0>(e0, tw.t, k);
-  store_h(a.dst[0] + cb.off, e0, ln);
-  gs_group<4, 3, 0>(e1, tw.t, k);
-  store_h(a.dst[1] + cb.off, e1, ln);
-}
 
 // ---------------------------------------------------------------------------
 // The low stages with 8 coefficients per lane instead of 16.
@@ -745,7 +660,7 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_MID8_MINWAVES) void tensor_m
   tw.load_l(ln, cb.wave0, a.logn, wi);               // inverse twiddles arrive under the products
   uint64_t d1[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {                      // operand ranges as in tensor_mid
+  for (int e = 0; e < 8; ++e) {                      // products: left operand < 2p, right operand < 4p  =>  a*b < 8p^2, as mulmod_lazy needs (TwTraits::left / right)8
     const uint64_t u0 = TT::left(a0[e], k), u1 = TT::left(a1[e], k);
     const uint64_t v0 = TT::right(b0[e], k), v1 = TT::right(b1[e], k);
     a0[e] = TT::inv_from4(mulmod_lazy(u0, v0, k), k);                                   // d0
@@ -849,50 +764,6 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void mulpt_mid8(PassArgs a) {
   ln.store_h(a.dst[0] + cb.off, x);
   L8::gs_hm(y, tw.t, k);
   ln.store_h(a.dst[1] + cb.off, y);
-}
-
-// keyswitch_mid in the 8-per-lane geometry (used for n = 2^17: LOW = 9; at n = 2^16 the 16-per-lane form is faster)
-template <typename TW, int LOW>
-__global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid8(KeyswitchArgs ka) {
-  using TT = TwTraits<TW>;
-  using L8 = Lane8<LOW>;
-  __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
-  const PassArgs &a = ka.p;
-  const L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
-  const Block8 cb(a);
-  const PrimeK k = a.tabs[cb.limb].k;
-  const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
-  const size_t koff = ((size_t)blockIdx.z << a.logn) + cb.wave0;
-  uint64_t x[8], e0[8], e1[8];
-  Tw8<TW, LOW> tw;
-  ln.load_h(x, a.src[0] + cb.off);
-  tw.load_h(ln, cb.wave0, a.logn, wf);
-  L8::ct_h(x, tw.t, k);
-  tw.load_m(ln, cb.wave0, a.logn, wf);
-  ln.h_to_m(x);
-  L8::ct_m(x, tw.t, k);
-  tw.load_l(ln, cb.wave0, a.logn, wf);
-  ln.m_to_l(x);
-  L8::ct_l(x, tw.u, k);
-  ln.load_l(e0, ka.evk0 + koff);
-  ln.load_l(e1, ka.evk1 + koff);
-  tw.load_l(ln, cb.wave0, a.logn, wi);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const uint64_t u = TT::right(x[e], k);
-    e0[e] = TT::inv_from4(mulmod_lazy(u, e0[e], k), k);
-    e1[e] = TT::inv_from4(mulmod_lazy(u, e1[e], k), k);
-  }
-  L8::gs_l(e0, tw.u, k); ln.l_to_m(e0);
-  L8::gs_l(e1, tw.u, k); ln.l_to_m(e1);
-  tw.load_m(ln, cb.wave0, a.logn, wi);
-  L8::gs_hm(e0, tw.t, k); ln.m_to_h(e0);
-  L8::gs_hm(e1, tw.t, k); ln.m_to_h(e1);
-  tw.load_h(ln, cb.wave0, a.logn, wi);
-  L8::gs_hm(e0, tw.t, k);
-  ln.store_h(a.dst[0] + cb.off, e0);
-  L8::gs_hm(e1, tw.t, k);
-  ln.store_h(a.dst[1] + cb.off, e1);
 }
 
 // Key switch with TWO polynomials of the same limb and tile per workgroup: the key limbs (shared by the batch) and every

@@ -91,6 +91,10 @@ class PolyContext:
     def set_chunk(self, chunk):
         _native.check(self.lib.gpq_set_chunk(self.h, chunk), "gpq_set_chunk")
 
+    def set_limb_classes(self, wide, split):
+        """first `wide` limbs wide-split butterflies, up to `split` split-twiddle ones, the rest 7-mad (clamped; bit-identical)"""
+        _native.check(self.lib.gpq_set_limb_classes(self.h, wide, split), "gpq_set_limb_classes")
+
     def set_limb_block(self, limbs):
         _native.check(self.lib.gpq_set_limb_block(self.h, limbs), "gpq_set_limb_block")
 

@@ -119,6 +119,12 @@ int gpq_set_chunk(gpq_ctx *ctx, unsigned chunk);
  * kernels of a block run back to back, so a block of chunk x limbs x 7 slabs x n x 8 bytes that fits the 256 MiB
  * Infinity Cache is re-read from there instead of from HBM.  Results do not depend on either setting. */
 int gpq_set_limb_block(gpq_ctx *ctx, unsigned limbs);
+/* Butterfly classes (modarith.hpp): by default every limb runs the cheapest arithmetic its prime p = 2^59 + c admits --
+ * the first limbs (c < 2^27) the wide-split butterflies, the limbs up to c < 2^29/3 the split-twiddle ones, the rest the
+ * 7-multiply ones.  This call restricts the first two classes to the first `wide` / `split` limbs (clamped to what the
+ * chain admits; (0, 0) = the general butterflies everywhere).  Results are bit-identical for every setting; it exists so
+ * that each class can be run on every limb and compared (tests/test_ntt_gpu.py). */
+int gpq_set_limb_classes(gpq_ctx *ctx, unsigned wide, unsigned split);
 
 /* Bytes of scratch the two fused operations below need for this shape. */
 size_t gpq_tensor_workspace_bytes(const gpq_ctx *ctx, unsigned dim, unsigned batch);

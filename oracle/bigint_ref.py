@@ -28,6 +28,9 @@ class RnsBasis:
         self.P_2 = self.P // 2
         self.phat = [self.P // x for x in self.p]
         self.phat_invmp = [pow(self.phat[d] % self.p[d], self.p[d] - 2, self.p[d]) for d in range(self.dim)]
+        # (phat_d * phat_invmp_d) mod P: the first mpi_mulm of src/rns.c:60-75 depends on d only; kept per basis so that the
+        # full-size expectations (65,536 coefficients x 45 limbs) stay within a test's time
+        self.crt_coef = [(self.phat[d] * self.phat_invmp[d]) % self.P for d in range(self.dim)]
 
 
 def rns_decompose(a, p):
@@ -37,8 +40,7 @@ def rns_decompose(a, p):
 def rns_reconstruct(ahat_limbs, i, basis):
     acc = 0
     for d in range(basis.dim):
-        c = (basis.phat[d] * basis.phat_invmp[d]) % basis.P
-        acc = (acc + (int(ahat_limbs[d][i]) * c) % basis.P) % basis.P
+        acc = (acc + (int(ahat_limbs[d][i]) * basis.crt_coef[d]) % basis.P) % basis.P
     return acc
 
 

@@ -162,31 +162,24 @@ def test_largest_c_of_the_supported_chains(engine_ctx, oracle_ctx):
     assert np.array_equal(to_host(outs[0]), e0) and np.array_equal(to_host(outs[1]), e1) and np.array_equal(to_host(outs[2]), e2)
 
 
-@pytest.mark.parametrize("switch,value", [("GPQHE_NO_SPLIT", "1"), ("GPQHE_NO_WIDE", "1"), ("GPQHE_MID8", "0"), ("GPQHE_N17_LOW8", "1"),
-                                          ("GPQHE_NO_FUSED_POLYMUL", "1"), ("GPQHE_KS_PAIRS", "0")])
+@pytest.mark.parametrize("classes", [(0, 0), (0, 1 << 20), (3, 7)])
 @pytest.mark.parametrize("logn,dim", [(16, 58), (17, 57), (13, 20)])
-def test_kernel_families_agree_bit_for_bit(logn, dim, switch, value):
+def test_kernel_families_agree_bit_for_bit(logn, dim, classes):
     """The default contexts pick, per limb, the cheapest butterflies its c allows -- wide-split (c < 2^27: a conditional
     subtraction every other forward stage), split (5-mad multiply), plain (7-mad) -- so one transform at n = 2^17 runs all
-    three, and run the tensor stage on the 8-coefficients-per-lane kernel.  Each development switch removes one of these
-    choices at context creation (GPQHE_NO_SPLIT=1: 7-mad butterflies only; GPQHE_NO_WIDE=1: a subtraction in every stage;
-    GPQHE_MID8=0: the 16-per-lane tensor kernel; GPQHE_N17_LOW8=1: n = 2^17 as 9 strided + 8 low stages instead of 8 + 9;
-    GPQHE_NO_FUSED_POLYMUL=1: poly_mul's limb loop as four separate transforms and a pointwise product; GPQHE_KS_PAIRS=0: the key
-    switch one polynomial per workgroup instead of two).  Same slabs
-    through both contexts, whole he_mul core included: bit-identical."""
+    three.  gpq_set_limb_classes moves limbs to the more general classes: (0, 0) = 7-mad butterflies on every limb, (0, all) =
+    no wide-split ones (a subtraction in every stage), (3, 7) = all three classes inside one transform at every ring size.  Same
+    slabs through both settings, whole he_mul core and the poly_mul limb loop included: bit-identical."""
     import os
     import torch
     import gpqhe_amd
     gen = torch.Generator(device="cuda")
     gen.manual_seed(4242)
     outs = []
-    for setting in (None, value):
+    for setting in (None, classes):
+        g = gpqhe_amd.PolyContext(logn, dim)
         if setting is not None:
-            os.environ[switch] = setting
-        try:
-            g = gpqhe_amd.PolyContext(logn, dim)
-        finally:
-            os.environ.pop(switch, None)
+            g.set_limb_classes(*setting)
         if not outs:
             batch = 3
             slabs = []

@@ -3,10 +3,10 @@
 set -o pipefail
 mkdir -p gpurun_out; export TMPDIR=/tmp
 for v in 0 1; do
-  export GPQHE_NO_MFMA=$v
+  export GPQ_BRIDGE_VALU=$v
   rm -rf gpurun_out/prof_mpi$v
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_mpi$v -- python3 tools/mpi_profile.py > gpurun_out/prof_mpi$v.txt 2> gpurun_out/prof_mpi$v.err || { tail gpurun_out/prof_mpi$v.err; exit 1; }
-  echo "== GPQHE_NO_MFMA=$v"; cat gpurun_out/prof_mpi$v.txt
+  echo "== GPQ_BRIDGE_VALU=$v"; cat gpurun_out/prof_mpi$v.txt
   python3 - <<PY
 import csv,glob
 f=glob.glob('gpurun_out/prof_mpi$v/*/*kernel_stats.csv')[0]

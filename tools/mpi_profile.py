@@ -4,4 +4,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, gpqhe_amd
 from bench import he_mul_mpi_rate
 ctx = gpqhe_amd.PolyContext(16, 45)
+if os.environ.get("GPQ_BRIDGE_VALU") == "1":      # tool-side switch (tools/gpu_prof_mpi.sh): the library itself reads no environment
+    ctx.set_bridge_mfma(False)
 print(he_mul_mpi_rate(torch, gpqhe_amd, ctx, 16, iters=6))

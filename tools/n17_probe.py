@@ -1,4 +1,4 @@
-"""n = 2^17: NTT pair and he_mul tensor stage, per-kernel (dev tool).  GPQHE_N17_LOW8=1 selects the 9+8 split."""
+"""n = 2^17: NTT pair and he_mul tensor stage, per-kernel (dev tool)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, gpqhe_amd

@@ -1,4 +1,4 @@
-"""gpq_poly_mul_rns rate (dev tool).  GPQHE_NO_FUSED_POLYMUL=1 selects the four-transform form."""
+"""gpq_poly_mul_rns rate (dev tool)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, gpqhe_amd
