@@ -748,8 +748,10 @@ void shr1(Words &a) { for (size_t i = 0; i < a.size(); ++i) a[i] = (a[i] >> 1) |
 MPI mpi_of(const Words &w) {                       // a fresh libgcrypt integer with this value
   MPI r = G.mpi_new(0);
   if (w.empty()) { G.mpi_set_ui(r, 0); return r; }
+  Words padded = w;
+  padded.push_back(0);                                    // one more (zero) word: the value is non-negative
   poly_mpi_t one{&r};
-  from_slab(&one, w.data(), 1, (unsigned)w.size() + 1);   // one more (zero) word: the value is non-negative
+  from_slab(&one, padded.data(), 1, (unsigned)padded.size());
   return r;
 }
 uint64_t powm64(uint64_t b, uint64_t e, uint64_t m) {

@@ -68,7 +68,8 @@ static void ctx_init(unsigned logn, unsigned logq)         /* polyctx_init(logn,
   MPI q = pow2(logq);
   polyctx_init(logn, q);
   gcry_mpi_release(q);
-  if (polyctx.dimub != gpq_dimub(logn, logq) || !polyctx.rns || polyctx.rns->dim != 1 || !polyctx.rns->P || !polyctx.ring.cyc_group) {
+  /* dimub follows logqub: the security table for 10 <= logn <= 15, logq otherwise (src/precomp.c:338-340, :357) */
+  if (polyctx.dimub != gpq_dimub(logn, polyctx.logqub) || !polyctx.rns || polyctx.rns->dim != 1 || !polyctx.rns->P || !polyctx.ring.cyc_group) {
     fprintf(stderr, "polyctx_init left an incomplete context\n");
     exit(1);
   }
