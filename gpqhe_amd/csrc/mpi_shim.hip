@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <condition_variable>
 #include <functional>
 #include <map>
@@ -44,6 +45,7 @@ struct Gcry {
   int (*mpi_test_bit)(MPI, unsigned);
   unsigned (*mpi_print)(int, unsigned char *, size_t, size_t *, MPI);
   unsigned (*mpi_scan)(MPI *, int, const void *, size_t, size_t *);
+  void (*mpi_snatch)(MPI, MPI);
   void *(*xmalloc)(size_t);
   void (*xfree)(void *);
   bool ok = false;
@@ -74,6 +76,7 @@ void need_gcrypt() {
   G.mpi_test_bit = (int (*)(MPI, unsigned))get("gcry_mpi_test_bit");
   G.mpi_print = (unsigned (*)(int, unsigned char *, size_t, size_t *, MPI))get("gcry_mpi_print");
   G.mpi_scan = (unsigned (*)(MPI *, int, const void *, size_t, size_t *))get("gcry_mpi_scan");
+  G.mpi_snatch = (void (*)(MPI, MPI))get("gcry_mpi_snatch");
   G.xmalloc = (void *(*)(size_t))get("gcry_malloc");
   G.xfree = (void (*)(void *))get("gcry_free");
   G.ok = true;
@@ -94,11 +97,6 @@ bool is_pow2(const std::vector<uint64_t> &w) {
   unsigned ones = 0;
   for (uint64_t v : w) ones += __builtin_popcountll(v);
   return ones == 1;
-}
-unsigned max_bits(const poly_mpi_t *a, unsigned n) {
-  unsigned m = 0;
-  for (unsigned i = 0; i < n; ++i) { const unsigned b = G.mpi_get_nbits(a->coeffs[i]); if (b > m) m = b; }
-  return m;
 }
 
 // The conversions are per coefficient and independent (gcry_mpi_print only reads its MPI, gcry_mpi_scan / gcry_mpi_set write
@@ -171,16 +169,41 @@ void for_ranges(unsigned n, F f) {
   workers().run(nt, job);
 }
 
-// MPI coefficients -> host big slab [W][n], two's complement
+unsigned max_bits(const poly_mpi_t *a, unsigned n) {       // widest coefficient (the MPIs are scattered heap objects: worth the threads)
+  std::mutex mu;
+  unsigned m = 0;
+  for_ranges(n, [&](unsigned lo, unsigned hi) {
+    unsigned mine = 0;
+    for (unsigned i = lo; i < hi; ++i) { const unsigned b = G.mpi_get_nbits(a->coeffs[i]); if (b > mine) mine = b; }
+    std::lock_guard<std::mutex> lock(mu);
+    if (mine > m) m = mine;
+  });
+  return m;
+}
+
+// MPI coefficients -> host big slab [W][n], two's complement.  libgcrypt hands out / takes big-endian magnitude bytes; words are
+// assembled eight bytes at a time (the byte-at-a-time form cost as much as gcry_mpi_print itself).
 void to_slab_range(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W, unsigned lo, unsigned hi) {
-  std::vector<unsigned char> buf(8 * W);
+  unsigned char buf[8 * 64 + 8];
   for (unsigned i = lo; i < hi; ++i) {
     MPI v = a->coeffs[i];
     if (G.mpi_get_nbits(v) > 64 * W - 1) die("coefficient does not fit the big slab");
     size_t nw = 0;
-    if (G.mpi_print(FMT_USG, buf.data(), buf.size(), &nw, v)) die("gcry_mpi_print failed");
-    uint64_t w[64] = {0};
-    for (size_t b = 0; b < nw; ++b) w[(nw - 1 - b) >> 3] |= (uint64_t)buf[b] << (8 * ((nw - 1 - b) & 7));
+    if (G.mpi_print(FMT_USG, buf, 8 * W, &nw, v)) die("gcry_mpi_print failed");
+    uint64_t w[64];
+    const unsigned full = (unsigned)(nw >> 3), rest = (unsigned)(nw & 7);
+    for (unsigned j = 0; j < full; ++j) {                     // word j = bytes [nw - 8 (j + 1), nw - 8 j) of the big-endian string
+      uint64_t x;
+      memcpy(&x, buf + nw - 8 * (size_t)(j + 1), 8);
+      w[j] = __builtin_bswap64(x);
+    }
+    unsigned used = full;
+    if (rest) {
+      uint64_t x = 0;
+      for (unsigned k = 0; k < rest; ++k) x = (x << 8) | buf[k];
+      w[used++] = x;
+    }
+    for (unsigned j = used; j < W; ++j) w[j] = 0;
     if (G.mpi_is_neg(v)) {
       uint64_t carry = 1;
       for (unsigned j = 0; j < W; ++j) { w[j] = ~w[j] + carry; carry = carry && w[j] == 0; }
@@ -195,7 +218,7 @@ void to_slab(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W) {
 
 // host big slab -> existing MPIs (the caller allocated them, src/poly.c:46-51)
 void from_slab_range(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W, unsigned lo, unsigned hi) {
-  std::vector<unsigned char> buf(8 * W);
+  unsigned char buf[8 * 64];
   for (unsigned i = lo; i < hi; ++i) {
     uint64_t w[64];
     for (unsigned j = 0; j < W; ++j) w[j] = src[(size_t)j * n + i];
@@ -204,16 +227,18 @@ void from_slab_range(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W,
       uint64_t carry = 1;
       for (unsigned j = 0; j < W; ++j) { w[j] = ~w[j] + carry; carry = carry && w[j] == 0; }
     }
-    size_t len = 8 * W;
-    for (size_t b = 0; b < len; ++b) buf[b] = (unsigned char)(w[(len - 1 - b) >> 3] >> (8 * ((len - 1 - b) & 7)));
-    size_t skip = 0;
-    while (skip < len && buf[skip] == 0) ++skip;
-    if (skip == len) { G.mpi_set_ui(r->coeffs[i], 0); continue; }
+    unsigned top = W;                                         // words in use
+    while (top && w[top - 1] == 0) --top;
+    if (!top) { G.mpi_set_ui(r->coeffs[i], 0); continue; }
+    for (unsigned j = 0; j < top; ++j) {                      // big-endian bytes, most significant word first
+      const uint64_t x = __builtin_bswap64(w[top - 1 - j]);
+      memcpy(buf + 8 * (size_t)j, &x, 8);
+    }
+    const size_t len = 8 * (size_t)top, skip = (size_t)__builtin_clzll(w[top - 1]) >> 3;
     MPI t = nullptr;
-    if (G.mpi_scan(&t, FMT_USG, buf.data() + skip, len - skip, nullptr)) die("gcry_mpi_scan failed");
-    G.mpi_set(r->coeffs[i], t);
-    G.mpi_release(t);
-    if (neg) G.mpi_neg(r->coeffs[i], r->coeffs[i]);
+    if (G.mpi_scan(&t, FMT_USG, buf + skip, len - skip, nullptr)) die("gcry_mpi_scan failed");
+    if (neg) G.mpi_neg(t, t);
+    G.mpi_snatch(r->coeffs[i], t);                            // r->coeffs[i] takes t's limbs (no copy) and t is released
   }
 }
 void from_slab(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W) {
@@ -247,8 +272,9 @@ struct DevBuf {
   void *p = nullptr;
   size_t bytes;
   explicit DevBuf(size_t b) : bytes(b ? b : 8) {
-    auto it = g_pool.find(bytes);
-    if (it != g_pool.end() && !it->second.empty()) { p = it->second.back(); it->second.pop_back(); return; }
+    // the smallest kept buffer that is large enough (and not more than twice the request): slabs of 13 and 14 words share buffers
+    for (auto it = g_pool.lower_bound(bytes); it != g_pool.end() && it->first <= 2 * bytes; ++it)
+      if (!it->second.empty()) { p = it->second.back(); it->second.pop_back(); bytes = it->first; return; }
     if (gpq_malloc(&p, bytes) != GPQ_OK) die("device allocation failed");
   }
   ~DevBuf() { g_pool[bytes].push_back(p); }
@@ -269,8 +295,8 @@ struct HostBuf {
   void *p = nullptr;
   size_t bytes;
   explicit HostBuf(size_t b) : bytes(b ? b : 8) {
-    auto it = g_pinned.find(bytes);
-    if (it != g_pinned.end() && !it->second.empty()) { p = it->second.back(); it->second.pop_back(); return; }
+    for (auto it = g_pinned.lower_bound(bytes); it != g_pinned.end() && it->first <= 2 * bytes; ++it)
+      if (!it->second.empty()) { p = it->second.back(); it->second.pop_back(); bytes = it->first; return; }
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) die("page-locked allocation failed");
   }
   ~HostBuf() { g_pinned[bytes].push_back(p); }
@@ -329,6 +355,16 @@ void download_polys(poly_mpi_t *const dst[], const HostBuf *const stage[], const
     }
   };
   if (ranges < 2) job(0); else workers().run(ranges, job);
+}
+
+// Where the wall time of the last he_mul call went (gpq_mpi_shim_last_timing): conversions + uploads, kernels (HIP events),
+// downloads + conversions, whole call.
+double g_last_ms[4] = {0, 0, 0, 0};
+hipEvent_t g_tick[2] = {nullptr, nullptr};
+double wall_ms() {
+  timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
 }
 
 // Evaluation keys are 2 x dim x n words (47 MB at the headline shape) and the same key multiplies many ciphertexts: the device
@@ -484,16 +520,26 @@ void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t 
       ws(pow2 ? gpq_he_mul_workspace_bytes(c, W, dimA, dimB, dimP, 1) : gpq_he_general_workspace_bytes(c, W, dimA, dimB, dimP, 1));
   const DevBuf *dd[4] = {&d0, &d1, &d2, &d3}, *oo[2] = {&o0, &o1};
   const HostBuf *ss[4] = {&s0, &s1, &s2, &s3};
+  const double t0 = wall_ms();
   upload_polys(dd, ss, in, 4, n, W);
   uint64_t *k0, *k1;
   key_on_device(rlk, evk, &k0, &k1);
+  if (!g_tick[0]) { (void)hipEventCreate(&g_tick[0]); (void)hipEventCreate(&g_tick[1]); }
+  (void)hipEventRecord(g_tick[0], nullptr);
+  const double t1 = wall_ms();
   const int rc = pow2 ? gpq_he_mul(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), d2.u64(), d3.u64(), k0, k1, W, logql, dimA, dimB, dimP,
                                    1, ws.p, nullptr)
                       : gpq_he_mul_general(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), d2.u64(), d3.u64(), k0, k1, W, qw.data(),
                                            (unsigned)qw.size(), dimA, dimB, dimP, 1, ws.p, nullptr);
   if (rc != GPQ_OK) die("he_mul failed");
+  (void)hipEventRecord(g_tick[1], nullptr);
+  const double t2 = wall_ms();
   poly_mpi_t *out[2] = {&ct->c0, &ct->c1};
   download_polys(out, ss, oo, 2, n, W);
+  const double t3 = wall_ms();
+  float dev_ms = 0;
+  (void)hipEventElapsedTime(&dev_ms, g_tick[0], g_tick[1]);
+  g_last_ms[0] = t1 - t0; g_last_ms[1] = dev_ms; g_last_ms[2] = t3 - t2; g_last_ms[3] = t3 - t0;
   ct->l = l; ct->nu = nu; ct->B = B;                                                           // :92-95
 }
 
@@ -682,6 +728,10 @@ void he_genrk(he_evk_t *rk, const poly_mpi_t *sk) {                             
   for (unsigned rot = 0; rot < hectx.slots; ++rot) genswk(&rk[rot], permuted(hs, W, false, rot), hs, W);
   printf("done.\n");
 }
+
+// wall milliseconds of the last he_mul(he_ct_t*, ...) call: [0] MPI -> slab conversions and uploads, [1] device kernels,
+// [2] downloads and slab -> MPI conversions (includes waiting for [1]), [3] the whole call
+void gpq_mpi_shim_last_timing(double ms[4]) { for (int i = 0; i < 4; ++i) ms[i] = g_last_ms[i]; }
 
 // frees the device buffers the MPI-typed calls keep between calls, and the engine context
 void gpq_mpi_shim_release(void) {

@@ -161,6 +161,9 @@ void gpq_release_rns_chain(struct rns_ctx *nodes);
 void gpq_dropin_set_logn(unsigned int logn);
 /* Releases the device tables the drop-in calls cached (per rns_ctx). */
 void gpq_dropin_reset(void);
+/* Wall milliseconds of the last he_mul(he_ct_t *, ...) call: [0] MPI -> slab conversions + uploads, [1] device kernels (HIP
+ * events), [2] downloads + slab -> MPI conversions (includes waiting for [1]), [3] the whole call. */
+void gpq_mpi_shim_last_timing(double ms[4]);
 /* Releases the device buffers and the engine context the MPI-typed calls keep between calls. */
 void gpq_mpi_shim_release(void);
 

@@ -372,10 +372,14 @@ static int hemultime(unsigned logn, unsigned logq)
   const double t0 = now_ms();
   for (int i = 0; i < 3; i++) he_mul(&ct, &ct1, &ct2, &rlk);
   const double dt = (now_ms() - t0) / 3;
+  double part[4];
+  gpq_mpi_shim_last_timing(part);
+  ct.l = hectx.L; he_rescale(&ct);                            /* first call at this shape allocates the staging buffers */
   const double t1 = now_ms();
   for (int i = 0; i < 3; i++) { ct.l = hectx.L; he_rescale(&ct); }
   const double dr = (now_ms() - t1) / 3;
   printf("he_mul(MPI) n=2^%u logq=%u dims %u/%u: %.1f ms per call; he_rescale %.1f ms\n", logn, logq, hectx.dim, hectx.dimevk, dt, dr);
+  printf("  last he_mul: convert+upload %.2f ms, kernels %.2f ms, download+convert %.2f ms, call %.2f ms\n", part[0], part[1], part[2], part[3]);
   return 0;
 }
 
