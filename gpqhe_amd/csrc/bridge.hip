@@ -814,16 +814,26 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
     uint64_t *h[4] = {sA, sA + pa, sA + 2 * pa, sA + 3 * pa};
     uint64_t *d0h = sA + 4 * pa, *d1h = sA + 5 * pa, *d2h = sA + 6 * pa;
     const uint64_t *in[4] = {ct1c0, ct1c1, ct2c0, ct2c1};
-    for (int i = 0; i < 4; ++i)                                                             // :117-120
-      if ((rc = launch_decompose(c, h[i], in[i] + k0 * bigpoly, W, 0, dimA, polys, s))) return rc;
+    {
+      StageRange stage("gpq_he_mul: rns_decompose x4");
+      for (int i = 0; i < 4; ++i)                                                           // :117-120
+        if ((rc = launch_decompose(c, h[i], in[i] + k0 * bigpoly, W, 0, dimA, polys, s))) return rc;
+    }
     if ((rc = gpq_he_mul_tensor(c, d0h, d1h, d2h, h[0], h[1], h[2], h[3], dimA, polys, wsT, stream))) return rc;  // :121-136
     uint64_t *d0 = dbig, *d1 = dbig + polys * bigpoly, *d2 = dbig + 2 * polys * bigpoly;
     // poly_rns2mpi of d0, d2, d1 (:139-141): the three slabs are adjacent on both sides, one launch
-    if ((rc = launch_reconstruct(c, bA, d0, W, d0h, dimA, 0, 3 * polys, logql, true, nullptr, s))) return rc;
+    {
+      StageRange stage("gpq_he_mul: poly_rns2mpi d0,d1,d2 (CRT)");
+      if ((rc = launch_reconstruct(c, bA, d0, W, d0h, dimA, 0, 3 * polys, logql, true, nullptr, s))) return rc;
+    }
     // he_relin, :40-85
     uint64_t *d2hat = sB, *c0hat = sB + pb, *c1hat = sB + 2 * pb;
-    if ((rc = launch_decompose(c, d2hat, d2, W, 0, dimB, polys, s))) return rc;                                    // :59
+    {
+      StageRange stage("gpq_he_mul: he_relin rns_decompose d2");
+      if ((rc = launch_decompose(c, d2hat, d2, W, 0, dimB, polys, s))) return rc;                                  // :59
+    }
     if ((rc = gpq_keyswitch(c, c0hat, c1hat, d2hat, rlk0, rlk1, dimB, polys, wsK, stream))) return rc;             // :60-64
+    StageRange stage("gpq_he_mul: he_relin tail (CRT, exact division by P, + d)");
     if ((rc = relin_tail(c, out_c0 + k0 * bigpoly, c0hat, d0, W, dimP, dimB, logql, polys, wsTail, s))) return rc; // :67-77
     if ((rc = relin_tail(c, out_c1 + k0 * bigpoly, c1hat, d1, W, dimP, dimB, logql, polys, wsTail, s))) return rc;
   }

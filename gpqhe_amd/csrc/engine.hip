@@ -28,6 +28,40 @@ int gpq_fail(int code, const char *fmt, ...) {
 }
 extern "C" const char *gpq_last_error(void) { return g_err; }
 
+// ---------------------------------------------------------------------------
+// roctx ranges (engine_internal.hpp)
+// ---------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <atomic>
+namespace {
+typedef int (*roctx_push_t)(const char *);
+typedef int (*roctx_pop_t)(void);
+std::atomic<int> g_roctx_state{0};        // 0 = not looked up, 1 = available, 2 = absent
+roctx_push_t g_roctx_push = nullptr;
+roctx_pop_t g_roctx_pop = nullptr;
+bool roctx_ready() {
+  int st = g_roctx_state.load(std::memory_order_acquire);
+  if (st == 0) {
+    void *h = RTLD_DEFAULT;
+    void *push = dlsym(h, "roctxRangePushA");
+    for (const char *lib : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4"}) {
+      if (push) break;
+      // only a library that is ALREADY in the process (a profiler loaded it): never pull a tracing runtime in ourselves
+      if ((h = dlopen(lib, RTLD_NOW | RTLD_NOLOAD))) push = dlsym(h, "roctxRangePushA");
+    }
+    if (push) {
+      g_roctx_push = (roctx_push_t)push;
+      g_roctx_pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+    }
+    st = (g_roctx_push && g_roctx_pop) ? 1 : 2;
+    g_roctx_state.store(st, std::memory_order_release);
+  }
+  return st == 1;
+}
+}  // namespace
+void gpq_range_push(const char *name) { if (roctx_ready()) (void)g_roctx_push(name); }
+void gpq_range_pop() { if (roctx_ready()) (void)g_roctx_pop(); }
+
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
     hipError_t e_ = (expr);                                                                \
@@ -459,6 +493,7 @@ int inverse_slabs(const gpq_ctx *c, PassArgs a, unsigned dim, unsigned polys, hi
 extern "C" int gpq_ntt(gpq_ctx *c, uint64_t *slab, unsigned dim, unsigned batch, void *stream) {
   int rc = check_shape(c, dim, batch, "gpq_ntt");
   if (rc) return rc;
+  StageRange stage("gpq_ntt");
   if (!slab) return gpq_fail(GPQ_ERR_INVALID, "gpq_ntt: null slab");
   for (unsigned k0 = 0; k0 < batch; k0 += kMaxPolysPerLaunch) {
     const unsigned polys = batch - k0 < kMaxPolysPerLaunch ? batch - k0 : kMaxPolysPerLaunch;
@@ -472,6 +507,7 @@ extern "C" int gpq_ntt(gpq_ctx *c, uint64_t *slab, unsigned dim, unsigned batch,
 extern "C" int gpq_invntt(gpq_ctx *c, uint64_t *slab, unsigned dim, unsigned batch, void *stream) {
   int rc = check_shape(c, dim, batch, "gpq_invntt");
   if (rc) return rc;
+  StageRange stage("gpq_invntt");
   if (!slab) return gpq_fail(GPQ_ERR_INVALID, "gpq_invntt: null slab");
   for (unsigned k0 = 0; k0 < batch; k0 += kMaxPolysPerLaunch) {
     const unsigned polys = batch - k0 < kMaxPolysPerLaunch ? batch - k0 : kMaxPolysPerLaunch;
@@ -637,6 +673,7 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
       const unsigned limbs = dim - l0 < lblock ? dim - l0 : lblock;
       const size_t loff = (size_t)l0 << c->logn;
       // 1. strided forward pass, inputs -> workspace
+      StageRange stage("gpq_he_mul_tensor: strided fwd x4 / tensor_mid8 / strided inv x3");
       PassArgs f = make_args(c, dim, 4);
       f.limb0 = l0;
       for (int i = 0; i < 4; ++i) { f.src[i] = in[i] + k0 * poly + loff; f.dst[i] = ws + (size_t)i * chunk * poly + loff; }
@@ -691,6 +728,7 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
     for (unsigned l0 = 0; l0 < dim; l0 += lblock) {       // launch groups as in gpq_he_mul_tensor
       const unsigned limbs = dim - l0 < lblock ? dim - l0 : lblock;
       const size_t loff = (size_t)l0 << c->logn;
+      StageRange stage("gpq_keyswitch: strided fwd / keyswitch_mid8x2 / strided inv x2");
       PassArgs f = make_args(c, dim, 1);
       f.limb0 = l0;
       f.src[0] = x + k0 * poly + loff; f.dst[0] = ws + loff;

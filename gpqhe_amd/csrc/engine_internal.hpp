@@ -87,5 +87,17 @@ struct DeviceScope {
   ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// roctx range around a stage of the path (tracing).  The marker library is looked up at run time
+// (librocprofiler-sdk-roctx / libroctx64, normally brought in by rocprofv3 --marker-trace); without it a range costs one
+// pointer test.  Host-side ranges: they bracket the LAUNCHES of a stage, the kernels themselves appear in the kernel trace.
+void gpq_range_push(const char *name);
+void gpq_range_pop();
+struct StageRange {
+  explicit StageRange(const char *name) { gpq_range_push(name); }
+  ~StageRange() { gpq_range_pop(); }
+  StageRange(const StageRange &) = delete;
+  StageRange &operator=(const StageRange &) = delete;
+};
+
 int gpq_fail(int code, const char *fmt, ...);
 void gpq_bridge_release(gpq_ctx *c);
