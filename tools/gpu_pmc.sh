@@ -26,7 +26,7 @@ for k,v in out.items():
     res[k]['launches']=max(v[c] for c in v if c.startswith('_n_'))
 res["_chunk"]=16
 import os
-res["_head"]=open("gpurun_out/.head").read().strip() if os.path.exists("gpurun_out/.head") else None
+res["_head"]=open("tools/.head").read().strip() if os.path.exists("tools/.head") else None
 res["_command"]="python3 bench.py --steps 1 --warmup 1 --batch 16 --cpu-sample 0 --no-ntt (one rocprofv3 --pmc pass per counter group)"
 json.dump(res, open('gpurun_out/pmc_summary.json','w'), indent=1)
 for k,v in res.items():
