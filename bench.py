@@ -86,6 +86,40 @@ def pmc_traffic(kernel, chunk):
     return None, src
 
 
+def valu_issue(value_per_gpu, sclk_mhz):
+    """How close the he_mul core runs to the integer-VALU issue rate -- the bound that actually binds it: VALU
+    wave-instructions per he_mul from the committed PMC pass (SQ_INSTS_VALU summed over the four kernels of the core, counted at
+    a group size of `_chunk` ciphertexts) against the SIMD cycles one he_mul takes at the measured shader clock.  3.9 cycles per
+    instruction is what this instruction mix (24 % v_mad_u64_u32) needs when nothing else is in the way
+    (profiles/r01/v10_probes.txt: the kernels timed with their arithmetic only)."""
+    import glob
+    import re
+    def order(path):
+        m = re.search(r"r(\d+)[/\\]v(\d+)_", path)
+        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json")), key=order)
+    if not files or not sclk_mhz:
+        return None
+    try:
+        data = json.load(open(files[-1]))
+        per_group = 0.0
+        for name, v in data.items():
+            if name.startswith("_"):
+                continue
+            launches_per_group = 2 if "strided_pass" in name else 1      # a strided pass runs once for the tensor stage and once for the key switch
+            per_group += v["SQ_INSTS_VALU"] * launches_per_group
+        insts = per_group / data.get("_chunk", 16)
+    except (OSError, ValueError, KeyError) as exc:
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+    simds = 256 * 4
+    cycles = sclk_mhz * 1e6 / value_per_gpu                                # SIMD cycles one he_mul occupies the chip for
+    cpi = cycles * simds / insts
+    return {"valu_wave_insts_per_he_mul": int(insts), "source": os.path.relpath(files[-1], ROOT), "profiled_head": data.get("_head"),
+            "simds": simds, "sclk_MHz": sclk_mhz, "cycles_per_valu_inst": round(cpi, 3), "issue_bound_cycles_per_valu_inst": 3.9,
+            "frac_of_valu_issue_rate": round(3.9 / cpi, 3),
+            "note": "the core is bound by integer-VALU issue at the power-capped clock, not by HBM; `roofline` above prices the same run against HBM"}
+
+
 def power_state(torch, step, seconds=2.5):
     """Shader clock and package power while the hot loop runs (rocm-smi polled during an extra, untimed stretch of steps):
     on this part the loop sits at the package power cap, which is what sets its clock.  None if rocm-smi is unavailable."""
@@ -448,6 +482,9 @@ def main(argv=None):
             pw = power_state(torch, step)
             if pw is not None:
                 out["power"] = pw
+                vi = valu_issue(value / world, pw["sclk_MHz"])
+                if vi is not None:
+                    out["valu_issue"] = vi
             # NTT GB/s at the headline ring (n=2^16, 30 limbs) and at BASELINE configs[1] (n=2^15, 10 limbs)
             out["ntt"] = [ntt_rate(torch, gpqhe_amd, 16, DIM_A, B), ntt_rate(torch, gpqhe_amd, 15, 10, 64)]
             del a0, a1, b0, b1, x, d0, d1, d2, c0, c1, wsA, wsB
