@@ -31,220 +31,11 @@ extern "C" struct he_ctx hectx __attribute__((weak));       // src/precomp.c:47
 extern "C" void sample_error(poly_mpi_t *r) __attribute__((weak));
 extern "C" void sample_uniform(poly_mpi_t *r, const gpq_MPI q) __attribute__((weak));
 
+#include "mpi_convert.hpp"
+
 namespace {
 
-typedef void *MPI;
-struct Gcry {
-  MPI (*mpi_new)(unsigned);
-  void (*mpi_release)(MPI);
-  MPI (*mpi_set)(MPI, MPI);
-  MPI (*mpi_set_ui)(MPI, unsigned long);
-  void (*mpi_neg)(MPI, MPI);
-  int (*mpi_is_neg)(MPI);
-  unsigned (*mpi_get_nbits)(MPI);
-  int (*mpi_test_bit)(MPI, unsigned);
-  unsigned (*mpi_print)(int, unsigned char *, size_t, size_t *, MPI);
-  unsigned (*mpi_scan)(MPI *, int, const void *, size_t, size_t *);
-  void (*mpi_snatch)(MPI, MPI);
-  void *(*xmalloc)(size_t);
-  void (*xfree)(void *);
-  bool ok = false;
-} G;
-const int FMT_USG = 5;  // GCRYMPI_FMT_USG: unsigned big-endian magnitude
-
-[[noreturn]] void die(const char *what) {
-  errno = EINVAL;  // the reference's error convention (src/reduce.c:95-100, src/precomp.c:344-350)
-  fprintf(stderr, "\033[1m\033[31merror:\033[0m \033[1m%s\033[0m. %s (%s)\n", strerror(errno), what, gpq_last_error());
-  abort();
-}
-
-void need_gcrypt() {
-  if (G.ok) return;
-  void *h = RTLD_DEFAULT;
-  if (!dlsym(h, "gcry_mpi_print")) {
-    h = dlopen("libgcrypt.so.20", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) die("libgcrypt is not loaded and libgcrypt.so.20 cannot be opened");
-  }
-  auto get = [&](const char *n) { void *p = dlsym(h, n); if (!p) die(n); return p; };
-  G.mpi_new = (MPI(*)(unsigned))get("gcry_mpi_new");
-  G.mpi_release = (void (*)(MPI))get("gcry_mpi_release");
-  G.mpi_set = (MPI(*)(MPI, MPI))get("gcry_mpi_set");
-  G.mpi_set_ui = (MPI(*)(MPI, unsigned long))get("gcry_mpi_set_ui");
-  G.mpi_neg = (void (*)(MPI, MPI))get("gcry_mpi_neg");
-  G.mpi_is_neg = (int (*)(MPI))get("gcry_mpi_is_neg");
-  G.mpi_get_nbits = (unsigned (*)(MPI))get("gcry_mpi_get_nbits");
-  G.mpi_test_bit = (int (*)(MPI, unsigned))get("gcry_mpi_test_bit");
-  G.mpi_print = (unsigned (*)(int, unsigned char *, size_t, size_t *, MPI))get("gcry_mpi_print");
-  G.mpi_scan = (unsigned (*)(MPI *, int, const void *, size_t, size_t *))get("gcry_mpi_scan");
-  G.mpi_snatch = (void (*)(MPI, MPI))get("gcry_mpi_snatch");
-  G.xmalloc = (void *(*)(size_t))get("gcry_malloc");
-  G.xfree = (void (*)(void *))get("gcry_free");
-  G.ok = true;
-}
-
-// magnitude of a positive MPI as little-endian words
-std::vector<uint64_t> words_of(MPI q, const char *what) {
-  const unsigned nb = G.mpi_get_nbits(q);
-  if (!nb || G.mpi_is_neg(q)) die(what);
-  std::vector<unsigned char> buf((nb + 7) / 8);
-  size_t nw = 0;
-  if (G.mpi_print(FMT_USG, buf.data(), buf.size(), &nw, q)) die("gcry_mpi_print failed");
-  std::vector<uint64_t> w((nb + 63) / 64, 0);
-  for (size_t b = 0; b < nw; ++b) w[(nw - 1 - b) >> 3] |= (uint64_t)buf[b] << (8 * ((nw - 1 - b) & 7));
-  return w;
-}
-bool is_pow2(const std::vector<uint64_t> &w) {
-  unsigned ones = 0;
-  for (uint64_t v : w) ones += __builtin_popcountll(v);
-  return ones == 1;
-}
-
-// The conversions are per coefficient and independent (gcry_mpi_print only reads its MPI, gcry_mpi_scan / gcry_mpi_set write
-// the caller's own, distinct MPIs), so large polynomials are cut into ranges for a few host threads: at n = 2^16 the MPI <-> slab
-// conversions are 40 ms of a 42 ms he_mul call on one thread.  The threads are started once and kept (starting 16 threads four
-// times per call cost more than the device work of the call).
-class Workers {
-  std::vector<std::thread> th_;
-  std::mutex mu_;
-  std::condition_variable wake_, idle_;
-  const std::function<void(unsigned)> *job_ = nullptr;
-  unsigned tasks_ = 0, next_ = 0, open_ = 0;
-  uint64_t round_ = 0;
-
-  void drain(std::unique_lock<std::mutex> &lk) {       // run tasks of the current round until none is left to take
-    while (next_ < tasks_) {
-      const unsigned t = next_++;
-      const std::function<void(unsigned)> *job = job_;
-      lk.unlock();
-      (*job)(t);
-      lk.lock();
-      if (--open_ == 0) idle_.notify_all();
-    }
-  }
-  void loop() {
-    std::unique_lock<std::mutex> lk(mu_);
-    uint64_t seen = 0;
-    for (;;) {
-      wake_.wait(lk, [&] { return round_ != seen; });
-      seen = round_;
-      drain(lk);
-    }
-  }
-
- public:
-  explicit Workers(unsigned helpers) {
-    for (unsigned i = 0; i < helpers; ++i) { th_.emplace_back([this] { loop(); }); th_.back().detach(); }
-  }
-  unsigned width() const { return (unsigned)th_.size() + 1; }
-  void run(unsigned tasks, const std::function<void(unsigned)> &f) {     // the caller works too; returns when every task is done
-    std::unique_lock<std::mutex> lk(mu_);
-    job_ = &f; tasks_ = tasks; next_ = 0; open_ = tasks; ++round_;
-    wake_.notify_all();
-    drain(lk);
-    idle_.wait(lk, [&] { return open_ == 0; });
-    job_ = nullptr; tasks_ = 0;
-  }
-};
-Workers &workers() {       // never destroyed: its threads wait detached and vanish with the process
-  static Workers *w = [] {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt > 16) nt = 16;
-    if (nt < 1) nt = 1;
-    return new Workers(nt - 1);
-  }();
-  return *w;
-}
 int g_dev = 0;             // device of the engine context: HIP's current device is per thread, the workers set it for their copies
-
-// f(task, lo, hi) over [0, n) cut into ranges; small polynomials stay on the calling thread
-template <typename F>
-void for_ranges(unsigned n, F f) {
-  const unsigned nt = n >= 4096 ? workers().width() : 1;
-  if (nt < 2) { f(0u, n); return; }
-  const unsigned per = (n + nt - 1) / nt;
-  const std::function<void(unsigned)> job = [&](unsigned t) {
-    const unsigned lo = t * per, hi = lo + per < n ? lo + per : n;
-    if (lo < hi) f(lo, hi);
-  };
-  workers().run(nt, job);
-}
-
-unsigned max_bits(const poly_mpi_t *a, unsigned n) {       // widest coefficient (the MPIs are scattered heap objects: worth the threads)
-  std::mutex mu;
-  unsigned m = 0;
-  for_ranges(n, [&](unsigned lo, unsigned hi) {
-    unsigned mine = 0;
-    for (unsigned i = lo; i < hi; ++i) { const unsigned b = G.mpi_get_nbits(a->coeffs[i]); if (b > mine) mine = b; }
-    std::lock_guard<std::mutex> lock(mu);
-    if (mine > m) m = mine;
-  });
-  return m;
-}
-
-// MPI coefficients -> host big slab [W][n], two's complement.  libgcrypt hands out / takes big-endian magnitude bytes; words are
-// assembled eight bytes at a time (the byte-at-a-time form cost as much as gcry_mpi_print itself).
-void to_slab_range(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W, unsigned lo, unsigned hi) {
-  unsigned char buf[8 * 64 + 8];
-  for (unsigned i = lo; i < hi; ++i) {
-    MPI v = a->coeffs[i];
-    if (G.mpi_get_nbits(v) > 64 * W - 1) die("coefficient does not fit the big slab");
-    size_t nw = 0;
-    if (G.mpi_print(FMT_USG, buf, 8 * W, &nw, v)) die("gcry_mpi_print failed");
-    uint64_t w[64];
-    const unsigned full = (unsigned)(nw >> 3), rest = (unsigned)(nw & 7);
-    for (unsigned j = 0; j < full; ++j) {                     // word j = bytes [nw - 8 (j + 1), nw - 8 j) of the big-endian string
-      uint64_t x;
-      memcpy(&x, buf + nw - 8 * (size_t)(j + 1), 8);
-      w[j] = __builtin_bswap64(x);
-    }
-    unsigned used = full;
-    if (rest) {
-      uint64_t x = 0;
-      for (unsigned k = 0; k < rest; ++k) x = (x << 8) | buf[k];
-      w[used++] = x;
-    }
-    for (unsigned j = used; j < W; ++j) w[j] = 0;
-    if (G.mpi_is_neg(v)) {
-      uint64_t carry = 1;
-      for (unsigned j = 0; j < W; ++j) { w[j] = ~w[j] + carry; carry = carry && w[j] == 0; }
-    }
-    for (unsigned j = 0; j < W; ++j) dst[(size_t)j * n + i] = w[j];
-  }
-}
-void to_slab(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W) {
-  if (W < 1 || W > 32) die("coefficients wider than 2047 bits");      // the device kernels hold at most 32 words; w[64] below is sized for that
-  for_ranges(n, [=](unsigned lo, unsigned hi) { to_slab_range(dst, a, n, W, lo, hi); });
-}
-
-// host big slab -> existing MPIs (the caller allocated them, src/poly.c:46-51)
-void from_slab_range(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W, unsigned lo, unsigned hi) {
-  unsigned char buf[8 * 64];
-  for (unsigned i = lo; i < hi; ++i) {
-    uint64_t w[64];
-    for (unsigned j = 0; j < W; ++j) w[j] = src[(size_t)j * n + i];
-    const bool neg = w[W - 1] >> 63;
-    if (neg) {
-      uint64_t carry = 1;
-      for (unsigned j = 0; j < W; ++j) { w[j] = ~w[j] + carry; carry = carry && w[j] == 0; }
-    }
-    unsigned top = W;                                         // words in use
-    while (top && w[top - 1] == 0) --top;
-    if (!top) { G.mpi_set_ui(r->coeffs[i], 0); continue; }
-    for (unsigned j = 0; j < top; ++j) {                      // big-endian bytes, most significant word first
-      const uint64_t x = __builtin_bswap64(w[top - 1 - j]);
-      memcpy(buf + 8 * (size_t)j, &x, 8);
-    }
-    const size_t len = 8 * (size_t)top, skip = (size_t)__builtin_clzll(w[top - 1]) >> 3;
-    MPI t = nullptr;
-    if (G.mpi_scan(&t, FMT_USG, buf + skip, len - skip, nullptr)) die("gcry_mpi_scan failed");
-    if (neg) G.mpi_neg(t, t);
-    G.mpi_snatch(r->coeffs[i], t);                            // r->coeffs[i] takes t's limbs (no copy) and t is released
-  }
-}
-void from_slab(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W) {
-  if (W < 1 || W > 64) die("big slab wider than 64 words");
-  for_ranges(n, [=](unsigned lo, unsigned hi) { from_slab_range(r, src, n, W, lo, hi); });
-}
 
 // one engine context per (logn, chain length), checked against the caller's prime list
 gpq_ctx *g_engine = nullptr;
@@ -765,50 +556,6 @@ void he_moddown(he_ct_t *ct) { rescale_common(ct, false); }       // src/he-resc
 // kemctx / bootstrapctx belong to the KEM and the bootstrapping skeleton (out of scope) and are not defined.
 // ======================================================================================================================
 namespace {
-
-typedef std::vector<uint64_t> Words;   // non-negative integer, little-endian 64-bit words, no leading zero word (0 = empty)
-typedef unsigned __int128 u128s;
-
-void trim(Words &a) { while (!a.empty() && a.back() == 0) a.pop_back(); }
-void mul_word(Words &a, uint64_t m) {
-  uint64_t carry = 0;
-  for (uint64_t &w : a) { const u128s t = (u128s)w * m + carry; w = (uint64_t)t; carry = (uint64_t)(t >> 64); }
-  if (carry) a.push_back(carry);
-  trim(a);
-}
-uint64_t divmod_word(Words &a, uint64_t d) {      // a <- floor(a / d), returns a mod d
-  uint64_t rem = 0;
-  for (size_t i = a.size(); i-- > 0;) { const u128s t = ((u128s)rem << 64) | a[i]; a[i] = (uint64_t)(t / d); rem = (uint64_t)(t % d); }
-  trim(a);
-  return rem;
-}
-Words mul_words(const Words &a, const Words &b) {
-  Words r(a.size() + b.size() + 1, 0);
-  for (size_t i = 0; i < a.size(); ++i) {
-    uint64_t carry = 0;
-    for (size_t j = 0; j < b.size(); ++j) { const u128s t = (u128s)a[i] * b[j] + r[i + j] + carry; r[i + j] = (uint64_t)t; carry = (uint64_t)(t >> 64); }
-    r[i + b.size()] += carry;
-  }
-  trim(r);
-  return r;
-}
-unsigned bits_of(const Words &a) { return a.empty() ? 0 : 64 * (unsigned)(a.size() - 1) + (64 - (unsigned)__builtin_clzll(a.back())); }
-void shr1(Words &a) { for (size_t i = 0; i < a.size(); ++i) a[i] = (a[i] >> 1) | (i + 1 < a.size() ? a[i + 1] << 63 : 0); trim(a); }
-
-MPI mpi_of(const Words &w) {                       // a fresh libgcrypt integer with this value
-  MPI r = G.mpi_new(0);
-  if (w.empty()) { G.mpi_set_ui(r, 0); return r; }
-  Words padded = w;
-  padded.push_back(0);                                    // one more (zero) word: the value is non-negative
-  poly_mpi_t one{&r};
-  from_slab(&one, padded.data(), 1, (unsigned)padded.size());
-  return r;
-}
-uint64_t powm64(uint64_t b, uint64_t e, uint64_t m) {
-  uint64_t r = 1;
-  for (b %= m; e; e >>= 1) { if (e & 1) r = (uint64_t)((u128s)r * b % m); b = (uint64_t)((u128s)b * b % m); }
-  return r;
-}
 
 // logqub of the homomorphic-encryption standard for 128-bit classical security (the reference's build: GPQHE_CQ 'C',
 // GPQHE_SEC_LEVEL 128, src/params.h:39-46; table src/precomp.c:53-64); 0 outside 10..15
