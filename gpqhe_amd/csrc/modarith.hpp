@@ -49,6 +49,14 @@ __device__ __forceinline__ uint64_t mad_u64(uint32_t a, uint32_t b, uint64_t acc
   return (uint64_t)a * b + acc;  // v_mad_u64_u32
 }
 __device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+// ~x & 0x7ffffff in ONE instruction (v_bitop3_b32, truth table 0x0c = ~a & b).  Written as plain C the compiler emits
+// v_and + v_xor with two 32-bit literals inside the big kernels (VOP3 takes no literal and it would not spend an SGPR on
+// the mask): one VALU instruction of 21.5 per butterfly, -3 % on tensor_mid8 and +1.7 % he_mul/s in an interleaved A/B
+// (profiles/r02/v6_instruction_trims_ab.txt).  The same table shows what did NOT pay: forming the carry word {x >> 32, 0} of
+// a column sum with one v_pk_mov_b32 (op_sel picks the high dword, the inline constant 0 the other half) instead of the two
+// v_mov the middle kernels spend on it removes another 2-5 % of their VALU instructions and makes them 3 % SLOWER: the packed
+// move issues like a 64-bit operation.
+__device__ __forceinline__ uint32_t not_low27(uint32_t x) { return __builtin_amdgcn_bitop3_b32(x, 0x7ffffffu, x, 0x0c); }
 
 // Core of the modular multiply: returns T' with  a*w == T' + (c+1)  (mod p).
 //   x = a*w by 32-bit pieces (a < 2^62.1, w < 2^60: the middle column cannot overflow),
@@ -74,7 +82,7 @@ __device__ __forceinline__ uint64_t mulmod_raw_t(uint64_t a, uint64_t w, const P
   const uint64_t t1 = mad_u64(k.c, xh1, (uint32_t)(t0 >> 32)); // t = t1 : lo32(t0)
   const uint32_t t1lo = (uint32_t)t1, t1hi = (uint32_t)(t1 >> 32);
   const uint32_t th = __builtin_amdgcn_alignbit(t1hi, t1lo, 27);
-  const uint64_t ntl = pack64(~(uint32_t)t0, ~t1lo & 0x7ffffffu);  // 2^59 - 1 - tl
+  const uint64_t ntl = pack64(~(uint32_t)t0, not_low27(t1lo));  // 2^59 - 1 - tl
   return mad_u64(k.c, th, xl) + ntl;
 }
 
@@ -156,7 +164,7 @@ __device__ __forceinline__ uint64_t mulmod_split(uint64_t a, const W &w, const P
   t1 = mad_u64(ah, (uint32_t)(w.y >> 32), t1);                 // sum >> 32, < 0.75p
   const uint32_t t1lo = (uint32_t)t1, t1hi = (uint32_t)(t1 >> 32);
   const uint32_t th = __builtin_amdgcn_alignbit(t1hi, t1lo, 27);
-  const uint64_t ntl = pack64(~(uint32_t)t0, ~t1lo & 0x7ffffffu);  // 2^59 - 1 - tl
+  const uint64_t ntl = pack64(~(uint32_t)t0, not_low27(t1lo));  // 2^59 - 1 - tl
   return mad_u64(k.c, th, ntl);
 }
 
