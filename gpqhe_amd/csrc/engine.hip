@@ -190,6 +190,7 @@ static int upload_tables(gpq_ctx *c) {
     t.k.p = p; t.k.p2 = 2 * p; t.k.p4 = 4 * p; t.k.c = (uint32_t)(p - (1ull << 59)); t.k.c1 = t.k.c + 1;
     t.k.kx0 = t.k.c1; t.k.kx1 = (uint64_t)t.k.c1 - 4 * p; t.k.ky = 4 * p - 2 * (uint64_t)t.k.c1;
     t.k.kx1s = (uint64_t)t.k.c1 - 2 * p; t.k.kys = 2 * p - 2 * (uint64_t)t.k.c1;
+    t.k.np = (uint64_t)0 - p; t.k.np2 = (uint64_t)0 - 2 * p; t.k.np4 = (uint64_t)0 - 4 * p;
     t.ninv = from_mont(c->ninv_mont[d]);
     t.winv1_ninv = n >= 2 ? mulm(wistd[d * n + 1], t.ninv, p) : t.ninv;
     t.ninv_s = t.winv1_ninv_s = TwS{0, 0};

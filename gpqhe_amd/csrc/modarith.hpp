@@ -41,6 +41,7 @@ struct PrimeK {        // per-limb constants handed to kernels (uniform per bloc
   uint64_t kx0, kx1;   // c+1 and c+1-4p (mod 2^64): the two addends of the CT x-leg select
   uint64_t ky;         // 4p - 2(c+1)
   uint64_t kx1s, kys;  // split-twiddle butterflies (data < 4p): c+1-2p (mod 2^64) and 2p - 2(c+1)
+  uint64_t np, np2, np4;  // -p, -2p, -4p (mod 2^64): a conditional subtraction is an ADD of one of these or of zero (csub1/2/4)
   uint32_t c;          // p - 2^59
   uint32_t c1;         // c + 1
 };
@@ -99,19 +100,21 @@ __device__ __forceinline__ uint64_t mulmod_lazy(uint64_t a, uint64_t w, const Pr
   return mulmod_raw(a, w, k) + k.c1;
 }
 
-// x - m if x >= m else x
-__device__ __forceinline__ uint64_t csub(uint64_t x, uint64_t m) {
-  const uint64_t d = x - m;
-  return x >= m ? d : x;
-}
+// x - m if x >= m else x, for m = p, 2p, 4p: compare, select the addend (-m or 0), one 64-bit add = 4 VALU instructions.
+// Written as `x >= m ? x - m : x` (or with `0 - m` the compiler can see through) it becomes compare, select, v_sub_co,
+// v_subb_co: 5 instructions and a carry hazard.  The negated moduli come from the table so that they stay opaque.
+__device__ __forceinline__ uint64_t csub_by(uint64_t x, uint64_t m, uint64_t neg_m) { return x + (x >= m ? neg_m : (uint64_t)0); }
+__device__ __forceinline__ uint64_t csub1(uint64_t x, const PrimeK &k) { return csub_by(x, k.p, k.np); }
+__device__ __forceinline__ uint64_t csub2(uint64_t x, const PrimeK &k) { return csub_by(x, k.p2, k.np2); }
+__device__ __forceinline__ uint64_t csub4(uint64_t x, const PrimeK &k) { return csub_by(x, k.p4, k.np4); }
 
 // value < 8p -> [0,p)
 __device__ __forceinline__ uint64_t canon8(uint64_t x, const PrimeK &k) {
-  return csub(csub(csub(x, k.p4), k.p2), k.p);
+  return csub1(csub2(csub4(x, k), k), k);
 }
 // value < 4p -> [0,p)
 __device__ __forceinline__ uint64_t canon4(uint64_t x, const PrimeK &k) {
-  return csub(csub(x, k.p2), k.p);
+  return csub1(csub2(x, k), k);
 }
 
 // Cooley-Tukey butterfly of src/ntt.c:45-49 in lazy form.
@@ -130,7 +133,7 @@ __device__ __forceinline__ void ct_bfly(uint64_t &x, uint64_t &y, uint64_t w, co
 __device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, uint64_t w, const PrimeK &k) {
   const uint64_t v = x + y;
   const uint64_t d = x + k.p4 - y;  // (0, 8p)
-  x = v + (v >= k.p4 ? (uint64_t)0 - k.p4 : (uint64_t)0);
+  x = csub4(v, k);
   y = mulmod_raw_t<GPQ_PIN_GS>(d, w, k) + k.c1;
 }
 
@@ -180,7 +183,7 @@ template <typename W>
 __device__ __forceinline__ void gs_bfly_split(uint64_t &x, uint64_t &y, const W &w, const PrimeK &k) {
   const uint64_t v = x + y;
   const uint64_t d = x + k.p2 - y;  // (0, 4p)
-  x = v + (v >= k.p2 ? (uint64_t)0 - k.p2 : (uint64_t)0);
+  x = csub2(v, k);
   y = mulmod_split(d, w, k) + k.c1;
 }
 __device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, const TwS &w, const PrimeK &k) { gs_bfly_split(x, y, w, k); }
@@ -223,7 +226,7 @@ __device__ __forceinline__ uint64_t mulmod_canon_lazy(uint64_t a, uint64_t b, co
 }
 // Exact a+b mod p for canonical a,b (poly_rns_add, src/poly.c:71-76).
 __device__ __forceinline__ uint64_t addmod_canon(uint64_t a, uint64_t b, const PrimeK &k) {
-  return csub(a + b, k.p);
+  return csub1(a + b, k);
 }
 
 }  // namespace gpq

@@ -128,8 +128,8 @@ __device__ __forceinline__ void gs_last(uint64_t &x, uint64_t &y, const LastK<ui
 __device__ __forceinline__ void gs_last(uint64_t &x, uint64_t &y, const LastK<TwS> &t, const PrimeK &k) {   // in: x,y < 2p
   const uint64_t s = x + y;                 // < 4p
   const uint64_t d = x + k.p2 - y;          // (0, 4p)
-  x = csub(mulmod_split(s, t.ninv, k) + k.c1, k.p);
-  y = csub(mulmod_split(d, t.winv1_ninv, k) + k.c1, k.p);
+  x = csub1(mulmod_split(s, t.ninv, k) + k.c1, k);
+  y = csub1(mulmod_split(d, t.winv1_ninv, k) + k.c1, k);
 }
 
 // Per twiddle type: the table pointers of a launch and the lazy ranges the butterflies keep.
@@ -140,18 +140,18 @@ template <> struct TwTraits<uint64_t> {
   __device__ static __forceinline__ uint64_t canon_inv(uint64_t x, const PrimeK &k) { return canon4(x, k); }   // inverse data < 4p
   // into the inverse range from a value < 4p / < 8p
   __device__ static __forceinline__ uint64_t inv_from4(uint64_t x, const PrimeK &) { return x; }
-  __device__ static __forceinline__ uint64_t inv_from8(uint64_t x, const PrimeK &k) { return csub(x, k.p4); }
+  __device__ static __forceinline__ uint64_t inv_from8(uint64_t x, const PrimeK &k) { return csub4(x, k); }
   // a forward-range value as the left (< 2p) / right (< 4p) operand of a variable*variable mulmod_lazy
-  __device__ static __forceinline__ uint64_t left(uint64_t x, const PrimeK &k) { return csub(csub(x, k.p4), k.p2); }
-  __device__ static __forceinline__ uint64_t right(uint64_t x, const PrimeK &k) { return csub(x, k.p4); }
+  __device__ static __forceinline__ uint64_t left(uint64_t x, const PrimeK &k) { return csub2(csub4(x, k), k); }
+  __device__ static __forceinline__ uint64_t right(uint64_t x, const PrimeK &k) { return csub4(x, k); }
 };
 template <> struct TwTraits<TwS> {
   __device__ static __forceinline__ const TwS *table(const PassArgs &a, bool inv) { return inv ? a.winvs : a.ws; }
   __device__ static __forceinline__ uint64_t canon_fwd(uint64_t x, const PrimeK &k) { return canon4(x, k); }   // forward data < 4p
-  __device__ static __forceinline__ uint64_t canon_inv(uint64_t x, const PrimeK &k) { return csub(x, k.p); }   // inverse data < 2p
-  __device__ static __forceinline__ uint64_t inv_from4(uint64_t x, const PrimeK &k) { return csub(x, k.p2); }
-  __device__ static __forceinline__ uint64_t inv_from8(uint64_t x, const PrimeK &k) { return csub(csub(x, k.p4), k.p2); }
-  __device__ static __forceinline__ uint64_t left(uint64_t x, const PrimeK &k) { return csub(x, k.p2); }
+  __device__ static __forceinline__ uint64_t canon_inv(uint64_t x, const PrimeK &k) { return csub1(x, k); }   // inverse data < 2p
+  __device__ static __forceinline__ uint64_t inv_from4(uint64_t x, const PrimeK &k) { return csub2(x, k); }
+  __device__ static __forceinline__ uint64_t inv_from8(uint64_t x, const PrimeK &k) { return csub2(csub4(x, k), k); }
+  __device__ static __forceinline__ uint64_t left(uint64_t x, const PrimeK &k) { return csub2(x, k); }
   __device__ static __forceinline__ uint64_t right(uint64_t x, const PrimeK &) { return x; }
 };
 
@@ -165,11 +165,11 @@ __device__ __forceinline__ void gs_last(uint64_t &x, uint64_t &y, const LastK<Tw
 template <> struct TwTraits<TwW> {
   __device__ static __forceinline__ const TwW *table(const PassArgs &a, bool inv) { return reinterpret_cast<const TwW *>(inv ? a.winvs : a.ws); }
   __device__ static __forceinline__ uint64_t canon_fwd(uint64_t x, const PrimeK &k) { return canon_fold(x, k.p, k.c); }
-  __device__ static __forceinline__ uint64_t canon_inv(uint64_t x, const PrimeK &k) { return csub(x, k.p); }
-  __device__ static __forceinline__ uint64_t inv_from4(uint64_t x, const PrimeK &k) { return csub(x, k.p2); }
-  __device__ static __forceinline__ uint64_t inv_from8(uint64_t x, const PrimeK &k) { return csub(csub(x, k.p4), k.p2); }
+  __device__ static __forceinline__ uint64_t canon_inv(uint64_t x, const PrimeK &k) { return csub1(x, k); }
+  __device__ static __forceinline__ uint64_t inv_from4(uint64_t x, const PrimeK &k) { return csub2(x, k); }
+  __device__ static __forceinline__ uint64_t inv_from8(uint64_t x, const PrimeK &k) { return csub2(csub4(x, k), k); }
   // products (mulmod_lazy wants a*b < 2^122.8): left < 4p, right < 6p as it comes: 24 p^2 = 2^122.6
-  __device__ static __forceinline__ uint64_t left(uint64_t x, const PrimeK &k) { return csub(x, k.p4); }
+  __device__ static __forceinline__ uint64_t left(uint64_t x, const PrimeK &k) { return csub4(x, k); }
   __device__ static __forceinline__ uint64_t right(uint64_t x, const PrimeK &) { return x; }
 };
 
