@@ -89,9 +89,10 @@ def pmc_traffic(kernel, chunk):
 def valu_issue(value_per_gpu, sclk_mhz):
     """How close the he_mul core runs to the integer-VALU issue rate -- the bound that actually binds it: VALU
     wave-instructions per he_mul from the committed PMC pass (SQ_INSTS_VALU summed over the four kernels of the core, counted at
-    a group size of `_chunk` ciphertexts) against the SIMD cycles one he_mul takes at the measured shader clock.  3.9 cycles per
-    instruction is what this instruction mix (24 % v_mad_u64_u32) needs when nothing else is in the way
-    (profiles/r01/v10_probes.txt: the kernels timed with their arithmetic only)."""
+    a group size of `_chunk` ciphertexts) against the SIMD cycles one he_mul takes at the measured shader clock.  3.95 cycles per
+    instruction is what this instruction mix (25 % v_mad_u64_u32, 18 % 64-bit adds) needs when nothing else is in the way: 3.9 by
+    the arithmetic-only probes of profiles/r01/v10_probes.txt for round 1's 71.0 M instructions, of which round 2 removed 4.9 M
+    cheap ones."""
     import glob
     import re
     def order(path):
@@ -115,8 +116,8 @@ def valu_issue(value_per_gpu, sclk_mhz):
     cycles = sclk_mhz * 1e6 / value_per_gpu                                # SIMD cycles one he_mul occupies the chip for
     cpi = cycles * simds / insts
     return {"valu_wave_insts_per_he_mul": int(insts), "source": os.path.relpath(files[-1], ROOT), "profiled_head": data.get("_head"),
-            "simds": simds, "sclk_MHz": sclk_mhz, "cycles_per_valu_inst": round(cpi, 3), "issue_bound_cycles_per_valu_inst": 3.9,
-            "frac_of_valu_issue_rate": round(3.9 / cpi, 3),
+            "simds": simds, "sclk_MHz": sclk_mhz, "cycles_per_valu_inst": round(cpi, 3), "issue_bound_cycles_per_valu_inst": 3.95,
+            "frac_of_valu_issue_rate": round(3.95 / cpi, 3),
             "note": "the core is bound by integer-VALU issue at the power-capped clock, not by HBM; `roofline` above prices the same run against HBM"}
 
 
