@@ -420,7 +420,8 @@ int launch_strided_t(const PassArgs &a, unsigned gy, unsigned gz, hipStream_t s)
 // strided pass over `polys` polynomials of each of a.nslab slabs, all `dim` limbs
 template <bool INV>
 int launch_strided(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigned polys, hipStream_t s) {
-  return for_limb_ranges<!INV>(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
+  // (forward and inverse passes of a limb must use the same class: the wide class keeps other lazy ranges between kernels)
+  return for_limb_ranges<true>(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
     using TW = decltype(tag);
     ProfScope prof(c, INV ? GPQ_K_STRIDED_INV : GPQ_K_STRIDED_FWD, s);
     switch (c->logn) {
@@ -438,7 +439,7 @@ int launch_strided(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigne
 template <bool INV>
 int launch_contig(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigned polys, hipStream_t s) {
   if (args.nslab != 1) return gpq_fail(GPQ_ERR_INVALID, "contig_pass walks one slab");
-  return for_limb_ranges<!INV>(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
+  return for_limb_ranges<true>(c, args, dim, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned limbs) {
     using TW = decltype(tag);
     ProfScope prof(c, INV ? GPQ_K_CONTIG_INV : GPQ_K_CONTIG_FWD, s);
     if (c->low9) {

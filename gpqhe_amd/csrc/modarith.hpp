@@ -187,7 +187,23 @@ __device__ __forceinline__ void gs_bfly_split(uint64_t &x, uint64_t &y, const W 
   y = mulmod_split(d, w, k) + k.c1;
 }
 __device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, const TwS &w, const PrimeK &k) { gs_bfly_split(x, y, w, k); }
-__device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, const TwW &w, const PrimeK &k) { gs_bfly_split(x, y, w, k); }
+
+// Gentleman-Sande for the wide class (c < GPQ_WIDE_CMAX): inverse data lives in [0, 4p) instead of [0, 2p).
+//   v = x + y < 8p;   d = x + 4p - y in (0, 8p): a legal multiplicand (8p - 1 = 2^62 + 8c - 1 <= 2^62 + 2^31 - 2 for c < 2^27),
+//   so the product leg y' = T' + (c+1) < 2p as in ct_bfly_wide;   sum leg x' = v - [v >= 4p] 4p < 4p.
+// What the wider range buys: a butterfly whose two inputs are BOTH product legs of the stage before (each < 2p) has
+// v < 4p already and needs no conditional subtraction (CSUB = false).  Inside a register group that is known at compile time
+// -- the pair (e, e + 2^B) of stage B shares bit B-1, and bit B-1 set means "product leg of the previous stage" -- so half
+// of the butterflies of every stage but a group's first drop their compare / select / add (a quarter of a GS butterfly's
+// issue cost).  The products of the fused kernels enter at < 4p without any subtraction either.
+template <bool CSUB>
+__device__ __forceinline__ void gs_bfly_wide(uint64_t &x, uint64_t &y, const TwW &w, const PrimeK &k) {
+  const uint64_t v = x + y;
+  const uint64_t d = x + k.p4 - y;
+  x = CSUB ? csub4(v, k) : v;
+  y = mulmod_split(d, w, k) + k.c1;
+}
+__device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, const TwW &w, const PrimeK &k) { gs_bfly_wide<true>(x, y, w, k); }
 
 // Cooley-Tukey, split twiddle, one conditional subtraction per TWO stages (c < GPQ_WIDE_CMAX <= 2^27).
 // The split multiply only needs th < 2^32, i.e. al + ah <= 2^32 - 2, which holds for every multiplicand

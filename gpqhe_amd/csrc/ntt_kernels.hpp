@@ -91,18 +91,31 @@ __device__ __forceinline__ void ct_group(uint64_t (&x)[1 << EL], const TW (&tw)[
   ct_bits<EL, BHI, BHI, BLO, RS>(x, tw, k);
 }
 
-// Inverse: stages run from bit BLO up to BHI; tw[] is laid out as load_tw fills it (BHI first).
-template <int EL, int BHI, int B, int NTW, typename TW>
+// One inverse butterfly; BOTH_PRODUCT_LEGS = its two inputs are product legs of the previous stage of the same register
+// group (only the wide class makes use of it: gs_bfly_wide).
+template <bool BOTH_PRODUCT_LEGS, typename TW>
+__device__ __forceinline__ void gs_stage(uint64_t &x, uint64_t &y, const TW &w, const PrimeK &k) { gs_bfly(x, y, w, k); }
+template <bool BOTH_PRODUCT_LEGS>
+__device__ __forceinline__ void gs_stage(uint64_t &x, uint64_t &y, const TwW &w, const PrimeK &k) { gs_bfly_wide<!BOTH_PRODUCT_LEGS>(x, y, w, k); }
+
+// Inverse: stages run from bit BLO up to BHI; tw[] is laid out as load_tw fills it (BHI first).  FIRST = the stage on the
+// group's lowest bit, whose inputs come from outside the group (any leg).
+template <int EL, int BHI, int B, bool FIRST, int NTW, typename TW>
 __device__ __forceinline__ void gs_bits(uint64_t (&x)[1 << EL], const TW (&tw)[NTW], const PrimeK &k) {
 #pragma unroll
   for (int e = 0; e < (1 << EL); ++e)
-    if (!(e & (1 << B))) gs_bfly(x[e], x[e + (1 << B)], tw[tw_off(EL, BHI, B) + (e >> (B + 1))], k);
-  if constexpr (B < BHI) gs_bits<EL, BHI, B + 1>(x, tw, k);
+    if (!(e & (1 << B))) {
+      const TW &w = tw[tw_off(EL, BHI, B) + (e >> (B + 1))];
+      // e is a constant after unrolling: the pair (e, e + 2^B) shares bit B-1, set = both came out of a multiplication
+      if (!FIRST && B > 0 && ((e >> (B > 0 ? B - 1 : 0)) & 1)) gs_stage<true>(x[e], x[e + (1 << B)], w, k);
+      else gs_stage<false>(x[e], x[e + (1 << B)], w, k);
+    }
+  if constexpr (B < BHI) gs_bits<EL, BHI, B + 1, false>(x, tw, k);
 }
 template <int EL, int BHI, int BLO, typename TW>
 __device__ __forceinline__ void gs_group(uint64_t (&x)[1 << EL], const TW (&tw)[tw_count(EL, BHI, BLO)],
                                          const PrimeK &k) {
-  gs_bits<EL, BHI, BLO>(x, tw, k);
+  gs_bits<EL, BHI, BLO, true>(x, tw, k);
 }
 
 // Last inverse stage (len = n/2, twiddle winv[1]) with the n^-1 scaling of
@@ -155,19 +168,22 @@ template <> struct TwTraits<TwS> {
   __device__ static __forceinline__ uint64_t right(uint64_t x, const PrimeK &) { return x; }
 };
 
-template <> struct LastK<TwW> : LastK<TwS> {      // (the inverse passes of wide limbs run as TwS; this only has to compile)
+template <> struct LastK<TwW> : LastK<TwS> {      // the same two constants as the split class
   __device__ __forceinline__ explicit LastK(const LimbTab &t) : LastK<TwS>(t) {}
 };
-__device__ __forceinline__ void gs_last(uint64_t &x, uint64_t &y, const LastK<TwW> &t, const PrimeK &k) {
-  gs_last(x, y, static_cast<const LastK<TwS> &>(t), k);
+__device__ __forceinline__ void gs_last(uint64_t &x, uint64_t &y, const LastK<TwW> &t, const PrimeK &k) {   // in: x,y < 4p
+  const uint64_t s = x + y;                 // < 8p: a legal multiplicand for the wide class (gs_bfly_wide)
+  const uint64_t d = x + k.p4 - y;          // (0, 8p)
+  x = csub1(mulmod_split(s, t.ninv, k) + k.c1, k);
+  y = csub1(mulmod_split(d, t.winv1_ninv, k) + k.c1, k);
 }
-// Wide-split limbs: forward data < 6p after a finished transform (< 8p inside one), inverse side exactly as TwS.
+// Wide-split limbs: forward data < 6p after a finished transform (< 8p inside one), inverse data < 4p (gs_bfly_wide).
 template <> struct TwTraits<TwW> {
   __device__ static __forceinline__ const TwW *table(const PassArgs &a, bool inv) { return reinterpret_cast<const TwW *>(inv ? a.winvs : a.ws); }
   __device__ static __forceinline__ uint64_t canon_fwd(uint64_t x, const PrimeK &k) { return canon_fold(x, k.p, k.c); }
-  __device__ static __forceinline__ uint64_t canon_inv(uint64_t x, const PrimeK &k) { return csub1(x, k); }
-  __device__ static __forceinline__ uint64_t inv_from4(uint64_t x, const PrimeK &k) { return csub2(x, k); }
-  __device__ static __forceinline__ uint64_t inv_from8(uint64_t x, const PrimeK &k) { return csub2(csub4(x, k), k); }
+  __device__ static __forceinline__ uint64_t canon_inv(uint64_t x, const PrimeK &k) { return canon4(x, k); }   // inverse data < 4p
+  __device__ static __forceinline__ uint64_t inv_from4(uint64_t x, const PrimeK &) { return x; }                  // a product (< 4p) enters the inverse stages as it is
+  __device__ static __forceinline__ uint64_t inv_from8(uint64_t x, const PrimeK &k) { return csub4(x, k); }
   // products (mulmod_lazy wants a*b < 2^122.8): left < 4p, right < 6p as it comes: 24 p^2 = 2^122.6
   __device__ static __forceinline__ uint64_t left(uint64_t x, const PrimeK &k) { return csub4(x, k); }
   __device__ static __forceinline__ uint64_t right(uint64_t x, const PrimeK &) { return x; }

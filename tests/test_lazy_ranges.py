@@ -88,3 +88,36 @@ def test_product_operands_of_the_wide_class_fit_the_general_multiply():
     assert (t >> 59) < (1 << 32)
     tprime = (x & ((1 << 59) - 1)) + c * (t >> 59) + ((1 << 59) - 1 - (t & ((1 << 59) - 1)))
     assert tprime + c + 1 < 4 * p and (tprime + c + 1) % p == x % p
+
+
+@pytest.mark.parametrize("c", [4849665, 113508353, WIDE_CMAX - 1])
+def test_wide_gs_stage_ranges_close(c):
+    """gs_bfly_wide: inverse data of the wide class lives in [0, 4p).  v = x + y < 8p; d = x + 4p - y is a legal multiplicand
+    (8p - 1 <= 2^62 + 2^31 - 2); the product leg comes out below 2p, the sum leg below 4p after ONE conditional subtraction of
+    4p -- and needs none when both inputs are product legs of the stage before (< 2p each): the case the kernels skip statically.
+    gs_last takes the same ranges to canonical outputs."""
+    p = (1 << 59) + c
+    c1 = c + 1
+    assert 8 * p - 1 <= (1 << 62) + (1 << 31) - 2
+    rnd = random.Random(c + 1)
+    edge = [0, 1, p - 1, p, 2 * p - 1, 2 * p, 4 * p - 1, 4 * p - 2, (1 << 61) - 1, 1 << 61]
+    for _ in range(4000):
+        w = rnd.choice([1, 2, p - 1, rnd.randrange(1, p)])
+        wx, wy = pairs(p, w)
+        for both_product_legs in (False, True):
+            lim = 2 * p if both_product_legs else 4 * p
+            x = rnd.choice(edge + [rnd.randrange(lim)]) % lim
+            y = rnd.choice(edge + [rnd.randrange(lim)]) % lim
+            v, d = x + y, x + 4 * p - y
+            assert 0 < d < 8 * p and d <= M64
+            x2 = v if both_product_legs else (v - 4 * p if v >= 4 * p else v)
+            y2 = mulmod_split(d, wx, wy, c) + c1
+            assert x2 < 4 * p and x2 % p == (x + y) % p
+            assert y2 < 2 * p and y2 % p == (x - y) * w % p
+        # last stage with the n^-1 scaling folded in: both legs are multiplied, then one subtraction of p
+        x, y = rnd.randrange(4 * p), rnd.randrange(4 * p)
+        for val, arg in ((x + y, (x + y)), (x - y, x + 4 * p - y)):
+            t = mulmod_split(arg, wx, wy, c) + c1
+            assert t < 2 * p
+            r = t - p if t >= p else t
+            assert r == val * w % p
