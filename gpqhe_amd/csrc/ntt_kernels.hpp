@@ -72,6 +72,9 @@ __device__ __forceinline__ void load_tw(TW (&tw)[tw_count(EL, BHI, BLO)], unsign
 }
 
 // One forward butterfly of the stage on index bit S (len = 2^S).  Only the wide-split butterflies care about S.
+// (Leaving out the even stage's conditional subtraction among a transform's first two stages -- canonical inputs never
+// trigger it -- was measured: -2 % instructions in the forward strided pass, no change in its time: that pass waits on
+// memory, profiles/r02/v6_instruction_trims_ab.txt.)
 template <int S, typename TW>
 __device__ __forceinline__ void ct_stage(uint64_t &x, uint64_t &y, const TW &w, const PrimeK &k) { ct_bfly(x, y, w, k); }
 template <int S>
@@ -98,24 +101,26 @@ __device__ __forceinline__ void gs_stage(uint64_t &x, uint64_t &y, const TW &w, 
 template <bool BOTH_PRODUCT_LEGS>
 __device__ __forceinline__ void gs_stage(uint64_t &x, uint64_t &y, const TwW &w, const PrimeK &k) { gs_bfly_wide<!BOTH_PRODUCT_LEGS>(x, y, w, k); }
 
-// Inverse: stages run from bit BLO up to BHI; tw[] is laid out as load_tw fills it (BHI first).  FIRST = the stage on the
-// group's lowest bit, whose inputs come from outside the group (any leg).
-template <int EL, int BHI, int B, bool FIRST, int NTW, typename TW>
+// Inverse: stages run from bit BLO up to BHI; tw[] is laid out as load_tw fills it (BHI first).  NTH = how many stages of
+// the group ran before this one (0: inputs come from outside the group, any leg).  CANON_IN = the group holds a transform's
+// FIRST stages and its inputs are canonical (< p): the first stage leaves everything < 2p, the second < 4p, so for the wide
+// class neither needs a conditional subtraction at all.
+template <int EL, int BHI, int B, int NTH, bool CANON_IN, int NTW, typename TW>
 __device__ __forceinline__ void gs_bits(uint64_t (&x)[1 << EL], const TW (&tw)[NTW], const PrimeK &k) {
 #pragma unroll
   for (int e = 0; e < (1 << EL); ++e)
     if (!(e & (1 << B))) {
       const TW &w = tw[tw_off(EL, BHI, B) + (e >> (B + 1))];
       // e is a constant after unrolling: the pair (e, e + 2^B) shares bit B-1, set = both came out of a multiplication
-      if (!FIRST && B > 0 && ((e >> (B > 0 ? B - 1 : 0)) & 1)) gs_stage<true>(x[e], x[e + (1 << B)], w, k);
+      if ((CANON_IN && NTH < 2) || (NTH > 0 && B > 0 && ((e >> (B > 0 ? B - 1 : 0)) & 1))) gs_stage<true>(x[e], x[e + (1 << B)], w, k);
       else gs_stage<false>(x[e], x[e + (1 << B)], w, k);
     }
-  if constexpr (B < BHI) gs_bits<EL, BHI, B + 1, false>(x, tw, k);
+  if constexpr (B < BHI) gs_bits<EL, BHI, B + 1, NTH + 1, CANON_IN>(x, tw, k);
 }
-template <int EL, int BHI, int BLO, typename TW>
+template <int EL, int BHI, int BLO, bool CANON_IN = false, typename TW>
 __device__ __forceinline__ void gs_group(uint64_t (&x)[1 << EL], const TW (&tw)[tw_count(EL, BHI, BLO)],
                                          const PrimeK &k) {
-  gs_bits<EL, BHI, BLO, true>(x, tw, k);
+  gs_bits<EL, BHI, BLO, 0, CANON_IN>(x, tw, k);
 }
 
 // Last inverse stage (len = n/2, twiddle winv[1]) with the n^-1 scaling of
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTI
         for (int e = 0; e < 16; ++e) x[e] = TT::canon_fwd(x[e], k);
       } else {
         ln.h_to_l(x);
-        gs_group<4, 3, 0>(x, twl.t, k);
+        gs_group<4, 3, 0, true>(x, twl.t, k);      // gpq_invntt's first stages: canonical inputs
         ln.l_to_h(x);
         gs_group<4, 3, 0>(x, twh.t, k);
       }
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTI
       for (int j = 0; j < CONTIG_POLYS; ++j)
         if (j < (int)cnt) {
           ln.h_to_l(x[j]);
-          gs_group<4, 3, 0>(x[j], tw.t, k);
+          gs_group<4, 3, 0, true>(x[j], tw.t, k);      // gpq_invntt's first stages: canonical inputs
           ln.l_to_h(x[j]);
         }
       tw.load_h(ln, wave0, a.logn, wt);
@@ -610,6 +615,8 @@ struct Lane8 {
   template <typename TW> __device__ static __forceinline__ void ct_l(uint64_t (&x)[8], const TW (&u)[tw_count(3, LHI, 0)], const PrimeK &k) { ct_group<3, LHI, 0, 0>(x, u, k); }
   template <typename TW> __device__ static __forceinline__ void gs_hm(uint64_t (&x)[8], const TW (&t)[7], const PrimeK &k) { gs_group<3, 2, 0>(x, t, k); }
   template <typename TW> __device__ static __forceinline__ void gs_l(uint64_t (&x)[8], const TW (&u)[tw_count(3, LHI, 0)], const PrimeK &k) { gs_group<3, LHI, 0>(x, u, k); }
+  // ... the same group when it opens a standalone inverse transform (canonical inputs)
+  template <typename TW> __device__ static __forceinline__ void gs_l_canon(uint64_t (&x)[8], const TW (&u)[tw_count(3, LHI, 0)], const PrimeK &k) { gs_group<3, LHI, 0, true>(x, u, k); }
 };
 
 // twiddles of one group of one direction: 7 for H and M, 6 or 7 for L
@@ -893,7 +900,7 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 4) void contig_pass8(PassArgs a,
   } else {
     tw.load_l(ln, wave0, a.logn, wt);
 #pragma unroll
-    for (int j = 0; j < CONTIG8_POLYS; ++j) if (j < (int)cnt) { ln.h_to_l(x[j]); L8::gs_l(x[j], tw.u, k); }
+    for (int j = 0; j < CONTIG8_POLYS; ++j) if (j < (int)cnt) { ln.h_to_l(x[j]); L8::gs_l_canon(x[j], tw.u, k); }
     tw.load_m(ln, wave0, a.logn, wt);
 #pragma unroll
     for (int j = 0; j < CONTIG8_POLYS; ++j) if (j < (int)cnt) { ln.l_to_m(x[j]); L8::gs_hm(x[j], tw.t, k); }
