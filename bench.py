@@ -277,7 +277,7 @@ ROCPROF_NAMES = {   # how rocprofv3 names the kernels of the default n = 2^16 pa
     "tensor_mid": "gpq::tensor_mid8<gpq::TwW, 8>",
     "keyswitch_mid": "gpq::keyswitch_mid8x2<gpq::TwW, 8>",
     "strided_fwd": "gpq::strided_pass<8, 4, false, false, gpq::TwW, 8>",
-    "strided_inv": "gpq::strided_pass<8, 4, true, false, HIP_vector_type<unsigned long long, 2u>, 8>",
+    "strided_inv": "gpq::strided_pass<8, 4, true, false, gpq::TwW, 8>",
 }
 
 
@@ -431,8 +431,10 @@ def main(argv=None):
     if rank == 0:
         total_he_mul = total_batch * args.steps
         value = total_he_mul / dt
-        # dominant kernel by accumulated device time
-        kname, (kms, kcnt) = max(prof.items(), key=lambda kv: kv[1][0])
+        # Dominant kernel by accumulated device time.  tensor_mid8 (10 launches) and the inverse strided pass (20 launches: it runs for
+        # both stages) are within a few per cent of each other, and which one leads changes with the device: among the kernels within
+        # 5 % of the largest share the one with the LOWER fraction of the roofline is reported (the conservative reading, and the same
+        # kernel from run to run); `kernels` carries the rate of every kernel either way.
         # strided kernels run for both stages: average units per launch from the launch mix
         chunk = min(B, args.chunk or 32)
         lb = args.limb_block or 0
@@ -440,6 +442,9 @@ def main(argv=None):
         units = {"tensor_mid": la * chunk, "keyswitch_mid": lbb * chunk,
                  "strided_fwd": (4 * DIM_A + 1 * DIM_B) * chunk / (DIM_A / la + DIM_B / lbb),
                  "strided_inv": (3 * DIM_A + 2 * DIM_B) * chunk / (DIM_A / la + DIM_B / lbb)}
+        top = max(v[0] for v in prof.values())
+        kname, (kms, kcnt) = min(((n, v) for n, v in prof.items() if v[0] >= 0.95 * top),
+                                 key=lambda nv: KERNEL_LIMB_PASSES[nv[0]] * units[nv[0]] / (nv[1][0] / nv[1][1]))
         kernels = {}
         for name, (ms, cnt) in prof.items():
             avg_ms = ms / cnt
