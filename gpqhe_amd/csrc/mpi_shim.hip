@@ -524,6 +524,15 @@ void he_genrk(he_evk_t *rk, const poly_mpi_t *sk) {                             
 // [2] downloads and slab -> MPI conversions (includes waiting for [1]), [3] the whole call
 void gpq_mpi_shim_last_timing(double ms[4]) { for (int i = 0; i < 4; ++i) ms[i] = g_last_ms[i]; }
 
+// Drops the device copies of evaluation keys (he_mul / he_rot / he_conj keep up to six, recognised by the caller's pointers, the
+// length and a fingerprint of ~1000 sampled words).  A program that rewrites a key IN PLACE in a way the samples may miss calls
+// this after the rewrite; freeing or regenerating a key through he_gen*k changes the fingerprint anyway.
+void gpq_mpi_shim_forget_keys(void) {
+  (void)gpq_stream_sync(nullptr);
+  for (KeySlot &k : g_keys) { (void)gpq_free(k.d0); (void)gpq_free(k.d1); }
+  g_keys.clear();
+}
+
 // frees the device buffers the MPI-typed calls keep between calls, and the engine context
 void gpq_mpi_shim_release(void) {
   (void)gpq_stream_sync(nullptr);

@@ -164,6 +164,9 @@ void gpq_dropin_reset(void);
 /* Wall milliseconds of the last he_mul(he_ct_t *, ...) call: [0] MPI -> slab conversions + uploads, [1] device kernels (HIP
  * events), [2] downloads + slab -> MPI conversions (includes waiting for [1]), [3] the whole call. */
 void gpq_mpi_shim_last_timing(double ms[4]);
+/* Drops the device copies of evaluation keys the MPI-typed calls keep (recognised by pointers, length and a fingerprint of sampled
+ * words): call after rewriting a key in place. */
+void gpq_mpi_shim_forget_keys(void);
 /* Releases the device buffers and the engine context the MPI-typed calls keep between calls. */
 void gpq_mpi_shim_release(void);
 

@@ -40,6 +40,7 @@ unsigned int gcry_mpi_scan(MPI *ret, int format, const void *buffer, size_t bufl
 unsigned int gcry_mpi_aprint(int format, unsigned char **buffer, size_t *nwritten, const MPI a);
 void gcry_free(void *p);
 void gcry_mpi_mod(MPI r, MPI dividend, MPI divisor);
+int gcry_mpi_cmp(const MPI u, const MPI v);
 #define FMT_HEX 4
 
 /* `polyctx`, `hectx`, polyctx_init, hectx_init, poly_mpi_alloc come from libgpqhe_hip.so (weak definitions, gpqhe_hip_compat.h):
@@ -369,6 +370,24 @@ static int hemultime(unsigned logn, unsigned logq)
       rlk.p1.coeffs[(size_t)d * polyctx.n + i] = splitmix64(&st) % r->p;
     }
   he_mul(&ct, &ct1, &ct2, &rlk);                              /* first call builds the device tables */
+  /* the key stays on the device between calls; a key rewritten in place must give the new key's result (fingerprint), and the
+   * same after an explicit gpq_mpi_shim_forget_keys() */
+  {
+    he_ct_t a, b;
+    poly_alloc(&a.c0); poly_alloc(&a.c1); poly_alloc(&b.c0); poly_alloc(&b.c1);
+    r = polyctx.rns;
+    for (unsigned d = 0; d < hectx.dimevk; d++, r = r->next)                                  /* (nearly) every word changes, residues stay canonical */
+      for (unsigned i = 0; i < polyctx.n; i++) { uint64_t *w = &rlk.p0.coeffs[(size_t)d * polyctx.n + i]; if ((*w ^ 1) < r->p) *w ^= 1; }
+    he_mul(&a, &ct1, &ct2, &rlk);
+    gpq_mpi_shim_forget_keys();
+    he_mul(&b, &ct1, &ct2, &rlk);
+    int same_as_old = 1, consistent = 1;
+    for (unsigned i = 0; i < polyctx.n; i++) {
+      if (gcry_mpi_cmp(a.c0.coeffs[i], ct.c0.coeffs[i])) same_as_old = 0;
+      if (gcry_mpi_cmp(a.c0.coeffs[i], b.c0.coeffs[i]) || gcry_mpi_cmp(a.c1.coeffs[i], b.c1.coeffs[i])) consistent = 0;
+    }
+    printf("key cache: rewritten key %s, cached vs fresh upload %s\n", same_as_old ? "IGNORED" : "seen", consistent ? "identical" : "DIFFER");
+  }
   const double t0 = now_ms();
   for (int i = 0; i < 3; i++) he_mul(&ct, &ct1, &ct2, &rlk);
   const double dt = (now_ms() - t0) / 3;

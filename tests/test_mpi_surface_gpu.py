@@ -317,3 +317,19 @@ def test_context_symbols_of_the_library(mpi_host, oracle_ctx, golden, logn, logq
     assert next(it).split() == ["alloc", "0", str(dimevk * n - 1)]
     assert next(it).split() == ["exit", "1", "1"]
     assert next(it).split() == ["again", str(dimub), str(dimevk)]
+
+
+@pytest.mark.timeout(600)
+def test_reference_signature_he_mul_at_the_headline_shape_keeps_its_key_on_the_device(mpi_host):
+    """`mpi_host hemultime 16 850`: he_mul(he_ct_t*, ...) / he_rescale with real MPIs at n = 2^16, q = 2^850 (hectx_init of the library:
+    L = 17, dims 15 / 45).  The evaluation key is uploaded once and recognised afterwards; a key rewritten in place is seen (fingerprint)
+    and gives the same result as after gpq_mpi_shim_forget_keys(); the per-stage timing of the last call adds up."""
+    import re
+    res = subprocess.run([mpi_host, "hemultime", "16", "850"], capture_output=True, text=True, timeout=560)
+    assert res.returncode == 0, res.stderr
+    assert "key cache: rewritten key seen, cached vs fresh upload identical" in res.stdout, res.stdout
+    m = re.search(r"dims 15/45: ([0-9.]+) ms per call; he_rescale ([0-9.]+) ms", res.stdout)
+    assert m and 0.3 < float(m.group(1)) < 200 and 0.1 < float(m.group(2)) < 200, res.stdout
+    t = re.search(r"convert\+upload ([0-9.]+) ms, kernels ([0-9.]+) ms, download\+convert ([0-9.]+) ms, call ([0-9.]+) ms", res.stdout)
+    parts = [float(v) for v in t.groups()]
+    assert 0.1 < parts[1] < 5 and parts[0] + parts[2] <= parts[3] * 1.05 and parts[3] < 200
