@@ -31,6 +31,12 @@ SIGNATURES = {
     "gpq_upload": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "gpq_download": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "gpq_stream_sync": (C.c_int, [vp]),
+    "gpq_device_count": (C.c_int, []),
+    "gpq_set_device": (C.c_int, [C.c_int]),
+    "gpq_stream_create": (C.c_int, [C.POINTER(vp)]),
+    "gpq_stream_destroy": (C.c_int, [vp]),
+    "gpq_malloc_host": (C.c_int, [C.POINTER(vp), C.c_size_t]),
+    "gpq_free_host": (C.c_int, [vp]),
     "gpq_ntt": (C.c_int, [vp, vp, C.c_uint, C.c_uint, vp]),
     "gpq_invntt": (C.c_int, [vp, vp, C.c_uint, C.c_uint, vp]),
     "gpq_rns_mul": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, vp]),

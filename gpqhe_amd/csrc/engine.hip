@@ -341,6 +341,26 @@ extern "C" int gpq_download(void *dst, const void *src, size_t bytes, void *stre
 }
 extern "C" int gpq_stream_sync(void *stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return GPQ_OK; }
 
+// Several devices from one C program (independent ciphertexts, one shard per GPU): the calling thread's current
+// device decides where gpq_malloc allocates and where a new stream lives; a context is bound to the device it was created on.
+extern "C" int gpq_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+extern "C" int gpq_set_device(int device) { HIP_TRY(hipSetDevice(device)); return GPQ_OK; }
+extern "C" int gpq_stream_create(void **stream) {
+  if (!stream) return gpq_fail(GPQ_ERR_INVALID, "gpq_stream_create: null pointer");
+  hipStream_t s;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (void *)s;
+  return GPQ_OK;
+}
+extern "C" int gpq_stream_destroy(void *stream) { HIP_TRY(hipStreamDestroy((hipStream_t)stream)); return GPQ_OK; }
+// page-locked host memory: gpq_upload / gpq_download from / to it are asynchronous DMA (with pageable memory they are staged and
+// the download waits for the stream)
+extern "C" int gpq_malloc_host(void **hptr, size_t bytes) { HIP_TRY(hipHostMalloc(hptr, bytes, hipHostMallocDefault)); return GPQ_OK; }
+extern "C" int gpq_free_host(void *hptr) { HIP_TRY(hipHostFree(hptr)); return GPQ_OK; }
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------

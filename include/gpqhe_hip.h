@@ -86,6 +86,17 @@ int gpq_free(void *dptr);
 int gpq_upload(void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int gpq_download(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int gpq_stream_sync(void *stream);
+/* Several devices from one C program: gpq_malloc and gpq_stream_create act on the calling thread's current device
+ * (gpq_set_device); a context belongs to the device given to gpq_ctx_create and is used with streams and buffers of that
+ * device.  Independent ciphertexts shard over devices without any exchange (tests/c/shard_host.c). */
+int gpq_device_count(void);
+int gpq_set_device(int device);
+int gpq_stream_create(void **stream);        /* non-blocking stream on the current device */
+int gpq_stream_destroy(void *stream);
+/* Page-locked host memory: gpq_upload / gpq_download from / to it are asynchronous DMA; with pageable memory the copies
+ * are staged and a download waits for the work queued before it. */
+int gpq_malloc_host(void **hptr, size_t bytes);
+int gpq_free_host(void *hptr);
 
 /* ---- slab operations ------------------------------------------------------
  * All slabs are device pointers to uint64_t[batch][dim][n] using primes

@@ -1,0 +1,133 @@
+/*
+ * shard_host.c -- a batch of independent ciphertext multiplications sharded over several devices from ONE plain-C process
+ * ("one ciphertext per GPU", no exchange inside a transform; src/he-mult.c:116-138 and :58-66 carry no
+ * cross-ciphertext state).  Only the C ABI of include/gpqhe_hip.h is used -- no HIP headers, no torch:
+ *
+ *   shard_host <logn> <dimA> <dimB> <batch> <dev,dev,...>
+ *
+ * Shard s (block partition of the batch, the first batch % shards shards take one more) lives on device <dev_s>: its own
+ * context, stream, buffers.  All shards are launched before any is waited for, so the devices work concurrently; listing a
+ * device twice ("0,0") puts two shards with separate contexts and streams on it (what a one-GPU box can exercise).
+ * Inputs: ciphertext k uses gen(1000 + 4k .. 1003 + 4k, dimA) and gen(2000 + k, dimB), one key gen(3000 / 3001, dimB) --
+ * the synthetic batch of SURVEY.md 8d.  Prints, per ciphertext, the FNV-1a-64 digests of d0, d1, d2, c0, c1; the pytest
+ * wrapper compares them with the oracle's.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gpqhe_hip.h"
+
+static uint64_t splitmix64(uint64_t *s)
+{
+  uint64_t z = (*s += 0x9e3779b97f4a7c15ull);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+static uint64_t fnv(const uint64_t *a, size_t n)
+{
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (size_t i = 0; i < n; i++)
+    for (int b = 0; b < 8; b++) { h ^= (a[i] >> (8 * b)) & 0xff; h *= 0x100000001b3ull; }
+  return h;
+}
+
+/* gen(seed, dim) of SURVEY.md 8c: limb-major, a[d n + i] = splitmix64() % p_d from one running state */
+static void gen(uint64_t *out, uint64_t seed, unsigned dim, size_t n, const uint64_t *p)
+{
+  uint64_t st = seed;
+  for (unsigned d = 0; d < dim; d++)
+    for (size_t i = 0; i < n; i++) out[d * n + i] = splitmix64(&st) % p[d];
+}
+
+#define CHECK(x) do { if ((x) != GPQ_OK) { fprintf(stderr, "%s: %s\n", #x, gpq_last_error()); return 1; } } while (0)
+
+struct shard {
+  int device; unsigned lo, hi;
+  gpq_ctx *ctx; void *stream;
+  uint64_t *d_in[4], *d_x, *d_e[2], *d_out[5], *d_wsA, *d_wsB;
+  uint64_t *h_out[5];
+};
+
+int main(int argc, char **argv)
+{
+  if (argc < 6) return 2;
+  const unsigned logn = (unsigned)atoi(argv[1]), dimA = (unsigned)atoi(argv[2]), dimB = (unsigned)atoi(argv[3]), batch = (unsigned)atoi(argv[4]);
+  const size_t n = (size_t)1 << logn, perA = dimA * n, perB = dimB * n;
+  int devs[64], shards = 0;
+  for (char *tok = strtok(argv[5], ","); tok && shards < 64; tok = strtok(NULL, ",")) devs[shards++] = atoi(tok);
+  if (!shards || batch < (unsigned)shards || dimA > dimB) return 2;
+  printf("devices visible %d, shards %d\n", gpq_device_count(), shards);
+  for (int s = 0; s < shards; s++)
+    if (devs[s] < 0 || devs[s] >= gpq_device_count()) { fprintf(stderr, "device %d is not there\n", devs[s]); return 1; }
+
+  struct shard *sh = calloc((size_t)shards, sizeof *sh);
+  uint64_t *primes = malloc(dimB * 8), *host = malloc((perA > perB ? perA : perB) * 8);
+  const unsigned base = batch / shards, extra = batch % shards;
+
+  /* launch every shard: uploads, tensor stage, key switch, downloads -- all asynchronous on the shard's own stream */
+  for (int s = 0; s < shards; s++) {
+    struct shard *h = &sh[s];
+    h->device = devs[s];
+    h->lo = s * base + ((unsigned)s < extra ? (unsigned)s : extra);
+    h->hi = h->lo + base + ((unsigned)s < extra ? 1 : 0);
+    const unsigned cnt = h->hi - h->lo;
+    CHECK(gpq_set_device(h->device));
+    CHECK(gpq_ctx_create(&h->ctx, logn, dimB, h->device));
+    if (gpq_ctx_device(h->ctx) != h->device) { fprintf(stderr, "context on the wrong device\n"); return 1; }
+    CHECK(gpq_stream_create(&h->stream));
+    for (unsigned d = 0; d < dimB; d++) primes[d] = gpq_ctx_const(h->ctx, d, 0);
+    for (int i = 0; i < 4; i++) CHECK(gpq_malloc((void **)&h->d_in[i], cnt * perA * 8));
+    CHECK(gpq_malloc((void **)&h->d_x, cnt * perB * 8));
+    for (int i = 0; i < 2; i++) CHECK(gpq_malloc((void **)&h->d_e[i], perB * 8));
+    for (int i = 0; i < 5; i++) {
+      const size_t per = i < 3 ? perA : perB;
+      CHECK(gpq_malloc((void **)&h->d_out[i], cnt * per * 8));
+      CHECK(gpq_malloc_host((void **)&h->h_out[i], cnt * per * 8));       /* page-locked: the download does not block the host */
+    }
+    CHECK(gpq_malloc((void **)&h->d_wsA, gpq_tensor_workspace_bytes(h->ctx, dimA, cnt)));
+    CHECK(gpq_malloc((void **)&h->d_wsB, gpq_keyswitch_workspace_bytes(h->ctx, dimB, cnt)));
+    for (unsigned k = h->lo; k < h->hi; k++) {
+      for (int i = 0; i < 4; i++) {
+        gen(host, 1000 + 4 * k + i, dimA, n, primes);
+        CHECK(gpq_upload(h->d_in[i] + (k - h->lo) * perA, host, perA * 8, h->stream));
+        CHECK(gpq_stream_sync(h->stream));                 /* `host` is reused (pageable memory: the copy is staged anyway) */
+      }
+      gen(host, 2000 + k, dimB, n, primes);
+      CHECK(gpq_upload(h->d_x + (k - h->lo) * perB, host, perB * 8, h->stream));
+      CHECK(gpq_stream_sync(h->stream));
+    }
+    for (int i = 0; i < 2; i++) {                            /* the key is replicated on every device */
+      gen(host, 3000 + i, dimB, n, primes);
+      CHECK(gpq_upload(h->d_e[i], host, perB * 8, h->stream));
+      CHECK(gpq_stream_sync(h->stream));
+    }
+    CHECK(gpq_he_mul_tensor(h->ctx, h->d_out[0], h->d_out[1], h->d_out[2], h->d_in[0], h->d_in[1], h->d_in[2], h->d_in[3], dimA, cnt, h->d_wsA, h->stream));
+    CHECK(gpq_keyswitch(h->ctx, h->d_out[3], h->d_out[4], h->d_x, h->d_e[0], h->d_e[1], dimB, cnt, h->d_wsB, h->stream));
+    for (int i = 0; i < 5; i++) CHECK(gpq_download(h->h_out[i], h->d_out[i], cnt * (i < 3 ? perA : perB) * 8, h->stream));
+    /* no wait here: the next shard's device starts while this one computes */
+  }
+  /* gather: wait for each shard and print its ciphertexts in batch order */
+  for (int s = 0; s < shards; s++) {
+    struct shard *h = &sh[s];
+    CHECK(gpq_set_device(h->device));
+    CHECK(gpq_stream_sync(h->stream));
+    for (unsigned k = h->lo; k < h->hi; k++) {
+      printf("ct %u dev %d", k, h->device);
+      for (int i = 0; i < 5; i++) {
+        const size_t per = i < 3 ? perA : perB;
+        printf(" %016llx", (unsigned long long)fnv(h->h_out[i] + (k - h->lo) * per, per));
+      }
+      printf("\n");
+    }
+    for (int i = 0; i < 4; i++) gpq_free(h->d_in[i]);
+    gpq_free(h->d_x); gpq_free(h->d_e[0]); gpq_free(h->d_e[1]); gpq_free(h->d_wsA); gpq_free(h->d_wsB);
+    for (int i = 0; i < 5; i++) { gpq_free(h->d_out[i]); gpq_free_host(h->h_out[i]); }
+    CHECK(gpq_stream_destroy(h->stream));
+    gpq_ctx_destroy(h->ctx);
+  }
+  free(sh); free(primes); free(host);
+  return 0;
+}

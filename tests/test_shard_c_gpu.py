@@ -1,0 +1,53 @@
+"""Several devices from ONE plain-C process through the C ABI alone (tests/c/shard_host.c): a batch of independent ciphertext
+multiplications (src/he-mult.c:116-138 + :58-66: no cross-ciphertext state) is block-partitioned over a list of devices, one
+context / stream / buffer set per shard, every shard launched before any is waited for.  The box has one GPU, so the list is
+"0" (one shard) and "0,0,0" (three shards with their own contexts and streams on that GPU, ragged 3 + 2 + 2); on an 8-GPU node the
+same binary takes "0,1,...,7".  Every ciphertext's five outputs must equal the oracle's, whatever the sharding."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle.oracle import fnv
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def shard_host(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("shard") / "shard_host")
+    lib_dir = os.path.join(ROOT, "gpqhe_amd")
+    subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "shard_host.c"),
+                           "-L", lib_dir, "-lgpqhe_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+    return out
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("logn,dim_a,dim_b,batch", [(13, 3, 4, 7), (16, 30, 45, 3)])
+def test_batch_sharded_over_a_device_list_from_plain_c(shard_host, oracle_ctx, logn, dim_a, dim_b, batch):
+    o = oracle_ctx(logn, dim_b)
+    n = o.n
+    expect = {}
+    ev = [o.gen(3000, dim_b), o.gen(3001, dim_b)]
+    for k in range(batch):
+        ins = [o.gen(1000 + 4 * k + i, dim_a) for i in range(4)]
+        d = o.he_mul_tensor(*ins, dim_a)
+        c = o.keyswitch(o.gen(2000 + k, dim_b), ev[0], ev[1], dim_b)
+        expect[k] = [fnv(v) for v in list(d) + list(c)]
+    for devs in ("0", "0,0,0"):
+        res = subprocess.run([shard_host, str(logn), str(dim_a), str(dim_b), str(batch), devs], capture_output=True, text=True, timeout=500)
+        assert res.returncode == 0, res.stderr
+        lines = res.stdout.strip().split("\n")
+        assert lines[0].split()[:3] == ["devices", "visible", lines[0].split()[2]] and lines[0].endswith("shards %d" % len(devs.split(",")))
+        got = {}
+        for ln in lines[1:]:
+            f = ln.split()
+            assert f[0] == "ct" and f[2] == "dev" and f[3] == "0"
+            got[int(f[1])] = f[4:]
+        assert sorted(got) == list(range(batch))
+        for k in range(batch):
+            assert got[k] == expect[k], (devs, k)
+    if logn == 16:
+        assert expect[0] == ["99655f317c50d5c1", "e7658c5a00ed9eac", "12600b1bac18b63e", "466a17f24e0654d2", "578cf3337a189ad0"]   # SURVEY.md 8c, k = 0
