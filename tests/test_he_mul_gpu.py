@@ -71,6 +71,31 @@ def test_batched_core_matches_oracle(engine_ctx, oracle_ctx, logn, dim, batch, c
     g.set_chunk(4)
 
 
+@pytest.mark.parametrize("logn,dim,batch,chunk,limb_block", [(13, 7, 5, 2, 3), (16, 6, 3, 2, 4), (17, 44, 2, 1, 7), (17, 44, 1, 4, 1)])
+def test_limb_blocked_launch_groups_match_oracle(oracle_ctx, logn, dim, batch, chunk, limb_block):
+    """gpq_set_limb_block: the three kernels of the tensor stage / key switch run per block of limbs inside a group of polynomials.
+    Blocks that do not divide the limb count, that are cut again by the butterfly-class boundaries of the chain (n = 2^17: wide /
+    split / plain limbs inside 44) and a ragged last group of polynomials: bit-exact against the oracle for every setting."""
+    import gpqhe_amd
+    o = oracle_ctx(logn, dim)
+    g = gpqhe_amd.PolyContext(logn, dim)          # own context: the session-wide ones keep their defaults
+    g.set_chunk(chunk)
+    g.set_limb_block(limb_block)
+    per = dim * o.n
+    ins = [np.concatenate([o.gen(300 * s + k, dim) for k in range(batch)]) for s in range(4)]
+    d0, d1, d2 = _tensor(g, ins, dim)
+    x = np.concatenate([o.gen(950 + k, dim) for k in range(batch)])
+    ev0, ev1 = o.gen(7100, dim), o.gen(7101, dim)
+    c0, c1 = _keyswitch(g, x, ev0, ev1, dim)
+    for k in range(batch):
+        sl = slice(k * per, (k + 1) * per)
+        e = o.he_mul_tensor(*[v[sl].copy() for v in ins], dim)
+        f = o.keyswitch(x[sl].copy(), ev0, ev1, dim)
+        for got, exp in zip((d0, d1, d2, c0, c1), list(e) + list(f)):
+            assert np.array_equal(got[sl], exp)
+    g.close()
+
+
 @pytest.mark.parametrize("logn,dim,batch", [(7, 5, 1), (13, 2, 3), (14, 3, 2), (16, 4, 2), (17, 33, 1)])
 def test_poly_mul_limb_loop(engine_ctx, oracle_ctx, logn, dim, batch):
     """src/poly.c:96-103 without rns_decompose (small rings: four transforms; n >= 2^13: strided pass, fused middle, strided pass;
