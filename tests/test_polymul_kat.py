@@ -59,3 +59,43 @@ def test_polymul_kat_gpu(engine_ctx, oracle_ctx):
         g.poly_mul_rns(r, da, db, DIM)
         rh = to_host(r)
         assert poly_rns2mpi([rh[d * N:(d + 1) * N] for d in range(DIM)], basis, Q) == _expected(a, b)
+
+
+# ---- BASELINE.json configs[0] as it is worded: "single poly_mul at N = 2^12, 1 RNS prime" ------------------------------------------------
+# One 60-bit prime carries the product exactly when every coefficient of a*b mod x^n+1 stays below p/2 in magnitude: signed 20-bit
+# operands give |coefficient| <= 4096 * 2^40 = 2^52.  q = 2^55, so the centred reductions of poly_mul (src/poly.c:84-107, 109-120) leave
+# the integer product itself, which an independent int64 convolution provides (tests/polymul.gp's formula at this size).
+N12, Q12 = 1 << 12, 1 << 55
+
+
+def _inputs12():
+    rng = np.random.default_rng(2012)
+    a = rng.integers(-(1 << 20) + 1, 1 << 20, N12, dtype=np.int64)
+    b = rng.integers(-(1 << 20) + 1, 1 << 20, N12, dtype=np.int64)
+    a[:3], b[:3] = [(1 << 20) - 1, -(1 << 20) + 1, 0], [-(1 << 20) + 1, -(1 << 20) + 1, 1]     # the extremes ride along
+    full = np.convolve(a, b)                                          # exact in int64: |sum| <= 2^52
+    neg = full[:N12].copy()
+    neg[: N12 - 1] -= full[N12:]                                      # x^n = -1
+    return [int(v) for v in a], [int(v) for v in b], [int(v) for v in neg]
+
+
+def test_polymul_n4096_one_prime_cpu(oracle_ctx):
+    o = oracle_ctx(12, 1)
+    a, b, exp = _inputs12()
+    assert max(abs(v) for v in exp) < min(o.p[0], Q12) // 2
+    r = o.poly_mul_rns(_slab(a, o.p[:1]), _slab(b, o.p[:1]), 1)       # src/poly.c:96-103 with dim = 1
+    assert poly_rns2mpi([r], RnsBasis(o.p[:1]), Q12) == exp
+
+
+@pytest.mark.gpu
+def test_polymul_n4096_one_prime_gpu(engine_ctx):
+    """The same through the device's whole poly_mul (decompose, NTT, product, INTT, CRT + both centrings on big slabs)."""
+    import torch
+    from gpqhe_amd import big_to_ints, ints_to_big, to_device, to_host
+    g = engine_ctx(12, 1)
+    a, b, exp = _inputs12()
+    W = 1
+    da, db = to_device(ints_to_big(a, W)), to_device(ints_to_big(b, W))
+    r = torch.empty_like(da)
+    g.poly_mul(r, da, db, W, 1, 55)
+    assert big_to_ints(to_host(r), W, N12)[0] == exp
