@@ -181,3 +181,56 @@ def test_repeatable_under_load(engine_ctx, oracle_ctx):
     c = o.keyswitch(to_host(x[k * perB:(k + 1) * perB]), to_host(e0), to_host(e1), dB)
     for got, exp, per in zip(first, list(d) + list(c), (perA, perA, perA, perB, perB)):
         assert np.array_equal(to_host(got[k * per:(k + 1) * per]), exp)
+
+
+@pytest.mark.timeout(600)
+def test_configs2_full_batch_is_consistent_with_single_ciphertext_runs(engine_ctx, oracle_ctx):
+    """BASELINE configs[2] at its full size inside the suite: n = 2^16, 30 / 45 limbs, batch 64 (two launch groups of 32).  Every
+    ciphertext of the batch must come out exactly as when it is run alone (batch 1: other grid, other launch-group boundaries), the
+    XOR of all outputs is a checksum of checksums across the two runs, and ciphertexts 0 and 63 equal the oracle."""
+    import torch
+    import gpqhe_amd
+    logn, dA, dB, B = 16, 30, 45, 64
+    g, o = engine_ctx(logn, dB), oracle_ctx(logn, dB)
+    n = g.n
+    perA, perB = dA * n, dB * n
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(6464)
+
+    def slab(dim, batch):
+        s = torch.empty((batch, dim, n), dtype=torch.int64, device="cuda")
+        for d in range(dim):
+            s[:, d, :] = torch.randint(0, g.p[d], (batch, n), dtype=torch.int64, device="cuda", generator=gen)
+        return s.reshape(-1)
+
+    ins = [slab(dA, B) for _ in range(4)]
+    x = slab(dB, B)
+    e0, e1 = slab(dB, 1), slab(dB, 1)
+    d = [torch.empty_like(ins[0]) for _ in range(3)]
+    c = [torch.empty_like(x) for _ in range(2)]
+    g.he_mul_tensor(d[0], d[1], d[2], *ins, dA)
+    g.he_keyswitch(c[0], c[1], x, e0, e1, dB)
+    one_d = [torch.empty(perA, dtype=torch.int64, device="cuda") for _ in range(3)]
+    one_c = [torch.empty(perB, dtype=torch.int64, device="cuda") for _ in range(2)]
+    acc_batch = torch.zeros(perB, dtype=torch.int64, device="cuda")
+    acc_single = torch.zeros(perB, dtype=torch.int64, device="cuda")
+    for k in range(B):
+        sa, sb = slice(k * perA, (k + 1) * perA), slice(k * perB, (k + 1) * perB)
+        g.he_mul_tensor(one_d[0], one_d[1], one_d[2], *[v[sa].contiguous() for v in ins], dA)
+        g.he_keyswitch(one_c[0], one_c[1], x[sb].contiguous(), e0, e1, dB)
+        for i in range(3):
+            assert torch.equal(d[i][sa], one_d[i]), (k, i)
+            acc_batch[:perA] ^= d[i][sa]
+            acc_single[:perA] ^= one_d[i]
+        for i in range(2):
+            assert torch.equal(c[i][sb], one_c[i]), (k, i)
+            acc_batch ^= c[i][sb]
+            acc_single ^= one_c[i]
+    assert torch.equal(acc_batch, acc_single) and bool((acc_batch != 0).any())
+    for k in (0, B - 1):
+        sa, sb = slice(k * perA, (k + 1) * perA), slice(k * perB, (k + 1) * perB)
+        exp = list(o.he_mul_tensor(*[gpqhe_amd.to_host(v[sa]) for v in ins], dA)) + list(o.keyswitch(gpqhe_amd.to_host(x[sb]), gpqhe_amd.to_host(e0), gpqhe_amd.to_host(e1), dB))
+        for got, want, sl in zip(d + c, exp, (sa, sa, sa, sb, sb)):
+            assert np.array_equal(gpqhe_amd.to_host(got[sl]), want)
+    del ins, x, d, c
+    torch.cuda.empty_cache()
