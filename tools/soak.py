@@ -1,0 +1,81 @@
+"""Randomised parity soak (dev tool, GPU box): random ring sizes, limb counts, batches, launch-group settings and butterfly-class
+restrictions through gpq_ntt / gpq_invntt / gpq_he_mul_tensor / gpq_keyswitch / gpq_poly_mul_rns against the oracle, for SECONDS
+seconds.  Prints every configuration it ran and stops at the first mismatch.
+
+    python tools/soak.py [seconds] [seed]
+"""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import gpqhe_amd  # noqa: E402
+from gpqhe_amd import to_device, to_host  # noqa: E402
+from oracle.oracle import OracleCtx  # noqa: E402
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    torch.cuda.set_device(0)
+    oracles, t0, runs = {}, time.time(), 0
+    while time.time() - t0 < seconds:
+        logn = rng.choice([13, 13, 14, 15, 16, 17])
+        dim = rng.choice([1, 2, 3, 5, 7]) if logn < 17 else rng.choice([1, 2, 12, 40])       # n = 2^17: 40 limbs cross the three butterfly classes
+        batch = rng.choice([1, 2, 3, 5])
+        chunk, lblock = rng.choice([1, 2, 3, 32]), rng.choice([0, 0, 1, 2, 3])
+        classes = rng.choice([None, None, (0, 0), (0, 99), (1, 2), (2, 3)])
+        key = (logn, dim)
+        if key not in oracles:
+            if len(oracles) > 6:
+                oracles.pop(next(iter(oracles)))
+            oracles[key] = OracleCtx(logn, dim)
+        o = oracles[key]
+        g = gpqhe_amd.PolyContext(logn, dim)
+        g.set_chunk(chunk)
+        g.set_limb_block(lblock)
+        if classes:
+            g.set_limb_classes(*classes)
+        per = dim * o.n
+        seeds = [rng.randrange(1 << 30) for _ in range(7)]
+        ins = [np.concatenate([o.gen(s + k, dim) for k in range(batch)]) for s in seeds[:5]]
+        if rng.random() < 0.3:                                   # extremes: all p-1 / all zero limbs
+            for d in range(dim):
+                ins[0][d * o.n:(d + 1) * o.n] = o.p[d] - 1
+                ins[1][d * o.n:(d + 1) * o.n] = 0
+        ev = [o.gen(seeds[5], dim), o.gen(seeds[6], dim)]
+        dev = [to_device(v) for v in ins]
+        f = dev[0].clone(); g.poly_ntt(f, dim)
+        i = dev[1].clone(); g.poly_invntt(i, dim)
+        d = [torch.empty_like(dev[0]) for _ in range(3)]
+        g.he_mul_tensor(d[0], d[1], d[2], dev[0], dev[1], dev[2], dev[3], dim)
+        c = [torch.empty_like(dev[0]) for _ in range(2)]
+        g.he_keyswitch(c[0], c[1], dev[4], to_device(ev[0]), to_device(ev[1]), dim)
+        pa, pb, pr = dev[0].clone(), dev[2].clone(), torch.empty_like(dev[0])
+        g.poly_mul_rns(pr, pa, pb, dim)
+        torch.cuda.synchronize()
+        got = [to_host(t) for t in (f, i, d[0], d[1], d[2], c[0], c[1], pr)]
+        for k in range(batch):
+            sl = slice(k * per, (k + 1) * per)
+            exp = [o.ntt_slab(ins[0][sl].copy(), dim), o.ntt_slab(ins[1][sl].copy(), dim, inverse=True)]
+            exp += list(o.he_mul_tensor(*[v[sl].copy() for v in ins[:4]], dim))
+            exp += list(o.keyswitch(ins[4][sl].copy(), ev[0], ev[1], dim))
+            exp.append(o.poly_mul_rns(ins[0][sl].copy(), ins[2][sl].copy(), dim))
+            for name, a, b in zip(("ntt", "invntt", "d0", "d1", "d2", "c0", "c1", "polymul"), got, exp):
+                if not np.array_equal(a[sl], b):
+                    print("MISMATCH", name, "ciphertext", k, dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, seeds=seeds), flush=True)
+                    sys.exit(1)
+        runs += 1
+        print("ok", dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes), flush=True)
+        g.close()
+    print("soak: %d configurations, no mismatch, %.0f s" % (runs, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
