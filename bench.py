@@ -238,6 +238,34 @@ def keyswitch_n17_rate(torch, gpqhe_amd, batch=16, iters=3):
             "algo_GBps": round(algo / (ms * 1e-3) / 1e9, 1)}
 
 
+def squaring_rate(torch, gpqhe_amd, ctx, batch, iters=5):
+    """The RNS core of a SQUARING, he_mul(&ct, &ct, &ct, rlk) (src/he-algo.c:151; he_exp / he_inv square repeatedly): the tensor stage
+    with both operands the same slabs runs two forward transforms instead of four (tensor_sq_mid8); key switch unchanged."""
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(151)
+    a0, a1 = rand_slab(torch, ctx, DIM_A, batch, gen), rand_slab(torch, ctx, DIM_A, batch, gen)
+    x = rand_slab(torch, ctx, DIM_B, batch, gen)
+    e0, e1 = rand_slab(torch, ctx, DIM_B, 1, gen), rand_slab(torch, ctx, DIM_B, 1, gen)
+    d = [torch.empty_like(a0) for _ in range(3)]
+    c = [torch.empty_like(x) for _ in range(2)]
+    wsA, wsB = ctx.tensor_workspace(DIM_A, batch), ctx.keyswitch_workspace(DIM_B, batch)
+
+    def step():
+        ctx.he_mul_tensor(d[0], d[1], d[2], a0, a1, a0, a1, DIM_A, wsA)
+        ctx.he_keyswitch(c[0], c[1], x, e0, e1, DIM_B, wsB)
+
+    for _ in range(2):
+        step()
+    t = gpqhe_amd.StreamTimer()
+    t.start()
+    for _ in range(iters):
+        step()
+    t.stop()
+    ms = t.elapsed_ms() / iters
+    return {"shape": "n=2^16, dimA=30 (2 forward + 3 inverse transforms per limb), dimB=45, batch %d" % batch, "ms_per_batch": round(ms, 3),
+            "he_mul_per_s": round(batch / (ms * 1e-3), 1)}
+
+
 def cpu_baseline(ctx, host_inputs, gpu_outputs, sample):
     """The oracle (CPU restatement of the reference loops) timed on this host, one
     thread like the reference, on `sample` ciphertexts of the same workload; its
@@ -498,6 +526,7 @@ def main(argv=None):
             out["ntt"].append(ntt_rate(torch, gpqhe_amd, 16, DIM_A, 4 * B))   # launch size matters: 4 GiB slab
             out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, B, iters=3)   # BASELINE configs[2]: he_mul + he_rescale, batch 64
             out["keyswitch_n17"] = keyswitch_n17_rate(torch, gpqhe_amd)
+            out["squaring_core"] = squaring_rate(torch, gpqhe_amd, ctx, B)
     if dist is not None and not args.no_scatter_gather:
         # BASELINE configs[3] with the transfers inside the timed region: rank 0 owns the whole batch, every rank works on its
         # shard, results return to rank 0.  A root-GPU scatter is bound by one xGMI link per peer.  This leg is

@@ -814,12 +814,15 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
     uint64_t *h[4] = {sA, sA + pa, sA + 2 * pa, sA + 3 * pa};
     uint64_t *d0h = sA + 4 * pa, *d1h = sA + 5 * pa, *d2h = sA + 6 * pa;
     const uint64_t *in[4] = {ct1c0, ct1c1, ct2c0, ct2c1};
+    // he_mul(&ct, &ct, &ct, rlk) (src/he-algo.c:151, the squarings of he_exp / he_inv): both operands are the same slabs --
+    // two decompositions and two forward transforms instead of four, same residues
+    const bool square = ct1c0 == ct2c0 && ct1c1 == ct2c1;
     {
-      StageRange stage("gpq_he_mul: rns_decompose x4");
-      for (int i = 0; i < 4; ++i)                                                           // :117-120
+      StageRange stage(square ? "gpq_he_mul: rns_decompose x2 (squaring)" : "gpq_he_mul: rns_decompose x4");
+      for (int i = 0; i < (square ? 2 : 4); ++i)                                            // :117-120
         if ((rc = launch_decompose(c, h[i], in[i] + k0 * bigpoly, W, 0, dimA, polys, s))) return rc;
     }
-    if ((rc = gpq_he_mul_tensor(c, d0h, d1h, d2h, h[0], h[1], h[2], h[3], dimA, polys, wsT, stream))) return rc;  // :121-136
+    if ((rc = gpq_he_mul_tensor(c, d0h, d1h, d2h, h[0], h[1], square ? h[0] : h[2], square ? h[1] : h[3], dimA, polys, wsT, stream))) return rc;  // :121-136
     uint64_t *d0 = dbig, *d1 = dbig + polys * bigpoly, *d2 = dbig + 2 * polys * bigpoly;
     // poly_rns2mpi of d0, d2, d1 (:139-141): the three slabs are adjacent on both sides, one launch
     {
@@ -1226,9 +1229,10 @@ extern "C" int gpq_he_mul_general(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1
     uint64_t *h[4] = {sA, sA + pa, sA + 2 * pa, sA + 3 * pa};
     uint64_t *dh[3] = {sA + 4 * pa, sA + 5 * pa, sA + 6 * pa};   // d0hat, d1hat, d2hat
     const uint64_t *in[4] = {ct1c0, ct1c1, ct2c0, ct2c1};
-    for (int i = 0; i < 4; ++i)
+    const bool square = ct1c0 == ct2c0 && ct1c1 == ct2c1;       // he_mul(&ct, &ct, &ct, rlk): as in gpq_he_mul
+    for (int i = 0; i < (square ? 2 : 4); ++i)
       if ((rc = launch_decompose(c, h[i], in[i] + k0 * bigpoly, W, 0, dimA, polys, s))) return rc;
-    if ((rc = gpq_he_mul_tensor(c, dh[0], dh[1], dh[2], h[0], h[1], h[2], h[3], dimA, polys, wsT, stream))) return rc;
+    if ((rc = gpq_he_mul_tensor(c, dh[0], dh[1], dh[2], h[0], h[1], square ? h[0] : h[2], square ? h[1] : h[3], dimA, polys, wsT, stream))) return rc;
     uint64_t *dd[3] = {dbig, dbig + polys * bigpoly, dbig + 2 * polys * bigpoly};
     uint64_t *dconst = xfull + (size_t)polys * Wx * n;
     for (int i = 0; i < 3; ++i) {                                                                   // :139-141

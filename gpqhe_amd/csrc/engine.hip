@@ -685,6 +685,9 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
     return gpq_invntt(c, d2, dim, batch, stream);
   }
 
+  // Both operands the same ciphertext (he_mul(&ct, &ct, &ct, rlk), src/he-algo.c:151): two forward transforms instead of four
+  const bool square = a0 == b0 && a1 == b1;
+  const unsigned nin = square ? 2 : 4;
   const unsigned chunk = tensor_chunk(c, batch);
   const unsigned lblock = limb_block(c, dim);
   for (unsigned k0 = 0; k0 < batch; k0 += chunk) {
@@ -696,19 +699,21 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
       const size_t loff = (size_t)l0 << c->logn;
       // 1. strided forward pass, inputs -> workspace
       StageRange stage("gpq_he_mul_tensor: strided fwd x4 / tensor_mid8 / strided inv x3");
-      PassArgs f = make_args(c, dim, 4);
+      PassArgs f = make_args(c, dim, nin);
       f.limb0 = l0;
-      for (int i = 0; i < 4; ++i) { f.src[i] = in[i] + k0 * poly + loff; f.dst[i] = ws + (size_t)i * chunk * poly + loff; }
+      for (unsigned i = 0; i < nin; ++i) { f.src[i] = in[i] + k0 * poly + loff; f.dst[i] = ws + (size_t)i * chunk * poly + loff; }
       if ((rc = launch_strided<false>(c, f, limbs, polys, s))) return rc;
       // 2. low forward stages, products, low inverse stages -> outputs
       PassArgs m = make_args(c, dim, 1);
       m.limb0 = l0;
-      for (int i = 0; i < 4; ++i) m.src[i] = f.dst[i];
+      for (unsigned i = 0; i < nin; ++i) m.src[i] = f.dst[i];
       m.dst[0] = d0 + k0 * poly + loff; m.dst[1] = d1 + k0 * poly + loff; m.dst[2] = d2 + k0 * poly + loff;
       if ((rc = for_limb_ranges<true>(c, m, limbs, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned nl) {
             using TW = decltype(tag);
             ProfScope prof(c, GPQ_K_TENSOR_MID, s);
-            if (c->low9) hipLaunchKernelGGL((tensor_mid8<TW, 9>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
+            if (square && c->low9) hipLaunchKernelGGL((tensor_sq_mid8<TW, 9>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
+            else if (square) hipLaunchKernelGGL((tensor_sq_mid8<TW, 8>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
+            else if (c->low9) hipLaunchKernelGGL((tensor_mid8<TW, 9>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
             else hipLaunchKernelGGL((tensor_mid8<TW, 8>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
             return (int)GPQ_OK;
           }))) return rc;

@@ -311,16 +311,19 @@ void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t 
       ws(pow2 ? gpq_he_mul_workspace_bytes(c, W, dimA, dimB, dimP, 1) : gpq_he_general_workspace_bytes(c, W, dimA, dimB, dimP, 1));
   const DevBuf *dd[4] = {&d0, &d1, &d2, &d3}, *oo[2] = {&o0, &o1};
   const HostBuf *ss[4] = {&s0, &s1, &s2, &s3};
+  // he_mul(&ct, &ct, &ct, rlk), src/he-algo.c:151: one ciphertext on both sides -- convert and upload it once, square on the device
+  const bool square = ct1->c0.coeffs == ct2->c0.coeffs && ct1->c1.coeffs == ct2->c1.coeffs;
   const double t0 = wall_ms();
-  upload_polys(dd, ss, in, 4, n, W);
+  upload_polys(dd, ss, in, square ? 2 : 4, n, W);
   uint64_t *k0, *k1;
   key_on_device(rlk, evk, &k0, &k1);
   if (!g_tick[0]) { (void)hipEventCreate(&g_tick[0]); (void)hipEventCreate(&g_tick[1]); }
   (void)hipEventRecord(g_tick[0], nullptr);
   const double t1 = wall_ms();
-  const int rc = pow2 ? gpq_he_mul(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), d2.u64(), d3.u64(), k0, k1, W, logql, dimA, dimB, dimP,
+  uint64_t *const e0 = square ? d0.u64() : d2.u64(), *const e1 = square ? d1.u64() : d3.u64();
+  const int rc = pow2 ? gpq_he_mul(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), e0, e1, k0, k1, W, logql, dimA, dimB, dimP,
                                    1, ws.p, nullptr)
-                      : gpq_he_mul_general(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), d2.u64(), d3.u64(), k0, k1, W, qw.data(),
+                      : gpq_he_mul_general(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), e0, e1, k0, k1, W, qw.data(),
                                            (unsigned)qw.size(), dimA, dimB, dimP, 1, ws.p, nullptr);
   if (rc != GPQ_OK) die("he_mul failed");
   (void)hipEventRecord(g_tick[1], nullptr);

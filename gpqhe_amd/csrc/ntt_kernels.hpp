@@ -706,6 +706,59 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_MID8_MINWAVES) void tensor_m
   ln.store_h(a.dst[2] + cb.off, a1);
 }
 
+// The tensor stage of a SQUARING, he_mul(&ct, &ct, &ct, rlk) (src/he-algo.c:151 and the repeated squarings of he_exp / he_inv call
+// src/he-mult.c:88-156 with both operands the same ciphertext): two forward low-halves instead of four,
+//   d0 = c0 c0, d2 = c1 c1, d1 = c0 c1 + c1 c0 = 2 c0 c1   (the same residues as the general kernel gives for b = a),
+// three inverse low-halves.  src[0..1] = c0, c1 after the strided forward pass; dst[0..2] = d0, d1, d2.
+template <typename TW, int LOW>
+__global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_MID8_MINWAVES) void tensor_sq_mid8(PassArgs a) {
+  using TT = TwTraits<TW>;
+  using L8 = Lane8<LOW>;
+  __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
+  const L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
+  const Block8 cb(a);
+  const PrimeK k = a.tabs[cb.limb].k;
+  const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
+  uint64_t a0[8], a1[8];
+  Tw8<TW, LOW> tw;
+  ln.load_h(a0, a.src[0] + cb.off);
+  tw.load_h(ln, cb.wave0, a.logn, wf);
+  ln.load_h(a1, a.src[1] + cb.off);
+  L8::ct_h(a0, tw.t, k);
+  L8::ct_h(a1, tw.t, k);
+  tw.load_m(ln, cb.wave0, a.logn, wf);
+  ln.h_to_m(a0); L8::ct_m(a0, tw.t, k);
+  ln.h_to_m(a1); L8::ct_m(a1, tw.t, k);
+  tw.load_l(ln, cb.wave0, a.logn, wf);
+  ln.m_to_l(a0); L8::ct_l(a0, tw.u, k);
+  ln.m_to_l(a1); L8::ct_l(a1, tw.u, k);
+  tw.load_l(ln, cb.wave0, a.logn, wi);
+  uint64_t d1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {                      // left operand < 2p or < 4p, right operand as it comes: the ranges of tensor_mid8
+    const uint64_t u0 = TT::left(a0[e], k), u1 = TT::left(a1[e], k);
+    const uint64_t v0 = TT::right(a0[e], k), v1 = TT::right(a1[e], k);
+    const uint64_t cross = mulmod_lazy(u0, v1, k);                                      // c0 c1, in (0, 4p)
+    a0[e] = TT::inv_from4(mulmod_lazy(u0, v0, k), k);                                   // d0
+    d1[e] = TT::inv_from8(cross + cross, k);                                            // d1
+    a1[e] = TT::inv_from4(mulmod_lazy(u1, v1, k), k);                                   // d2
+  }
+  L8::gs_l(a0, tw.u, k); ln.l_to_m(a0);
+  L8::gs_l(d1, tw.u, k); ln.l_to_m(d1);
+  L8::gs_l(a1, tw.u, k); ln.l_to_m(a1);
+  tw.load_m(ln, cb.wave0, a.logn, wi);
+  L8::gs_hm(a0, tw.t, k); ln.m_to_h(a0);
+  L8::gs_hm(d1, tw.t, k); ln.m_to_h(d1);
+  L8::gs_hm(a1, tw.t, k); ln.m_to_h(a1);
+  tw.load_h(ln, cb.wave0, a.logn, wi);
+  L8::gs_hm(a0, tw.t, k);
+  ln.store_h(a.dst[0] + cb.off, a0);
+  L8::gs_hm(d1, tw.t, k);
+  ln.store_h(a.dst[1] + cb.off, d1);
+  L8::gs_hm(a1, tw.t, k);
+  ln.store_h(a.dst[2] + cb.off, a1);
+}
+
 // Middle of poly_mul's limb loop (src/poly.c:96-103): low forward stages of a and b, a (*) b, low inverse stages.
 // src[0], src[1] = a, b after the strided forward pass; dst[0] = r before the strided inverse pass (r may be a or b: a
 // workgroup reads its 2048 coefficients of both before it writes them).

@@ -144,7 +144,8 @@ size_t gpq_keyswitch_workspace_bytes(const gpq_ctx *ctx, unsigned dim, unsigned 
 /* Tensor stage of he_mul, src/he-mult.c:116-138 without the rns_decompose
  * calls: a0,a1,b0,b1 stand for the decomposed ct1.c0, ct1.c1, ct2.c0, ct2.c1;
  *   d0 = a0*b0, d2 = a1*b1, d1 = a0*b1 + a1*b0   (negacyclic, per limb).
- * Inputs are preserved.  Outputs may not alias inputs. */
+ * Inputs are preserved.  Outputs may not alias inputs.  b0 == a0 and b1 == a1 (a squaring: he_mul(&ct, &ct, &ct, rlk),
+ * src/he-algo.c:151) is recognised and runs two forward transforms instead of four; the results are the same residues. */
 int gpq_he_mul_tensor(gpq_ctx *ctx, uint64_t *d0, uint64_t *d1, uint64_t *d2,
                       const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1,
                       unsigned dim, unsigned batch, void *workspace, void *stream);

@@ -391,14 +391,20 @@ static int hemultime(unsigned logn, unsigned logq)
   const double t0 = now_ms();
   for (int i = 0; i < 3; i++) he_mul(&ct, &ct1, &ct2, &rlk);
   const double dt = (now_ms() - t0) / 3;
-  double part[4];
+  double part[8];
   gpq_mpi_shim_last_timing(part);
+  he_mul(&ct, &ct1, &ct1, &rlk);                              /* a squaring, as he_mul(&bn, &bn, &bn, rlk) at src/he-algo.c:151 */
+  const double ts = now_ms();
+  for (int i = 0; i < 3; i++) he_mul(&ct, &ct1, &ct1, &rlk);
+  const double dsq = (now_ms() - ts) / 3;
+  gpq_mpi_shim_last_timing(part + 4);
   ct.l = hectx.L; he_rescale(&ct);                            /* first call at this shape allocates the staging buffers */
   const double t1 = now_ms();
   for (int i = 0; i < 3; i++) { ct.l = hectx.L; he_rescale(&ct); }
   const double dr = (now_ms() - t1) / 3;
   printf("he_mul(MPI) n=2^%u logq=%u dims %u/%u: %.1f ms per call; he_rescale %.1f ms\n", logn, logq, hectx.dim, hectx.dimevk, dt, dr);
   printf("  last he_mul: convert+upload %.2f ms, kernels %.2f ms, download+convert %.2f ms, call %.2f ms\n", part[0], part[1], part[2], part[3]);
+  printf("  squaring he_mul(&ct, &a, &a): %.1f ms per call (convert+upload %.2f ms, kernels %.2f ms, download+convert %.2f ms)\n", dsq, part[4], part[5], part[6]);
   return 0;
 }
 

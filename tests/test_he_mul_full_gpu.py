@@ -456,3 +456,30 @@ def test_he_swk_bit_exact_at_full_size_through_sparse_keys(engine_ctx, oracle_ct
     g.he_swk(o0, o1, a0, a1, to_device(slab(dense_of(k0))), to_device(slab(dense_of(k1))), W, logq, dimB, dimP)
     assert big_to_ints(to_host(o0), W, n)[0] == exp0
     assert big_to_ints(to_host(o1), W, n)[0] == exp1
+
+
+def test_he_mul_squaring_path_equals_the_general_path(engine_ctx):
+    """gpq_he_mul with ct2 the same slabs as ct1 (he_mul(&ct, &ct, &ct, rlk), src/he-algo.c:151) decomposes and transforms the ciphertext
+    once; the result equals the call with copies of the operands (general path), batch 3, n = 2^13, q = 2^438."""
+    torch = _torch()
+    logn, logq = 13, 438
+    probe = engine_ctx(logn, 20)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logq, logq)
+    g = engine_ctx(logn, dimevk)
+    n, W, batch = g.n, (logq + 64) // 64, 3
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(151)
+
+    def centred():
+        big = torch.randint(-(1 << 62), 1 << 62, (batch, W, n), dtype=torch.int64, device="cuda", generator=gen)
+        big[:, W - 1] = torch.randint(-(1 << 20), 1 << 20, (batch, n), dtype=torch.int64, device="cuda", generator=gen)
+        return big.reshape(-1).contiguous()
+
+    c0, c1 = centred(), centred()
+    rlk = [torch.cat([torch.randint(0, g.p[d], (n,), dtype=torch.int64, device="cuda", generator=gen) for d in range(dimB)]) for _ in range(2)]
+    s0, s1 = torch.empty_like(c0), torch.empty_like(c0)
+    g.he_mul(s0, s1, c0, c1, c0, c1, rlk[0], rlk[1], W, logq, dimA, dimB, dimP)                       # aliased: squaring path
+    t0, t1 = torch.empty_like(c0), torch.empty_like(c0)
+    g.he_mul(t0, t1, c0, c1, c0.clone(), c1.clone(), rlk[0], rlk[1], W, logq, dimA, dimB, dimP)       # copies: general path
+    torch.cuda.synchronize()
+    assert torch.equal(s0, t0) and torch.equal(s1, t1) and bool((s0 != 0).any())

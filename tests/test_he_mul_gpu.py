@@ -234,3 +234,30 @@ def test_configs2_full_batch_is_consistent_with_single_ciphertext_runs(engine_ct
             assert np.array_equal(gpqhe_amd.to_host(got[sl]), want)
     del ins, x, d, c
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("logn,dim,batch", [(7, 5, 2), (13, 3, 3), (16, 30, 2), (17, 40, 1)])
+def test_squaring_takes_the_two_transform_path_and_gives_the_same_residues(engine_ctx, oracle_ctx, logn, dim, batch):
+    """he_mul(&ct, &ct, &ct, rlk) (src/he-algo.c:151; the repeated squarings of he_exp / he_inv): gpq_he_mul_tensor with b0 = a0, b1 = a1
+    runs tensor_sq_mid8 (two forward transforms).  Bit-identical with the general kernel fed copies of the operands and with the oracle;
+    all-(p-1) limbs drive the doubled cross term to its bound."""
+    import torch
+    o, g = oracle_ctx(logn, dim), engine_ctx(logn, dim)
+    per = dim * o.n
+    a0 = np.concatenate([o.gen(77 + k, dim) for k in range(batch)])
+    a1 = np.concatenate([o.gen(177 + k, dim) for k in range(batch)])
+    for d in range(dim):                                   # extremes in the last ciphertext
+        a0[(batch - 1) * per + d * o.n:(batch - 1) * per + (d + 1) * o.n] = o.p[d] - 1
+        a1[(batch - 1) * per + d * o.n:(batch - 1) * per + (d + 1) * o.n:2] = o.p[d] - 1
+    da0, da1 = to_device(a0), to_device(a1)
+    sq = [torch.empty_like(da0) for _ in range(3)]
+    g.he_mul_tensor(sq[0], sq[1], sq[2], da0, da1, da0, da1, dim)                 # aliased operands: the squaring kernel
+    gen = [torch.empty_like(da0) for _ in range(3)]
+    g.he_mul_tensor(gen[0], gen[1], gen[2], da0, da1, da0.clone(), da1.clone(), dim)   # distinct buffers: the general kernel
+    for s, t in zip(sq, gen):
+        assert torch.equal(s, t)
+    for k in range(batch):
+        sl = slice(k * per, (k + 1) * per)
+        exp = o.he_mul_tensor(a0[sl].copy(), a1[sl].copy(), a0[sl].copy(), a1[sl].copy(), dim)
+        for s, e in zip(sq, exp):
+            assert np.array_equal(to_host(s[sl]), e)
