@@ -111,6 +111,7 @@ SIGNATURES = {
     "gpq_dropin_reset": (None, []),
     "gpq_mpi_shim_release": (None, []),
     "gpq_mpi_shim_forget_keys": (None, []),
+    "gpq_mpi_shim_set_key_slots": (None, [C.c_uint]),
     "gpq_mpi_shim_last_timing": (None, [C.POINTER(C.c_double)]),
     "gpq_fill_rns_chain": (C.c_int, [vp, C.c_uint, vp, C.c_int]),
     "gpq_release_rns_chain": (None, [vp]),

@@ -164,6 +164,7 @@ double wall_ms() {
 struct KeySlot { const uint64_t *h0, *h1; size_t words; uint64_t print; void *d0, *d1; uint64_t used; };
 std::vector<KeySlot> g_keys;
 uint64_t g_key_clock = 0;
+size_t g_key_slots = 16;      // resident keys (rlk, ck, the rotation keys in use): 45 MiB each at the headline shape; gpq_mpi_shim_set_key_slots
 uint64_t key_print(const uint64_t *a, const uint64_t *b, size_t words) {
   uint64_t h = 0xcbf29ce484222325ull;
   auto mix = [&](uint64_t v) { h = (h ^ v) * 0x100000001b3ull; h ^= h >> 29; };
@@ -179,9 +180,9 @@ void key_on_device(const he_evk_t *key, size_t words, uint64_t **d0, uint64_t **
     if (k.h0 == h0 && k.h1 == h1 && k.words == words && k.print == print) { k.used = ++g_key_clock; *d0 = (uint64_t *)k.d0; *d1 = (uint64_t *)k.d1; return; }
   KeySlot slot{h0, h1, words, print, nullptr, nullptr, ++g_key_clock};
   size_t victim = g_keys.size();
-  for (size_t i = 0; i < g_keys.size(); ++i)               // same host key at another state / length, else the least recently used of 6
+  for (size_t i = 0; i < g_keys.size(); ++i)               // same host key at another state / length, else the least recently used
     if (g_keys[i].h0 == h0 && g_keys[i].h1 == h1 && g_keys[i].words == words) victim = i;
-  if (victim == g_keys.size() && g_keys.size() >= 6) {
+  if (victim == g_keys.size() && g_keys.size() >= g_key_slots) {
     victim = 0;
     for (size_t i = 1; i < g_keys.size(); ++i) if (g_keys[i].used < g_keys[victim].used) victim = i;
   }
@@ -527,7 +528,11 @@ void he_genrk(he_evk_t *rk, const poly_mpi_t *sk) {                             
 // [2] downloads and slab -> MPI conversions (includes waiting for [1]), [3] the whole call
 void gpq_mpi_shim_last_timing(double ms[4]) { for (int i = 0; i < 4; ++i) ms[i] = g_last_ms[i]; }
 
-// Drops the device copies of evaluation keys (he_mul / he_rot / he_conj keep up to six, recognised by the caller's pointers, the
+// How many evaluation keys stay on the device between calls (default 16; he_rot over many rotation keys -- the gemv of
+// src/he-algo.c:63-85 walks rk[0..slots) -- wants as many as it cycles through: 45 MiB each at n = 2^16, 45 limbs).
+void gpq_mpi_shim_set_key_slots(unsigned slots) { g_key_slots = slots ? slots : 1; }
+
+// Drops the device copies of evaluation keys (he_mul / he_rot / he_conj keep up to gpq_mpi_shim_set_key_slots of them, recognised by the caller's pointers, the
 // length and a fingerprint of ~1000 sampled words).  A program that rewrites a key IN PLACE in a way the samples may miss calls
 // this after the rewrite; freeing or regenerating a key through he_gen*k changes the fingerprint anyway.
 void gpq_mpi_shim_forget_keys(void) {

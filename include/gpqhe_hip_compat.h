@@ -164,6 +164,8 @@ void gpq_dropin_reset(void);
 /* Wall milliseconds of the last he_mul(he_ct_t *, ...) call: [0] MPI -> slab conversions + uploads, [1] device kernels (HIP
  * events), [2] downloads + slab -> MPI conversions (includes waiting for [1]), [3] the whole call. */
 void gpq_mpi_shim_last_timing(double ms[4]);
+/* Number of evaluation keys the MPI-typed calls keep on the device between calls (default 16, least recently used out). */
+void gpq_mpi_shim_set_key_slots(unsigned slots);
 /* Drops the device copies of evaluation keys the MPI-typed calls keep (recognised by pointers, length and a fingerprint of sampled
  * words): call after rewriting a key in place. */
 void gpq_mpi_shim_forget_keys(void);
