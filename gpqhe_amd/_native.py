@@ -39,6 +39,7 @@ SIGNATURES = {
     "gpq_free_host": (C.c_int, [vp]),
     "gpq_ntt": (C.c_int, [vp, vp, C.c_uint, C.c_uint, vp]),
     "gpq_invntt": (C.c_int, [vp, vp, C.c_uint, C.c_uint, vp]),
+    "gpq_ntt_reference": (C.c_int, [vp, vp, C.c_uint, C.c_uint, C.c_int, vp]),
     "gpq_rns_mul": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, vp]),
     "gpq_rns_add": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, vp]),
     "gpq_poly_mul_rns": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, vp]),

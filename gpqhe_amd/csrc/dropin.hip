@@ -70,8 +70,13 @@ void transform(uint64_t a[], const struct rns_ctx *rns, bool inverse) {
   std::lock_guard<std::mutex> lock(g_mu);
   Slot &s = slot_for(rns);
   const size_t bytes = sizeof(uint64_t) << s.logn;
+  // The slab kernels take canonical residues (what rns_decompose / poly_rns_mul hand the reference's ntt / invntt); a limb
+  // holding any other word -- p itself out of an earlier ntt, or garbage -- runs src/ntt.c as written instead (gpq_ntt_reference).
+  bool canonical = true;
+  for (size_t i = 0; i < ((size_t)1 << s.logn); ++i) canonical &= a[i] < s.p;
   int rc = gpq_upload(s.dev[0], a, bytes, nullptr);
-  if (rc == GPQ_OK) rc = inverse ? gpq_invntt(s.ctx, s.dev[0], 1, 1, nullptr) : gpq_ntt(s.ctx, s.dev[0], 1, 1, nullptr);
+  if (rc == GPQ_OK && !canonical) rc = gpq_ntt_reference(s.ctx, s.dev[0], 1, 1, inverse ? 1 : 0, nullptr);
+  else if (rc == GPQ_OK) rc = inverse ? gpq_invntt(s.ctx, s.dev[0], 1, 1, nullptr) : gpq_ntt(s.ctx, s.dev[0], 1, 1, nullptr);
   if (rc == GPQ_OK) rc = gpq_download(a, s.dev[0], bytes, nullptr);
   if (rc == GPQ_OK) rc = gpq_stream_sync(nullptr);
   if (rc != GPQ_OK) die(inverse ? "invntt failed" : "ntt failed");

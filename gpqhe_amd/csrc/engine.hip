@@ -300,6 +300,7 @@ extern "C" void gpq_ctx_destroy(gpq_ctx *c) {
   if (c->d_ws) (void)hipFree(c->d_ws);
   if (c->d_winvs) (void)hipFree(c->d_winvs);
   if (c->d_tabs) (void)hipFree(c->d_tabs);
+  if (c->d_zflag) (void)hipFree(c->d_zflag);
   gpq_bridge_release(c);
   for (gpq_prof_rec &r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
@@ -367,7 +368,7 @@ extern "C" int gpq_free_host(void *hptr) { HIP_TRY(hipHostFree(hptr)); return GP
 namespace {
 
 static const char *const kKernelNames[GPQ_K_COUNT] = {"strided_fwd", "strided_inv", "contig_fwd", "contig_inv",
-                                                      "tensor_mid", "keyswitch_mid", "pointwise", "small_ntt"};
+                                                      "tensor_mid", "keyswitch_mid", "pointwise", "small_ntt", "reference_redo"};
 
 // Brackets one kernel launch with two events on its stream when profiling is on.
 struct ProfScope {
@@ -421,6 +422,7 @@ int for_limb_ranges(const gpq_ctx *c, PassArgs a, unsigned dim, const uint64_t *
     for (int i = 0; i < GPQ_MAX_SLABS; ++i) { if (a.src[i]) a.src[i] += shift; if (a.dst[i]) a.dst[i] += shift; }
     if (evk0) *evk0 += shift;
     if (evk1) *evk1 += shift;
+    if (a.zflag) a.zflag += limbs;
   };
   int rc;
   if constexpr (WIDE)
@@ -492,13 +494,41 @@ int after_launch(const char *who) {
   return GPQ_OK;
 }
 
-// in-place forward transform of nslab slabs given in a.src/a.dst
+// The zero flags of a forward launch (tables.hpp: PassArgs::zflag), polys * dim words, all zero between calls (ref_zero_redo
+// clears what it finds set).  An outgrown buffer is retired, not freed: a HIP graph captured earlier may still use it.
+int zero_flags(gpq_ctx *c, size_t count, hipStream_t s, unsigned **out) {
+  if (count > c->zflag_cap) {
+    DeviceScope on_device(c->device);
+    unsigned *fresh = nullptr;
+    const size_t cap = count < 4096 ? 4096 : count;
+    HIP_TRY(hipMalloc((void **)&fresh, cap * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(fresh, 0, cap * sizeof(unsigned), s));
+    if (c->d_zflag) c->retired.push_back(c->d_zflag);
+    c->d_zflag = fresh; c->zflag_cap = cap;
+  }
+  *out = c->d_zflag;
+  return GPQ_OK;
+}
+
+// src/ntt.c as written, one workgroup per limb (ref_zero_redo in ntt_kernels.hpp): mode 0 = redo the limbs the forward kernels flagged.
+int launch_reference(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned polys, unsigned mode, hipStream_t s) {
+  const unsigned total = polys * dim;
+  ProfScope prof(c, GPQ_K_REFERENCE, s);
+  hipLaunchKernelGGL(ref_zero_redo, dim3(total < 1024 ? total : 1024), dim3(1024), 0, s, a, polys, dim, mode);
+  return GPQ_OK;
+}
+
+// in-place forward transform of the slab given in a.src[0] = a.dst[0], in the reference's representation (a.zflag set)
 int forward_slabs(const gpq_ctx *c, PassArgs a, unsigned dim, unsigned polys, hipStream_t s) {
   int rc;
-  if (!two_pass(c)) return launch_small<false>(c, a, dim, polys, s);
-  if ((rc = launch_strided<false>(c, a, dim, polys, s)) != GPQ_OK) return rc;
-  for (unsigned i = 0; i < a.nslab; ++i) a.src[i] = a.dst[i];
-  return launch_contig<false>(c, a, dim, polys, s);
+  if (!two_pass(c)) rc = launch_small<false>(c, a, dim, polys, s);
+  else {
+    if ((rc = launch_strided<false>(c, a, dim, polys, s)) != GPQ_OK) return rc;
+    for (unsigned i = 0; i < a.nslab; ++i) a.src[i] = a.dst[i];
+    rc = launch_contig<false>(c, a, dim, polys, s);
+  }
+  if (rc != GPQ_OK) return rc;
+  return launch_reference(c, a, dim, polys, 0, s);
 }
 
 int inverse_slabs(const gpq_ctx *c, PassArgs a, unsigned dim, unsigned polys, hipStream_t s) {
@@ -521,9 +551,27 @@ extern "C" int gpq_ntt(gpq_ctx *c, uint64_t *slab, unsigned dim, unsigned batch,
     const unsigned polys = batch - k0 < kMaxPolysPerLaunch ? batch - k0 : kMaxPolysPerLaunch;
     PassArgs a = make_args(c, dim, 1);
     a.src[0] = a.dst[0] = slab + (size_t)k0 * ((size_t)dim << c->logn);
+    if ((rc = zero_flags(c, (size_t)polys * dim, (hipStream_t)stream, &a.zflag)) != GPQ_OK) return rc;
+    a.zstride = dim;
     if ((rc = forward_slabs(c, a, dim, polys, (hipStream_t)stream)) != GPQ_OK) return rc;
   }
   return after_launch("gpq_ntt");
+}
+
+// src/ntt.c:37-73 executed as written (inverse = 0: ntt, else invntt) on every limb of the slab, for ANY input words --
+// the kernel gpq_ntt redoes flagged limbs with.  Slow (one workgroup per limb, a barrier per stage); what the drop-in
+// `ntt` uses for inputs outside [0, p), and an in-device cross-check of the two-pass kernels.
+extern "C" int gpq_ntt_reference(gpq_ctx *c, uint64_t *slab, unsigned dim, unsigned batch, int inverse, void *stream) {
+  int rc = check_shape(c, dim, batch, "gpq_ntt_reference");
+  if (rc) return rc;
+  if (!slab) return gpq_fail(GPQ_ERR_INVALID, "gpq_ntt_reference: null slab");
+  for (unsigned k0 = 0; k0 < batch; k0 += kMaxPolysPerLaunch) {
+    const unsigned polys = batch - k0 < kMaxPolysPerLaunch ? batch - k0 : kMaxPolysPerLaunch;
+    PassArgs a = make_args(c, dim, 1);
+    a.src[0] = a.dst[0] = slab + (size_t)k0 * ((size_t)dim << c->logn);
+    if ((rc = launch_reference(c, a, dim, polys, inverse ? 2 : 1, (hipStream_t)stream)) != GPQ_OK) return rc;
+  }
+  return after_launch("gpq_ntt_reference");
 }
 
 extern "C" int gpq_invntt(gpq_ctx *c, uint64_t *slab, unsigned dim, unsigned batch, void *stream) {

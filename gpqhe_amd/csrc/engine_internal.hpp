@@ -9,7 +9,7 @@
 // (bench.py's roofline leg).  Off by default: no events are created.
 struct gpq_prof_rec { int kernel; hipEvent_t a, b; };
 enum { GPQ_K_STRIDED_FWD = 0, GPQ_K_STRIDED_INV, GPQ_K_CONTIG_FWD, GPQ_K_CONTIG_INV, GPQ_K_TENSOR_MID,
-       GPQ_K_KEYSWITCH_MID, GPQ_K_POINTWISE, GPQ_K_SMALL, GPQ_K_COUNT };
+       GPQ_K_KEYSWITCH_MID, GPQ_K_POINTWISE, GPQ_K_SMALL, GPQ_K_REFERENCE, GPQ_K_COUNT };
 
 // Constant matrix of the matrix-core CRT fast path for one basis and result width WL (bridge_mfma.hpp)
 struct gpq_recon_mfma {
@@ -73,6 +73,8 @@ struct gpq_ctx {
   size_t redo_cap = 0;
   std::vector<void *> retired;        // outgrown d_redo buffers: a HIP graph captured earlier may still write them, so they live as long as the context
   bool exact_crt = false;             // force the exact CRT kernel (tests)
+  unsigned *d_zflag = nullptr;        // per-(polynomial, limb) "output contains a residue 0" flags of gpq_ntt (tables.hpp); zero between calls
+  size_t zflag_cap = 0;
   // profiling
   bool prof_on = false;
   std::vector<gpq_prof_rec> prof;     // launches recorded since the last reset

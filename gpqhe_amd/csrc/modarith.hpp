@@ -240,9 +240,10 @@ __device__ __forceinline__ uint64_t canon_fold(uint64_t v, uint64_t p, uint32_t 
 __device__ __forceinline__ uint64_t mulmod_canon_lazy(uint64_t a, uint64_t b, const PrimeK &k) {
   return canon4(mulmod_lazy(a, b, k), k);
 }
-// Exact a+b mod p for canonical a,b (poly_rns_add, src/poly.c:71-76).
+// Exact a+b mod p for a, b in [0, p] (poly_rns_add, src/poly.c:71-76: barrett_reduce of the sum is canonical; operands that
+// come out of ntt may be p itself, src/ntt.c:47).
 __device__ __forceinline__ uint64_t addmod_canon(uint64_t a, uint64_t b, const PrimeK &k) {
-  return csub1(a + b, k);
+  return canon4(a + b, k);
 }
 
 }  // namespace gpq

@@ -194,6 +194,16 @@ template <> struct TwTraits<TwW> {
   __device__ static __forceinline__ uint64_t right(uint64_t x, const PrimeK &) { return x; }
 };
 
+// Zero watch of the canonical forward stores (PassArgs::zflag): m = min over the lane's outputs of (lo | hi); m == 0 <=> one of
+// them is the residue 0.  2 VALU instructions per coefficient; the atomic runs only in the (rare) lanes that saw one.
+__device__ __forceinline__ void zero_watch(uint32_t &m, uint64_t x) {
+  const uint32_t t = (uint32_t)x | (uint32_t)(x >> 32);
+  m = t < m ? t : m;
+}
+__device__ __forceinline__ void zero_note(const PassArgs &a, uint32_t m, unsigned poly, unsigned limb_in_launch) {
+  if (m == 0 && a.zflag) atomicOr(a.zflag + (size_t)poly * a.zstride + limb_in_launch, 1u);
+}
+
 // ---------------------------------------------------------------------------
 // Strided pass: the M1 = logn-8 stages with len >= 256.
 // Tile = 2^M1 rows x 16 columns, T = 2^(M1+4-EL) threads, tid = col + 16*q.
@@ -440,8 +450,10 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTI
         ln.h_to_l(x);
         ct_group<4, 3, 0, 0>(x, twl.t, k);
         ln.l_to_h(x);
+        uint32_t zm = ~0u;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) x[e] = TT::canon_fwd(x[e], k);
+        for (int e = 0; e < 16; ++e) { x[e] = TT::canon_fwd(x[e], k); zero_watch(zm, x[e]); }
+        zero_note(a, zm, p0 + i, blockIdx.z);
       } else {
         ln.h_to_l(x);
         gs_group<4, 3, 0, true>(x, twl.t, k);      // gpq_invntt's first stages: canonical inputs
@@ -471,8 +483,10 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTI
           ln.h_to_l(x[j]);
           ct_group<4, 3, 0, 0>(x[j], tw.t, k);
           ln.l_to_h(x[j]);
+          uint32_t zm = ~0u;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) x[j][e] = TT::canon_fwd(x[j][e], k);
+          for (int e = 0; e < 16; ++e) { x[j][e] = TT::canon_fwd(x[j][e], k); zero_watch(zm, x[j][e]); }
+          zero_note(a, zm, p0 + j, blockIdx.z);
           store_h(dst + (size_t)j * a.poly_stride, x[j], ln);
         }
     } else {
@@ -945,8 +959,10 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 4) void contig_pass8(PassArgs a,
       if (j < (int)cnt) {
         ln.m_to_l(x[j]);
         L8::ct_l(x[j], tw.u, k);
+        uint32_t zm = ~0u;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[j][e] = TT::canon_fwd(x[j][e], k);
+        for (int e = 0; e < 8; ++e) { x[j][e] = TT::canon_fwd(x[j][e], k); zero_watch(zm, x[j][e]); }
+        zero_note(a, zm, p0 + j, blockIdx.z);
         ln.l_to_h(x[j]);
         ln.store_h(dst + (size_t)j * a.poly_stride, x[j]);
       }
@@ -1038,7 +1054,81 @@ __global__ __launch_bounds__(256) void small_ntt(PassArgs a) {
       __syncthreads();
     }
   }
-  for (unsigned i = threadIdx.x; i < n; i += 256) dst[i] = s[i];
+  uint32_t zm = ~0u;
+  for (unsigned i = threadIdx.x; i < n; i += 256) { dst[i] = s[i]; zero_watch(zm, s[i]); }
+  if (!INV && a.nslab == 1) zero_note(a, zm, blockIdx.y, blockIdx.z);
+}
+
+// ---------------------------------------------------------------------------
+// The reference's representation of zero.  src/ntt.c:45-48 keeps its data in [0, p], not [0, p): the sum leg
+//   a[j] = (a[j] <= q - t) ? a[j] + t : a[j] + t - q
+// stores q itself when a[j] + t == q, and such a q survives a later stage whenever its partner's product t is 0.  A
+// finished forward transform therefore holds p at some of the positions whose residue is 0 (every other residue is
+// canonical: the product leg fqmul is).  The lazy kernels above cannot tell which; instead the forward kernels that hand
+// canonical output to the caller flag every (polynomial, limb) whose output contains a 0 (zero_watch) and this kernel
+// redoes the flagged limbs with the reference's own arithmetic, literally: src/ntt.c:54-73 on the canonical output gives the
+// canonical input back (the input domain of gpq_ntt), src/ntt.c:37-52 on that gives the reference's output.
+// fqmul(a, zeta) of src/ntt.c:32-35 is a * zeta_std mod p in [0, p) for every 64-bit a (montgomery_reduce, src/reduce.c:59-66:
+// hi < p, t < p), which is what ref_fqmul computes from the standard-form tables; everything else is the reference's
+// unsigned 64-bit arithmetic as written, wrap-around included, so mode 1 / 2 reproduce src/ntt.c for ANY input words.
+// One workgroup per limb, stages through global memory (L2-resident: a limb is at most 1 MiB), a barrier per stage.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ref_fqmul(uint64_t a, uint64_t w, const PrimeK &k) {
+  if (a >= 2 * k.p4) a %= k.p;                // only words outside the reference's own [0, p] domain get here
+  return mulmod_canon(a, w, k);
+}
+template <bool INV>
+__device__ void ref_transform_limb(uint64_t *__restrict__ v, unsigned logn, const uint64_t *__restrict__ w, const LimbTab &tab) {
+  const PrimeK k = tab.k;
+  const uint64_t q = k.p;
+  const unsigned n = 1u << logn, half = n >> 1, T = blockDim.x;
+  if (!INV) {
+    for (unsigned ls = logn; ls-- > 0;) {                          // len = 2^ls = n/2 .. 1          src/ntt.c:42
+      const unsigned len = 1u << ls;
+      for (unsigned b = threadIdx.x; b < half; b += T) {
+        const unsigned blk = b >> ls, j = (blk << (ls + 1)) + (b & (len - 1));
+        const uint64_t zeta = w[(n >> (ls + 1)) + blk];            // zetas[k++], k = n/(2 len) + block index
+        const uint64_t x = v[j];
+        const uint64_t t = ref_fqmul(v[j + len], zeta, k);
+        v[j + len] = (x >= t) ? x - t : x - t + q;                 // src/ntt.c:46
+        v[j] = (x <= q - t) ? x + t : x + t - q;                   // src/ntt.c:47
+      }
+      __syncthreads();
+    }
+  } else {
+    for (unsigned ls = 0; ls < logn; ++ls) {                       // len = 1 .. n/2                  src/ntt.c:60
+      const unsigned len = 1u << ls;
+      for (unsigned b = threadIdx.x; b < half; b += T) {
+        const unsigned blk = b >> ls, j = (blk << (ls + 1)) + (b & (len - 1));
+        const uint64_t zeta_inv = w[(n >> (ls + 1)) + blk];
+        const uint64_t t = v[j], y = v[j + len];
+        v[j] = (y <= q - t) ? t + y : t + y - q;                   // src/ntt.c:65
+        const uint64_t d = (y <= t) ? t - y : t - y + q;           // src/ntt.c:66
+        v[j + len] = ref_fqmul(d, zeta_inv, k);                    // src/ntt.c:67
+      }
+      __syncthreads();
+    }
+    for (unsigned i = threadIdx.x; i < n; i += T) v[i] = ref_fqmul(v[i], tab.ninv, k);   // src/ntt.c:71-72
+    __syncthreads();
+  }
+}
+
+// mode 0: redo the flagged limbs of a finished gpq_ntt (and clear their flags); 1: src/ntt.c:37-52 on every limb;
+// 2: src/ntt.c:54-73 on every limb.  a.dst[0] = slab, grid.x workgroups walk the polys * limbs limbs of the launch.
+__global__ __launch_bounds__(1024) void ref_zero_redo(PassArgs a, unsigned polys, unsigned limbs, unsigned mode) {
+  const unsigned total = polys * limbs;
+  for (unsigned idx = blockIdx.x; idx < total; idx += gridDim.x) {
+    const unsigned poly = idx / limbs, z = idx % limbs;
+    unsigned *flag = a.zflag + (size_t)poly * a.zstride + z;
+    if (mode == 0 && *flag == 0) continue;                         // uniform per workgroup
+    const unsigned limb = a.limb0 + z;
+    const LimbTab &tab = a.tabs[limb];
+    uint64_t *v = a.dst[0] + (size_t)poly * a.poly_stride + ((size_t)z << a.logn);
+    const size_t toff = (size_t)limb << a.logn;
+    if (mode != 1) ref_transform_limb<true>(v, a.logn, a.winv + toff, tab);
+    if (mode != 2) ref_transform_limb<false>(v, a.logn, a.w + toff, tab);
+    if (mode == 0) { __syncthreads(); if (threadIdx.x == 0) *flag = 0; }
+  }
 }
 
 }  // namespace gpq

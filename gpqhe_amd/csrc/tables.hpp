@@ -29,6 +29,11 @@ struct PassArgs {
   unsigned logn;
   unsigned limb0;
   unsigned nslab;                    // blockIdx.y = poly * nslab + slab
+  // Forward transforms that hand canonical output to the caller (gpq_ntt) note every (polynomial, limb) whose output
+  // contains a residue 0: zflag[poly * zstride + blockIdx.z] |= 1.  Those limbs are redone by ref_zero_redo, which
+  // reproduces the reference's representation of zero (src/ntt.c:47 stores p, not 0, for a sum x + t == p).
+  unsigned *zflag;
+  unsigned zstride;
 };
 
 }  // namespace gpq

@@ -263,6 +263,11 @@ class PolyContext:
         _native.check(self.lib.gpq_invntt(self.h, self._ptr(slab), dim, self._shape(slab, dim), self._stream()), "gpq_invntt")
         return slab
 
+    def poly_ntt_reference(self, slab, dim, inverse=False):
+        """src/ntt.c executed as written on the device (any input words): the kernel gpq_ntt redoes flagged limbs with."""
+        _native.check(self.lib.gpq_ntt_reference(self.h, self._ptr(slab), dim, self._shape(slab, dim), 1 if inverse else 0, self._stream()), "gpq_ntt_reference")
+        return slab
+
     # --- src/poly.c:71-82 over slabs ---
     def poly_rns_mul(self, r, a, b, dim):
         _native.check(self.lib.gpq_rns_mul(self.h, self._ptr(r), self._ptr(a), self._ptr(b), dim, self._shape(a, dim), self._stream()), "gpq_rns_mul")

@@ -104,9 +104,17 @@ int gpq_free_host(void *hptr);
  */
 
 /* ntt / invntt over every limb of every polynomial, in place.
- * Replaces the per-limb calls `ntt(a, rns)` / `invntt(a, rns)`, src/ntt.c:37,54. */
+ * Replaces the per-limb calls `ntt(a, rns)` / `invntt(a, rns)`, src/ntt.c:37,54.
+ * Inputs are canonical residues in [0, p_d) (what rns_decompose and poly_rns_mul produce).  Outputs are the reference's
+ * words: gpq_invntt's are canonical; gpq_ntt's are canonical except that a residue 0 is stored as p_d wherever
+ * src/ntt.c:47 stores it so (a sum leg x + t == p is kept as p, and survives while its partner's product is 0):
+ * limbs whose output contains a zero are redone with the reference's own arithmetic (ref_zero_redo, ntt_kernels.hpp). */
 int gpq_ntt(gpq_ctx *ctx, uint64_t *slab, unsigned dim, unsigned batch, void *stream);
 int gpq_invntt(gpq_ctx *ctx, uint64_t *slab, unsigned dim, unsigned batch, void *stream);
+/* src/ntt.c:37-52 (inverse = 0) or :54-73 executed as written on every limb, for ANY 64-bit input words (the reference's
+ * unsigned wrap-around included): the slow kernel gpq_ntt redoes flagged limbs with, what the drop-in `ntt` / `invntt`
+ * take for inputs outside [0, p), and an in-device cross-check of the two-pass kernels. */
+int gpq_ntt_reference(gpq_ctx *ctx, uint64_t *slab, unsigned dim, unsigned batch, int inverse, void *stream);
 
 /* r = a (*) b and r = a + b, coefficient-wise mod p_d; r may alias a or b.
  * Replace poly_rns_mul / poly_rns_add, src/poly.c:71-82 (decl src/poly.h:84-85). */

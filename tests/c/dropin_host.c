@@ -35,8 +35,49 @@ static uint64_t fnv(const uint64_t *a, size_t n)
   return h;
 }
 
+/* dropin_host xform <logn> <dim> <fwd|inv> <infile> <outfile>: the limbs of a uint64[polys][dim][n] slab read from a file, each through
+ * the reference-named symbol `ntt` / `invntt` with its own struct rns_ctx, written back -- any input words (the zero-representation
+ * and out-of-domain cases of tests/test_ntt_zero_repr_gpu.py). */
+static int xform(int argc, char **argv)
+{
+  if (argc < 7) return 2;
+  unsigned logn = (unsigned)atoi(argv[2]), dim = (unsigned)atoi(argv[3]);
+  const int inverse = strcmp(argv[4], "inv") == 0;
+  size_t n = (size_t)1 << logn;
+  memset(&polyctx, 0, sizeof polyctx);
+  polyctx.logn = logn; polyctx.n = (unsigned)n; polyctx.m = 2 * (unsigned)n;
+  polyctx.logR = 64; polyctx.R = (gpq_u128)1 << 64; polyctx.Rsub1 = polyctx.R - 1;
+  polyctx.dimub = dim;
+  gpq_ctx *ctx = NULL;
+  if (gpq_ctx_create(&ctx, logn, dim, 0) != GPQ_OK) { fprintf(stderr, "%s\n", gpq_last_error()); return 1; }
+  struct rns_ctx *nodes = calloc(dim, sizeof *nodes);
+  if (gpq_fill_rns_chain(nodes, dim, ctx, 0) != GPQ_OK) { fprintf(stderr, "gpq_fill_rns_chain failed\n"); return 1; }
+  polyctx.rns = nodes;
+  FILE *f = fopen(argv[5], "rb");
+  if (!f) { fprintf(stderr, "cannot read %s\n", argv[5]); return 1; }
+  fseek(f, 0, SEEK_END);
+  const size_t limbs = (size_t)ftell(f) / (8 * n);                  /* limb k belongs to prime k mod dim */
+  fseek(f, 0, SEEK_SET);
+  uint64_t *a = malloc(limbs * n * 8);
+  if (fread(a, 8, limbs * n, f) != limbs * n) { fprintf(stderr, "cannot read %s\n", argv[5]); return 1; }
+  fclose(f);
+  for (size_t k = 0; k < limbs; k++) {
+    const struct rns_ctx *rns = &nodes[k % dim];
+    if (inverse) invntt(a + k * n, rns); else ntt(a + k * n, rns);
+  }
+  f = fopen(argv[6], "wb");
+  if (!f || fwrite(a, 8, limbs * n, f) != limbs * n) { fprintf(stderr, "cannot write %s\n", argv[6]); return 1; }
+  fclose(f);
+  gpq_dropin_reset();
+  gpq_release_rns_chain(nodes);
+  gpq_ctx_destroy(ctx);
+  free(nodes); free(a);
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
+  if (argc > 1 && strcmp(argv[1], "xform") == 0) return xform(argc, argv);
   if (argc < 4) return 2;
   unsigned logn = (unsigned)atoi(argv[1]), dim = (unsigned)atoi(argv[2]);
   uint64_t seed = strtoull(argv[3], NULL, 10);
