@@ -39,6 +39,7 @@ LOGN, DIM_A, DIM_B = 16, 30, 45
 ALGO_BYTES_PER_HE_MUL = (7 * DIM_A + 5 * DIM_B) * (8 << LOGN)  # 228,065,280
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SG_DEADLINE_S = 150    # watchdog of the secondary scatter/gather leg (N > 1)
+SG_FAILED_STATUS = 3   # exit status of every rank when that leg stalls or fails (the line is still printed first)
 
 # own read+write bytes of one (limb, polynomial) unit of each kernel, in limbs of n*8 bytes
 KERNEL_LIMB_PASSES = {"strided_fwd": 2, "strided_inv": 2, "tensor_mid": 7, "keyswitch_mid": 5,
@@ -326,6 +327,8 @@ def parse_args(argv=None):
                     "rank 0 and the outputs gathered back inside the timed region (SURVEY.md 8d config 4)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path with several ranks on one GPU)")
+    ap.add_argument("--sg-deadline", type=float, default=SG_DEADLINE_S, help="seconds the scatter/gather leg may take before every rank gives up (exit status %d)" % SG_FAILED_STATUS)
+    ap.add_argument("--sg-stall-rank", type=int, default=-1, help="testing: this rank never enters the scatter/gather leg (rehearses a stalled transfer)")
     return ap.parse_args(argv)
 
 
@@ -467,9 +470,10 @@ def main(argv=None):
         chunk = min(B, args.chunk or 32)
         lb = args.limb_block or 0
         la, lbb = (min(lb, DIM_A), min(lb, DIM_B)) if lb else (DIM_A, DIM_B)
-        units = {"tensor_mid": la * chunk, "keyswitch_mid": lbb * chunk,
-                 "strided_fwd": (4 * DIM_A + 1 * DIM_B) * chunk / (DIM_A / la + DIM_B / lbb),
-                 "strided_inv": (3 * DIM_A + 2 * DIM_B) * chunk / (DIM_A / la + DIM_B / lbb)}
+        na, nb = -(-DIM_A // la), -(-DIM_B // lbb)               # launch groups per stage: ceil(limbs / limb block)
+        units = {"tensor_mid": DIM_A * chunk / na, "keyswitch_mid": DIM_B * chunk / nb,
+                 "strided_fwd": (4 * DIM_A + 1 * DIM_B) * chunk / (na + nb),
+                 "strided_inv": (3 * DIM_A + 2 * DIM_B) * chunk / (na + nb)}
         top = max(v[0] for v in prof.values())
         kname, (kms, kcnt) = min(((n, v) for n, v in prof.items() if v[0] >= 0.95 * top),
                                  key=lambda nv: KERNEL_LIMB_PASSES[nv[0]] * units[nv[0]] / (nv[1][0] / nv[1][1]))
@@ -534,22 +538,36 @@ def main(argv=None):
         # line and ends the ranks -- it can never cost the headline.
         import threading
         finished = threading.Event()
+        progress = {"stage": "not started"}                  # what this rank was doing when the leg stalled or failed
+
+        def abandon(reason):
+            """The leg did not finish on this rank: rank 0 prints the (complete) compute-only line with the reason, then EVERY rank
+            leaves with a non-zero status -- a stalled or failed transfer must never look like success to launch_ranks / the driver."""
+            if rank == 0:
+                out["with_scatter_gather"] = {"error": reason, "rank": rank, "stage": progress["stage"],
+                                              "note": "the compute-only figures of this line are complete"}
+                print(json.dumps(out), flush=True)
+            else:
+                print("bench.py: rank %d gives up on the scatter/gather leg at stage %r: %s" % (rank, progress["stage"], reason), file=sys.stderr, flush=True)
+            os._exit(SG_FAILED_STATUS)
 
         def give_up():
-            if finished.is_set():
-                return
-            if rank == 0:
-                out["with_scatter_gather"] = {"error": "no result within %d s; the compute-only figures of this line are complete" % SG_DEADLINE_S}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+            if not finished.is_set():
+                abandon("no result within %g s" % args.sg_deadline)
 
-        watchdog = threading.Timer(SG_DEADLINE_S, give_up)
+        watchdog = threading.Timer(args.sg_deadline, give_up)
         watchdog.daemon = True
         watchdog.start()
         try:
-            sg = scatter_gather_step(torch, dist, ctx, (a0, a1, b0, b1), x, (e0, e1), (wsA, wsB), min(total_batch // world, 16), world, rank, barrier)
+            if rank == args.sg_stall_rank:
+                progress["stage"] = "stalled on purpose (--sg-stall-rank)"
+                threading.Event().wait()
+            sg = scatter_gather_step(torch, dist, ctx, (a0, a1, b0, b1), x, (e0, e1), (wsA, wsB), min(total_batch // world, 16), world, rank, barrier, progress)
         except Exception as exc:           # noqa: BLE001
-            sg = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            # the peers may be inside a transfer with this rank: no barrier any more (it could never complete); their own watchdogs
+            # (or launch_ranks, which stops the other ranks at the first non-zero exit) end them
+            finished.set()
+            abandon("%s: %s" % (type(exc).__name__, exc))
         finished.set()
         watchdog.cancel()
         if rank == 0:
@@ -561,7 +579,7 @@ def main(argv=None):
         dist.destroy_process_group()
 
 
-def scatter_gather_step(torch, dist, ctx, ins, x, evk, wss, Bs, world, rank, barrier):
+def scatter_gather_step(torch, dist, ctx, ins, x, evk, wss, Bs, world, rank, barrier, progress=None):
     """One step over Bs ciphertexts per rank with the transfers timed: rank 0 holds the Bs*world inputs, every rank receives
     its shard (grouped isend/irecv = one RCCL group over xGMI), computes, and returns its five output slabs to rank 0."""
     from gpqhe_amd.dist import scatter_slab, gather_slab, max_over_ranks
@@ -570,15 +588,27 @@ def scatter_gather_step(torch, dist, ctx, ins, x, evk, wss, Bs, world, rank, bar
     per_a, per_b = DIM_A * ctx.n, DIM_B * ctx.n
     full_in = [torch.cat([v[: Bs * per_a]] * world) if rank == 0 else None for v in (a0, a1, b0, b1)]
     full_x = torch.cat([x[: Bs * per_b]] * world) if rank == 0 else None
+    progress = progress if progress is not None else {}
+    progress["stage"] = "barrier before the scatter"
     barrier()
     t1 = time.perf_counter()
-    sa = [scatter_slab(f, per_a, Bs * world, 0, dev) for f in full_in]
+    sa = []
+    for i, f in enumerate(full_in):
+        progress["stage"] = "scatter of input slab %d of 5 (rank 0 -> all)" % (i + 1)
+        sa.append(scatter_slab(f, per_a, Bs * world, 0, dev))
+    progress["stage"] = "scatter of input slab 5 of 5 (rank 0 -> all)"
     sx = scatter_slab(full_x, per_b, Bs * world, 0, dev)
+    progress["stage"] = "compute"
     o = [torch.empty_like(sa[0]) for _ in range(3)] + [torch.empty_like(sx) for _ in range(2)]
     ctx.he_mul_tensor(o[0], o[1], o[2], sa[0], sa[1], sa[2], sa[3], DIM_A, wss[0])
     ctx.he_keyswitch(o[3], o[4], sx, evk[0], evk[1], DIM_B, wss[1])
-    back = [gather_slab(o[i], per_a if i < 3 else per_b, Bs * world, 0) for i in range(5)]
+    back = []
+    for i in range(5):
+        progress["stage"] = "gather of output slab %d of 5 (all -> rank 0)" % (i + 1)
+        back.append(gather_slab(o[i], per_a if i < 3 else per_b, Bs * world, 0))
+    progress["stage"] = "barrier after the gather"
     barrier()
+    progress["stage"] = "done"
     dsg = max_over_ranks(time.perf_counter() - t1)
     moved = (4 * per_a + per_b + 3 * per_a + 2 * per_b) * 8 * Bs * (world - 1)
     sg = {"batch_per_gpu": Bs, "he_mul_per_s": round(Bs * world / dsg, 1), "ms": round(dsg * 1e3, 2), "bytes_over_links": moved,

@@ -30,6 +30,7 @@ SIGNATURES = {
     "gpq_free": (C.c_int, [vp]),
     "gpq_upload": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "gpq_download": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "gpq_copy": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "gpq_stream_sync": (C.c_int, [vp]),
     "gpq_device_count": (C.c_int, []),
     "gpq_set_device": (C.c_int, [C.c_int]),

@@ -340,6 +340,10 @@ extern "C" int gpq_download(void *dst, const void *src, size_t bytes, void *stre
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   return GPQ_OK;
 }
+extern "C" int gpq_copy(void *dst, const void *src, size_t bytes, void *stream) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return GPQ_OK;
+}
 extern "C" int gpq_stream_sync(void *stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return GPQ_OK; }
 
 // Several devices from one C program (independent ciphertexts, one shard per GPU): the calling thread's current

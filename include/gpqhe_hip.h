@@ -85,6 +85,7 @@ int gpq_malloc(void **dptr, size_t bytes);
 int gpq_free(void *dptr);
 int gpq_upload(void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int gpq_download(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int gpq_copy(void *dst_dev, const void *src_dev, size_t bytes, void *stream);      /* device to device, same device */
 int gpq_stream_sync(void *stream);
 /* Several devices from one C program: gpq_malloc and gpq_stream_create act on the calling thread's current device
  * (gpq_set_device); a context belongs to the device given to gpq_ctx_create and is used with streams and buffers of that

@@ -3,14 +3,15 @@
  * ("one ciphertext per GPU", no exchange inside a transform; src/he-mult.c:116-138 and :58-66 carry no
  * cross-ciphertext state).  Only the C ABI of include/gpqhe_hip.h is used -- no HIP headers, no torch:
  *
- *   shard_host <logn> <dimA> <dimB> <batch> <dev,dev,...>
+ *   shard_host <logn> <dimA> <dimB> <batch> <dev,dev,...> [period]
  *
  * Shard s (block partition of the batch, the first batch % shards shards take one more) lives on device <dev_s>: its own
  * context, stream, buffers.  All shards are launched before any is waited for, so the devices work concurrently; listing a
  * device twice ("0,0") puts two shards with separate contexts and streams on it (what a one-GPU box can exercise).
  * Inputs: ciphertext k uses gen(1000 + 4k .. 1003 + 4k, dimA) and gen(2000 + k, dimB), one key gen(3000 / 3001, dimB) --
  * the synthetic batch of SURVEY.md 8d.  Prints, per ciphertext, the FNV-1a-64 digests of d0, d1, d2, c0, c1; the pytest
- * wrapper compares them with the oracle's.
+ * wrapper compares them with the oracle's.  With a `period` P > 0 ciphertext k carries the inputs of ciphertext k mod P (BASELINE
+ * configs[3]'s batch of 512 with P oracle evaluations instead of 512: every ciphertext must print the digests of k mod P).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -59,6 +60,7 @@ int main(int argc, char **argv)
   int devs[64], shards = 0;
   for (char *tok = strtok(argv[5], ","); tok && shards < 64; tok = strtok(NULL, ",")) devs[shards++] = atoi(tok);
   if (!shards || batch < (unsigned)shards || dimA > dimB) return 2;
+  const unsigned period = argc > 6 ? (unsigned)atoi(argv[6]) : 0;
   printf("devices visible %d, shards %d\n", gpq_device_count(), shards);
   for (int s = 0; s < shards; s++)
     if (devs[s] < 0 || devs[s] >= gpq_device_count()) { fprintf(stderr, "device %d is not there\n", devs[s]); return 1; }
@@ -90,12 +92,19 @@ int main(int argc, char **argv)
     CHECK(gpq_malloc((void **)&h->d_wsA, gpq_tensor_workspace_bytes(h->ctx, dimA, cnt)));
     CHECK(gpq_malloc((void **)&h->d_wsB, gpq_keyswitch_workspace_bytes(h->ctx, dimB, cnt)));
     for (unsigned k = h->lo; k < h->hi; k++) {
+      const unsigned ks = period ? k % period : k;           /* whose inputs ciphertext k carries */
+      if (period && k - h->lo >= period) {                    /* a repeat inside this shard: device-side copies of the first occurrence */
+        const unsigned src = k - h->lo - period;
+        for (int i = 0; i < 4; i++) CHECK(gpq_copy(h->d_in[i] + (k - h->lo) * perA, h->d_in[i] + src * perA, perA * 8, h->stream));
+        CHECK(gpq_copy(h->d_x + (k - h->lo) * perB, h->d_x + src * perB, perB * 8, h->stream));
+        continue;
+      }
       for (int i = 0; i < 4; i++) {
-        gen(host, 1000 + 4 * k + i, dimA, n, primes);
+        gen(host, 1000 + 4 * ks + i, dimA, n, primes);
         CHECK(gpq_upload(h->d_in[i] + (k - h->lo) * perA, host, perA * 8, h->stream));
         CHECK(gpq_stream_sync(h->stream));                 /* `host` is reused (pageable memory: the copy is staged anyway) */
       }
-      gen(host, 2000 + k, dimB, n, primes);
+      gen(host, 2000 + ks, dimB, n, primes);
       CHECK(gpq_upload(h->d_x + (k - h->lo) * perB, host, perB * 8, h->stream));
       CHECK(gpq_stream_sync(h->stream));
     }

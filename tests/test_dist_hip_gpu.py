@@ -124,3 +124,20 @@ def test_bench_starts_its_own_ranks():
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
     sg = out["with_scatter_gather"]
     assert "error" not in sg and sg["shards_identical"] is True and sg["he_mul_per_s"] > 0
+
+
+@pytest.mark.timeout(600)
+def test_a_stalled_scatter_gather_leg_is_a_failure_not_a_success():
+    """One rank never enters the transfers: every rank gives up at the deadline, rank 0 still prints the complete compute-only
+    line (with the error, its rank and the stage it was stuck in), and the exit status that reaches the caller is non-zero."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--total-batch", "4",
+           "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--no-ntt", "--sg-stall-rank", "1", "--sg-deadline", "10"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=540, cwd=ROOT)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["n_gpus"] == 2
+    sg = out["with_scatter_gather"]
+    assert "no result within" in sg["error"] and sg["rank"] == 0 and "scatter" in sg["stage"]

@@ -51,3 +51,27 @@ def test_batch_sharded_over_a_device_list_from_plain_c(shard_host, oracle_ctx, l
             assert got[k] == expect[k], (devs, k)
     if logn == 16:
         assert expect[0] == ["99655f317c50d5c1", "e7658c5a00ed9eac", "12600b1bac18b63e", "466a17f24e0654d2", "578cf3337a189ad0"]   # SURVEY.md 8c, k = 0
+
+
+@pytest.mark.timeout(900)
+def test_eight_shards_with_their_own_contexts_on_one_device(shard_host, oracle_ctx):
+    """BASELINE configs[3]'s layout rehearsed on the one GPU of the box: eight shards ("0,0,0,0,0,0,0,0" stands for "0,1,...,7"),
+    each with its own context, stream and buffers, at the headline shape; 32 ciphertexts (4 per shard) carrying the inputs of
+    ciphertext k mod 4, so four oracle evaluations price all of them.  The full batch of 512 (64 per shard) is the same command with
+    512 in place of 32: profiles/r03/ keeps that run."""
+    logn, dim_a, dim_b, batch, period = 16, 30, 45, 32, 4
+    o = oracle_ctx(logn, dim_b)
+    ev = [o.gen(3000, dim_b), o.gen(3001, dim_b)]
+    expect = []
+    for k in range(period):
+        d = o.he_mul_tensor(*[o.gen(1000 + 4 * k + i, dim_a) for i in range(4)], dim_a)
+        c = o.keyswitch(o.gen(2000 + k, dim_b), ev[0], ev[1], dim_b)
+        expect.append([fnv(v) for v in list(d) + list(c)])
+    res = subprocess.run([shard_host, str(logn), str(dim_a), str(dim_b), str(batch), "0,0,0,0,0,0,0,0", str(period)], capture_output=True, text=True, timeout=800)
+    assert res.returncode == 0, res.stderr
+    lines = res.stdout.strip().split("\n")
+    assert lines[0].endswith("shards 8")
+    got = {int(f[1]): f[4:] for f in (ln.split() for ln in lines[1:])}
+    assert sorted(got) == list(range(batch))
+    for k in range(batch):
+        assert got[k] == expect[k % period], k

@@ -1,4 +1,4 @@
-"""rocprofv3 target: a few MPI-level he_mul's (dev tool)."""
+"""rocprofv3 target: a few MPI-level he_mul's (dev tool).  MPI_BATCH (default 64) ciphertexts per call."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, gpqhe_amd
@@ -6,4 +6,4 @@ from bench import he_mul_mpi_rate
 ctx = gpqhe_amd.PolyContext(16, 45)
 if os.environ.get("GPQ_BRIDGE_VALU") == "1":      # tool-side switch (tools/gpu_prof_mpi.sh): the library itself reads no environment
     ctx.set_bridge_mfma(False)
-print(he_mul_mpi_rate(torch, gpqhe_amd, ctx, 16, iters=6))
+print(he_mul_mpi_rate(torch, gpqhe_amd, ctx, int(os.environ.get("MPI_BATCH", "64")), iters=int(os.environ.get("MPI_ITERS", "6"))))
