@@ -114,19 +114,24 @@ SIGNATURES = {
     "gpq_mpi_shim_release": (None, []),
     "gpq_mpi_shim_forget_keys": (None, []),
     "gpq_mpi_shim_set_key_slots": (None, [C.c_uint]),
+    "gpq_mpi_shim_set_key_check": (None, [C.c_int]),
+    "gpq_mpi_shim_engine": (C.c_void_p, []),
+    "gpq_compat_view": (C.c_void_p, [C.c_char_p]),
+    "gpq_mpi_shim_resident_keys": (C.c_uint, []),
     "gpq_mpi_shim_last_timing": (None, [C.POINTER(C.c_double)]),
     "gpq_fill_rns_chain": (C.c_int, [vp, C.c_uint, vp, C.c_int]),
     "gpq_release_rns_chain": (None, [vp]),
-    "poly_rns_alloc": (None, [vp, C.c_uint]),
-    "poly_rns_free": (None, [vp]),
 }
 # by-value unsigned __int128 arguments cannot be expressed in ctypes; these two are
 # exercised from C (tests/c/dropin_host.c)
 EXPORTED_ONLY = ["montgomery_reduce", "barrett_reduce",
                  # MPI-typed surface: driven from C with real libgcrypt MPIs (tests/c/mpi_host.c)
                  "rns_decompose", "rns_reconstruct", "poly_rns2mpi", "poly_mul", "he_mul", "he_rs", "he_rescale", "he_moddown", "he_mulpt", "he_conj", "he_rot", "he_genrlk", "he_genck", "he_genrk",
-                 # context construction / MPI storage (weak definitions, need libgcrypt MPIs: driven from C) and the data symbols
-                 "polyctx_init", "polyctx_exit", "hectx_init", "hectx_exit", "poly_mpi_alloc", "poly_mpi_free", "polyctx", "hectx", "GPQHE_TWO"]
+                 ]
+# libgpqhe_hip_ctx.so (ctx_compat.hip): context construction / storage names for hosts that are not GPQHE; driven from C
+CTX_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgpqhe_hip_ctx.so")
+CTX_EXPORTS = ["polyctx_init", "polyctx_exit", "hectx_init", "hectx_exit", "poly_mpi_alloc", "poly_mpi_free", "poly_rns_alloc", "poly_rns_free",
+               "polyctx", "hectx", "GPQHE_TWO"]
 
 _lib = None
 

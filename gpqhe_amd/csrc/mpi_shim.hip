@@ -114,15 +114,23 @@ void copy_range(void *dst, const void *src, unsigned n, unsigned W, unsigned lo,
 
 // MPI polynomials -> device big slabs: every host thread converts its range of a polynomial into page-locked memory and sends
 // that range off at once, so conversion of the next range / polynomial overlaps the DMA of the previous one.
-void upload_polys(const DevBuf *const dst[], const HostBuf *const stage[], const poly_mpi_t *const src[], int count, unsigned n, unsigned W) {
+// `extra` more tasks (side(0) .. side(extra - 1)) are handed out to the same threads behind the ranges -- the evaluation-key
+// fingerprint of he_mul / he_rot / he_conj, which only reads memory while the conversions compute.
+void upload_polys(const DevBuf *const dst[], const HostBuf *const stage[], const poly_mpi_t *const src[], int count, unsigned n, unsigned W,
+                  unsigned extra = 0, const std::function<void(unsigned)> *side = nullptr) {
   if (W < 1 || W > 32) die("coefficients wider than 2047 bits");
-  for_ranges(n, [=](unsigned lo, unsigned hi) {
+  const unsigned nt = n >= 4096 ? workers().width() : 1, per = (n + nt - 1) / nt;
+  const std::function<void(unsigned)> job = [&](unsigned t) {
+    if (t >= nt) { (*side)(t - nt); return; }
+    const unsigned lo = t * per, hi = lo + per < n ? lo + per : n;
+    if (lo >= hi) return;
     (void)hipSetDevice(g_dev);
     for (int i = 0; i < count; ++i) {
       to_slab_range(stage[i]->u64(), src[i], n, W, lo, hi);
       copy_range(dst[i]->p, stage[i]->p, n, W, lo, hi, hipMemcpyHostToDevice);
     }
-  });
+  };
+  if (nt + extra < 2) job(0); else workers().run(nt + extra, job);
 }
 
 // device big slabs -> the caller's MPIs: the ranges come back one DMA each, in order, an event behind every one; a host thread
@@ -159,13 +167,16 @@ double wall_ms() {
 }
 
 // Evaluation keys are 2 x dim x n words (47 MB at the headline shape) and the same key multiplies many ciphertexts: the device
-// copy is kept, identified by the caller's two pointers, the length and a fingerprint of sampled words (a key rewritten in
-// place at the same address is uploaded again).  A handful of keys (rlk, ck, the rotation keys in use) stay resident.
+// copy is kept, identified by the caller's two pointers, the length and a fingerprint of EVERY word (the reference reads the key
+// it is given on every call, src/he-mult.c:60-64: a key edited in place, in however few words, must multiply as edited).  The
+// fingerprint is computed by the conversion threads next to the ciphertext conversions (KeyPrint: it only reads memory while they
+// compute); gpq_mpi_shim_set_key_check(0) goes back to ~1000 sampled words for callers that never edit a key in place.
 struct KeySlot { const uint64_t *h0, *h1; size_t words; uint64_t print; void *d0, *d1; uint64_t used; };
 std::vector<KeySlot> g_keys;
 uint64_t g_key_clock = 0;
 size_t g_key_slots = 16;      // resident keys (rlk, ck, the rotation keys in use): 45 MiB each at the headline shape; gpq_mpi_shim_set_key_slots
-uint64_t key_print(const uint64_t *a, const uint64_t *b, size_t words) {
+bool g_key_check_full = true; // gpq_mpi_shim_set_key_check
+uint64_t key_print_sampled(const uint64_t *a, const uint64_t *b, size_t words) {
   uint64_t h = 0xcbf29ce484222325ull;
   auto mix = [&](uint64_t v) { h = (h ^ v) * 0x100000001b3ull; h ^= h >> 29; };
   const size_t step = words > 512 ? words / 509 : 1;     // ~512 samples of each polynomial, plus both ends
@@ -173,9 +184,46 @@ uint64_t key_print(const uint64_t *a, const uint64_t *b, size_t words) {
   for (size_t i = 0; i < 8 && i < words; ++i) { mix(a[i]); mix(b[i]); mix(a[words - 1 - i]); mix(b[words - 1 - i]); }
   return h;
 }
-void key_on_device(const he_evk_t *key, size_t words, uint64_t **d0, uint64_t **d1) {
-  const uint64_t *h0 = key->p0.coeffs, *h1 = key->p1.coeffs;
-  const uint64_t print = key_print(h0, h1, words);
+// words [lo, hi) of one polynomial: four multiply-xor lanes (the multiply's latency is covered, the loop runs at memory speed)
+uint64_t hash_words(const uint64_t *a, size_t lo, size_t hi) {
+  uint64_t h[4] = {0x9e3779b97f4a7c15ull, 0xbf58476d1ce4e5b9ull, 0x94d049bb133111ebull, 0xcbf29ce484222325ull};
+  size_t i = lo;
+  for (; i + 4 <= hi; i += 4)
+    for (int j = 0; j < 4; ++j) { h[j] = (h[j] ^ a[i + j]) * 0xff51afd7ed558ccdull; h[j] ^= h[j] >> 32; }
+  for (; i < hi; ++i) { h[0] = (h[0] ^ a[i]) * 0xff51afd7ed558ccdull; h[0] ^= h[0] >> 32; }
+  return ((h[0] * 3 + h[1]) * 5 + h[2]) * 7 + h[3];
+}
+struct KeyPrint {                 // fingerprint of a host key, in `parts` pieces that any thread may compute
+  const uint64_t *h0, *h1; size_t words; unsigned parts; std::vector<uint64_t> part;
+  std::function<void(unsigned)> task;
+  KeyPrint(const he_evk_t *key, size_t w) : h0(key->p0.coeffs), h1(key->p1.coeffs), words(w) {
+    parts = (g_key_check_full && words >= 65536) ? 2 * workers().width() : 1;
+    part.assign(parts, 0);
+    task = [this](unsigned t) {
+      if (!g_key_check_full) { part[t] = key_print_sampled(h0, h1, words); return; }
+      const size_t lo = words * t / parts, hi = words * (t + 1) / parts;
+      part[t] = hash_words(h0, lo, hi) * 0x100000001b3ull + hash_words(h1, lo, hi);
+    };
+  }
+  uint64_t value() const {
+    uint64_t h = 0xcbf29ce484222325ull ^ words;
+    for (uint64_t v : part) { h = (h ^ v) * 0x100000001b3ull; h ^= h >> 29; }
+    return h;
+  }
+};
+void drop_key_slot(size_t i) {
+  (void)gpq_stream_sync(nullptr);
+  (void)gpq_free(g_keys[i].d0); (void)gpq_free(g_keys[i].d1);
+  g_keys.erase(g_keys.begin() + i);
+}
+void forget_key_at(const uint64_t *h0, const uint64_t *h1) {          // the host key at these addresses was rewritten (he_gen*k)
+  for (size_t i = g_keys.size(); i-- > 0;)
+    if (g_keys[i].h0 == h0 || g_keys[i].h1 == h1 || g_keys[i].h0 == h1 || g_keys[i].h1 == h0) drop_key_slot(i);
+}
+void key_on_device(const KeyPrint &kp, uint64_t **d0, uint64_t **d1) {
+  const uint64_t *h0 = kp.h0, *h1 = kp.h1;
+  const size_t words = kp.words;
+  const uint64_t print = kp.value();
   for (KeySlot &k : g_keys)
     if (k.h0 == h0 && k.h1 == h1 && k.words == words && k.print == print) { k.used = ++g_key_clock; *d0 = (uint64_t *)k.d0; *d1 = (uint64_t *)k.d1; return; }
   KeySlot slot{h0, h1, words, print, nullptr, nullptr, ++g_key_clock};
@@ -187,15 +235,19 @@ void key_on_device(const he_evk_t *key, size_t words, uint64_t **d0, uint64_t **
     for (size_t i = 1; i < g_keys.size(); ++i) if (g_keys[i].used < g_keys[victim].used) victim = i;
   }
   if (victim < g_keys.size()) {
-    if (g_keys[victim].words == words) { slot.d0 = g_keys[victim].d0; slot.d1 = g_keys[victim].d1; }
-    else { (void)gpq_stream_sync(nullptr); (void)gpq_free(g_keys[victim].d0); (void)gpq_free(g_keys[victim].d1); }
-    g_keys.erase(g_keys.begin() + victim);
+    if (g_keys[victim].words == words) { slot.d0 = g_keys[victim].d0; slot.d1 = g_keys[victim].d1; g_keys.erase(g_keys.begin() + victim); }
+    else drop_key_slot(victim);
   }
   if (!slot.d0 && (gpq_malloc(&slot.d0, words * 8) != GPQ_OK || gpq_malloc(&slot.d1, words * 8) != GPQ_OK)) die("device allocation failed");
   if (gpq_upload(slot.d0, h0, words * 8, nullptr) != GPQ_OK || gpq_upload(slot.d1, h1, words * 8, nullptr) != GPQ_OK) die("upload failed");
   g_keys.push_back(slot);
   *d0 = (uint64_t *)slot.d0; *d1 = (uint64_t *)slot.d1;
 }
+
+// The MPI-typed entry points share the staging buffers, the buffer pools, the key cache and the worker threads: one call at a
+// time (the reference itself is single-threaded; a second host thread simply waits here).  Recursive: he_rescale -> he_rs etc.
+std::recursive_mutex g_call_mu;
+#define SHIM_CALL() std::lock_guard<std::recursive_mutex> shim_call_lock(g_call_mu)
 
 }  // namespace
 
@@ -209,6 +261,7 @@ static unsigned limb_of(gpq_ctx *c, const struct rns_ctx *rns, const char *who) 
 
 // src/rns.c:37-48 -- one limb: ahat[i] = a[i] mod rns->p, non-negative
 void rns_decompose(uint64_t ahat[], const gpq_MPI a[], const struct rns_ctx *rns) {
+  SHIM_CALL();
   need_gcrypt();
   gpq_ctx *c = engine();
   const unsigned n = polyctx.n, limb = limb_of(c, rns, "rns_decompose: the node is not one of the caller's prime chain");
@@ -230,6 +283,7 @@ static void set_from_words(MPI r, const uint64_t *w, unsigned W) {
 
 // src/rns.c:60-75 -- coefficient i of a slab with rns->dim limbs, value in [0, P)
 void rns_reconstruct(gpq_MPI a, const uint64_t ahat[], const unsigned int i, const struct rns_ctx *rns) {
+  SHIM_CALL();
   need_gcrypt();
   gpq_ctx *c = engine();
   const unsigned n = polyctx.n;
@@ -244,6 +298,7 @@ void rns_reconstruct(gpq_MPI a, const uint64_t ahat[], const unsigned int i, con
 
 // src/poly.c:109-120 -- every coefficient: reconstruct, centre mod P, centre mod q
 void poly_rns2mpi(poly_mpi_t *r, const poly_rns_t *rhat, const struct rns_ctx *rns, const gpq_MPI q) {
+  SHIM_CALL();
   need_gcrypt();
   gpq_ctx *c = engine();
   const unsigned n = polyctx.n;
@@ -264,6 +319,7 @@ void poly_rns2mpi(poly_mpi_t *r, const poly_rns_t *rhat, const struct rns_ctx *r
 
 // src/poly.c:84-107
 void poly_mul(poly_mpi_t *r, const poly_mpi_t *a, const poly_mpi_t *b, const unsigned int dim, const gpq_MPI q) {
+  SHIM_CALL();
   need_gcrypt();
   gpq_ctx *c = engine();
   const unsigned n = polyctx.n;
@@ -290,6 +346,7 @@ void poly_mul(poly_mpi_t *r, const poly_mpi_t *a, const poly_mpi_t *b, const uns
 
 // src/he-mult.c:88-156
 void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t *rlk) {
+  SHIM_CALL();
   need_gcrypt();
   if (&hectx == nullptr || !hectx.q) die("`hectx` is not initialised (hectx_init first)");
   if (ct1->l != ct2->l) die("he_mul: operands at different levels");   // assert at src/he-mult.c:90
@@ -315,9 +372,10 @@ void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t 
   // he_mul(&ct, &ct, &ct, rlk), src/he-algo.c:151: one ciphertext on both sides -- convert and upload it once, square on the device
   const bool square = ct1->c0.coeffs == ct2->c0.coeffs && ct1->c1.coeffs == ct2->c1.coeffs;
   const double t0 = wall_ms();
-  upload_polys(dd, ss, in, square ? 2 : 4, n, W);
+  KeyPrint kp(rlk, evk);
+  upload_polys(dd, ss, in, square ? 2 : 4, n, W, kp.parts, &kp.task);
   uint64_t *k0, *k1;
-  key_on_device(rlk, evk, &k0, &k1);
+  key_on_device(kp, &k0, &k1);
   if (!g_tick[0]) { (void)hipEventCreate(&g_tick[0]); (void)hipEventCreate(&g_tick[1]); }
   (void)hipEventRecord(g_tick[0], nullptr);
   const double t1 = wall_ms();
@@ -339,6 +397,7 @@ void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t 
 }
 
 static void rescale_common(he_ct_t *ct, bool divide) {
+  SHIM_CALL();
   need_gcrypt();
   if (&hectx == nullptr || !hectx.q) die("`hectx` is not initialised (hectx_init first)");
   gpq_ctx *c = engine();
@@ -373,6 +432,7 @@ static void rescale_common(he_ct_t *ct, bool divide) {
 
 // src/he-mult.c:159-196
 void he_mulpt(struct he_ct *dest, const struct he_ct *src, const struct he_pt *pt) {
+  SHIM_CALL();
   need_gcrypt();
   if (&hectx == nullptr || !hectx.q) die("`hectx` is not initialised (hectx_init first)");
   gpq_ctx *c = engine();
@@ -403,6 +463,7 @@ void he_mulpt(struct he_ct *dest, const struct he_ct *src, const struct he_pt *p
 
 // he_rot / he_conj, src/he-automorphism.c:87-115: permute both polynomials, then he_swk (:40-85) in place
 static void automorphism(he_ct_t *ct, const he_evk_t *key, bool conj, unsigned rot) {
+  SHIM_CALL();
   need_gcrypt();
   if (&hectx == nullptr || !hectx.q) die("`hectx` is not initialised (hectx_init first)");
   gpq_ctx *c = engine();
@@ -419,9 +480,10 @@ static void automorphism(he_ct_t *ct, const he_evk_t *key, bool conj, unsigned r
   const DevBuf *dd[2] = {&a0, &a1}, *oo[2] = {&o0, &o1};
   const HostBuf *ss[2] = {&s0, &s1};
   const poly_mpi_t *in[2] = {&ct->c0, &ct->c1};
-  upload_polys(dd, ss, in, 2, n, W);
+  KeyPrint kp(key, evk);
+  upload_polys(dd, ss, in, 2, n, W, kp.parts, &kp.task);
   uint64_t *k0, *k1;
-  key_on_device(key, evk, &k0, &k1);
+  key_on_device(kp, &k0, &k1);
   int rc = conj ? gpq_poly_conj(c, r0.u64(), a0.u64(), W, 1, nullptr) : gpq_poly_rot(c, r0.u64(), a0.u64(), W, rot, 1, nullptr);      // :95-96 / :108-109
   if (rc == GPQ_OK) rc = conj ? gpq_poly_conj(c, r1.u64(), a1.u64(), W, 1, nullptr) : gpq_poly_rot(c, r1.u64(), a1.u64(), W, rot, 1, nullptr);
   if (rc == GPQ_OK)                                                                                                                       // :97 / :110
@@ -439,6 +501,8 @@ void he_rot(he_ct_t *ct, const int rot, const he_evk_t *rk) { automorphism(ct, &
 // he_genswk (static in the reference, :74-118) with the hidden polynomial given as a host big slab of W words.  The reference's
 // samplers are called in its order (error, then uniform mod P q_L), so a seeded RNG gives the reference's own keys.
 static void genswk(he_evk_t *swk, const std::vector<uint64_t> &sp, const std::vector<uint64_t> &hs, unsigned W) {
+  SHIM_CALL();
+  forget_key_at(swk->p0.coeffs, swk->p1.coeffs);         // the host key is about to be rewritten: its device copy (if any) goes first
   if (!sample_error || !sample_uniform) die("he_gen*k: the host program does not provide sample_error / sample_uniform (src/sample.c)");
   gpq_ctx *c = engine();
   const unsigned n = polyctx.n;
@@ -465,6 +529,7 @@ static void genswk(he_evk_t *swk, const std::vector<uint64_t> &sp, const std::ve
 }
 
 static unsigned keygen_words() {
+  SHIM_CALL();
   need_gcrypt();
   if (&hectx == nullptr || !hectx.q) die("`hectx` is not initialised (hectx_init first)");
   return G.mpi_get_nbits(hectx.PqL) / 64 + 1;
@@ -484,6 +549,7 @@ static std::vector<uint64_t> permuted(const std::vector<uint64_t> &hs, unsigned 
 }
 
 void he_genrlk(he_evk_t *rlk, const poly_mpi_t *sk) {                                              // :120-137
+  SHIM_CALL();
   const unsigned W = keygen_words(), n = polyctx.n;
   gpq_ctx *c = engine();
   printf("Generating rlk ... ");
@@ -505,6 +571,7 @@ void he_genrlk(he_evk_t *rlk, const poly_mpi_t *sk) {                           
 }
 
 void he_genck(he_evk_t *ck, const poly_mpi_t *sk) {                                                // :140-154
+  SHIM_CALL();
   const unsigned W = keygen_words(), n = polyctx.n;
   printf("Generating ck ... ");
   fflush(stdout);
@@ -515,6 +582,7 @@ void he_genck(he_evk_t *ck, const poly_mpi_t *sk) {                             
 }
 
 void he_genrk(he_evk_t *rk, const poly_mpi_t *sk) {                                                // :156-170
+  SHIM_CALL();
   const unsigned W = keygen_words(), n = polyctx.n;
   printf("Generating rk ... ");
   fflush(stdout);
@@ -530,12 +598,25 @@ void gpq_mpi_shim_last_timing(double ms[4]) { for (int i = 0; i < 4; ++i) ms[i] 
 
 // How many evaluation keys stay on the device between calls (default 16; he_rot over many rotation keys -- the gemv of
 // src/he-algo.c:63-85 walks rk[0..slots) -- wants as many as it cycles through: 45 MiB each at n = 2^16, 45 limbs).
-void gpq_mpi_shim_set_key_slots(unsigned slots) { g_key_slots = slots ? slots : 1; }
+void gpq_mpi_shim_set_key_slots(unsigned slots) {
+  SHIM_CALL();
+  g_key_slots = slots ? slots : 1;
+  while (g_keys.size() > g_key_slots) {                     // resident keys beyond the new limit go at once, least recently used first
+    size_t victim = 0;
+    for (size_t i = 1; i < g_keys.size(); ++i) if (g_keys[i].used < g_keys[victim].used) victim = i;
+    drop_key_slot(victim);
+  }
+}
+// 1 (default): a resident key is recognised by a fingerprint of every word, computed by the conversion threads beside the
+// ciphertext conversions; 0: by ~1000 sampled words (for programs that never edit a key in place; gpq_mpi_shim_forget_keys covers the rest)
+void gpq_mpi_shim_set_key_check(int full) { SHIM_CALL(); g_key_check_full = full != 0; }
+unsigned gpq_mpi_shim_resident_keys(void) { SHIM_CALL(); return (unsigned)g_keys.size(); }
 
 // Drops the device copies of evaluation keys (he_mul / he_rot / he_conj keep up to gpq_mpi_shim_set_key_slots of them, recognised by the caller's pointers, the
-// length and a fingerprint of ~1000 sampled words).  A program that rewrites a key IN PLACE in a way the samples may miss calls
-// this after the rewrite; freeing or regenerating a key through he_gen*k changes the fingerprint anyway.
+// length and a fingerprint of every word -- of ~1000 sampled words after gpq_mpi_shim_set_key_check(0), and then a program that rewrites a
+// key IN PLACE in a way the samples may miss must call this after the rewrite).  he_gen*k drop the slot of the key they write themselves.
 void gpq_mpi_shim_forget_keys(void) {
+  SHIM_CALL();
   (void)gpq_stream_sync(nullptr);
   for (KeySlot &k : g_keys) { (void)gpq_free(k.d0); (void)gpq_free(k.d1); }
   g_keys.clear();
@@ -543,6 +624,7 @@ void gpq_mpi_shim_forget_keys(void) {
 
 // frees the device buffers the MPI-typed calls keep between calls, and the engine context
 void gpq_mpi_shim_release(void) {
+  SHIM_CALL();
   (void)gpq_stream_sync(nullptr);
   for (auto &kv : g_pool) for (void *q : kv.second) (void)gpq_free(q);
   g_pool.clear();
@@ -562,36 +644,32 @@ void he_moddown(he_ct_t *ct) { rescale_common(ct, false); }       // src/he-resc
 }  // extern "C"
 
 // ======================================================================================================================
-// Context construction and polynomial storage with the reference's names (exports a replacement provides).
+// gpq_fill_rns_chain: the per-prime chain `struct rns_ctx` (src/poly.h:28-41) out of an engine context.
 //
-//   gpq_fill_rns_chain           the per-prime chain `struct rns_ctx` (src/poly.h:28-41) out of an engine context
-//   polyctx_init / polyctx_exit  src/precomp.c:328-384, :463-487        hectx_init / hectx_exit  src/precomp.c:386-450, :489-503
-//   poly_mpi_alloc/free, poly_rns_alloc/free                            src/poly.c:46-69
-//   data symbols polyctx, hectx, GPQHE_TWO                              src/precomp.c:37-47
-// All of them are WEAK definitions: a program that links GPQHE's own precomp.o / poly.o keeps GPQHE's (strong) ones and this
-// library reads them; a host that is not GPQHE (tests/c/*.c) gets a complete context from here without restating precomp.c.
-// kemctx / bootstrapctx belong to the KEM and the bootstrapping skeleton (out of scope) and are not defined.
+// The context-construction and storage names of the reference (polyctx_init/exit, hectx_init/exit, poly_mpi_alloc/free,
+// poly_rns_alloc/free, the data symbols polyctx, hectx, GPQHE_TWO; src/precomp.c, src/poly.c:46-69) are NOT defined in this
+// library: it only REFERENCES polyctx / hectx (weakly).  A GPQHE build keeps its own precomp.o / poly.o and any link order works
+// (nothing here can shadow them); a host that is not GPQHE adds -lgpqhe_hip_ctx (ctx_compat.hip), which defines them on top of
+// this library.  tests/test_link_order.py checks both orders and the dlopen case.
 // ======================================================================================================================
 namespace {
 
-// logqub of the homomorphic-encryption standard for 128-bit classical security (the reference's build: GPQHE_CQ 'C',
-// GPQHE_SEC_LEVEL 128, src/params.h:39-46; table src/precomp.c:53-64); 0 outside 10..15
-unsigned std_logqub(unsigned logn) {
-  static const unsigned tab[6] = {27, 54, 109, 218, 438, 881};
-  return (logn >= 10 && logn <= 15) ? tab[logn - 10] : 0;
-}
-
 struct ChainOwner { struct rns_ctx *nodes; unsigned count; bool mpi; };
 std::vector<ChainOwner> g_chains;        // what gpq_fill_rns_chain allocated, for gpq_release_rns_chain
-bool g_own_polyctx = false, g_own_hectx = false;
 
 }  // namespace
 
 extern "C" {
 
-__attribute__((weak)) struct poly_ctx polyctx;      // src/precomp.c:41
-__attribute__((weak)) struct he_ctx hectx;          // src/precomp.c:47
-__attribute__((weak)) gpq_MPI GPQHE_TWO;            // src/precomp.c:37
+// the engine context of the MPI-typed calls for the caller's `polyctx` (ctx_compat.hip builds the prime chain from it)
+gpq_ctx *gpq_mpi_shim_engine(void) { SHIM_CALL(); return engine(); }
+// addresses of `polyctx` / `hectx` as THIS library is bound to them (null when no object of the process defines them):
+// what tests/test_link_order.py compares with the host's own view
+const void *gpq_compat_view(const char *name) {
+  if (!strcmp(name, "polyctx")) return (const void *)&polyctx;
+  if (!strcmp(name, "hectx")) return (const void *)&hectx;
+  return nullptr;
+}
 
 // Fills nodes[0..count) -- an array the caller owns -- like polyctx_init's loop does (src/precomp.c:359-380): node d
 // describes the prefix of d + 1 primes; dim, p, pinv_mont, pinv_barr, ninv as src/precomp.c:246-248; zetas / zetas_inv
@@ -655,146 +733,6 @@ void gpq_release_rns_chain(struct rns_ctx *nodes) {
     g_chains.erase(g_chains.begin() + i);
     return;
   }
-}
-
-// src/precomp.c:328-384.  The chain is built by the engine (same primes, constants and tables: tests/test_ntt_gpu.py pins them
-// to SURVEY.md 8c) and handed out in the reference's representation; the ring part (src/precomp.c:295-326) is the encoder's.
-__attribute__((weak)) void polyctx_init(unsigned int logn, gpq_MPI q) {
-  need_gcrypt();
-  if (logn < 1 || logn > 17) die("polyctx_init: 1 <= logn <= 17");
-  memset(&polyctx, 0, sizeof polyctx);
-  GPQHE_TWO = G.mpi_set_ui(G.mpi_new(0), 2);
-  polyctx.logn = logn; polyctx.n = 1u << logn; polyctx.m = 2 * polyctx.n;
-  polyctx.logq = G.mpi_get_nbits(q) - 1;
-  polyctx.logqub = std_logqub(logn);
-  if (logn < 10 || logn > 15) polyctx.logqub = polyctx.logq;                     // :339-340
-  if (polyctx.logq > polyctx.logqub) {                                           // :343-350
-    errno = EINVAL;
-    fprintf(stderr, "\033[1m\033[31merror:\033[0m \033[1m%s\033[0m. The input modulus q is too large. Must guarantee log(q)<=log(qub).\n", strerror(errno));
-    abort();
-  }
-  polyctx.q = G.mpi_set(G.mpi_new(0), q);
-  polyctx.logR = 64; polyctx.R = (gpq_u128)1 << 64; polyctx.Rsub1 = polyctx.R - 1;
-  polyctx.dimub = (1 + logn + 4 * polyctx.logqub) / 59 + 1;                      // :357
-  polyctx.rns = (struct rns_ctx *)calloc(polyctx.dimub, sizeof(struct rns_ctx));
-  // engine() builds the context for (logn, dimub) -- it needs n and dimub, and compares primes only once rns is set
-  struct rns_ctx *nodes = polyctx.rns;
-  polyctx.rns = nullptr;
-  gpq_ctx *c = engine();
-  if (gpq_fill_rns_chain(nodes, polyctx.dimub, c, 1) != GPQ_OK) die("polyctx_init: cannot build the prime chain");
-  polyctx.rns = nodes;
-  // ring_init, src/precomp.c:295-311: the rotation group 5^i mod m and the m-th roots of unity the encoder reads
-  const unsigned nh = polyctx.n / 2, m = polyctx.m;
-  polyctx.ring.cyc_group = (unsigned int *)malloc((nh ? nh : 1) * sizeof(unsigned int));
-  polyctx.ring.cyc_group[0] = 1;
-  for (unsigned i = 1; i < nh; ++i) polyctx.ring.cyc_group[i] = (unsigned)((5ull * polyctx.ring.cyc_group[i - 1]) % m);
-  double *z = (double *)malloc((size_t)(m + 1) * 2 * sizeof(double));           // _Complex double = (re, im)
-  for (unsigned i = 0; i < m; ++i) {
-    const double theta = 2 * 3.141592653589793238462643383279502884 * i / m;
-    z[2 * i] = cos(theta); z[2 * i + 1] = sin(theta);
-  }
-  z[2 * m] = z[0]; z[2 * m + 1] = z[1];
-  polyctx.ring.zetas = (_Complex double *)z;
-  g_own_polyctx = true;
-}
-
-__attribute__((weak)) void polyctx_exit(void) {                                  // src/precomp.c:463-487
-  if (!g_own_polyctx) return;
-  G.mpi_release(GPQHE_TWO);
-  G.mpi_release(polyctx.q);
-  gpq_release_rns_chain(polyctx.rns);
-  free(polyctx.rns);
-  free(polyctx.ring.cyc_group);
-  free(polyctx.ring.zetas);
-  memset(&polyctx, 0, sizeof polyctx);
-  g_own_polyctx = false;
-  gpq_mpi_shim_release();
-}
-
-// src/precomp.c:386-450: qtable_init (q[l] = floor(q[l+1] / Delta), P = first hectx.dim primes, P q_L, dimevk), bounds_init
-// (the noise bounds of the CKKS paper, host doubles) and the argument checks.
-__attribute__((weak)) void hectx_init(unsigned int logn, gpq_MPI q, unsigned int slots, uint64_t Delta) {
-  polyctx_init(logn, q);
-  if (slots & (slots - 1)) { errno = EINVAL; fprintf(stderr, "\033[1m\033[31merror:\033[0m \033[1m%s\033[0m. The slots must be the power of 2.\n", strerror(errno)); abort(); }
-  if (slots > polyctx.n / 2) { errno = EINVAL; fprintf(stderr, "\033[1m\033[31merror:\033[0m \033[1m%s\033[0m. Must guarantee slots<=(n/2).\n", strerror(errno)); abort(); }
-  if (Delta < 2) die("hectx_init: Delta must be at least 2");
-  memset(&hectx, 0, sizeof hectx);
-  hectx.slots = slots;
-  hectx.Delta = (double)Delta;
-  hectx.p = G.mpi_set_ui(G.mpi_new(0), Delta);
-  const unsigned logq = polyctx.logq, logDelta = 63 - (unsigned)__builtin_clzll(Delta);
-  hectx.L = logq / logDelta;                                                     // "ceil" of an integer quotient, :391
-  hectx.q = (gpq_MPI *)G.xmalloc((hectx.L + 1) * sizeof(gpq_MPI));
-  hectx.qh = (gpq_MPI *)G.xmalloc((hectx.L + 1) * sizeof(gpq_MPI));
-  Words cur = words_of(q, "hectx_init: q must be positive");
-  const Words qL = cur;
-  Words q0;
-  for (int l = (int)hectx.L; l >= 0; --l) {                                      // :394-400
-    hectx.q[l] = mpi_of(cur);
-    Words h = cur;
-    shr1(h);
-    hectx.qh[l] = mpi_of(h);
-    if (l == 0) q0 = cur;
-    (void)divmod_word(cur, Delta);
-  }
-  hectx.dim = (bits_of(qL) + logn) / 59 + 1;                                     // :401
-  if (hectx.dim > polyctx.dimub) die("hectx_init: the chain is shorter than hectx.dim");
-  Words P(1, 1);
-  const struct rns_ctx *r = polyctx.rns;
-  for (unsigned d = 0; d < hectx.dim; ++d, r = r->next) mul_word(P, r->p);
-  hectx.P = mpi_of(P);                                                           // :402-404
-  const Words PqL = mul_words(P, qL);
-  hectx.PqL = mpi_of(PqL);                                                       // :405-406
-  hectx.dimevk = (bits_of(qL) + bits_of(PqL) + logn) / 59 + 1;                   // :407
-  // bounds_init, :411-432
-  const double n = polyctx.n, h = 64 /* GPQHE_BLKSIZ */, sigma = 3.1915382432114616 /* GPQHE_SIGMA */;
-  hectx.bnd.Bclean = 8 * sqrt(2) * sigma * n + 6 * sigma * sqrt(n) + 16 * sigma * sqrt(h * n);
-  hectx.bnd.Brs = sqrt(n / 3.) * (3 + 8 * sqrt(h));
-  hectx.bnd.Bks = 8 * sigma * n / sqrt(3);
-  hectx.bnd.Bmult = (double *)malloc((hectx.L + 1) * sizeof(double));
-  long double Pinv = 1;
-  for (r = polyctx.rns; r; r = r->next) Pinv *= 1. / r->p;
-  long double Pinvql = Pinv * (q0.empty() ? 0 : q0[0]);                          // mpi_to_u64(q[0])
-  hectx.bnd.Bmult[0] = (double)(Pinvql * hectx.bnd.Bks + hectx.bnd.Brs);
-  for (unsigned l = 1; l <= hectx.L; ++l) {
-    Pinvql *= hectx.Delta;
-    hectx.bnd.Bmult[l] = (double)(Pinvql * hectx.bnd.Bks + hectx.bnd.Brs);
-  }
-  if (!((double)Delta > polyctx.n + 2 * hectx.bnd.Bclean)) die("hectx_init: Delta <= n + 2 Bclean (assert at src/precomp.c:449)");
-  g_own_hectx = true;
-}
-
-__attribute__((weak)) void hectx_exit(void) {                                    // src/precomp.c:489-503
-  if (g_own_hectx) {
-    for (unsigned l = 0; l <= hectx.L; ++l) { G.mpi_release(hectx.q[l]); G.mpi_release(hectx.qh[l]); }
-    G.xfree(hectx.q); G.xfree(hectx.qh);
-    G.mpi_release(hectx.p); G.mpi_release(hectx.P); G.mpi_release(hectx.PqL);
-    free(hectx.bnd.Bmult);
-    memset(&hectx, 0, sizeof hectx);
-    g_own_hectx = false;
-  }
-  polyctx_exit();
-}
-
-// src/poly.c:46-69.  poly_rns_alloc: the reference clears only the first 8 bytes; contents are indeterminate
-// until written either way, so this one clears nothing.
-__attribute__((weak)) void poly_mpi_alloc(poly_mpi_t *a) {
-  need_gcrypt();
-  a->coeffs = (gpq_MPI *)G.xmalloc((size_t)polyctx.n * sizeof(gpq_MPI));
-  for (unsigned i = 0; i < polyctx.n; ++i) a->coeffs[i] = G.mpi_new(0);
-}
-__attribute__((weak)) void poly_mpi_free(poly_mpi_t *a) {
-  need_gcrypt();
-  for (unsigned i = 0; i < polyctx.n; ++i) G.mpi_release(a->coeffs[i]);
-  G.xfree(a->coeffs);
-  a->coeffs = nullptr;
-}
-__attribute__((weak)) void poly_rns_alloc(poly_rns_t *a, const unsigned int dim) {
-  a->coeffs = (uint64_t *)malloc((size_t)dim * polyctx.n * sizeof(uint64_t));
-}
-__attribute__((weak)) void poly_rns_free(poly_rns_t *a) {
-  free(a->coeffs);
-  a->coeffs = nullptr;
 }
 
 }  // extern "C"

@@ -133,28 +133,21 @@ void he_genrlk(he_evk_t *rlk, const poly_mpi_t *sk);
 void he_genck(he_evk_t *ck, const poly_mpi_t *sk);
 void he_genrk(he_evk_t *rk, const poly_mpi_t *sk);
 
-/* ---- context construction and polynomial storage (weak definitions) ---------------------------------
- * A program that links GPQHE's own precomp.o / poly.o keeps GPQHE's definitions (put libgpqhe / its objects BEFORE
- * -lgpqhe_hip on the link line) and this library only reads `polyctx` / `hectx`.  A host that is not GPQHE gets the
- * same context from here: the prime chain, constants and tables come from the engine (bit-identical with
- * src/precomp.c:244-293, pinned in tests/), the MPI fields are built through libgcrypt's runtime ABI. */
+/* ---- context construction and polynomial storage -------------------------------------------------------------------
+ * polyctx_init / hectx_init / poly_*_alloc and the data symbols polyctx, hectx, GPQHE_TWO are GPQHE's own (src/precomp.c,
+ * src/poly.c:46-69).  libgpqhe_hip.so does not define them (it only reads `polyctx` / `hectx`), so it can sit anywhere on a
+ * GPQHE link line.  A host that is not GPQHE gets them from libgpqhe_hip_ctx.so: include/gpqhe_hip_ctx.h. */
 struct gpq_ctx;
-extern struct poly_ctx polyctx;                                                          /* src/precomp.c:41 */
-extern struct he_ctx hectx;                                                              /* src/precomp.c:47 */
-extern gpq_MPI GPQHE_TWO;                                                                /* src/precomp.c:37 */
-void polyctx_init(unsigned int logn, gpq_MPI q);                                        /* src/poly.h:94  */
-void polyctx_exit(void);                                                                /* src/poly.h:95  */
-void hectx_init(unsigned int logn, gpq_MPI q, unsigned int slots, uint64_t Delta);      /* src/gpqhe.h:100 */
-void hectx_exit(void);                                                                  /* src/gpqhe.h:101 */
-void poly_mpi_alloc(poly_mpi_t *a);                                                     /* src/poly.h:80  */
-void poly_mpi_free(poly_mpi_t *a);                                                      /* src/poly.h:81  */
-void poly_rns_alloc(poly_rns_t *a, const unsigned int dim);                             /* src/poly.h:82  */
-void poly_rns_free(poly_rns_t *a);                                                      /* src/poly.h:83  */
 /* The chain of `struct rns_ctx` nodes (src/poly.h:28-41) for the first `count` primes of an engine context, in a
  * caller-owned array: scalars and table pointers always (tables stay owned by `ctx`), phat_invmp malloc'ed, and with
  * with_mpi != 0 the libgcrypt integers P, P_2, phat[] (src/precomp.c:266-293).  Returns GPQ_OK or GPQ_ERR_INVALID. */
 int gpq_fill_rns_chain(struct rns_ctx *nodes, unsigned count, const struct gpq_ctx *ctx, int with_mpi);
 void gpq_release_rns_chain(struct rns_ctx *nodes);
+
+/* The engine context the MPI-typed calls use for the caller's `polyctx` (built on first use; ctx_compat.hip takes its prime chain from it). */
+struct gpq_ctx *gpq_mpi_shim_engine(void);
+/* Address of `polyctx` / `hectx` as this library is bound to them (NULL when no object of the process defines them). */
+const void *gpq_compat_view(const char *name);
 
 /* When the host program has no `polyctx` symbol (the library references it
  * weakly), the ring degree for the drop-in calls is set here instead. */
@@ -164,11 +157,21 @@ void gpq_dropin_reset(void);
 /* Wall milliseconds of the last he_mul(he_ct_t *, ...) call: [0] MPI -> slab conversions + uploads, [1] device kernels (HIP
  * events), [2] downloads + slab -> MPI conversions (includes waiting for [1]), [3] the whole call. */
 void gpq_mpi_shim_last_timing(double ms[4]);
-/* Number of evaluation keys the MPI-typed calls keep on the device between calls (default 16, least recently used out). */
+/* Number of evaluation keys the MPI-typed calls keep on the device between calls (default 16, least recently used out; lowering
+ * the number evicts at once). */
 void gpq_mpi_shim_set_key_slots(unsigned slots);
-/* Drops the device copies of evaluation keys the MPI-typed calls keep (recognised by pointers, length and a fingerprint of sampled
- * words): call after rewriting a key in place. */
+/* How a resident key is recognised: by the caller's two pointers, the length and a fingerprint of EVERY word (full != 0, the
+ * default: a key edited in place multiplies as edited, like the reference, which reads its key on every call), computed by the
+ * conversion threads beside the ciphertext conversions; or of ~1000 sampled words (full == 0), for programs that never edit a key
+ * in place. */
+void gpq_mpi_shim_set_key_check(int full);
+unsigned gpq_mpi_shim_resident_keys(void);
+/* Drops the device copies of the evaluation keys.  Never needed with the default key check; he_genrlk / he_genck / he_genrk drop
+ * the copy of the key they write themselves. */
 void gpq_mpi_shim_forget_keys(void);
+/* The MPI-typed entry points keep staging buffers, device buffers, the key cache and a pool of conversion threads between calls:
+ * they serialise on one lock (the reference itself is single-threaded); calls from several host threads are safe and run one
+ * after another. */
 /* Releases the device buffers and the engine context the MPI-typed calls keep between calls. */
 void gpq_mpi_shim_release(void);
 

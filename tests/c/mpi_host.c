@@ -21,6 +21,7 @@
 
 #include "gpqhe_hip.h"
 #include "gpqhe_hip_compat.h"
+#include "gpqhe_hip_ctx.h"     /* polyctx_init / hectx_init / poly_*_alloc: this host is not GPQHE, it links -lgpqhe_hip_ctx for them */
 
 typedef void *MPI;
 MPI gcry_mpi_new(unsigned int nbits);
@@ -338,6 +339,8 @@ static int keygen(unsigned logn, unsigned logq)
 #include <time.h>
 static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 
+static int cmp_double(const void *a, const void *b) { const double x = *(const double *)a, y = *(const double *)b; return (x > y) - (x < y); }
+
 /* wall time of the MPI-typed he_mul (host conversions and PCIe copies included) on random centred ciphertexts */
 static int hemultime(unsigned logn, unsigned logq)
 {
@@ -387,24 +390,45 @@ static int hemultime(unsigned logn, unsigned logq)
       if (gcry_mpi_cmp(a.c0.coeffs[i], b.c0.coeffs[i]) || gcry_mpi_cmp(a.c1.coeffs[i], b.c1.coeffs[i])) consistent = 0;
     }
     printf("key cache: rewritten key %s, cached vs fresh upload %s\n", same_as_old ? "IGNORED" : "seen", consistent ? "identical" : "DIFFER");
+    /* ONE word changed, at an index no sampling scheme of ~1000 words looks at: the product must be the edited key's (the
+     * reference reads its key on every call), i.e. differ from the product before the edit and equal a fresh upload's */
+    const size_t words = (size_t)hectx.dimevk * polyctx.n, step = words / 509, at = 3 * step + step / 2 + 1;
+    rlk.p1.coeffs[at] = rlk.p1.coeffs[at] > 5 ? rlk.p1.coeffs[at] - 5 : rlk.p1.coeffs[at] + 5;
+    he_ct_t e;
+    poly_alloc(&e.c0); poly_alloc(&e.c1);
+    he_mul(&e, &ct1, &ct2, &rlk);
+    gpq_mpi_shim_forget_keys();
+    he_mul(&b, &ct1, &ct2, &rlk);
+    int seen = 0, fresh = 1;
+    for (unsigned i = 0; i < polyctx.n; i++) {
+      if (gcry_mpi_cmp(e.c0.coeffs[i], a.c0.coeffs[i]) || gcry_mpi_cmp(e.c1.coeffs[i], a.c1.coeffs[i])) seen = 1;
+      if (gcry_mpi_cmp(e.c0.coeffs[i], b.c0.coeffs[i]) || gcry_mpi_cmp(e.c1.coeffs[i], b.c1.coeffs[i])) fresh = 0;
+    }
+    printf("key cache: one unsampled word edited in place %s, cached vs fresh upload %s\n", seen ? "seen" : "IGNORED", fresh ? "identical" : "DIFFER");
+    /* lowering the number of resident keys evicts at once */
+    he_mul(&e, &ct1, &ct2, &rlk);
+    const unsigned before = gpq_mpi_shim_resident_keys();
+    gpq_mpi_shim_set_key_slots(1);
+    const unsigned one = gpq_mpi_shim_resident_keys();
+    gpq_mpi_shim_set_key_slots(16);
+    printf("key cache: resident %u, after set_key_slots(1) %u\n", before, one);
   }
-  const double t0 = now_ms();
+  enum { CALLS = 50 };
+  double tm[CALLS], tsq[CALLS], trs[CALLS], part[8];
   for (int i = 0; i < 3; i++) he_mul(&ct, &ct1, &ct2, &rlk);
-  const double dt = (now_ms() - t0) / 3;
-  double part[8];
+  for (int i = 0; i < CALLS; i++) { const double t0 = now_ms(); he_mul(&ct, &ct1, &ct2, &rlk); tm[i] = now_ms() - t0; }
   gpq_mpi_shim_last_timing(part);
   he_mul(&ct, &ct1, &ct1, &rlk);                              /* a squaring, as he_mul(&bn, &bn, &bn, rlk) at src/he-algo.c:151 */
-  const double ts = now_ms();
-  for (int i = 0; i < 3; i++) he_mul(&ct, &ct1, &ct1, &rlk);
-  const double dsq = (now_ms() - ts) / 3;
+  for (int i = 0; i < CALLS; i++) { const double t0 = now_ms(); he_mul(&ct, &ct1, &ct1, &rlk); tsq[i] = now_ms() - t0; }
   gpq_mpi_shim_last_timing(part + 4);
   ct.l = hectx.L; he_rescale(&ct);                            /* first call at this shape allocates the staging buffers */
-  const double t1 = now_ms();
-  for (int i = 0; i < 3; i++) { ct.l = hectx.L; he_rescale(&ct); }
-  const double dr = (now_ms() - t1) / 3;
-  printf("he_mul(MPI) n=2^%u logq=%u dims %u/%u: %.1f ms per call; he_rescale %.1f ms\n", logn, logq, hectx.dim, hectx.dimevk, dt, dr);
+  for (int i = 0; i < CALLS; i++) { ct.l = hectx.L; const double t0 = now_ms(); he_rescale(&ct); trs[i] = now_ms() - t0; }
+  qsort(tm, CALLS, sizeof *tm, cmp_double); qsort(tsq, CALLS, sizeof *tsq, cmp_double); qsort(trs, CALLS, sizeof *trs, cmp_double);
+  printf("he_mul(MPI) n=2^%u logq=%u dims %u/%u: %.1f ms per call; he_rescale %.1f ms\n", logn, logq, hectx.dim, hectx.dimevk, tm[CALLS / 2], trs[CALLS / 2]);
+  printf("  %d calls each: he_mul p50 %.2f p95 %.2f min %.2f max %.2f ms; squaring p50 %.2f p95 %.2f ms; he_rescale p50 %.2f p95 %.2f ms\n", CALLS,
+         tm[CALLS / 2], tm[CALLS * 95 / 100], tm[0], tm[CALLS - 1], tsq[CALLS / 2], tsq[CALLS * 95 / 100], trs[CALLS / 2], trs[CALLS * 95 / 100]);
   printf("  last he_mul: convert+upload %.2f ms, kernels %.2f ms, download+convert %.2f ms, call %.2f ms\n", part[0], part[1], part[2], part[3]);
-  printf("  squaring he_mul(&ct, &a, &a): %.1f ms per call (convert+upload %.2f ms, kernels %.2f ms, download+convert %.2f ms)\n", dsq, part[4], part[5], part[6]);
+  printf("  squaring he_mul(&ct, &a, &a): %.1f ms per call (convert+upload %.2f ms, kernels %.2f ms, download+convert %.2f ms)\n", tsq[CALLS / 2], part[4], part[5], part[6]);
   return 0;
 }
 

@@ -27,6 +27,14 @@ def test_library_loads_and_exports_all_declared_symbols():
     assert not missing, "declared in include/ but not exported: %s" % missing
     bound = set(_native.SIGNATURES) | set(_native.EXPORTED_ONLY)
     assert declared <= bound, "not bound in gpqhe_amd/_native.py: %s" % sorted(declared - bound)
+    # the context / storage names of the reference live in libgpqhe_hip_ctx.so and nowhere else: the engine library must not
+    # be able to shadow GPQHE's own precomp.o / poly.o, whatever the link order (tests/test_link_order.py)
+    import ctypes
+    ctx_declared = _declared("gpqhe_hip_ctx.h") | {"polyctx", "hectx", "GPQHE_TWO"}
+    assert ctx_declared == set(_native.CTX_EXPORTS)
+    assert not [n for n in sorted(ctx_declared) if hasattr(lib, n)], "libgpqhe_hip.so defines a context symbol"
+    ctx = ctypes.CDLL(_native.CTX_LIB_PATH)
+    assert not [n for n in sorted(ctx_declared) if not hasattr(ctx, n)]
 
 
 def test_scalar_helpers_match_reference_semantics(golden):

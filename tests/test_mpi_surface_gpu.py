@@ -18,7 +18,7 @@ def mpi_host(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("mpi") / "mpi_host")
     lib_dir = os.path.join(ROOT, "gpqhe_amd")
     subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "mpi_host.c"),
-                           "-L", lib_dir, "-lgpqhe_hip", "-l:libgcrypt.so.20", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+                           "-L", lib_dir, "-lgpqhe_hip", "-lgpqhe_hip_ctx", "-l:libgcrypt.so.20", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", out])
     return out
 
 
@@ -328,6 +328,9 @@ def test_reference_signature_he_mul_at_the_headline_shape_keeps_its_key_on_the_d
     res = subprocess.run([mpi_host, "hemultime", "16", "850"], capture_output=True, text=True, timeout=560)
     assert res.returncode == 0, res.stderr
     assert "key cache: rewritten key seen, cached vs fresh upload identical" in res.stdout, res.stdout
+    # safe by default: ONE word edited in place, at an index a sampled fingerprint never looks at, multiplies as edited
+    assert "key cache: one unsampled word edited in place seen, cached vs fresh upload identical" in res.stdout, res.stdout
+    assert "key cache: resident 1, after set_key_slots(1) 1" in res.stdout or re.search(r"after set_key_slots\(1\) 1\b", res.stdout), res.stdout
     m = re.search(r"dims 15/45: ([0-9.]+) ms per call; he_rescale ([0-9.]+) ms", res.stdout)
     assert m and 0.3 < float(m.group(1)) < 200 and 0.1 < float(m.group(2)) < 200, res.stdout
     t = re.search(r"convert\+upload ([0-9.]+) ms, kernels ([0-9.]+) ms, download\+convert ([0-9.]+) ms, call ([0-9.]+) ms", res.stdout)

@@ -11,8 +11,8 @@ echo "instrumented library built" | tee gpurun_out/ubsan.txt
 LD_PRELOAD=$RT UBSAN_OPTIONS=print_stacktrace=1 GPQHE_HIP_LIB=$PWD/gpqhe_amd/libgpqhe_hip_UBSAN.so \
   timeout -k 10 1000 python -m pytest tests -m gpu -q -k "not c_host and not mpi_surface and not dropin and not reference_signature" >> gpurun_out/ubsan.txt 2>&1
 tail -3 gpurun_out/ubsan.txt
-D=$(mktemp -d) && cp gpqhe_amd/libgpqhe_hip_UBSAN.so $D/libgpqhe_hip.so
-gcc -O1 -std=gnu11 -I include tests/c/mpi_host.c -L $D -lgpqhe_hip -l:libgcrypt.so.20 -Wl,-rpath,$D -Wl,-rpath,/opt/rocm/lib -Wl,--unresolved-symbols=ignore-in-shared-libs -o $D/mpi_host || exit 1
+D=$(mktemp -d) && cp gpqhe_amd/libgpqhe_hip_UBSAN.so $D/libgpqhe_hip.so && cp gpqhe_amd/libgpqhe_hip_ctx.so $D/
+gcc -O1 -std=gnu11 -I include tests/c/mpi_host.c -L $D -lgpqhe_hip -lgpqhe_hip_ctx -l:libgcrypt.so.20 -Wl,-rpath,$D -Wl,-rpath,/opt/rocm/lib -Wl,--unresolved-symbols=ignore-in-shared-libs -o $D/mpi_host || exit 1
 gcc -O1 -std=gnu11 -I include tests/c/dropin_host.c -L $D -lgpqhe_hip -Wl,-rpath,$D -Wl,-rpath,/opt/rocm/lib -Wl,--unresolved-symbols=ignore-in-shared-libs -o $D/dropin_host || exit 1
 for cmd in "mpi_host polymul" "mpi_host polymulodd" "mpi_host crt" "mpi_host polymulmono 13" "mpi_host keygen 7 120" "mpi_host ctxcheck 7 61 1073741824" \
            "mpi_host ctxcheck 16 850 1125899906842624" "mpi_host hemultime 16 850" "dropin_host 13 3 1" "dropin_host 16 2 5"; do
