@@ -268,16 +268,19 @@ int launch_low_mfma(const ReconMfmaArgs &a, size_t lds, hipStream_t s) {
 struct ReconExtra {
   const unsigned char *only = nullptr;
   bool prescaled = false;
-  const uint64_t *addend = nullptr;
+  Two<const uint64_t> addend{nullptr, nullptr, ~0u};
   const unsigned char *rflags = nullptr;
   bool *fused = nullptr;
+  uint64_t *big_b = nullptr;      // the polynomials from `split` on are written here instead (Two<>, bridge_kernels.hpp)
+  unsigned split = ~0u;
 };
 
 int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned slab_dim,
                        unsigned slab_first, unsigned batch, unsigned logq, bool centre, unsigned char *tie, hipStream_t s, int logn_override = -1,
                        const ReconExtra &x = ReconExtra()) {
   const unsigned logn = logn_override < 0 ? c->logn : (unsigned)logn_override, n = 1u << logn;
-  ReconstructArgs a{c->d_tabs, slab, big, b->d_phat, b->d_phat_inv, b->d_pmult, b->d_phalf, tie, x.only, b->d_inv128,
+  const Two<uint64_t> bigs{big, x.big_b, x.split};
+  ReconstructArgs a{c->d_tabs, slab, bigs, b->d_phat, b->d_phat_inv, b->d_pmult, b->d_phalf, tie, x.only, b->d_inv128,
                     b->dim, logn, Wout, logq, b->first, slab_dim, slab_first, centre ? 1u : 0u, x.prescaled ? 1u : 0u};
   if (x.fused) *x.fused = false;
   // fast path: centred result modulo a power of two that needs fewer words than P has
@@ -307,7 +310,7 @@ int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, uns
       if (rc) return rc;
       if (t->d_bfrag) {
         const unsigned gpp = n >> 6;
-        ReconMfmaArgs m{slab, big, (const v4i *)t->d_bfrag, t->d_lk, t->d_kc, t->d_pm, c->d_redo, tie, b->dim, t->KS, logn, Wout, logq,
+        ReconMfmaArgs m{slab, bigs, (const v4i *)t->d_bfrag, t->d_lk, t->d_kc, t->d_pm, c->d_redo, tie, b->dim, t->KS, logn, Wout, logq,
                         slab_dim, slab_first, gpp, gpp * batch, x.addend, x.rflags, x.prescaled ? 1u : 0u};
         if (x.fused && x.rflags) *x.fused = true;
         switch (WL) {
@@ -412,7 +415,12 @@ int launch_decompose_mfma_t(const DecomposeMfmaArgs &a, size_t lds, hipStream_t 
   return GPQ_OK;
 }
 
+int launch_decompose(gpq_ctx *c, uint64_t *slab, const BigSources &big, unsigned W, unsigned limb0, unsigned dim, unsigned batch, hipStream_t s);
 int launch_decompose(gpq_ctx *c, uint64_t *slab, const uint64_t *big, unsigned W, unsigned limb0, unsigned dim, unsigned batch, hipStream_t s) {
+  return launch_decompose(c, slab, one_source(big), W, limb0, dim, batch, s);
+}
+// `batch` polynomials in all, `big.per` from each source slab in turn, written one after another to `slab`
+int launch_decompose(gpq_ctx *c, uint64_t *slab, const BigSources &big, unsigned W, unsigned limb0, unsigned dim, unsigned batch, hipStream_t s) {
   if (c->bridge_mfma && c->logn >= 6 && W <= 32 && dim >= 4) {
     gpq_decomp_mfma *t;
     int rc = get_decomp_mfma(c, limb0, dim, W, &t);
@@ -687,7 +695,9 @@ int launch_relin_front_t(const RelinFrontArgs &a, size_t lds, hipStream_t s) {
 }
 
 // src/he-mult.c:67-77 (d != null: c = rdiv(c,P) + d) and src/he-automorphism.c:68-76, for q_l = 2^logql.
-int relin_tail(gpq_ctx *c, uint64_t *out, const uint64_t *chat, const uint64_t *dbig, unsigned W, unsigned dimP, unsigned dimB,
+// `polys` polynomials of chat; the first `split` of them go to out.a (+ addend d.a), the rest to out.b (+ d.b): c0 and c1 of a
+// launch group are one batch (their chat slabs are adjacent in the workspace), half the launches and twice their size.
+int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const uint64_t> dbig, unsigned W, unsigned dimP, unsigned dimB,
                unsigned logql, unsigned polys, void *ws, hipStream_t s) {
   TailPlan tp;
   int rc = tail_plan(c, W, dimP, dimB, polys, &tp);
@@ -702,6 +712,9 @@ int relin_tail(gpq_ctx *c, uint64_t *out, const uint64_t *chat, const uint64_t *
   unsigned char *tie = (unsigned char *)(qc + (size_t)polys * W * n);
   const dim3 cgrid((c->n + 255) / 256, polys), cblock(256);
   const uint64_t *piq = bq->d_pmult + (size_t)5 * (bq->WP + 1);
+  const Two<const uint64_t> qc_one{qc, nullptr, ~0u};
+  // in place (out IS d) the exact kernel must not park Q over d: Q goes through qc
+  const bool in_place = (dbig.a && dbig.a == out.a) || (dbig.b && dbig.b == out.b);
 
   if (c->bridge_mfma && c->logn >= 6 && (rc = get_relin_front(c, dimP, dimB, rt, bp, bq))) return rc;
   if (c->bridge_mfma && c->logn >= 6 && rt->d_bfrag) {
@@ -727,11 +740,12 @@ int relin_tail(gpq_ctx *c, uint64_t *out, const uint64_t *chat, const uint64_t *
     q.prescaled = true; q.fused = &fused;
     // Fused finish straight into `out` (the exact kernel parks Q of its few coefficients there before bridge_addround
     // adds d, so `out` must not BE d); otherwise Q goes to qc and bridge_addround finishes every coefficient.
-    const bool direct = dbig != out;
-    if (direct) { q.addend = dbig; q.rflags = flags; }
-    uint64_t *target = direct ? out : qc;
+    const bool direct = !in_place;
+    if (direct) { q.addend = dbig; q.rflags = flags; q.big_b = out.b; q.split = out.split; }
+    uint64_t *target = direct ? out.a : qc;
     if ((rc = launch_reconstruct(c, bq, target, W, qhat, tp.cnt, 0, polys, logql, true, tie, s, -1, q))) return rc;
-    AddRoundArgs ar{out, target, nullptr, dbig, bp->d_phalf, piq, tie, W, tp.Wr, c->logn, logql, fused ? c->d_redo : nullptr, flags};
+    AddRoundArgs ar{out, direct ? Two<const uint64_t>{out.a, out.b, out.split} : qc_one, nullptr, dbig, bp->d_phalf, piq, tie, W, tp.Wr, c->logn, logql,
+                    fused ? c->d_redo : nullptr, flags};
     hipLaunchKernelGGL(bridge_addround, cgrid, cblock, 0, s, ar);
     return launched("relin_tail");
   }
@@ -743,7 +757,7 @@ int relin_tail(gpq_ctx *c, uint64_t *out, const uint64_t *chat, const uint64_t *
   hipLaunchKernelGGL(bridge_exactdiv, dim3((c->n + 255) / 256, polys, tp.cnt), dim3(256), 0, s, e);
   // Q = (x - r)/P over the remaining limbs, centred, already reduced smod 2^logql
   if ((rc = launch_reconstruct(c, bq, qc, W, qhat, tp.cnt, 0, polys, logql, true, tie, s))) return rc;
-  AddRoundArgs ar{out, qc, r, dbig, bp->d_phalf, piq, tie, W, tp.Wr, c->logn, logql, nullptr, nullptr};
+  AddRoundArgs ar{out, qc_one, r, dbig, bp->d_phalf, piq, tie, W, tp.Wr, c->logn, logql, nullptr, nullptr};
   hipLaunchKernelGGL(bridge_addround, cgrid, cblock, 0, s, ar);
   return launched("relin_tail");
 }
@@ -772,7 +786,7 @@ extern "C" int gpq_he_dims(gpq_ctx *c, unsigned logqL, unsigned logql, unsigned 
 extern "C" size_t gpq_he_mul_workspace_bytes(gpq_ctx *c, unsigned W, unsigned dimA, unsigned dimB, unsigned dimP, unsigned batch) {
   const unsigned m = batch < c->chunk ? batch : c->chunk;
   TailPlan tp;
-  if (tail_plan(c, W, dimP, dimB, m, &tp) != GPQ_OK) return 0;
+  if (tail_plan(c, W, dimP, dimB, 2 * m, &tp) != GPQ_OK) return 0;      // c0 and c1 of a launch group go through the tail together
   const size_t n = c->n;
   size_t b = 0;
   b += align64((size_t)m * 7 * dimA * n * 8);                       // 4 decomposed inputs + d0hat,d1hat,d2hat
@@ -798,7 +812,7 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
   const size_t n = c->n, bigpoly = (size_t)W * n;
   const unsigned m = batch < c->chunk ? batch : c->chunk;
   TailPlan tp;
-  if ((rc = tail_plan(c, W, dimP, dimB, m, &tp))) return rc;
+  if ((rc = tail_plan(c, W, dimP, dimB, 2 * m, &tp))) return rc;
   char *w = (char *)workspace;
   uint64_t *sA = (uint64_t *)w; w += align64((size_t)m * 7 * dimA * n * 8);
   void *wsT = w; w += align64(gpq_tensor_workspace_bytes(c, dimA, m));
@@ -819,8 +833,9 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
     const bool square = ct1c0 == ct2c0 && ct1c1 == ct2c1;
     {
       StageRange stage(square ? "gpq_he_mul: rns_decompose x2 (squaring)" : "gpq_he_mul: rns_decompose x4");
-      for (int i = 0; i < (square ? 2 : 4); ++i)                                            // :117-120
-        if ((rc = launch_decompose(c, h[i], in[i] + k0 * bigpoly, W, 0, dimA, polys, s))) return rc;
+      const unsigned nin = square ? 2 : 4;                                                   // :117-120, one launch: h[0..3] are adjacent
+      BigSources src{{in[0] + k0 * bigpoly, in[1] + k0 * bigpoly, in[square ? 0 : 2] + k0 * bigpoly, in[square ? 1 : 3] + k0 * bigpoly}, polys};
+      if ((rc = launch_decompose(c, h[0], src, W, 0, dimA, nin * polys, s))) return rc;
     }
     if ((rc = gpq_he_mul_tensor(c, d0h, d1h, d2h, h[0], h[1], square ? h[0] : h[2], square ? h[1] : h[3], dimA, polys, wsT, stream))) return rc;  // :121-136
     uint64_t *d0 = dbig, *d1 = dbig + polys * bigpoly, *d2 = dbig + 2 * polys * bigpoly;
@@ -837,8 +852,9 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
     }
     if ((rc = gpq_keyswitch(c, c0hat, c1hat, d2hat, rlk0, rlk1, dimB, polys, wsK, stream))) return rc;             // :60-64
     StageRange stage("gpq_he_mul: he_relin tail (CRT, exact division by P, + d)");
-    if ((rc = relin_tail(c, out_c0 + k0 * bigpoly, c0hat, d0, W, dimP, dimB, logql, polys, wsTail, s))) return rc; // :67-77
-    if ((rc = relin_tail(c, out_c1 + k0 * bigpoly, c1hat, d1, W, dimP, dimB, logql, polys, wsTail, s))) return rc;
+    // c0 and c1 as one batch of 2 x polys polynomials: c0hat | c1hat and d0 | d1 are adjacent, the outputs are the caller's two slabs
+    if ((rc = relin_tail(c, Two<uint64_t>{out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, polys}, c0hat, Two<const uint64_t>{d0, d1, polys},
+                         W, dimP, dimB, logql, 2 * polys, wsTail, s))) return rc;                                  // :67-77
   }
   return launched("gpq_he_mul");
 }
@@ -856,7 +872,7 @@ extern "C" int gpq_he_swk(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
   const size_t n = c->n, bigpoly = (size_t)W * n;
   const unsigned m = batch < c->chunk ? batch : c->chunk;
   TailPlan tp;
-  if ((rc = tail_plan(c, W, dimP, dimB, m, &tp))) return rc;
+  if ((rc = tail_plan(c, W, dimP, dimB, 2 * m, &tp))) return rc;
   char *w = (char *)workspace;
   uint64_t *sB = (uint64_t *)w; w += align64((size_t)m * 3 * dimB * n * 8);
   void *wsK = w; w += align64(gpq_keyswitch_workspace_bytes(c, dimB, m));
@@ -867,15 +883,16 @@ extern "C" int gpq_he_swk(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
     uint64_t *d1hat = sB, *c0hat = sB + pb, *c1hat = sB + 2 * pb;
     if ((rc = launch_decompose(c, d1hat, d1 + k0 * bigpoly, W, 0, dimB, polys, s))) return rc;                     // :60
     if ((rc = gpq_keyswitch(c, c0hat, c1hat, d1hat, swk0, swk1, dimB, polys, wsK, stream))) return rc;             // :61-65
-    if ((rc = relin_tail(c, out_c0 + k0 * bigpoly, c0hat, d0 + k0 * bigpoly, W, dimP, dimB, logql, polys, wsTail, s))) return rc;  // :68-75
-    if ((rc = relin_tail(c, out_c1 + k0 * bigpoly, c1hat, nullptr, W, dimP, dimB, logql, polys, wsTail, s))) return rc;
+    // c0 (+ d0) and c1 (no addend) as one batch of 2 x polys polynomials                                           // :68-75
+    if ((rc = relin_tail(c, Two<uint64_t>{out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, polys}, c0hat, Two<const uint64_t>{d0 + k0 * bigpoly, nullptr, polys},
+                         W, dimP, dimB, logql, 2 * polys, wsTail, s))) return rc;
   }
   return launched("gpq_he_swk");
 }
 extern "C" size_t gpq_he_swk_workspace_bytes(gpq_ctx *c, unsigned W, unsigned dimB, unsigned dimP, unsigned batch) {
   const unsigned m = batch < c->chunk ? batch : c->chunk;
   TailPlan tp;
-  if (tail_plan(c, W, dimP, dimB, m, &tp) != GPQ_OK) return 0;
+  if (tail_plan(c, W, dimP, dimB, 2 * m, &tp) != GPQ_OK) return 0;
   return align64((size_t)m * 3 * dimB * c->n * 8) + align64(gpq_keyswitch_workspace_bytes(c, dimB, m)) + align64(tp.bytes);
 }
 
@@ -889,7 +906,7 @@ extern "C" int gpq_relin_tail(gpq_ctx *c, uint64_t *out, const uint64_t *chat, c
   int rc = check(c, dimB, batch, "gpq_relin_tail");
   if (rc) return rc;
   if (!out || !chat || !workspace || !logql || W < (logql + 63) / 64) return gpq_fail(GPQ_ERR_INVALID, "gpq_relin_tail: bad arguments");
-  return relin_tail(c, out, chat, d, W, dimP, dimB, logql, batch, workspace, (hipStream_t)stream);
+  return relin_tail(c, one_place(out), chat, one_place(d), W, dimP, dimB, logql, batch, workspace, (hipStream_t)stream);
 }
 
 // Tests: force the exact (full-width) CRT kernel instead of the low-word fast path.

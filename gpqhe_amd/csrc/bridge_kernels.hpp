@@ -17,6 +17,20 @@
 
 namespace gpq {
 
+// A batch whose polynomials live in two places: polynomials [0, split) at a, the rest at b (a null place: those polynomials
+// have none -- an absent addend).  The relinearisation tail runs c0 and c1 of a launch group as ONE batch of 2 x polys
+// polynomials: their inputs are adjacent in the workspace, their outputs (and he_swk's single addend) are the caller's separate slabs.
+template <typename T>
+struct Two {
+  T *a, *b;
+  unsigned split;
+  __device__ __forceinline__ T *at(unsigned poly, size_t stride) const {
+    return poly < split ? (a ? a + (size_t)poly * stride : nullptr) : (b ? b + (size_t)(poly - split) * stride : nullptr);
+  }
+};
+template <typename T> inline Two<T> one_place(T *a) { return Two<T>{a, nullptr, ~0u}; }
+
+
 constexpr uint64_t M59 = (1ull << 59) - 1;
 
 // r*2^59 + d (mod p), lazily: r < 4p, d < 2^59 -> (0, 4p).
@@ -36,9 +50,18 @@ __device__ __forceinline__ uint64_t horner59(uint64_t r, uint64_t d, const Prime
 // the same thread (the words are read once, the limb loop is uniform).
 // MAXW = words kept in registers (the value is sign-extended to 64*MAXW bits).
 // ---------------------------------------------------------------------------
+// Up to four big slabs decomposed by one launch (the four polynomials of he_mul's two ciphertexts are separate slabs of the
+// caller): polynomial k of the launch is polynomial k % per of slab k / per.
+struct BigSources {
+  const uint64_t *src[4];
+  unsigned per;             // polynomials per source slab
+  __device__ __forceinline__ const uint64_t *at(unsigned poly, size_t stride) const { return src[poly / per] + (size_t)(poly % per) * stride; }
+};
+inline BigSources one_source(const uint64_t *big) { return BigSources{{big, nullptr, nullptr, nullptr}, ~0u}; }
+
 struct DecomposeArgs {
   const LimbTab *tabs;
-  const uint64_t *big;      // [polys][W][n]
+  BigSources big;           // [polys][W][n]
   uint64_t *slab;           // [polys][dim][n]: limb d of the output is prime limb0 + d
   unsigned W, dim, logn, limb0;
 };
@@ -50,7 +73,7 @@ __global__ __launch_bounds__(256) void bridge_decompose(DecomposeArgs a) {
   const unsigned n = 1u << a.logn;
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const uint64_t *__restrict__ src = a.big + ((size_t)blockIdx.y * a.W << a.logn) + i;
+  const uint64_t *__restrict__ src = a.big.at(blockIdx.y, (size_t)a.W << a.logn) + i;
   uint64_t w[MAXW + 1];
 #pragma unroll
   for (int j = 0; j < MAXW; ++j) w[j] = j < (int)a.W ? src[(size_t)j << a.logn] : 0;
@@ -92,7 +115,7 @@ __global__ __launch_bounds__(256) void bridge_decompose(DecomposeArgs a) {
 struct ReconstructArgs {
   const LimbTab *tabs;
   const uint64_t *slab;        // [polys][dim][n]
-  uint64_t *big;               // [polys][Wout][n]
+  Two<uint64_t> big;           // [polys][Wout][n]
   const uint64_t *phat;        // [dim][WP]       P / p_d
   const uint64_t *phat_inv;    // [dim]           (P/p_d)^-1 mod p_d
   const uint64_t *pmult;       // [6][WP+1]       32P, 16P, 8P, 4P, 2P, P
@@ -170,7 +193,7 @@ __global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
     }
   }
   // mpi_smod(., 2^logq, 2^(logq-1)): keep logq bits, sign-extend from bit logq-1
-  uint64_t *__restrict__ dst = a.big + ((size_t)blockIdx.y * a.Wout << a.logn) + i;
+  uint64_t *__restrict__ dst = a.big.at(blockIdx.y, (size_t)a.Wout << a.logn) + i;
   const uint64_t sext = (uint64_t)((int64_t)S[WP] >> 63);
   uint64_t qsign = 0;
   if (a.logq) {
@@ -251,7 +274,7 @@ __global__ __launch_bounds__(256) void bridge_reconstruct_low(ReconstructArgs a,
     S[j] = (uint64_t)t;
     borrow = (uint64_t)(t >> 64) & 1;
   }
-  uint64_t *__restrict__ dst = a.big + ((size_t)blockIdx.y * a.Wout << a.logn) + i;
+  uint64_t *__restrict__ dst = a.big.at(blockIdx.y, (size_t)a.Wout << a.logn) + i;
   const unsigned sb = a.logq - 1;
   uint64_t qsign = 0;
 #pragma unroll
@@ -304,10 +327,10 @@ __global__ __launch_bounds__(256) void bridge_exactdiv(ExactDivArgs a) {
 // smod 2^k; `tie` marks the coefficients whose quotient sat exactly on floor(Pi'/2), where the
 // centring of x (not of Q) decides the wrap: add Pi' back when r < floor(P/2)  (see DESIGN.md).
 struct AddRoundArgs {
-  uint64_t *out;               // [polys][W][n]
-  const uint64_t *qc;          // [polys][W][n]
+  Two<uint64_t> out;           // [polys][W][n]
+  Two<const uint64_t> qc;      // [polys][W][n]
   const uint64_t *r;           // [polys][Wr][n]   in [0, P)
-  const uint64_t *d;           // [polys][W][n] or null
+  Two<const uint64_t> d;       // [polys][W][n] or null
   const uint64_t *phalf;       // [Wr]  floor(P/2)
   const uint64_t *piq;         // [>= W words of Pi' (low words)]
   const unsigned char *tie;    // [polys][n]
@@ -334,12 +357,16 @@ __global__ __launch_bounds__(256) void bridge_addround(AddRoundArgs a) {
   }
   uint64_t carry = cmp > 0;                               // mpi_rdiv: round up when r > floor(P/2)
   const bool fix = a.tie[((size_t)blockIdx.y << a.logn) + i] && cmp < 0;
-  const size_t base = ((size_t)blockIdx.y * a.W << a.logn) + i;
+  const size_t stride = (size_t)a.W << a.logn;
+  uint64_t *outp = a.out.at(blockIdx.y, stride) + i;
+  const uint64_t *qcp = a.qc.at(blockIdx.y, stride) + i;
+  const uint64_t *dbase = a.d.at(blockIdx.y, stride);
+  const uint64_t *dp = dbase ? dbase + i : nullptr;
   const unsigned sb = a.logql - 1;
   uint64_t qsign = 0;
   for (unsigned j = 0; j < a.W; ++j) {
-    const size_t o = base + ((size_t)j << a.logn);
-    const u128 t = (u128)a.qc[o] + carry + (a.d ? a.d[o] : 0) + (fix ? a.piq[j] : 0);
+    const size_t o = (size_t)j << a.logn;
+    const u128 t = (u128)qcp[o] + carry + (dp ? dp[o] : 0) + (fix ? a.piq[j] : 0);
     uint64_t v = (uint64_t)t;
     carry = (uint64_t)(t >> 64);                          // 0..2
     const unsigned lo = 64 * j;
@@ -349,7 +376,7 @@ __global__ __launch_bounds__(256) void bridge_addround(AddRoundArgs a) {
       const uint64_t mask = (1ull << (a.logql - lo)) - 1;
       v = (v & mask) | (qsign & ~mask);
     }
-    a.out[o] = v;
+    outp[o] = v;
   }
 }
 

@@ -18,6 +18,7 @@
 #pragma once
 #include "modarith.hpp"
 #include "tables.hpp"
+#include "bridge_kernels.hpp"
 
 #ifndef GPQ_FRONT_XG
 #define GPQ_FRONT_XG 8   /* k steps from which the relinearisation front stops fetching the next group early */
@@ -68,7 +69,7 @@ __device__ __forceinline__ uint64_t fold_word(int64_t L, int64_t H, int64_t &car
 // halves,  V = H 2^32 + L,  H = Hh 2^27 + Hl  =>  V == Hl 2^32 + L - c Hh  (mod p),  + Kq_j, in (0, 3p) -> canonical.
 // ---------------------------------------------------------------------------
 struct DecomposeMfmaArgs {
-  const uint64_t *big;       // [polys][W][n]
+  BigSources big;            // [polys][W][n]
   uint64_t *slab;            // [polys][dim][n]
   const v4i *bfrag;          // [NT][KS][64]: the constant (A) fragment of lane l for (row tile, k step)
   const uint64_t *pk;        // [4 NT][3]: p_j, Kq_j = 2^50 + ((K_j - 2^50) mod p_j), c_j   (zeros for padding primes)
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void bridge_decompose_mfma(DecomposeMfmaArg
   // the data fragments of a group of 64 coefficients: lane (r, h) holds words 4s+2h, 4s+2h+1 of coefficients r and 32+r
   auto load_X = [&](unsigned g) {
     const unsigned poly = g / a.groups_per_poly, coef0 = (g % a.groups_per_poly) << 6;
-    const uint64_t *__restrict__ src = a.big + ((size_t)poly * a.W << a.logn) + coef0 + r;
+    const uint64_t *__restrict__ src = a.big.at(poly, (size_t)a.W << a.logn) + coef0 + r;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void bridge_decompose_mfma(DecomposeMfmaArg
 // ---------------------------------------------------------------------------
 struct ReconMfmaArgs {
   const uint64_t *slab;      // [polys][slab_dim][n]
-  uint64_t *big;             // [polys][Wout][n]
+  Two<uint64_t> big;         // [polys][Wout][n]
   const v4i *bfrag;          // [KS][NT][64]
   const uint64_t *lk;        // [4 KS][2]: p_d, phat_invmp_d   (p = 0: padding limb)
   const uint64_t *kc;        // [WL + 2]: (unused: Kc lives in pm), then Kf (2 words)
@@ -171,7 +172,7 @@ struct ReconMfmaArgs {
   unsigned dim, KS, logn, Wout, logq, slab_dim, slab_first;
   unsigned groups_per_poly, total_groups;
   // tail of he_relin / he_swk fused in (bridge_addround's work for the coefficients decided here):
-  const uint64_t *addend;        // optional [polys][Wout][n]: d of src/he-mult.c:72-76
+  Two<const uint64_t> addend;    // optional [polys][Wout][n]: d of src/he-mult.c:72-76
   const unsigned char *rflags;   // optional [polys][n]: RF_GT = round the quotient up (mpi_rdiv)
   unsigned prescaled;            // the slab already holds y_d = ahat_d * phat_invmp_d (bridge_relin_front_mfma writes it so)
 };
@@ -265,8 +266,9 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
     // epilogue: this lane finishes coefficient coef0 + lane (tile h, column r)
     constexpr bool EARLY_D = WL <= 14;                     // (no registers left for it at WL = 16)
     uint64_t dd[WL];                                       // d of the fused tail, fetched under the column folding
-    if (EARLY_D && a.rflags && a.addend) {
-      const uint64_t *__restrict__ dp = a.addend + ((size_t)poly * a.Wout << a.logn) + coef0 + lane;
+    const uint64_t *addend = a.rflags ? a.addend.at(poly, (size_t)a.Wout << a.logn) : nullptr;   // uniform per group
+    if (EARLY_D && addend) {
+      const uint64_t *__restrict__ dp = addend + coef0 + lane;
 #pragma unroll
       for (int j = 0; j < WL; ++j) dd[j] = dp[(size_t)(j < (int)a.Wout ? j : 0) << a.logn];
     }
@@ -300,19 +302,19 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
         borrow = (uint64_t)(t >> 64) & 1;
       }
       if (a.rflags) {                                    // + [r > floor(P/2)] + d   (mod 2^logq: only the low words matter)
-        if (!EARLY_D && a.addend) {
-          const uint64_t *__restrict__ dp = a.addend + ((size_t)poly * a.Wout << a.logn) + coef0 + lane;
+        if (!EARLY_D && addend) {
+          const uint64_t *__restrict__ dp = addend + coef0 + lane;
 #pragma unroll
           for (int j = 0; j < WL; ++j) dd[j] = dp[(size_t)(j < (int)a.Wout ? j : 0) << a.logn];
         }
         uint64_t cr = a.rflags[flag_at] & RF_GT;
 #pragma unroll
         for (int j = 0; j < WL; ++j) {
-          const u128 t = (u128)V[j] + cr + ((a.addend && j < (int)a.Wout) ? dd[j] : 0);
+          const u128 t = (u128)V[j] + cr + ((addend && j < (int)a.Wout) ? dd[j] : 0);
           V[j] = (uint64_t)t; cr = (uint64_t)(t >> 64);
         }
       }
-      uint64_t *__restrict__ dst = a.big + ((size_t)poly * a.Wout << a.logn) + coef0 + lane;
+      uint64_t *__restrict__ dst = a.big.at(poly, (size_t)a.Wout << a.logn) + coef0 + lane;
       // mpi_smod by 2^logq: sign-extend from bit logq-1 (word sw, bit sbit); words above it are the sign
       const int sw = (int)((a.logq - 1) >> 6);
       const unsigned up = 63 - ((a.logq - 1) & 63);

@@ -36,6 +36,7 @@ struct Gcry {
   unsigned (*mpi_print)(int, unsigned char *, size_t, size_t *, MPI);
   unsigned (*mpi_scan)(MPI *, int, const void *, size_t, size_t *);
   void (*mpi_snatch)(MPI, MPI);
+  void (*mpi_set_bit)(MPI, unsigned);
   void *(*xmalloc)(size_t);
   void (*xfree)(void *);
   bool ok = false;
@@ -46,6 +47,60 @@ const int FMT_USG = 5;  // GCRYMPI_FMT_USG: unsigned big-endian magnitude
   errno = EINVAL;  // the reference's error convention (src/reduce.c:95-100, src/precomp.c:344-350)
   fprintf(stderr, "\033[1m\033[31merror:\033[0m \033[1m%s\033[0m. %s (%s)\n", strerror(errno), what, gpq_last_error());
   abort();
+}
+
+// ---- direct access to libgcrypt integers ------------------------------------------------------------------------------------
+// gcry_mpi_print / gcry_mpi_scan cost ~100 ns per coefficient (a format switch, a byte-order pass, an allocation for scan): at
+// n = 2^16 that was 3 of the 3.5 ms of a reference-signature he_mul.  A libgcrypt integer is
+//     struct gcry_mpi { int alloced; int nlimbs; int sign; unsigned flags; mpi_limb_t *d; }      (libgcrypt src/mpi.h, unchanged
+// since 1.2: little-endian 64-bit limbs of the magnitude, sign apart; flags 1 = secure memory, 4 = opaque, 16 = immutable, 32 = constant)
+// so the conversions read and write the limbs in place -- AFTER probe_mpi_layout() has checked, through the public API alone, that
+// this process's libgcrypt really lays its integers out like that (values built with gcry_mpi_scan read back through the struct;
+// values written through the struct read back with gcry_mpi_print).  If any check fails, or after gpq_mpi_shim_set_direct_mpi(0),
+// every conversion goes through gcry_mpi_print / gcry_mpi_scan as before; opaque / immutable / constant integers always do.
+struct MpiView { int alloced, nlimbs, sign; unsigned flags; uint64_t *d; };
+bool g_mpi_direct = false;        // the probe passed
+bool g_mpi_direct_wanted = true;  // gpq_mpi_shim_set_direct_mpi
+inline bool mpi_direct() { return g_mpi_direct && g_mpi_direct_wanted; }
+
+void probe_mpi_layout() {
+  g_mpi_direct = false;
+  if (sizeof(unsigned long) != 8 || sizeof(void *) != 8) return;
+  unsigned char bytes[24];
+  for (int i = 0; i < 24; ++i) bytes[i] = (unsigned char)(0x11 * (i % 13) + 3 + i);       // big-endian magnitude, top byte non-zero
+  uint64_t want[3];
+  for (int j = 0; j < 3; ++j) { uint64_t x; memcpy(&x, bytes + 16 - 8 * j, 8); want[j] = __builtin_bswap64(x); }
+  MPI a = nullptr;
+  if (G.mpi_scan(&a, FMT_USG, bytes, 24, nullptr) || !a) return;
+  bool ok = true;
+  const MpiView *v = (const MpiView *)a;
+  ok = ok && v->nlimbs == 3 && v->alloced >= 3 && v->sign == 0 && !(v->flags & 4) && v->d && !memcmp(v->d, want, 24);
+  G.mpi_neg(a, a);
+  ok = ok && v->sign == 1 && v->nlimbs == 3 && G.mpi_is_neg(a);
+  G.mpi_set_ui(a, 0);
+  ok = ok && v->nlimbs == 0;
+  G.mpi_set_ui(a, 0x1234567);
+  ok = ok && v->nlimbs == 1 && v->sign == 0 && v->d[0] == 0x1234567;
+  // writing: grow a fresh integer through the public API, fill the limbs in place, read back with gcry_mpi_print
+  MPI b = G.mpi_new(0);
+  MpiView *w = (MpiView *)b;
+  ok = ok && b && w->nlimbs == 0 && w->sign == 0;
+  if (ok) {
+    G.mpi_set_bit(b, 64 * 3 - 1);
+    ok = w->alloced >= 3 && w->d != nullptr;
+  }
+  if (ok) {
+    memcpy(w->d, want, 24);
+    w->nlimbs = 3; w->sign = 1;
+    unsigned char back[32];
+    size_t nw = 0;
+    ok = !G.mpi_print(FMT_USG, back, sizeof back, &nw, b) && nw == 24 && !memcmp(back, bytes, 24) && G.mpi_is_neg(b) && G.mpi_get_nbits(b) == 64 * 2 + (64 - (unsigned)__builtin_clzll(want[2]));
+    w->nlimbs = 0; w->sign = 0;
+    ok = ok && G.mpi_get_nbits(b) == 0 && !G.mpi_is_neg(b);
+  }
+  if (b) G.mpi_release(b);
+  G.mpi_release(a);
+  g_mpi_direct = ok;
 }
 
 void need_gcrypt() {
@@ -67,9 +122,11 @@ void need_gcrypt() {
   G.mpi_print = (unsigned (*)(int, unsigned char *, size_t, size_t *, MPI))get("gcry_mpi_print");
   G.mpi_scan = (unsigned (*)(MPI *, int, const void *, size_t, size_t *))get("gcry_mpi_scan");
   G.mpi_snatch = (void (*)(MPI, MPI))get("gcry_mpi_snatch");
+  G.mpi_set_bit = (void (*)(MPI, unsigned))get("gcry_mpi_set_bit");
   G.xmalloc = (void *(*)(size_t))get("gcry_malloc");
   G.xfree = (void (*)(void *))get("gcry_free");
   G.ok = true;
+  probe_mpi_layout();
 }
 
 // magnitude of a positive MPI as little-endian words
@@ -163,7 +220,17 @@ unsigned max_bits(const poly_mpi_t *a, unsigned n) {       // widest coefficient
   unsigned m = 0;
   for_ranges(n, [&](unsigned lo, unsigned hi) {
     unsigned mine = 0;
-    for (unsigned i = lo; i < hi; ++i) { const unsigned b = G.mpi_get_nbits(a->coeffs[i]); if (b > mine) mine = b; }
+    const bool direct = mpi_direct();
+    for (unsigned i = lo; i < hi; ++i) {
+      unsigned b;
+      const MpiView *m = (const MpiView *)a->coeffs[i];
+      if (direct && !(m->flags & 4)) {
+        unsigned nl = m->nlimbs > 0 ? (unsigned)m->nlimbs : 0;
+        while (nl && m->d[nl - 1] == 0) --nl;
+        b = nl ? 64 * (nl - 1) + (64 - (unsigned)__builtin_clzll(m->d[nl - 1])) : 0;
+      } else b = G.mpi_get_nbits(a->coeffs[i]);
+      if (b > mine) mine = b;
+    }
     std::lock_guard<std::mutex> lock(mu);
     if (mine > m) m = mine;
   });
@@ -174,8 +241,22 @@ unsigned max_bits(const poly_mpi_t *a, unsigned n) {       // widest coefficient
 // assembled eight bytes at a time (the byte-at-a-time form cost as much as gcry_mpi_print itself).
 void to_slab_range(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W, unsigned lo, unsigned hi) {
   unsigned char buf[8 * 64 + 8];
+  const bool direct = mpi_direct();
   for (unsigned i = lo; i < hi; ++i) {
     MPI v = a->coeffs[i];
+    if (direct && !(((const MpiView *)v)->flags & 4)) {          // limbs in place: little-endian magnitude + sign
+      const MpiView *m = (const MpiView *)v;
+      unsigned nl = m->nlimbs > 0 ? (unsigned)m->nlimbs : 0;
+      while (nl && m->d[nl - 1] == 0) --nl;
+      if (nl > W || (nl == W && (m->d[W - 1] >> 63))) die("coefficient does not fit the big slab");
+      if (m->sign && nl) {
+        uint64_t carry = 1;
+        for (unsigned j = 0; j < W; ++j) { const uint64_t x = ~(j < nl ? m->d[j] : 0) + carry; carry = carry && x == 0; dst[(size_t)j * n + i] = x; }
+      } else {
+        for (unsigned j = 0; j < W; ++j) dst[(size_t)j * n + i] = j < nl ? m->d[j] : 0;
+      }
+      continue;
+    }
     if (G.mpi_get_nbits(v) > 64 * W - 1) die("coefficient does not fit the big slab");
     size_t nw = 0;
     if (G.mpi_print(FMT_USG, buf, 8 * W, &nw, v)) die("gcry_mpi_print failed");
@@ -208,6 +289,7 @@ void to_slab(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W) {
 // host big slab -> existing MPIs (the caller allocated them, src/poly.c:46-51)
 void from_slab_range(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W, unsigned lo, unsigned hi) {
   unsigned char buf[8 * 64];
+  const bool direct = mpi_direct();
   for (unsigned i = lo; i < hi; ++i) {
     uint64_t w[64];
     for (unsigned j = 0; j < W; ++j) w[j] = src[(size_t)j * n + i];
@@ -218,6 +300,15 @@ void from_slab_range(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W,
     }
     unsigned top = W;                                         // words in use
     while (top && w[top - 1] == 0) --top;
+    if (direct && !(((MpiView *)r->coeffs[i])->flags & (4 | 16 | 32))) {     // limbs in place (the integer grows through the public API)
+      MpiView *m = (MpiView *)r->coeffs[i];
+      if (top && (unsigned)m->alloced < top) G.mpi_set_bit(r->coeffs[i], 64 * top - 1);
+      if (!top || ((unsigned)m->alloced >= top && m->d)) {
+        for (unsigned j = 0; j < top; ++j) m->d[j] = w[j];
+        m->nlimbs = (int)top; m->sign = (neg && top) ? 1 : 0;
+        continue;
+      }
+    }
     if (!top) { G.mpi_set_ui(r->coeffs[i], 0); continue; }
     for (unsigned j = 0; j < top; ++j) {                      // big-endian bytes, most significant word first
       const uint64_t x = __builtin_bswap64(w[top - 1 - j]);

@@ -611,6 +611,9 @@ void gpq_mpi_shim_set_key_slots(unsigned slots) {
 // ciphertext conversions; 0: by ~1000 sampled words (for programs that never edit a key in place; gpq_mpi_shim_forget_keys covers the rest)
 void gpq_mpi_shim_set_key_check(int full) { SHIM_CALL(); g_key_check_full = full != 0; }
 unsigned gpq_mpi_shim_resident_keys(void) { SHIM_CALL(); return (unsigned)g_keys.size(); }
+// 1 (default): libgcrypt integers are read and written limb by limb in place once the layout probe has passed (mpi_convert.hpp);
+// 0: every coefficient goes through gcry_mpi_print / gcry_mpi_scan.  Returns whether the direct path is in use afterwards.
+int gpq_mpi_shim_set_direct_mpi(int on) { SHIM_CALL(); need_gcrypt(); g_mpi_direct_wanted = on != 0; return mpi_direct() ? 1 : 0; }
 
 // Drops the device copies of evaluation keys (he_mul / he_rot / he_conj keep up to gpq_mpi_shim_set_key_slots of them, recognised by the caller's pointers, the
 // length and a fingerprint of every word -- of ~1000 sampled words after gpq_mpi_shim_set_key_check(0), and then a program that rewrites a

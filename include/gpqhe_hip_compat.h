@@ -166,6 +166,10 @@ void gpq_mpi_shim_set_key_slots(unsigned slots);
  * in place. */
 void gpq_mpi_shim_set_key_check(int full);
 unsigned gpq_mpi_shim_resident_keys(void);
+/* How coefficients cross between libgcrypt integers and big slabs: on != 0 (default) reads and writes the limbs of `struct gcry_mpi`
+ * in place, after a probe through libgcrypt's public API has confirmed the layout in this process (3x faster calls at n = 2^16);
+ * 0 goes through gcry_mpi_print / gcry_mpi_scan for every coefficient.  Returns 1 if the direct path is in use afterwards. */
+int gpq_mpi_shim_set_direct_mpi(int on);
 /* Drops the device copies of the evaluation keys.  Never needed with the default key check; he_genrlk / he_genck / he_genrk drop
  * the copy of the key they write themselves. */
 void gpq_mpi_shim_forget_keys(void);

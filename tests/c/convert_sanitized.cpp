@@ -46,7 +46,12 @@ int main() {
   uint64_t st = 20261004;
 
   // ---- round trips: n coefficients, W words, widths 0 .. 64 W - 1 bits, both signs ------------------------------
+  // once reading / writing the limbs of struct gcry_mpi in place (the layout probe must have passed against this libgcrypt), once
+  // through gcry_mpi_print / gcry_mpi_scan; the slabs of both paths must be the same words
+  if (!g_mpi_direct) { printf("FAIL the struct gcry_mpi layout probe did not pass\n"); return 1; }
+  for (int mode = 0; mode < 2; ++mode)
   for (unsigned n : {1u, 5u, 128u, 8192u}) {            // 8192 takes the worker threads (>= 4096)
+    g_mpi_direct_wanted = mode == 0;
     for (unsigned W : {1u, 2u, 14u, 28u, 32u}) {
       poly_mpi_t a, r;
       a.coeffs = (gpq_MPI *)malloc(n * sizeof(gpq_MPI));
@@ -56,7 +61,9 @@ int main() {
         if (i == 0) bits = 0;
         if (i == 1 % n) bits = 64 * W - 1;
         a.coeffs[i] = random_mpi(st, bits, splitmix(st) & 1);
-        r.coeffs[i] = G.mpi_set_ui(G.mpi_new(0), 12345);                 // stale content must be overwritten
+        r.coeffs[i] = (i % 3 == 0) ? G.mpi_new(0)                         // nothing allocated yet: the direct path grows it through gcry_mpi_set_bit
+                    : (i % 3 == 1) ? G.mpi_set_ui(G.mpi_new(0), 12345)   // stale content must be overwritten
+                                   : random_mpi(st, 64 * 33, true);       // more limbs than the result needs, negative
       }
       if (n > 2) {                                                       // -2^(64W-1) itself: the most negative value a slab holds
         G.mpi_release(a.coeffs[2]);
@@ -78,6 +85,12 @@ int main() {
         a.coeffs[2] = keep;
       } else {
         to_slab(slab.data(), &a, n, W);
+        std::vector<uint64_t> other((size_t)W * n, 0x5555555555555555ull);
+        g_mpi_direct_wanted = !g_mpi_direct_wanted;
+        to_slab(other.data(), &a, n, W);
+        g_mpi_direct_wanted = !g_mpi_direct_wanted;
+        if (other != slab) { printf("FAIL direct and gcry_mpi_print slabs differ n=%u W=%u\n", n, W); return 1; }
+        ++checks;
       }
       // layout: word j of coefficient i at j*n + i; sign bit = sign of the MPI (zero is non-negative)
       for (unsigned i = 0; i < n; ++i) {
@@ -138,6 +151,7 @@ int main() {
   MPI z = mpi_of(Words());
   if (G.mpi_get_nbits(z) != 0) { printf("FAIL zero\n"); return 1; }
   G.mpi_release(z);
+  g_mpi_direct_wanted = true;
   printf("ok %lu\n", checks);
   return 0;
 }

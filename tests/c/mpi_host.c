@@ -413,6 +413,22 @@ static int hemultime(unsigned logn, unsigned logq)
     gpq_mpi_shim_set_key_slots(16);
     printf("key cache: resident %u, after set_key_slots(1) %u\n", before, one);
   }
+  {
+    /* the conversions read / write libgcrypt's limbs in place (after the layout probe); through gcry_mpi_print / gcry_mpi_scan the
+     * product must be the same integers */
+    he_ct_t x, y;
+    poly_alloc(&x.c0); poly_alloc(&x.c1); poly_alloc(&y.c0); poly_alloc(&y.c1);
+    const int direct = gpq_mpi_shim_set_direct_mpi(1);
+    he_mul(&x, &ct1, &ct2, &rlk);
+    (void)gpq_mpi_shim_set_direct_mpi(0);
+    const double t0 = now_ms();
+    he_mul(&y, &ct1, &ct2, &rlk);
+    const double slow = now_ms() - t0;
+    (void)gpq_mpi_shim_set_direct_mpi(1);
+    int same = 1;
+    for (unsigned i = 0; i < polyctx.n; i++) if (gcry_mpi_cmp(x.c0.coeffs[i], y.c0.coeffs[i]) || gcry_mpi_cmp(x.c1.coeffs[i], y.c1.coeffs[i])) same = 0;
+    printf("direct mpi access: %s, print/scan path %s (%.2f ms per call that way)\n", direct ? "in use" : "NOT in use", same ? "identical" : "DIFFERS", slow);
+  }
   enum { CALLS = 50 };
   double tm[CALLS], tsq[CALLS], trs[CALLS], part[8];
   for (int i = 0; i < 3; i++) he_mul(&ct, &ct1, &ct2, &rlk);

@@ -328,6 +328,7 @@ def test_reference_signature_he_mul_at_the_headline_shape_keeps_its_key_on_the_d
     res = subprocess.run([mpi_host, "hemultime", "16", "850"], capture_output=True, text=True, timeout=560)
     assert res.returncode == 0, res.stderr
     assert "key cache: rewritten key seen, cached vs fresh upload identical" in res.stdout, res.stdout
+    assert "direct mpi access: in use, print/scan path identical" in res.stdout, res.stdout
     # safe by default: ONE word edited in place, at an index a sampled fingerprint never looks at, multiplies as edited
     assert "key cache: one unsampled word edited in place seen, cached vs fresh upload identical" in res.stdout, res.stdout
     assert "key cache: resident 1, after set_key_slots(1) 1" in res.stdout or re.search(r"after set_key_slots\(1\) 1\b", res.stdout), res.stdout
