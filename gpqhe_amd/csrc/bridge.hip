@@ -156,6 +156,36 @@ int get_relin(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables **out) 
   return GPQ_OK;
 }
 
+// The context's per-limb table with the constants of the LAST inverse stage -- n^-1 and winv[1] n^-1 (src/ntt.c:71-72 folded into the
+// stage, ntt_kernels.hpp gs_last) -- multiplied by (P/p_d)^-1 mod p_d for the limbs d of basis b: an inverse transform that reads it
+// hands out y_d = ahat_d * phat_invmp_d, the first product of rns_reconstruct (src/rns.c:66-68), for free -- one modular multiply
+// and a canonicalisation per (coefficient, limb) less in the CRT kernels that follow (`prescaled`).  Limbs outside the basis keep n^-1.
+int get_scaled_tabs(gpq_ctx *c, gpq_bridge_basis *b, const LimbTab **out) {
+  if (!b->d_tabs_scaled) {
+    std::vector<LimbTab> t = c->h_tabs;
+    auto pair_of = [](uint64_t w, uint64_t p) { return TwS{p - w, p - (uint64_t)(((u128h)w << 31) % p)}; };
+    for (unsigned d = 0; d < b->dim; ++d) {
+      LimbTab &e = t[b->first + d];
+      const uint64_t p = e.k.p, s = b->h_phat_inv[d];
+      e.ninv = (uint64_t)((u128h)e.ninv * s % p);
+      e.winv1_ninv = (uint64_t)((u128h)e.winv1_ninv * s % p);
+      if (b->first + d < c->nsplit_tables) { e.ninv_s = pair_of(e.ninv, p); e.winv1_ninv_s = pair_of(e.winv1_ninv, p); }
+    }
+    DeviceScope on_device(c->device);
+    HIP_TRY(hipMalloc((void **)&b->d_tabs_scaled, t.size() * sizeof(LimbTab)));
+    HIP_TRY(hipMemcpy(b->d_tabs_scaled, t.data(), t.size() * sizeof(LimbTab), hipMemcpyHostToDevice));
+  }
+  *out = b->d_tabs_scaled;
+  return GPQ_OK;
+}
+// for the duration of one gpq_he_mul_tensor / gpq_keyswitch call
+struct ScaledInverse {
+  gpq_ctx *c;
+  ScaledInverse(gpq_ctx *ctx, const LimbTab *tabs) : c(ctx) { c->inv_tabs_override = tabs; }
+  ~ScaledInverse() { c->inv_tabs_override = nullptr; }
+};
+inline bool can_prescale(const gpq_ctx *c) { return c->prescale && c->logn > 12 && !c->h_tabs.empty(); }   // the two-pass transforms only (small rings: gpq_invntt)
+
 template <int WP>
 void launch_exact(const ReconstructArgs &a, unsigned n, unsigned batch, hipStream_t s) {
   hipLaunchKernelGGL((bridge_reconstruct<WP>), dim3((n + 127) / 128, batch), dim3(128), 0, s, a);
@@ -273,7 +303,25 @@ struct ReconExtra {
   bool *fused = nullptr;
   uint64_t *big_b = nullptr;      // the polynomials from `split` on are written here instead (Two<>, bridge_kernels.hpp)
   unsigned split = ~0u;
+  bool exact_only = false;        // skip the fast paths: the exact kernel alone (restricted by `only`)
 };
+
+// per-coefficient "redo exactly" flags of the fast CRT paths
+int ensure_redo(gpq_ctx *c, size_t flags, hipStream_t s) {
+  if (flags <= c->redo_cap) return GPQ_OK;
+  // Growing inside a stream capture would put hipMalloc into the graph; and a graph captured earlier keeps the old
+  // pointer, so outgrown buffers are retired (freed with the context), never freed here.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return gpq_fail(GPQ_ERR_INVALID, "the first call at a new batch size allocates scratch: run it once outside stream capture");
+  DeviceScope on_device(c->device);
+  unsigned char *grown = nullptr;
+  HIP_TRY(hipMalloc((void **)&grown, flags));
+  if (c->d_redo) c->retired.push_back(c->d_redo);
+  c->d_redo = grown;
+  c->redo_cap = flags;
+  return GPQ_OK;
+}
 
 int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned slab_dim,
                        unsigned slab_first, unsigned batch, unsigned logq, bool centre, unsigned char *tie, hipStream_t s, int logn_override = -1,
@@ -287,21 +335,8 @@ int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, uns
   const unsigned need = (logq + 63) / 64;
   // (the centring threshold floor(P/2)/P differs from 1/2 by 1/(2P): negligible against the 2^-61 slack only for large P)
   const bool fast = logq && centre && !c->exact_crt && need + 1 < (unsigned)b->WP && need <= 16 && b->pbits >= 160;
-  if (fast) {
-    const size_t flags = (size_t)batch << logn;
-    if (flags > c->redo_cap) {
-      // Growing inside a stream capture would put hipMalloc into the graph; and a graph captured earlier keeps the old
-      // pointer, so outgrown buffers are retired (freed with the context), never freed here.
-      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-        return gpq_fail(GPQ_ERR_INVALID, "the first call at a new batch size allocates scratch: run it once outside stream capture");
-      DeviceScope on_device(c->device);
-      unsigned char *grown = nullptr;
-      HIP_TRY(hipMalloc((void **)&grown, flags));
-      if (c->d_redo) c->retired.push_back(c->d_redo);
-      c->d_redo = grown;
-      c->redo_cap = flags;
-    }
+  if (fast && !x.exact_only) {
+    if (int rc = ensure_redo(c, (size_t)batch << logn, s)) return rc;
     bool done = false;
     if (c->bridge_mfma && logn >= 6 && b->dim >= 4) {      // CRT sum as bytes x constant matrix on the matrix cores
       const int WL = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 7 ? 7 : need <= 10 ? 10 : need <= 14 ? 14 : 16;
@@ -464,6 +499,7 @@ void gpq_bridge_release(gpq_ctx *c) {
   for (auto &kv : c->bases) {
     (void)hipFree(kv.second.d_phat); (void)hipFree(kv.second.d_phat_inv);
     (void)hipFree(kv.second.d_pmult); (void)hipFree(kv.second.d_phalf); (void)hipFree(kv.second.d_inv128);
+    if (kv.second.d_tabs_scaled) (void)hipFree(kv.second.d_tabs_scaled);
     for (auto &m : kv.second.mfma) {
       if (m.second.d_bfrag) (void)hipFree(m.second.d_bfrag);
       if (m.second.d_lk) (void)hipFree(m.second.d_lk);
@@ -681,6 +717,16 @@ int get_relin_front(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables *
   return GPQ_OK;
 }
 
+template <int KS, int WL>
+int launch_relin_tail_t(const RelinTailArgs &a, size_t lds, hipStream_t s) {
+  static LdsRaised raised;
+  if (int rc = raised.raise(reinterpret_cast<const void *>(&bridge_relin_tail_mfma<KS, WL>), (int)kMfmaLdsMax)) return rc;
+  unsigned blocks = 256 * GPQ_TAIL_WAVES;                  // 4-wave workgroups, GPQ_TAIL_WAVES per CU (registers; their tables fit the LDS twice), persistent over the groups
+  if (blocks > (a.f.total_groups + 3) / 4) blocks = (a.f.total_groups + 3) / 4;
+  hipLaunchKernelGGL((bridge_relin_tail_mfma<KS, WL>), dim3(blocks), dim3(256), lds, s, a);
+  return GPQ_OK;
+}
+
 template <int KS>
 int launch_relin_front_t(const RelinFrontArgs &a, size_t lds, hipStream_t s) {
   static LdsRaised raised;
@@ -697,8 +743,9 @@ int launch_relin_front_t(const RelinFrontArgs &a, size_t lds, hipStream_t s) {
 // src/he-mult.c:67-77 (d != null: c = rdiv(c,P) + d) and src/he-automorphism.c:68-76, for q_l = 2^logql.
 // `polys` polynomials of chat; the first `split` of them go to out.a (+ addend d.a), the rest to out.b (+ d.b): c0 and c1 of a
 // launch group are one batch (their chat slabs are adjacent in the workspace), half the launches and twice their size.
+// chat_prescaled: the limbs below dimP already hold chat_d * (P/p_d)^-1 (ScaledInverse on the key switch's inverse pass).
 int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const uint64_t> dbig, unsigned W, unsigned dimP, unsigned dimB,
-               unsigned logql, unsigned polys, void *ws, hipStream_t s) {
+               unsigned logql, unsigned polys, void *ws, hipStream_t s, bool chat_prescaled = false) {
   TailPlan tp;
   int rc = tail_plan(c, W, dimP, dimB, polys, &tp);
   if (rc) return rc;
@@ -723,7 +770,42 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
     unsigned char *flags = (unsigned char *)rhat, *amb = flags + ((size_t)polys << c->logn);   // rhat's place is free in this flow
     const unsigned gpp = c->n >> 6;
     RelinFrontArgs f{chat, qhat, (const v4i *)rt->d_bfrag, rt->d_lk, rt->d_pk, rt->d_tkp, rt->d_kf, flags, amb,
-                     dimB, dimP, tp.cnt, c->logn, rt->NT, gpp, gpp * polys};
+                     dimB, dimP, tp.cnt, c->logn, rt->NT, gpp, gpp * polys, nullptr, chat_prescaled ? 1u : 0u};
+    // One pass per coefficient (bridge_relin_tail_mfma): the front and the CRT of Q without the round trip of Q's residues.
+    const unsigned need = (logql + 63) / 64;
+    const int WLf = need <= 7 ? 7 : 14;
+    gpq_recon_mfma *tq = nullptr;
+    const bool can_fuse = c->fuse_tail && !in_place && !c->exact_crt && need <= 14 && need + 1 < (unsigned)bq->WP && bq->pbits >= 160 && tp.cnt >= 4 && tp.cnt <= 4 * RELIN_TAIL_MAXTILES &&
+                          (rt->KS == 2 || rt->KS == 4);
+    if (can_fuse && (rc = get_recon_mfma(c, bq, WLf, &tq))) return rc;
+    if (can_fuse && tq->d_bfrag && tq->KS + 1 == rt->NT && rt->lds_bytes + (size_t)tq->KS * ((8 * WLf + 14 + 31) / 32) * 1024 <= kMfmaLdsMax) {
+      if ((rc = ensure_redo(c, (size_t)polys << c->logn, s))) return rc;
+      const size_t lds = rt->lds_bytes + (size_t)tq->KS * ((8 * WLf + 14 + 31) / 32) * 1024;
+      RelinTailArgs ft{f, (const v4i *)tq->d_bfrag, tq->d_kc, tq->d_pm, c->d_redo, tie, out, dbig, W, logql, tq->KS};
+      if (rt->KS == 2 && WLf == 7) rc = launch_relin_tail_t<2, 7>(ft, lds, s);
+      else if (rt->KS == 2) rc = launch_relin_tail_t<2, 14>(ft, lds, s);
+      else if (WLf == 7) rc = launch_relin_tail_t<4, 7>(ft, lds, s);
+      else rc = launch_relin_tail_t<4, 14>(ft, lds, s);
+      if (rc) return rc;
+      // the few coefficients it flagged: round bits settled exactly, Q's residues made for their groups, exact CRT, finish
+      ReconExtra only_amb;
+      only_amb.only = amb; only_amb.prescaled = chat_prescaled;
+      if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, only_amb))) return rc;
+      RoundFixArgs rf{r, bp->d_phalf, amb, flags, tp.Wr, c->logn};
+      hipLaunchKernelGGL(bridge_roundfix, cgrid, cblock, 0, s, rf);
+      f.only = c->d_redo;
+      switch (rt->KS) {
+        case 2: rc = launch_relin_front_t<2>(f, rt->lds_bytes, s); break;
+        default: rc = launch_relin_front_t<4>(f, rt->lds_bytes, s); break;
+      }
+      if (rc) return rc;
+      ReconExtra q;
+      q.prescaled = true; q.exact_only = true; q.only = c->d_redo; q.big_b = out.b; q.split = out.split;
+      if ((rc = launch_reconstruct(c, bq, out.a, W, qhat, tp.cnt, 0, polys, logql, true, tie, s, -1, q))) return rc;
+      AddRoundArgs ar{out, Two<const uint64_t>{out.a, out.b, out.split}, nullptr, dbig, bp->d_phalf, piq, tie, W, tp.Wr, c->logn, logql, c->d_redo, flags};
+      hipLaunchKernelGGL(bridge_addround, cgrid, cblock, 0, s, ar);
+      return launched("relin_tail");
+    }
     switch (rt->KS) {
       case 2: rc = launch_relin_front_t<2>(f, rt->lds_bytes, s); break;
       case 4: rc = launch_relin_front_t<4>(f, rt->lds_bytes, s); break;
@@ -731,7 +813,7 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
     }
     if (rc) return rc;
     ReconExtra only_amb;
-    only_amb.only = amb;
+    only_amb.only = amb; only_amb.prescaled = chat_prescaled;
     if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, only_amb))) return rc;
     RoundFixArgs rf{r, bp->d_phalf, amb, flags, tp.Wr, c->logn};
     hipLaunchKernelGGL(bridge_roundfix, cgrid, cblock, 0, s, rf);
@@ -751,7 +833,9 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
   }
 
   // r = x mod P from the first dimP limbs, unsigned
-  if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s))) return rc;
+  ReconExtra rx;
+  rx.prescaled = chat_prescaled;
+  if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, rx))) return rc;
   if ((rc = launch_decompose(c, rhat, r, tp.Wr, dimP, tp.cnt, polys, s))) return rc;
   ExactDivArgs e{c->d_tabs, chat, rhat, qhat, rt->d_pinv, dimB, dimP, tp.cnt, c->logn};
   hipLaunchKernelGGL(bridge_exactdiv, dim3((c->n + 255) / 256, polys, tp.cnt), dim3(256), 0, s, e);
@@ -820,8 +904,8 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
   void *wsK = w; w += align64(gpq_keyswitch_workspace_bytes(c, dimB, m));
   uint64_t *dbig = (uint64_t *)w; w += align64((size_t)m * 3 * W * n * 8);
   void *wsTail = w;
-  gpq_bridge_basis *bA;
-  if ((rc = get_basis(c, 0, dimA, &bA))) return rc;
+  gpq_bridge_basis *bA, *bP;
+  if ((rc = get_basis(c, 0, dimA, &bA)) || (rc = get_basis(c, 0, dimP, &bP))) return rc;
   for (unsigned k0 = 0; k0 < batch; k0 += m) {
     const unsigned polys = batch - k0 < m ? batch - k0 : m;
     const size_t pa = (size_t)polys * dimA * n, pb = (size_t)polys * dimB * n;
@@ -837,12 +921,20 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
       BigSources src{{in[0] + k0 * bigpoly, in[1] + k0 * bigpoly, in[square ? 0 : 2] + k0 * bigpoly, in[square ? 1 : 3] + k0 * bigpoly}, polys};
       if ((rc = launch_decompose(c, h[0], src, W, 0, dimA, nin * polys, s))) return rc;
     }
-    if ((rc = gpq_he_mul_tensor(c, d0h, d1h, d2h, h[0], h[1], square ? h[0] : h[2], square ? h[1] : h[3], dimA, polys, wsT, stream))) return rc;  // :121-136
+    const bool pre = can_prescale(c);      // the inverse passes hand the CRT kernels limbs already multiplied by (P/p_d)^-1
+    const LimbTab *tabsA = nullptr, *tabsP = nullptr;
+    if (pre && ((rc = get_scaled_tabs(c, bA, &tabsA)) || (rc = get_scaled_tabs(c, bP, &tabsP)))) return rc;
+    {
+      ScaledInverse scaled(c, tabsA);
+      if ((rc = gpq_he_mul_tensor(c, d0h, d1h, d2h, h[0], h[1], square ? h[0] : h[2], square ? h[1] : h[3], dimA, polys, wsT, stream))) return rc;  // :121-136
+    }
     uint64_t *d0 = dbig, *d1 = dbig + polys * bigpoly, *d2 = dbig + 2 * polys * bigpoly;
     // poly_rns2mpi of d0, d2, d1 (:139-141): the three slabs are adjacent on both sides, one launch
     {
       StageRange stage("gpq_he_mul: poly_rns2mpi d0,d1,d2 (CRT)");
-      if ((rc = launch_reconstruct(c, bA, d0, W, d0h, dimA, 0, 3 * polys, logql, true, nullptr, s))) return rc;
+      ReconExtra rx;
+      rx.prescaled = pre;
+      if ((rc = launch_reconstruct(c, bA, d0, W, d0h, dimA, 0, 3 * polys, logql, true, nullptr, s, -1, rx))) return rc;
     }
     // he_relin, :40-85
     uint64_t *d2hat = sB, *c0hat = sB + pb, *c1hat = sB + 2 * pb;
@@ -850,11 +942,14 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
       StageRange stage("gpq_he_mul: he_relin rns_decompose d2");
       if ((rc = launch_decompose(c, d2hat, d2, W, 0, dimB, polys, s))) return rc;                                  // :59
     }
-    if ((rc = gpq_keyswitch(c, c0hat, c1hat, d2hat, rlk0, rlk1, dimB, polys, wsK, stream))) return rc;             // :60-64
+    {
+      ScaledInverse scaled(c, tabsP);
+      if ((rc = gpq_keyswitch(c, c0hat, c1hat, d2hat, rlk0, rlk1, dimB, polys, wsK, stream))) return rc;           // :60-64
+    }
     StageRange stage("gpq_he_mul: he_relin tail (CRT, exact division by P, + d)");
     // c0 and c1 as one batch of 2 x polys polynomials: c0hat | c1hat and d0 | d1 are adjacent, the outputs are the caller's two slabs
     if ((rc = relin_tail(c, Two<uint64_t>{out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, polys}, c0hat, Two<const uint64_t>{d0, d1, polys},
-                         W, dimP, dimB, logql, 2 * polys, wsTail, s))) return rc;                                  // :67-77
+                         W, dimP, dimB, logql, 2 * polys, wsTail, s, pre))) return rc;                             // :67-77
   }
   return launched("gpq_he_mul");
 }
@@ -882,10 +977,17 @@ extern "C" int gpq_he_swk(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
     const size_t pb = (size_t)polys * dimB * n;
     uint64_t *d1hat = sB, *c0hat = sB + pb, *c1hat = sB + 2 * pb;
     if ((rc = launch_decompose(c, d1hat, d1 + k0 * bigpoly, W, 0, dimB, polys, s))) return rc;                     // :60
-    if ((rc = gpq_keyswitch(c, c0hat, c1hat, d1hat, swk0, swk1, dimB, polys, wsK, stream))) return rc;             // :61-65
+    const bool pre = can_prescale(c);
+    const LimbTab *tabsP = nullptr;
+    gpq_bridge_basis *bP;
+    if (pre && ((rc = get_basis(c, 0, dimP, &bP)) || (rc = get_scaled_tabs(c, bP, &tabsP)))) return rc;
+    {
+      ScaledInverse scaled(c, tabsP);
+      if ((rc = gpq_keyswitch(c, c0hat, c1hat, d1hat, swk0, swk1, dimB, polys, wsK, stream))) return rc;           // :61-65
+    }
     // c0 (+ d0) and c1 (no addend) as one batch of 2 x polys polynomials                                           // :68-75
     if ((rc = relin_tail(c, Two<uint64_t>{out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, polys}, c0hat, Two<const uint64_t>{d0 + k0 * bigpoly, nullptr, polys},
-                         W, dimP, dimB, logql, 2 * polys, wsTail, s))) return rc;
+                         W, dimP, dimB, logql, 2 * polys, wsTail, s, pre))) return rc;
   }
   return launched("gpq_he_swk");
 }
@@ -907,6 +1009,22 @@ extern "C" int gpq_relin_tail(gpq_ctx *c, uint64_t *out, const uint64_t *chat, c
   if (rc) return rc;
   if (!out || !chat || !workspace || !logql || W < (logql + 63) / 64) return gpq_fail(GPQ_ERR_INVALID, "gpq_relin_tail: bad arguments");
   return relin_tail(c, one_place(out), chat, one_place(d), W, dimP, dimB, logql, batch, workspace, (hipStream_t)stream);
+}
+
+// The relinearisation tail as one pass per coefficient (default) or as front + CRT kernels with Q's residues in memory between them;
+// bit-identical (tests run both).
+extern "C" int gpq_set_fused_tail(gpq_ctx *c, int on) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_fused_tail: null context");
+  c->fuse_tail = on != 0;
+  return GPQ_OK;
+}
+
+// gpq_he_mul / gpq_he_swk let their inverse transforms hand the CRT kernels limbs already multiplied by (P/p_d)^-1 (default on); off = the
+// CRT kernels do that multiplication themselves.  Same results (tests run both).
+extern "C" int gpq_set_prescale(gpq_ctx *c, int on) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_prescale: null context");
+  c->prescale = on != 0;
+  return GPQ_OK;
 }
 
 // Tests: force the exact (full-width) CRT kernel instead of the low-word fast path.

@@ -355,6 +355,10 @@ struct RelinFrontArgs {
   unsigned char *flags;      // [polys][n]  RF_*
   unsigned char *amb;        // [polys][n]  1 where RF_AMB
   unsigned dimB, dimP, cnt, logn, NT, groups_per_poly, total_groups;
+  // optional [polys][n]: when given, only the groups of 64 coefficients that hold a non-zero entry are processed and flags / amb
+  // are left alone -- the re-run behind bridge_relin_tail_mfma, which needs yq in memory for the few coefficients it could not finish
+  const unsigned char *only;
+  unsigned prescaled;        // the limbs below dimP already hold y_d = chat_d * phat_invmp_d (the key switch's inverse pass scaled them: ScaledInverse)
 };
 
 #ifndef GPQ_FRONT_OCC
@@ -390,13 +394,18 @@ __global__ __launch_bounds__(256, (KS <= 4 ? GPQ_FRONT_OCC : 2)) void bridge_rel
       }
   };
   const unsigned g0 = blockIdx.x * 4 + wave, gstep = gridDim.x * 4;
-  if (g0 < a.total_groups) load_raw(g0);
+  const bool masked = a.only != nullptr;
+  if (!masked && g0 < a.total_groups) load_raw(g0);
   for (unsigned g = g0; g < a.total_groups; g += gstep) {
     const unsigned poly = g / a.groups_per_poly, coef0 = (g % a.groups_per_poly) << 6;
+    if (masked) {
+      if (!__builtin_amdgcn_ballot_w64(a.only[((size_t)poly << a.logn) + coef0 + lane] != 0)) continue;
+      load_raw(g);
+    }
     // from here on this lane finishes coefficient coef0 + lane
     const uint64_t *__restrict__ src = a.chat + (((size_t)poly * a.dimB + a.dimP) << a.logn) + coef0 + lane;
     uint64_t *__restrict__ dst = a.yq + ((size_t)poly * a.cnt << a.logn) + coef0 + lane;
-    if (KS >= GPQ_FRONT_XG && g != g0) load_raw(g);     // no registers for the early fetch with 32 limbs in P
+    if (!masked && KS >= GPQ_FRONT_XG && g != g0) load_raw(g);     // no registers for the early fetch with 32 limbs in P
     v4i X[2][KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -408,14 +417,14 @@ __global__ __launch_bounds__(256, (KS <= 4 ? GPQ_FRONT_OCC : 2)) void bridge_rel
         PrimeK k;
         k.p = p; k.p2 = p << 1; k.c = (uint32_t)p; k.c1 = k.c + 1;
         const uint64_t m = p ? ~0ull : 0ull;
-        y[e] = (canon_fold(mulmod_lazy(raw[s][e], w, k), p, k.c) ^ 0x8080808080808080ull) & m;
-        y[2 + e] = (canon_fold(mulmod_lazy(raw[s][2 + e], w, k), p, k.c) ^ 0x8080808080808080ull) & m;
+        y[e] = ((a.prescaled ? raw[s][e] : canon_fold(mulmod_lazy(raw[s][e], w, k), p, k.c)) ^ 0x8080808080808080ull) & m;
+        y[2 + e] = ((a.prescaled ? raw[s][2 + e] : canon_fold(mulmod_lazy(raw[s][2 + e], w, k), p, k.c)) ^ 0x8080808080808080ull) & m;
       }
       X[0][s] = v4i{(int)(uint32_t)y[0], (int)(uint32_t)(y[0] >> 32), (int)(uint32_t)y[1], (int)(uint32_t)(y[1] >> 32)};
       X[1][s] = v4i{(int)(uint32_t)y[2], (int)(uint32_t)(y[2] >> 32), (int)(uint32_t)y[3], (int)(uint32_t)(y[3] >> 32)};
       __builtin_amdgcn_sched_barrier(0);   // four multiplies at a time: interleaving all 4 KS of them spills
     }
-    if (KS < GPQ_FRONT_XG && g + gstep < a.total_groups) load_raw(g + gstep);
+    if (!masked && KS < GPQ_FRONT_XG && g + gstep < a.total_groups) load_raw(g + gstep);
     // residues chat_j of this lane's coefficient, one row tile (4 limbs) ahead
     uint64_t xn[4];
     auto fetch_x = [&](unsigned q) {
@@ -447,8 +456,10 @@ __global__ __launch_bounds__(256, (KS <= 4 ? GPQ_FRONT_OCC : 2)) void bridge_rel
       const bool ambiguous = ((f_hi >> 2) & ((1ull << 38) - 1)) == ((1ull << 37) - 1);
       const unsigned gt = (unsigned)(f_hi >> 39) & 1;
       const size_t flag_at = ((size_t)poly << a.logn) + coef0 + lane;
-      a.flags[flag_at] = (unsigned char)(ambiguous ? RF_AMB : (gt ? RF_GT : RF_LT));
-      a.amb[flag_at] = ambiguous;
+      if (!masked) {
+        a.flags[flag_at] = (unsigned char)(ambiguous ? RF_AMB : (gt ? RF_GT : RF_LT));
+        a.amb[flag_at] = ambiguous;
+      }
       kk = (unsigned)(f_hi >> 40);
     }
     for (unsigned q = 0; q + 1 < a.NT; ++q) {
@@ -488,6 +499,303 @@ __global__ __launch_bounds__(256, (KS <= 4 ? GPQ_FRONT_OCC : 2)) void bridge_rel
         __builtin_amdgcn_sched_barrier(0);
 #endif
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The relinearisation tail in ONE pass over a coefficient: bridge_relin_front_mfma's work and the CRT of Q that
+// bridge_reconstruct_low_mfma does on its output, without the round trip of Q's residues (cnt limbs written and read again:
+// 60 of the 133 words the two kernels move per coefficient at the headline shape).  Row tile q of the front yields Q's scaled
+// residues of limbs 4q .. 4q+3 for the coefficient a lane finishes -- exactly k step q of the CRT product, whose data fragment
+// wants limbs 4q+2h, 4q+2h+1 of coefficients r (tile 0) and 32+r (tile 1) on lane (r, h): two v_permlane32_swap per pair of
+// limbs put them there (lower lanes keep limbs 4q, 4q+1 of their own coefficient and receive those of lane 32+r's; upper lanes
+// keep 4q+2, 4q+3 and receive lane r's), and the CRT accumulators take the step while the front works on its next row tile.
+// Epilogue = bridge_reconstruct_low_mfma's with the round bit taken from this kernel's own F columns.
+// What it cannot finish -- r / P within 2^-38 below 1/2 (RF_AMB) or Q / Pi' likewise (the CRT's own window) -- is flagged in
+// `redo` and finished as before: bridge_roundfix settles the round bits, bridge_relin_front_mfma re-runs on the flagged groups
+// only (a.only) to put Q's residues in memory, the exact CRT kernel and bridge_addround complete those coefficients.
+// ---------------------------------------------------------------------------
+struct RelinTailArgs {
+  RelinFrontArgs f;          // chat, tables of the front, flags / amb (written), yq unused, only = nullptr
+  const v4i *rfrag;          // [KSr][NTR][64]  constant fragments of the CRT over the cnt limbs (get_recon_mfma of that basis)
+  const uint64_t *rkc;       // [WL + 2]
+  const uint64_t *rpm;       // [65][WL]
+  unsigned char *redo;       // [polys][n]  1 = not finished here
+  unsigned char *tie;        // [polys][n]  cleared
+  Two<uint64_t> out;         // [polys][W][n]
+  Two<const uint64_t> addend;
+  unsigned W, logq, KSr;
+};
+
+// One wave per SIMD (4 per CU) with the whole register file: the CRT accumulators, the front's fragments and every global load
+// of the NEXT group (the limbs of P for the fragments, the cnt residues and the addend of the lane's own coefficient: ~120
+// registers) issued before the current group's arithmetic -- at two waves per SIMD the same code spills 80 registers and runs
+// 25 % slower than the two kernels it replaces (profiles/r03).
+#ifndef GPQ_TAIL_WAVES
+#define GPQ_TAIL_WAVES 1   /* waves per SIMD of bridge_relin_tail_mfma: 1 = the whole next group's residues in registers (no spill), 2 = residues one row tile ahead (73 spilled registers: slower) */
+#endif
+constexpr int RELIN_TAIL_MAXTILES = 8;     // row tiles of the front = k steps of the CRT: cnt <= 32 limbs above P
+
+template <int KS, int WL>
+__global__ __launch_bounds__(256, GPQ_TAIL_WAVES) void bridge_relin_tail_mfma(RelinTailArgs t) {
+  constexpr int NTR = (8 * WL + 14 + 31) / 32;
+  constexpr int MT = RELIN_TAIL_MAXTILES;
+  const RelinFrontArgs &a = t.f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  v4i *Bl = reinterpret_cast<v4i *>(smem);
+  const unsigned nB = a.NT * KS * 64, nR = t.KSr * NTR * 64;
+  v4i *Rl = Bl + nB;
+  uint64_t *lkl = reinterpret_cast<uint64_t *>(smem + (size_t)(nB + nR) * 16);          // 8 KS words
+  uint64_t *pkl = lkl + 8 * KS;                                                          // 12 (NT-1) words
+  // (the wave index is uniform, but the compiler only knows it after readfirstlane: with it every group / polynomial / limb offset
+  // below is scalar and the loads take an SGPR base + a 32-bit lane offset instead of thirty 64-bit VGPR addresses)
+  const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (unsigned i = threadIdx.x; i < nB; i += 256) Bl[i] = a.bfrag[i];
+  for (unsigned i = threadIdx.x; i < nR; i += 256) Rl[i] = t.rfrag[i];
+  for (unsigned i = threadIdx.x; i < 8u * KS; i += 256) lkl[i] = a.lk[i];
+  for (unsigned i = threadIdx.x; i < 12 * (a.NT - 1); i += 256) pkl[i] = a.pk[i];
+  __syncthreads();
+  const unsigned r = lane & 31, h = lane >> 5;
+  const unsigned lg = a.logn - 6;                                                        // groups per polynomial = n / 64: shifts, not a (vector) division
+  const unsigned ntp = a.NT - 1;                                                         // row tiles in use (<= MT)
+  const uint64_t kf0 = a.kf[0], kf1 = a.kf[1];
+  const unsigned g0 = blockIdx.x * 4 + wave, gstep = gridDim.x * 4;
+  // Everything a group reads from global memory is fetched one group ahead INTO THE SAME REGISTERS: a value is replaced by the
+  // next group's as soon as the current group has consumed it (the residues of limbs 4q .. 4q+3 after row tile q; the limbs of P
+  // for the next fragments and this group's addend at the start of the epilogue), so the loads fly under the group's arithmetic.
+#if GPQ_TAIL_WAVES >= 2
+  uint64_t raw[KS][4], xn[4], dd[WL];                                    // two waves per SIMD: the residues one row tile ahead only
+#else
+  uint64_t raw[KS][4], xj[4 * MT], dd[WL];
+#endif
+  // uniform bases (SGPRs): the limbs of P of a group, the limbs above P, the addend; lane offsets apart
+  const unsigned roff = ((2 * h) << a.logn) + r;                         // fragment lanes: limb 4s + 2h + e of coefficient r (+ 32 for tile 1)
+  auto src_p = [&](unsigned g) {
+    const unsigned poly = g >> lg, coef0 = (g & ((1u << lg) - 1)) << 6;
+    return a.chat + ((size_t)poly * a.dimB << a.logn) + coef0;
+  };
+  auto src_j = [&](unsigned g) {
+    const unsigned poly = g >> lg, coef0 = (g & ((1u << lg) - 1)) << 6;
+    return a.chat + (((size_t)poly * a.dimB + a.dimP) << a.logn) + coef0;
+  };
+  auto src_d = [&](unsigned g) -> const uint64_t * {
+    const unsigned poly = g >> lg, coef0 = (g & ((1u << lg) - 1)) << 6;
+    const uint64_t *base = t.addend.at(poly, (size_t)t.W << a.logn);                     // uniform per group
+    return base ? base + coef0 : nullptr;
+  };
+  // (limbs 4s + 2h + e up to 4 KS - 1 <= dimP + 3: the padding limbs read real limbs above P -- in bounds, cnt >= 4 -- and are masked)
+  auto load_raw = [&](const uint64_t *__restrict__ srcp) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const uint64_t *__restrict__ ub = srcp + ((size_t)(4 * s + e) << a.logn);
+        raw[s][e] = ub[roff];
+        raw[s][2 + e] = ub[roff + 32];
+      }
+  };
+  auto load_tile = [&](const uint64_t *__restrict__ src, int q) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned j = 4 * q + w, jc = __builtin_amdgcn_readfirstlane(j < a.cnt ? j : a.cnt - 1);   // scalar: left to the compiler the clamp and the
+#if GPQ_TAIL_WAVES >= 2
+      xn[w] = (src + ((size_t)jc << a.logn))[lane];
+#else
+      xj[4 * q + w] = (src + ((size_t)jc << a.logn))[lane];                                           // thirty 64-bit offsets end up in (hoisted) VGPRs
+#endif
+    }
+  };
+  auto load_dd = [&](const uint64_t *__restrict__ dp) {
+    if (dp) {
+#pragma unroll
+      for (int j = 0; j < WL; ++j) dd[j] = (dp + ((size_t)(j < (int)t.W ? j : 0) << a.logn))[lane];
+    }
+  };
+  if (g0 < a.total_groups) {
+    load_raw(src_p(g0));
+    const uint64_t *sj = src_j(g0);
+#if GPQ_TAIL_WAVES >= 2
+    load_tile(sj, 0);
+#else
+#pragma unroll
+    for (int q = 0; q < MT; ++q) load_tile(sj, q);
+#endif
+  }
+  for (unsigned g = g0; g < a.total_groups; g += gstep) {
+    const unsigned poly = g >> lg, coef0 = (g & ((1u << lg) - 1)) << 6;
+    const size_t flag_at = ((size_t)poly << a.logn) + coef0 + lane;
+    const bool has_addend = t.addend.at(poly, 0) != nullptr;
+    const unsigned gn = g + gstep < a.total_groups ? g + gstep : g;      // next group (or this one again: harmless reads)
+    // ---- the front's data fragments: y_d = chat_d * phat_invmp_d for the limbs of P
+    v4i X[2][KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      uint64_t y[4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned d = 4 * s + 2 * h + e;
+        const uint64_t p = lkl[2 * d], w = lkl[2 * d + 1];
+        PrimeK k;
+        k.p = p; k.p2 = p << 1; k.c = (uint32_t)p; k.c1 = k.c + 1;
+        const uint64_t m = p ? ~0ull : 0ull;
+        y[e] = ((a.prescaled ? raw[s][e] : canon_fold(mulmod_lazy(raw[s][e], w, k), p, k.c)) ^ 0x8080808080808080ull) & m;
+        y[2 + e] = ((a.prescaled ? raw[s][2 + e] : canon_fold(mulmod_lazy(raw[s][2 + e], w, k), p, k.c)) ^ 0x8080808080808080ull) & m;
+      }
+      X[0][s] = v4i{(int)(uint32_t)y[0], (int)(uint32_t)(y[0] >> 32), (int)(uint32_t)y[1], (int)(uint32_t)(y[1] >> 32)};
+      X[1][s] = v4i{(int)(uint32_t)y[2], (int)(uint32_t)(y[2] >> 32), (int)(uint32_t)y[3], (int)(uint32_t)(y[3] >> 32)};
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const uint64_t *__restrict__ sjn = src_j(gn);
+#if GPQ_TAIL_WAVES >= 2
+    const uint64_t *__restrict__ sjc = src_j(g);
+#endif
+    // ---- row tile NT-1 of the front first: F -> k and the round bit
+    unsigned kk, gt;
+    bool amb_front;
+    {
+      v16i f0, f1;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { f0[e] = 0; f1[e] = 0; }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const v4i cf = Bl[((a.NT - 1) * KS + s) * 64 + lane];
+        f0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[0][s], f0, 0, 0, 0);
+        f1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[1][s], f1, 0, 0, 0);
+      }
+      int64_t L0, H0, L1, H1, carry = 0;
+      swap_halves(horner4(f0[0], f0[1], f0[2], f0[3]), horner4(f1[0], f1[1], f1[2], f1[3]), L0, H0);
+      swap_halves(horner4(f0[4], f0[5], f0[6], f0[7]), horner4(f1[4], f1[5], f1[6], f1[7]), L1, H1);
+      const uint64_t F0 = fold_word(L0, H0, carry), F1 = fold_word(L1, H1, carry);
+      const u128 F = (((u128)F1 << 64) | F0) + (((u128)kf1 << 64) | kf0);
+      const uint64_t f_hi = (uint64_t)(F >> 64);
+      amb_front = ((f_hi >> 2) & ((1ull << 38) - 1)) == ((1ull << 37) - 1);
+      gt = (unsigned)(f_hi >> 39) & 1;
+      a.flags[flag_at] = (unsigned char)(amb_front ? RF_AMB : (gt ? RF_GT : RF_LT));
+      a.amb[flag_at] = amb_front;
+      kk = (unsigned)(f_hi >> 40);
+    }
+    // ---- row tiles of the front, each feeding one k step of the CRT of Q
+    v16i acc[2][NTR];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int qq = 0; qq < NTR; ++qq)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[tt][qq][e] = 0;
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+      if ((unsigned)q < ntp) {                                           // uniform
+        uint64_t tk[4];
+#if GPQ_TAIL_WAVES >= 2
+        uint64_t xc[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) xc[w] = xn[w];
+        if ((unsigned)q + 1 < ntp) load_tile(sjc, q + 1); else load_tile(sjn, 0);   // next row tile, or the next group's first
+#endif
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const unsigned j = 4 * q + w, jc = __builtin_amdgcn_readfirstlane(j < a.cnt ? j : a.cnt - 1);
+          tk[w] = (a.tkp + (size_t)jc * 64)[kk];
+        }
+        v16i acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0; acc1[e] = 0; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const v4i cf = Bl[(q * KS + s) * 64 + lane];
+          acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[0][s], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[1][s], acc1, 0, 0, 0);
+        }
+        uint64_t yb[4];                                                  // Q's scaled residues of limbs 4q .. 4q+3 as signed bytes (0 for padding limbs)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          int64_t L, H;
+          swap_halves(horner4(acc0[4 * w], acc0[4 * w + 1], acc0[4 * w + 2], acc0[4 * w + 3]),
+                      horner4(acc1[4 * w], acc1[4 * w + 1], acc1[4 * w + 2], acc1[4 * w + 3]), L, H);
+          const unsigned j = 4 * q + w;
+          const uint64_t p = pkl[3 * j], kq = pkl[3 * j + 1], wj = pkl[3 * j + 2];
+          PrimeK k;
+          k.p = p; k.p2 = p << 1; k.c = (uint32_t)p; k.c1 = k.c + 1;
+          const int Hh = (int)(H >> 27);
+          const uint64_t Hl = (uint64_t)H & 0x7ffffffu;
+          uint64_t v = (Hl << 32) + (uint64_t)L + kq;
+          v = (uint64_t)((int64_t)(-(int)k.c) * Hh + (int64_t)v) + tk[w];   // r mod p_j, lazily: in (0, 4p)
+#if GPQ_TAIL_WAVES >= 2
+          const uint64_t yq = canon_fold(mulmod_lazy(xc[w] + (p << 2) - v, wj, k), p, k.c);
+#else
+          const uint64_t yq = canon_fold(mulmod_lazy(xj[4 * q + w] + (p << 2) - v, wj, k), p, k.c);
+#endif
+          yb[w] = (yq ^ 0x8080808080808080ull) & (p ? ~0ull : 0ull);
+        }
+#if GPQ_TAIL_WAVES < 2
+        load_tile(sjn, q);                                               // these four registers now wait for the next group
+#endif
+        // limbs (4q, 4q+2) and (4q+1, 4q+3) change lane halves: [0] = tile 0's fragment words, [1] = tile 1's
+        const auto e0l = __builtin_amdgcn_permlane32_swap((unsigned)yb[0], (unsigned)yb[2], false, false);
+        const auto e0h = __builtin_amdgcn_permlane32_swap((unsigned)(yb[0] >> 32), (unsigned)(yb[2] >> 32), false, false);
+        const auto e1l = __builtin_amdgcn_permlane32_swap((unsigned)yb[1], (unsigned)yb[3], false, false);
+        const auto e1h = __builtin_amdgcn_permlane32_swap((unsigned)(yb[1] >> 32), (unsigned)(yb[3] >> 32), false, false);
+        const v4i A0 = v4i{(int)e0l[0], (int)e0h[0], (int)e1l[0], (int)e1h[0]};
+        const v4i A1 = v4i{(int)e0l[1], (int)e0h[1], (int)e1l[1], (int)e1h[1]};
+#pragma unroll
+        for (int qq = 0; qq < NTR; ++qq) {
+          const v4i b = Rl[(q * NTR + qq) * 64 + lane];
+          acc[0][qq] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A0, acc[0][qq], 0, 0, 0);
+          acc[1][qq] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A1, acc[1][qq], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);                               // one row tile at a time: hoisting the tiles' loads over each other spills
+      }
+    }
+    // ---- CRT epilogue (bridge_reconstruct_low_mfma's) + finish.  The front's fragments are dead: this group's addend and the
+    // next group's limbs of P are fetched under the column folding (earlier they would not fit the registers).
+    load_dd(src_d(g));
+    load_raw(src_p(gn));
+    uint64_t V[4 * NTR];
+    int64_t carry = 0;
+#pragma unroll
+    for (int qq = 0; qq < NTR; ++qq)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        int64_t L, H;
+        swap_halves(horner4(acc[0][qq][4 * w], acc[0][qq][4 * w + 1], acc[0][qq][4 * w + 2], acc[0][qq][4 * w + 3]),
+                    horner4(acc[1][qq][4 * w], acc[1][qq][4 * w + 1], acc[1][qq][4 * w + 2], acc[1][qq][4 * w + 3]), L, H);
+        if (4 * qq + w == WL) carry = 0;
+        V[4 * qq + w] = fold_word(L, H, carry);
+        if (w == 3) __builtin_amdgcn_sched_barrier(0);   // a row tile of accumulators at a time: read out all at once they spill
+      }
+    const u128 F = (((u128)V[WL + 1] << 64) | V[WL]) + (((u128)t.rkc[WL + 1] << 64) | t.rkc[WL]);
+    const uint64_t f1 = (uint64_t)(F >> 64);
+    const bool unfinished = amb_front || ((f1 >> 2) & ((1ull << 38) - 1)) == ((1ull << 37) - 1);
+    t.redo[flag_at] = unfinished;
+    t.tie[flag_at] = 0;
+    if (!unfinished) {
+      const unsigned mult = (unsigned)(f1 >> 40) + (unsigned)((f1 >> 39) & 1);
+      const uint64_t *__restrict__ P = t.rpm + (size_t)mult * WL;
+      uint64_t borrow = 0;
+#pragma unroll
+      for (int j = 0; j < WL; ++j) {
+        const u128 d2 = (u128)V[j] - P[j] - borrow;
+        V[j] = (uint64_t)d2;
+        borrow = (uint64_t)(d2 >> 64) & 1;
+      }
+      uint64_t cr = gt;                                    // + [r > floor(P/2)] + d   (mod 2^logq: only the low words matter)
+#pragma unroll
+      for (int j = 0; j < WL; ++j) {
+        const u128 s2 = (u128)V[j] + cr + ((has_addend && j < (int)t.W) ? dd[j] : 0);
+        V[j] = (uint64_t)s2; cr = (uint64_t)(s2 >> 64);
+      }
+      uint64_t *__restrict__ dst = t.out.at(poly, (size_t)t.W << a.logn) + coef0;        // uniform; + lane below
+      const int sw = (int)((t.logq - 1) >> 6);
+      const unsigned up = 63 - ((t.logq - 1) & 63);
+      uint64_t ext = 0;
+#pragma unroll
+      for (int j = 0; j < WL; ++j) if (j == sw) ext = (uint64_t)((int64_t)(V[j] << up) >> up);
+      const uint64_t qsign = (uint64_t)((int64_t)ext >> 63);
+#pragma unroll
+      for (int j = 0; j < WL; ++j)
+        if (j < (int)t.W) (dst + ((size_t)j << a.logn))[lane] = j < sw ? V[j] : (j == sw ? ext : qsign);
+      for (unsigned j = WL; j < t.W; ++j) (dst + ((size_t)j << a.logn))[lane] = qsign;
     }
   }
 }

@@ -224,6 +224,7 @@ static int upload_tables(gpq_ctx *c) {
   HIP_TRY(hipMemcpy(c->d_w, wstd.data(), np * n * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_winv, wistd.data(), np * n * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_tabs, tabs.data(), np * sizeof(LimbTab), hipMemcpyHostToDevice));
+  c->h_tabs = tabs;
   return GPQ_OK;
 }
 
@@ -772,6 +773,7 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
       // 3. strided inverse pass in place on the three outputs
       PassArgs b = make_args(c, dim, 3);
       b.limb0 = l0;
+      if (c->inv_tabs_override) b.tabs = c->inv_tabs_override;
       for (int i = 0; i < 3; ++i) { b.src[i] = m.dst[i]; b.dst[i] = m.dst[i]; }
       if ((rc = launch_strided<true>(c, b, limbs, polys, s))) return rc;
     }
@@ -827,6 +829,7 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
           }))) return rc;
       PassArgs b = make_args(c, dim, 2);
       b.limb0 = l0;
+      if (c->inv_tabs_override) b.tabs = c->inv_tabs_override;
       for (int i = 0; i < 2; ++i) { b.src[i] = m.p.dst[i]; b.dst[i] = m.p.dst[i]; }
       if ((rc = launch_strided<true>(c, b, limbs, polys, s))) return rc;
     }

@@ -28,6 +28,7 @@ struct gpq_bridge_basis {
   std::vector<uint64_t> h_P;          // the product itself, little-endian words
   std::vector<uint64_t> h_phat;       // [dim][WP]
   std::map<int, gpq_recon_mfma> mfma; // by result width WL
+  gpq::LimbTab *d_tabs_scaled = nullptr;   // the context's LimbTab array with n^-1 * (P/p_d)^-1 for the limbs of this basis (ScaledInverse, bridge.hip)
 };
 
 // Constant matrix of the matrix-core rns_decompose for (first limb, limbs, words) (bridge_mfma.hpp)
@@ -65,6 +66,11 @@ struct gpq_ctx {
   bool low9 = false;                              // n = 2^17: strided passes over 512-coefficient rows, 9 low stages (Lane8<9>)
   unsigned nwide = 0, nwide_max = 0;              // leading limbs with c < GPQ_WIDE_CMAX (<= nsplit): forward stages as ct_bfly_wide
   gpq::LimbTab *d_tabs = nullptr;
+  std::vector<gpq::LimbTab> h_tabs;               // host copy (bridge.hip derives tables with pre-scaled n^-1 from it)
+  // When set, the inverse strided pass of gpq_he_mul_tensor / gpq_keyswitch reads its per-limb constants here: the same tables
+  // with n^-1 (and winv[1] n^-1) multiplied by a CRT weight, so that the limbs leave the transform already scaled for the
+  // reconstruction that follows (bridge.hip: ScaledInverse).  Internal to gpq_he_mul / gpq_he_swk.
+  const gpq::LimbTab *inv_tabs_override = nullptr;
   std::map<std::pair<unsigned, unsigned>, gpq_bridge_basis> bases;   // by (first limb, count), built on first use
   std::map<std::pair<unsigned, unsigned>, gpq_relin_tables> relins;  // by (dimP, dimB)
   std::map<std::pair<std::pair<unsigned, unsigned>, unsigned>, gpq_decomp_mfma> decomps;  // by ((first limb, limbs), W)
@@ -73,6 +79,10 @@ struct gpq_ctx {
   size_t redo_cap = 0;
   std::vector<void *> retired;        // outgrown d_redo buffers: a HIP graph captured earlier may still write them, so they live as long as the context
   bool exact_crt = false;             // force the exact CRT kernel (tests)
+  bool prescale = true;               // gpq_he_mul / gpq_he_swk: inverse passes write limbs pre-multiplied by (P/p_d)^-1 for the CRT kernels (gpq_set_prescale)
+  bool fuse_tail = false;             // gpq_set_fused_tail(ctx, 1): the relinearisation tail in one pass per coefficient (bridge_relin_tail_mfma) -- measured 2 % SLOWER
+                                      // than the two-kernel form on the whole he_mul (profiles/r03/v3_fused_tail_ab.txt: both are bound by integer VALU work, not by the
+                                      // 60 words per coefficient the fusion saves), kept for the parity tests and as the record of the attempt
   unsigned *d_zflag = nullptr;        // per-(polynomial, limb) "output contains a residue 0" flags of gpq_ntt (tables.hpp); zero between calls
   size_t zflag_cap = 0;
   // profiling

@@ -115,6 +115,14 @@ class PolyContext:
         """matrix-core (default) or integer-VALU rns_decompose; both are exact, the tests compare them"""
         _native.check(self.lib.gpq_set_bridge_mfma(self.h, 1 if on else 0), "gpq_set_bridge_mfma")
 
+    def set_fused_tail(self, on):
+        """relinearisation tail in one pass per coefficient (default) or as front + CRT kernels; both exact, the tests compare them"""
+        _native.check(self.lib.gpq_set_fused_tail(self.h, 1 if on else 0), "gpq_set_fused_tail")
+
+    def set_prescale(self, on):
+        """he_mul / he_swk: inverse transforms write limbs pre-multiplied by the CRT weights (default) or not; both exact"""
+        _native.check(self.lib.gpq_set_prescale(self.h, 1 if on else 0), "gpq_set_prescale")
+
     def set_exact_crt(self, on):
         _native.check(self.lib.gpq_set_exact_crt(self.h, 1 if on else 0), "gpq_set_exact_crt")
 

@@ -198,6 +198,11 @@ int gpq_rns_reconstruct(gpq_ctx *ctx, uint64_t *big, unsigned Wout, const uint64
  * (rare) coefficients whose rounding it cannot decide with the exact full-width kernel; this forces the
  * exact kernel for everything (used by the tests to cross-check the two). */
 int gpq_set_exact_crt(gpq_ctx *ctx, int on);
+/* The tail of he_relin / he_swk as two kernels with Q's residues in memory between them (0, default) or in one pass per coefficient (1:
+ * measured 2 % slower on the whole he_mul -- both forms are bound by integer VALU work); same results. */
+int gpq_set_fused_tail(gpq_ctx *ctx, int on);
+/* gpq_he_mul / gpq_he_swk: the inverse transforms hand the CRT kernels limbs already multiplied by (P/p_d)^-1 (1, default) or not (0); same results. */
+int gpq_set_prescale(gpq_ctx *ctx, int on);
 /* rns_decompose is a product of the coefficients' bytes with a fixed matrix (256^k mod p_j) and runs on the matrix cores
  * (v_mfma_i32_32x32x32_i8, exact) by default; 0 selects the integer-VALU kernel instead (the tests cross-check the two). */
 int gpq_set_bridge_mfma(gpq_ctx *ctx, int on);

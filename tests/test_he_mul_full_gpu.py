@@ -75,7 +75,7 @@ def test_he_swk_matches_reference_semantics(engine_ctx, oracle_ctx, logn, logqL,
     assert big_to_ints(to_host(out1), W, n)[0] == e1
 
 
-@pytest.mark.parametrize("mfma", [True, False])
+@pytest.mark.parametrize("mfma", [True, False, "fused"])      # matrix-core front + CRT, integer-VALU kernels, the one-pass tail (gpq_set_fused_tail)
 @pytest.mark.parametrize("logqL", [120, 200, 438, 610])
 def test_relin_tail_rounding_ties_and_wrap_corner(engine_ctx, oracle_ctx, logqL, mfma):
     """mpi_rdiv rounds up only when the remainder is strictly above floor(P/2) (src/types.c:124): key-switch
@@ -86,7 +86,8 @@ def test_relin_tail_rounding_ties_and_wrap_corner(engine_ctx, oracle_ctx, logqL,
     probe = engine_ctx(logn, 12)
     dimP, dimA, dimB, dimevk = probe.he_dims(logqL, logqL)       # dimP = 3 (VALU tail only), 4, 8, 11 (matrix-core front)
     g, o = engine_ctx(logn, dimevk), oracle_ctx(logn, dimevk)
-    g.set_bridge_mfma(mfma)
+    g.set_bridge_mfma(bool(mfma))
+    g.set_fused_tail(mfma == "fused")
     n, W, ql = g.n, (logqL + 64) // 64, 1 << logqL
     P = ref.RnsBasis(o.p[:dimP]).P
     PiB = ref.RnsBasis(o.p[:dimB]).P
@@ -119,6 +120,7 @@ def test_relin_tail_rounding_ties_and_wrap_corner(engine_ctx, oracle_ctx, logqL,
         assert big_to_ints(to_host(inplace), W, n)[0] == exp[0]
     finally:
         g.set_bridge_mfma(True)
+        g.set_fused_tail(False)
 
 
 def test_he_mul_by_one_is_identity_full_size(engine_ctx):
@@ -483,3 +485,45 @@ def test_he_mul_squaring_path_equals_the_general_path(engine_ctx):
     g.he_mul(t0, t1, c0, c1, c0.clone(), c1.clone(), rlk[0], rlk[1], W, logq, dimA, dimB, dimP)       # copies: general path
     torch.cuda.synchronize()
     assert torch.equal(s0, t0) and torch.equal(s1, t1) and bool((s0 != 0).any())
+
+
+@pytest.mark.parametrize("logn,logq,batch", [(13, 438, 3), (16, 850, 2), (14, 300, 2)])
+def test_one_pass_relinearisation_tail_equals_the_two_kernel_form(engine_ctx, logn, logq, batch):
+    """gpq_set_fused_tail(ctx, 1): bridge_relin_tail_mfma (front + CRT of Q in one pass per coefficient, Q's residues never in memory)
+    against the default two-kernel tail on dense random ciphertexts, whole he_mul and he_swk (c1 without addend), at the headline
+    shape too: identical words."""
+    torch = _torch()
+    probe = engine_ctx(logn, 20)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logq, logq)
+    g = engine_ctx(logn, dimevk)
+    n, W = g.n, (logq + 64) // 64
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(977 + logn)
+
+    def centred():
+        big = torch.randint(-(1 << 62), 1 << 62, (batch, W, n), dtype=torch.int64, device="cuda", generator=gen)
+        top = logq - 1 - 64 * (W - 1)
+        big[:, W - 1] = torch.randint(-(1 << (top - 1)), 1 << (top - 1), (batch, n), dtype=torch.int64, device="cuda", generator=gen)
+        return big.reshape(-1).contiguous()
+
+    cts = [centred() for _ in range(4)]
+    rlk = [torch.cat([torch.randint(0, g.p[d], (n,), dtype=torch.int64, device="cuda", generator=gen) for d in range(dimB)]) for _ in range(2)]
+    outs = []
+    try:
+        # ... and with / without the inverse transforms pre-multiplying their output by the CRT weights (gpq_set_prescale)
+        for fused, prescale in ((False, True), (True, True), (False, False), (True, False)):
+            g.set_fused_tail(fused)
+            g.set_prescale(prescale)
+            o0, o1 = torch.empty_like(cts[0]), torch.empty_like(cts[0])
+            g.he_mul(o0, o1, *cts, rlk[0], rlk[1], W, logq, dimA, dimB, dimP)
+            s0, s1 = torch.empty_like(cts[0]), torch.empty_like(cts[0])
+            g.he_swk(s0, s1, cts[0], cts[1], rlk[0], rlk[1], W, logq, dimB, dimP)
+            torch.cuda.synchronize()
+            outs.append((o0, o1, s0, s1))
+    finally:
+        g.set_fused_tail(False)
+        g.set_prescale(True)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+    assert bool((outs[0][0] != 0).any()) and bool((outs[0][3] != 0).any())

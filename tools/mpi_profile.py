@@ -6,4 +6,8 @@ from bench import he_mul_mpi_rate
 ctx = gpqhe_amd.PolyContext(16, 45)
 if os.environ.get("GPQ_BRIDGE_VALU") == "1":      # tool-side switch (tools/gpu_prof_mpi.sh): the library itself reads no environment
     ctx.set_bridge_mfma(False)
+if os.environ.get("MPI_FUSED"):
+    ctx.set_fused_tail(os.environ["MPI_FUSED"] == "1")
+if os.environ.get("MPI_PRESCALE"):
+    ctx.set_prescale(os.environ["MPI_PRESCALE"] == "1")
 print(he_mul_mpi_rate(torch, gpqhe_amd, ctx, int(os.environ.get("MPI_BATCH", "64")), iters=int(os.environ.get("MPI_ITERS", "6"))))
