@@ -39,6 +39,12 @@ __global__ __launch_bounds__(256) void probe(uint64_t *out, uint64_t seed) {
       if (OP == 17) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(k32));
       if (OP == 18) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(a[i]) : "v"(k32));
       if (OP == 19) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(k32));
+      if (OP == 20) asm volatile("v_cmp_le_u64 s[22:23], %0, %1" : : "v"(v[i]), "v"(k64) : "s22", "s23");
+      if (OP == 21) asm volatile("v_cmp_le_u32 s[22:23], %0, %1" : : "v"(a[i]), "v"(k32) : "s22", "s23");
+      if (OP == 22) asm volatile("v_cndmask_b32 %0, %0, %1, s[24:25]" : "+v"(a[i]) : "v"(k32));
+      if (OP == 23) asm volatile("v_bitop3_b32 %0, %0, %1, %0 bitop3:0x0c" : "+v"(a[i]) : "v"(k32));
+      if (OP == 24) asm volatile("v_not_b32 %0, %0" : "+v"(a[i]));
+      if (OP == 25) asm volatile("v_mov_b64 %0, %1" : "+v"(v[i]) : "v"(k64));
     }
   }
   uint64_t acc = k64 + k32;
@@ -86,5 +92,11 @@ int main() {
   run<12>("v_add3_u32", 1, d_out);
   run<14>("v_bfi_b32", 1, d_out);
   run<19>("v_min_u32", 1, d_out);
+  run<20>("v_cmp_u64", 1, d_out);                       // compare into an SGPR pair, nothing depends on it
+  run<21>("v_cmp_u32", 1, d_out);
+  run<22>("v_cndmask_b32 (sgpr mask)", 1, d_out);       // select on a mask that no instruction of the loop writes
+  run<23>("v_bitop3_b32", 1, d_out);
+  run<24>("v_not_b32", 1, d_out);
+  run<25>("v_mov_b64", 1, d_out);
   return 0;
 }
