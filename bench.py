@@ -88,22 +88,26 @@ def pmc_traffic(kernel, chunk):
 
 
 def valu_issue(value_per_gpu, sclk_mhz):
-    """How close the he_mul core runs to the integer-VALU issue rate -- the bound that actually binds it: VALU
-    wave-instructions per he_mul from the committed PMC pass (SQ_INSTS_VALU summed over the four kernels of the core, counted at
-    a group size of `_chunk` ciphertexts) against the SIMD cycles one he_mul takes at the measured shader clock.  3.95 cycles per
-    instruction is what this instruction mix (25 % v_mad_u64_u32, 18 % 64-bit adds) needs when nothing else is in the way: 3.9 by
-    the arithmetic-only probes of profiles/r01/v10_probes.txt for round 1's 71.0 M instructions, of which round 2 removed 4.9 M
-    cheap ones."""
+    """How fast the he_mul core issues integer-VALU instructions against the rate at which the SAME instruction mix issues with no
+    memory traffic -- the bound that actually binds it.  Nothing here is a literal: the instruction count per he_mul comes
+    from the newest committed PMC pass (SQ_INSTS_VALU of the four kernels of the core, profiles/r*/v*_pmc_summary.json), the bound from
+    the newest committed probe evaluation (profiles/r*/v*_valu_bound.json: tools/issue_probe runs the library's own butterfly groups in a
+    register-resident loop on every SIMD; tools/valu_bound.py turns its run, the probe's assembly and the rocm-smi samples into VALU
+    wave-instructions per second, cycles per instruction, clock and package power).  Both files name the commit they were taken at; the
+    probe file also carries a hash of the kernel headers, and the object says `stale` when the sources of this run differ from it."""
     import glob
+    import hashlib
     import re
     def order(path):
         m = re.search(r"r(\d+)[/\\]v(\d+)_", path)
         return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json")), key=order)
-    if not files or not sclk_mhz:
+    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json")), key=order)
+    bounds = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*valu_bound.json")), key=order)
+    if not pmcs or not bounds:
         return None
     try:
-        data = json.load(open(files[-1]))
+        data = json.load(open(pmcs[-1]))
+        bound = json.load(open(bounds[-1]))
         per_group = 0.0
         for name, v in data.items():
             if name.startswith("_"):
@@ -111,15 +115,27 @@ def valu_issue(value_per_gpu, sclk_mhz):
             launches_per_group = 2 if "strided_pass" in name else 1      # a strided pass runs once for the tensor stage and once for the key switch
             per_group += v["SQ_INSTS_VALU"] * launches_per_group
         insts = per_group / data.get("_chunk", 16)
+        ib = bound["issue_bound"]
+        csrc = os.path.join(ROOT, "gpqhe_amd", "csrc")
+        now = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("modarith.hpp", "ntt_kernels.hpp"))).hexdigest()[:16]
     except (OSError, ValueError, KeyError) as exc:
         return {"error": "%s: %s" % (type(exc).__name__, exc)}
-    simds = 256 * 4
-    cycles = sclk_mhz * 1e6 / value_per_gpu                                # SIMD cycles one he_mul occupies the chip for
-    cpi = cycles * simds / insts
-    return {"valu_wave_insts_per_he_mul": int(insts), "source": os.path.relpath(files[-1], ROOT), "profiled_head": data.get("_head"),
-            "simds": simds, "sclk_MHz": sclk_mhz, "cycles_per_valu_inst": round(cpi, 3), "issue_bound_cycles_per_valu_inst": 3.95,
-            "frac_of_valu_issue_rate": round(3.95 / cpi, 3),
-            "note": "the core is bound by integer-VALU issue at the power-capped clock, not by HBM; `roofline` above prices the same run against HBM"}
+    rate = insts * value_per_gpu                                           # VALU wave-instructions per second, whole chip
+    out = {"valu_wave_insts_per_he_mul": int(insts), "valu_wave_insts_per_s": round(rate, -7),
+           "insts_source": {"file": os.path.relpath(pmcs[-1], ROOT), "profiled_head": data.get("_head")},
+           "bound_valu_wave_insts_per_s": ib["valu_wave_insts_per_s"],
+           "bound_source": {"file": os.path.relpath(bounds[-1], ROOT), "probe_head": bound.get("_head"), "probe_sclk_MHz": ib.get("sclk_MHz"),
+                            "probe_package_W": ib.get("package_W"), "probe_cycles_per_valu_inst": ib.get("cycles_per_valu_inst"),
+                            "kernel_source_sha16": bound.get("_kernel_source_sha16")},
+           "frac_of_valu_issue_rate": round(rate / ib["valu_wave_insts_per_s"], 3),
+           "stale": now != bound.get("_kernel_source_sha16"),
+           "note": "integer-VALU instructions per second of the core against the same instruction mix with no memory traffic (the probe runs un-capped at "
+                   "its clock; the core sits at the package power cap and a lower clock: `power`); `roofline` above prices the same run against HBM"}
+    if sclk_mhz:
+        cpi = sclk_mhz * 1e6 * 256 * 4 / rate
+        out.update({"sclk_MHz": sclk_mhz, "cycles_per_valu_inst": round(cpi, 3),
+                    "frac_of_probe_cycles_per_inst": round(ib["cycles_per_valu_inst"] / cpi, 3) if ib.get("cycles_per_valu_inst") else None})
+    return out
 
 
 def power_state(torch, step, seconds=2.5):

@@ -68,3 +68,24 @@ def test_total_batch_partition_is_configs3():
         assert [shard_range(512, world, r)[1] - shard_range(512, world, r)[0] for r in range(world)] == [per] * world
     a = _bench().parse_args(["--gpus", "8", "--total-batch", "512"])
     assert a.total_batch == 512 and a.gpus == 8 and not a.no_scatter_gather
+
+
+def test_valu_issue_is_computed_from_committed_evidence_not_from_a_literal():
+    """bench.py's `valu_issue`: the instruction count per he_mul comes from the newest committed PMC pass, the bound from the newest
+    committed probe evaluation (tools/issue_probe + tools/valu_bound.py); both are named in the object, with the commits they were
+    taken at, and the object says whether the kernel sources have changed since the probe was evaluated."""
+    import json
+    b = _bench()
+    v = b.valu_issue(7500.0, 1919)
+    assert "error" not in v, v
+    pmc = json.load(open(os.path.join(ROOT, v["insts_source"]["file"])))
+    bound = json.load(open(os.path.join(ROOT, v["bound_source"]["file"])))
+    assert v["insts_source"]["file"].startswith("profiles/r") and v["bound_source"]["file"].endswith("valu_bound.json")
+    per_group = sum(val["SQ_INSTS_VALU"] * (2 if "strided_pass" in k else 1) for k, val in pmc.items() if not k.startswith("_"))
+    assert v["valu_wave_insts_per_he_mul"] == int(per_group / pmc["_chunk"])
+    assert v["bound_valu_wave_insts_per_s"] == bound["issue_bound"]["valu_wave_insts_per_s"]
+    assert abs(v["frac_of_valu_issue_rate"] - v["valu_wave_insts_per_he_mul"] * 7500.0 / bound["issue_bound"]["valu_wave_insts_per_s"]) < 2e-3
+    assert 0.3 < v["frac_of_valu_issue_rate"] < 1.0 and isinstance(v["stale"], bool)
+    assert v["insts_source"]["profiled_head"] and v["bound_source"]["probe_head"]
+    import inspect
+    assert "3.95" not in inspect.getsource(b.valu_issue)

@@ -9,10 +9,11 @@
    opcodes the probe does not cover take the rate of their class (see CLASS below), and the table says which ones did;
 3. weights the kernels by their dynamic VALU instruction counts (SQ_INSTS_VALU of the PMC pass, when given) into one figure:
    the cycles per VALU wave-instruction this instruction mix needs when nothing but issue is in the way (`static` estimate);
-4. reads the run of tools/issue_probe -- the library's own butterfly groups in a register-resident loop, timed in shader-clock
-   cycles by the waves themselves -- and divides by the VALU instructions of the probe's loop bodies (its own assembly): the
-   MEASURED cycles per VALU instruction of this code at 8 / 4 / 3 / 2 / 1 waves per SIMD.  `issue_bound_cycles_per_valu_inst` is
-   the probe's figure for the forward + products + inverse mix at full occupancy: what bench.py prices the core against.
+4. reads the run of tools/issue_probe -- the library's own butterfly groups in a register-resident loop on every SIMD -- and
+   multiplies by the VALU instructions of the probe's loop bodies (its own assembly): the MEASURED VALU wave-instructions per
+   second of this code with no memory traffic, with the shader clock and package power rocm-smi showed meanwhile (the sustained
+   runs of tools/gpu_r3_probe.sh).  `issue_bound` is the best sustained run: what bench.py prices the core against.
+   (The static estimate is normalised to a nominal 2.4 GHz like tools/instr_rate itself.)
 bench.py reads the newest profiles/r*/*valu_bound.json for its `valu_issue` object and flags it stale when the kernel sources
 have changed since (sha256 of the two kernel headers)."""
 import collections, hashlib, json, os, re, subprocess, sys, tempfile
@@ -120,7 +121,7 @@ def main():
             cyc += c * n
             used_class[(o.replace("_e32", "").replace("_e64", ""), line)] += n
         tot = sum(valu.values())
-        out["kernels"][name] = {"valu_insts_per_wave": tot, "issue_cycles_per_wave": round(cyc, 1), "cycles_per_valu_inst": round(cyc / tot, 3),
+        out["kernels"][name] = {"valu_insts_per_wave": tot, "issue_cycles_per_wave": round(cyc, 1), "static_cycles_per_valu_inst_at_2400MHz": round(cyc / tot, 3),
                                 "multiplies": sum(n for o, n in valu.items() if o.startswith("v_mad_u64") or o.startswith("v_mad_i64")),
                                 "branches": branches, "top": dict(valu.most_common(12))}
     out["_pricing"] = {"%s <- %s" % k: n for k, n in used_class.most_common()}
@@ -135,13 +136,41 @@ def main():
         n_valu = len(loops[mix])
         static = sum(price(o, r)[0] for o in loops[mix]) / n_valu
         probe["runs"].append({"mix": m.group(2).strip(), "waves_per_simd": w, "valu_insts_per_iter": n_valu, "multiplies_per_iter": sum(1 for o in loops[mix] if o.startswith("v_mad_u64")),
-                              "cycles_per_iter_per_wave": float(m.group(5)), "cycles_per_valu_inst": round(float(m.group(5)) / (w * n_valu), 3),
-                              "static_estimate_cycles_per_valu_inst": round(static, 3), "clock_MHz": float(m.group(8))})
+                              "s_memtime_ticks_per_iter_per_wave_mean_max": [float(m.group(5)), float(m.group(6))],
+                              "static_estimate_cycles_per_valu_inst_at_2400MHz": round(static, 3),
+                              "valu_wave_insts_per_s": round(256 * 4 * w * n_valu * int(m.group(4)) / (float(m.group(7)) * 1e-3), -7)})
+    # the sustained runs (issue_probe long W) with the rocm-smi samples the script put under each of them
+    lines = open(probe_file).read().split("\n")
+    longs = []
+    for i, ln in enumerate(lines):
+        m = re.match(r"long mix 2 waves/SIMD (\d+)\s+launches (\d+)\s+iters (\d+)\s+waves (\d+)\s+total ([0-9.]+) ms", ln)
+        if not m:
+            continue
+        w, launches, iters, waves, ms = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), float(m.group(5))
+        smi = []
+        for nxt in lines[i + 1:]:
+            sm = re.match(r"\((\d+)Mhz\)\s+([0-9.]+)", nxt)
+            if not sm:
+                if nxt.startswith("#"):
+                    continue
+                break
+            smi.append((int(sm.group(1)), float(sm.group(2))))
+        busy = [x for x in smi if x[1] > 600]            # samples taken while the probe was running
+        rate = launches * iters * waves * len(loops[2]) / (ms * 1e-3)
+        rec = {"waves_per_simd": w, "valu_wave_insts_per_s": round(rate, -7), "valu_insts_per_iter": len(loops[2]), "total_ms": ms}
+        if busy:
+            rec["sclk_MHz"] = round(sum(x[0] for x in busy) / len(busy))
+            rec["package_W"] = round(sum(x[1] for x in busy) / len(busy))
+            rec["cycles_per_valu_inst"] = round(rec["sclk_MHz"] * 1e6 * 1024 / rate, 3)
+        longs.append(rec)
+    probe["sustained"] = longs
     out["probe"] = probe
-    full = [x for x in probe["runs"] if x["mix"].startswith("forward + 8 lazy products") and x["waves_per_simd"] == 8]
-    if full:
-        out["issue_bound_cycles_per_valu_inst"] = full[0]["cycles_per_valu_inst"]
-        out["issue_bound_source"] = "tools/issue_probe: forward group + 8 lazy products + inverse group of the library's wide-split class, 8 waves per SIMD, no memory traffic"
+    if longs:
+        best = max(longs, key=lambda x: x["valu_wave_insts_per_s"])
+        out["issue_bound"] = {"valu_wave_insts_per_s": best["valu_wave_insts_per_s"], "cycles_per_valu_inst": best.get("cycles_per_valu_inst"),
+                              "sclk_MHz": best.get("sclk_MHz"), "package_W": best.get("package_W"), "waves_per_simd": best["waves_per_simd"],
+                              "what": "tools/issue_probe long: the library's own forward group + 8 lazy products + inverse group (wide-split class) in a register-resident "
+                                      "loop on every SIMD, no memory traffic: the rate at which this instruction mix issues when nothing else is in the way"}
     if pmc_file:
         pmc = json.load(open(pmc_file))
         wsum = csum = 0.0
@@ -157,10 +186,10 @@ def main():
             w = v["SQ_INSTS_VALU"] * launches
             weights[key] = w
             wsum += w
-            csum += w * out["kernels"][key]["cycles_per_valu_inst"]
+            csum += w * out["kernels"][key]["static_cycles_per_valu_inst_at_2400MHz"]
         out["pipeline"] = {"pmc_file": os.path.relpath(pmc_file, ROOT), "pmc_head": pmc.get("_head"), "pmc_chunk": pmc.get("_chunk"), "valu_insts_per_launch_group": weights,
                            "valu_wave_insts_per_he_mul": int(wsum / pmc.get("_chunk", 16)),
-                           "static_estimate_cycles_per_valu_inst": round(csum / wsum, 3)}
+                           "static_estimate_cycles_per_valu_inst_at_2400MHz": round(csum / wsum, 3)}
     json.dump(out, sys.stdout, indent=1)
     print()
 
