@@ -215,11 +215,14 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6):
     for _ in range(3):
         ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
     t = gpqhe_amd.StreamTimer()
+    ctx.profile(True)                                # HIP events around every launch of this leg, on the launch stream
     t.start()
     for _ in range(iters):
         ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
     t.stop()
     ms = t.elapsed_ms() / iters
+    ctx.profile(False)
+    prof = ctx.profile_collect()
     # BASELINE configs[2] is "he_mul + he_rescale": the same with he_rs (src/he-rescale.c:33-54, Delta = 2^50) after each product
     t.start()
     for _ in range(iters):
@@ -227,9 +230,38 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6):
         ctx.he_rs(o0, o1, W, 50, logq - 50)
     t.stop()
     ms_rs = t.elapsed_ms() / iters
+    # Algorithmic bytes of the bridge per he_mul, each slab read or written once (words of 8 bytes per coefficient):
+    #   rns_decompose     4 x (W in, dimA out) + (W in, dimB out)                                   src/he-mult.c:117-120, :59
+    #   CRT (poly_rns2mpi) 3 x (dimA in, W out) for d0, d1, d2 + 2 x (cnt in, W addend in, W out)    :139-141, the tail's CRT of Q (:67-77)
+    #   relin front       2 x (dimB in, cnt out)                                                    exact division by P, :70
+    cnt = dimB - dimP
+    words = {"bridge_decompose": 4 * (W + dimA) + (W + dimB), "bridge_reconstruct": 3 * (dimA + W) + 2 * (cnt + 2 * W), "bridge_relin_front": 2 * (dimB + cnt)}
+    core = {"strided_fwd": 2 * (4 * dimA + dimB), "strided_inv": 2 * (3 * dimA + 2 * dimB), "tensor_mid": 7 * dimA, "keyswitch_mid": 5 * dimB}
+    total_ms = sum(v[0] for v in prof.values())
+    kernels = {}
+    for name, (kms, kcnt) in prof.items():
+        per_call = kms / iters
+        rec = {"ms_per_batch": round(per_call, 4), "launches_per_batch": round(kcnt / iters, 2), "share": round(kms / total_ms, 3)}
+        w = words.get(name, core.get(name))
+        if w:
+            rec["algo_words_per_coefficient"] = w
+            rec["algo_GBps"] = round(w * 8 * n * batch / (per_call * 1e-3) / 1e9, 1)
+        kernels[name] = rec
+    bridge = {k: v for k, v in kernels.items() if k.startswith("bridge_") and "algo_GBps" in v}
+    roof = None
+    if bridge:
+        kname = max(bridge, key=lambda k: bridge[k]["ms_per_batch"])
+        ach = bridge[kname]["algo_GBps"]
+        roof = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_batch": int(words[kname] * 8 * n * batch), "ms_per_batch": bridge[kname]["ms_per_batch"],
+                "note": "the bridge kernel with the largest share of this leg; all launches of the kind together (its launches differ in size); "
+                        "PMC of these kernels: profiles/r03/v5_mpi_pmc.txt"}
+    bridge_ms = sum(v["ms_per_batch"] for k, v in kernels.items() if k.startswith("bridge_"))
     return {"shape": "n=2^16, q=2^850 (W=14 words), dimA/dimB/dimP=%d/%d/%d, batch %d" % (dimA, dimB, dimP, batch),
             "ms_per_batch": round(ms, 3), "he_mul_per_s": round(batch / (ms * 1e-3), 1),
-            "he_mul_plus_he_rescale_per_s": round(batch / (ms_rs * 1e-3), 1)}
+            "he_mul_plus_he_rescale_per_s": round(batch / (ms_rs * 1e-3), 1),
+            "bridge_ms_per_batch": round(bridge_ms, 3), "core_ms_per_batch": round(sum(v["ms_per_batch"] for k, v in kernels.items() if not k.startswith("bridge_")), 3),
+            "bridge_algo_bytes_per_he_mul": int(sum(words.values()) * 8 * n), "kernels": kernels, "roofline": roof}
 
 
 def keyswitch_n17_rate(torch, gpqhe_amd, batch=16, iters=3):

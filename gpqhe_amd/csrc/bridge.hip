@@ -337,6 +337,7 @@ int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, uns
   const bool fast = logq && centre && !c->exact_crt && need + 1 < (unsigned)b->WP && need <= 16 && b->pbits >= 160;
   if (fast && !x.exact_only) {
     if (int rc = ensure_redo(c, (size_t)batch << logn, s)) return rc;
+    ProfScope prof(c, GPQ_K_RECONSTRUCT, s);
     bool done = false;
     if (c->bridge_mfma && logn >= 6 && b->dim >= 4) {      // CRT sum as bytes x constant matrix on the matrix cores
       const int WL = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 7 ? 7 : need <= 10 ? 10 : need <= 14 ? 14 : 16;
@@ -371,6 +372,7 @@ int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, uns
     else launch_low<16>(a, b->WP, c->d_redo, n, batch, s);
     a.only = c->d_redo;   // exact kernel below redoes only the flagged coefficients
   }
+  ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s);
   switch (b->WP) {
     case 8: launch_exact<8>(a, n, batch, s); break;
     case 16: launch_exact<16>(a, n, batch, s); break;
@@ -456,6 +458,7 @@ int launch_decompose(gpq_ctx *c, uint64_t *slab, const uint64_t *big, unsigned W
 }
 // `batch` polynomials in all, `big.per` from each source slab in turn, written one after another to `slab`
 int launch_decompose(gpq_ctx *c, uint64_t *slab, const BigSources &big, unsigned W, unsigned limb0, unsigned dim, unsigned batch, hipStream_t s) {
+  ProfScope prof(c, GPQ_K_DECOMPOSE, s);
   if (c->bridge_mfma && c->logn >= 6 && W <= 32 && dim >= 4) {
     gpq_decomp_mfma *t;
     int rc = get_decomp_mfma(c, limb0, dim, W, &t);
@@ -622,6 +625,7 @@ extern "C" int gpq_he_rs(gpq_ctx *c, uint64_t *c0, uint64_t *c1, unsigned W, uns
   const dim3 grid((c->n + 255) / 256, batch), block(256);
   for (uint64_t *p : {c0, c1}) {
     RescaleArgs a{p, W, c->logn, logDelta, logql};
+    ProfScope prof(c, GPQ_K_RESCALE, (hipStream_t)stream);
     hipLaunchKernelGGL(bridge_rescale, grid, block, 0, (hipStream_t)stream, a);
   }
   return launched("gpq_he_rs");
@@ -739,6 +743,14 @@ int launch_relin_front_t(const RelinFrontArgs &a, size_t lds, hipStream_t s) {
   hipLaunchKernelGGL((bridge_relin_front_mfma<KS>), dim3(blocks), dim3(256), lds, s, a);
   return GPQ_OK;
 }
+int launch_relin_front(const gpq_ctx *c, unsigned KS, const RelinFrontArgs &f, size_t lds, hipStream_t s) {
+  ProfScope prof(c, f.only ? GPQ_K_BRIDGE_EXACT : GPQ_K_RELIN_FRONT, s);
+  switch (KS) {
+    case 2: return launch_relin_front_t<2>(f, lds, s);
+    case 4: return launch_relin_front_t<4>(f, lds, s);
+    default: return launch_relin_front_t<8>(f, lds, s);
+  }
+}
 
 // src/he-mult.c:67-77 (d != null: c = rdiv(c,P) + d) and src/he-automorphism.c:68-76, for q_l = 2^logql.
 // `polys` polynomials of chat; the first `split` of them go to out.a (+ addend d.a), the rest to out.b (+ d.b): c0 and c1 of a
@@ -782,41 +794,35 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
       if ((rc = ensure_redo(c, (size_t)polys << c->logn, s))) return rc;
       const size_t lds = rt->lds_bytes + (size_t)tq->KS * ((8 * WLf + 14 + 31) / 32) * 1024;
       RelinTailArgs ft{f, (const v4i *)tq->d_bfrag, tq->d_kc, tq->d_pm, c->d_redo, tie, out, dbig, W, logql, tq->KS};
-      if (rt->KS == 2 && WLf == 7) rc = launch_relin_tail_t<2, 7>(ft, lds, s);
-      else if (rt->KS == 2) rc = launch_relin_tail_t<2, 14>(ft, lds, s);
-      else if (WLf == 7) rc = launch_relin_tail_t<4, 7>(ft, lds, s);
-      else rc = launch_relin_tail_t<4, 14>(ft, lds, s);
+      {
+        ProfScope prof(c, GPQ_K_RELIN_TAIL_FUSED, s);
+        if (rt->KS == 2 && WLf == 7) rc = launch_relin_tail_t<2, 7>(ft, lds, s);
+        else if (rt->KS == 2) rc = launch_relin_tail_t<2, 14>(ft, lds, s);
+        else if (WLf == 7) rc = launch_relin_tail_t<4, 7>(ft, lds, s);
+        else rc = launch_relin_tail_t<4, 14>(ft, lds, s);
+      }
       if (rc) return rc;
       // the few coefficients it flagged: round bits settled exactly, Q's residues made for their groups, exact CRT, finish
       ReconExtra only_amb;
       only_amb.only = amb; only_amb.prescaled = chat_prescaled;
       if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, only_amb))) return rc;
       RoundFixArgs rf{r, bp->d_phalf, amb, flags, tp.Wr, c->logn};
-      hipLaunchKernelGGL(bridge_roundfix, cgrid, cblock, 0, s, rf);
+      { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_roundfix, cgrid, cblock, 0, s, rf); }
       f.only = c->d_redo;
-      switch (rt->KS) {
-        case 2: rc = launch_relin_front_t<2>(f, rt->lds_bytes, s); break;
-        default: rc = launch_relin_front_t<4>(f, rt->lds_bytes, s); break;
-      }
-      if (rc) return rc;
+      if ((rc = launch_relin_front(c, rt->KS, f, rt->lds_bytes, s))) return rc;
       ReconExtra q;
       q.prescaled = true; q.exact_only = true; q.only = c->d_redo; q.big_b = out.b; q.split = out.split;
       if ((rc = launch_reconstruct(c, bq, out.a, W, qhat, tp.cnt, 0, polys, logql, true, tie, s, -1, q))) return rc;
       AddRoundArgs ar{out, Two<const uint64_t>{out.a, out.b, out.split}, nullptr, dbig, bp->d_phalf, piq, tie, W, tp.Wr, c->logn, logql, c->d_redo, flags};
-      hipLaunchKernelGGL(bridge_addround, cgrid, cblock, 0, s, ar);
+      { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_addround, cgrid, cblock, 0, s, ar); }
       return launched("relin_tail");
     }
-    switch (rt->KS) {
-      case 2: rc = launch_relin_front_t<2>(f, rt->lds_bytes, s); break;
-      case 4: rc = launch_relin_front_t<4>(f, rt->lds_bytes, s); break;
-      default: rc = launch_relin_front_t<8>(f, rt->lds_bytes, s); break;
-    }
-    if (rc) return rc;
+    if ((rc = launch_relin_front(c, rt->KS, f, rt->lds_bytes, s))) return rc;
     ReconExtra only_amb;
     only_amb.only = amb; only_amb.prescaled = chat_prescaled;
     if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, only_amb))) return rc;
     RoundFixArgs rf{r, bp->d_phalf, amb, flags, tp.Wr, c->logn};
-    hipLaunchKernelGGL(bridge_roundfix, cgrid, cblock, 0, s, rf);
+    { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_roundfix, cgrid, cblock, 0, s, rf); }
     bool fused = false;
     ReconExtra q;
     q.prescaled = true; q.fused = &fused;
@@ -828,7 +834,7 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
     if ((rc = launch_reconstruct(c, bq, target, W, qhat, tp.cnt, 0, polys, logql, true, tie, s, -1, q))) return rc;
     AddRoundArgs ar{out, direct ? Two<const uint64_t>{out.a, out.b, out.split} : qc_one, nullptr, dbig, bp->d_phalf, piq, tie, W, tp.Wr, c->logn, logql,
                     fused ? c->d_redo : nullptr, flags};
-    hipLaunchKernelGGL(bridge_addround, cgrid, cblock, 0, s, ar);
+    { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_addround, cgrid, cblock, 0, s, ar); }
     return launched("relin_tail");
   }
 
@@ -838,11 +844,11 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
   if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, rx))) return rc;
   if ((rc = launch_decompose(c, rhat, r, tp.Wr, dimP, tp.cnt, polys, s))) return rc;
   ExactDivArgs e{c->d_tabs, chat, rhat, qhat, rt->d_pinv, dimB, dimP, tp.cnt, c->logn};
-  hipLaunchKernelGGL(bridge_exactdiv, dim3((c->n + 255) / 256, polys, tp.cnt), dim3(256), 0, s, e);
+  { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_exactdiv, dim3((c->n + 255) / 256, polys, tp.cnt), dim3(256), 0, s, e); }
   // Q = (x - r)/P over the remaining limbs, centred, already reduced smod 2^logql
   if ((rc = launch_reconstruct(c, bq, qc, W, qhat, tp.cnt, 0, polys, logql, true, tie, s))) return rc;
   AddRoundArgs ar{out, qc_one, r, dbig, bp->d_phalf, piq, tie, W, tp.Wr, c->logn, logql, nullptr, nullptr};
-  hipLaunchKernelGGL(bridge_addround, cgrid, cblock, 0, s, ar);
+  { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_addround, cgrid, cblock, 0, s, ar); }
   return launched("relin_tail");
 }
 
@@ -1282,10 +1288,10 @@ int relin_tail_general(gpq_ctx *c, uint64_t *out, const uint64_t *chat, const ui
   if ((rc = launch_reconstruct(c, bp, r, gp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s))) return rc;
   if ((rc = launch_decompose(c, rhat, r, gp.Wr, dimP, gp.cnt, polys, s))) return rc;
   ExactDivArgs e{c->d_tabs, chat, rhat, qhat, rt->d_pinv, dimB, dimP, gp.cnt, c->logn};
-  hipLaunchKernelGGL(bridge_exactdiv, dim3((c->n + 255) / 256, polys, gp.cnt), dim3(256), 0, s, e);
+  { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_exactdiv, dim3((c->n + 255) / 256, polys, gp.cnt), dim3(256), 0, s, e); }
   if ((rc = launch_reconstruct(c, bq, qfull, gp.WQ, qhat, gp.cnt, 0, polys, 0, true, tie, s))) return rc;   // floor-quotient, full width
   AddRoundFullArgs ar{full, qfull, r, dbig, bp->d_phalf, bq->d_pmult + (size_t)5 * (bq->WP + 1), tie, gp.WF, gp.WQ, gp.Wr, W, c->logn};
-  hipLaunchKernelGGL(bridge_addround_full, dim3((c->n + 255) / 256, polys), dim3(256), 0, s, ar);
+  { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_addround_full, dim3((c->n + 255) / 256, polys), dim3(256), 0, s, ar); }
   if ((rc = launch_smod_general(c, out, W, full, gp.WF, ql_words, Lq, polys, dconst, s))) return rc;        // addm + smod, src/he-mult.c:73-76
   return launched("relin_tail_general");
 }

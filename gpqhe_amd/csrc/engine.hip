@@ -373,23 +373,8 @@ extern "C" int gpq_free_host(void *hptr) { HIP_TRY(hipHostFree(hptr)); return GP
 namespace {
 
 static const char *const kKernelNames[GPQ_K_COUNT] = {"strided_fwd", "strided_inv", "contig_fwd", "contig_inv",
-                                                      "tensor_mid", "keyswitch_mid", "pointwise", "small_ntt", "reference_redo"};
-
-// Brackets one kernel launch with two events on its stream when profiling is on.
-struct ProfScope {
-  gpq_ctx *c; hipStream_t s; gpq_prof_rec r; bool on;
-  ProfScope(const gpq_ctx *cc, int kernel, hipStream_t st) : c(const_cast<gpq_ctx *>(cc)), s(st), on(cc->prof_on) {
-    if (!on) return;
-    auto get = [&]() { hipEvent_t e; if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
-    r.kernel = kernel; r.a = get(); r.b = get();
-    (void)hipEventRecord(r.a, s);
-  }
-  ~ProfScope() {
-    if (!on) return;
-    (void)hipEventRecord(r.b, s);
-    c->prof.push_back(r);
-  }
-};
+                                                      "tensor_mid", "keyswitch_mid", "pointwise", "small_ntt", "reference_redo",
+                                                      "bridge_decompose", "bridge_reconstruct", "bridge_relin_front", "bridge_relin_tail_fused", "bridge_exact_paths", "bridge_rescale"};
 
 int check_shape(const gpq_ctx *c, unsigned dim, unsigned batch, const char *who) {
   if (!c) return gpq_fail(GPQ_ERR_INVALID, "%s: null context", who);

@@ -9,7 +9,10 @@
 // (bench.py's roofline leg).  Off by default: no events are created.
 struct gpq_prof_rec { int kernel; hipEvent_t a, b; };
 enum { GPQ_K_STRIDED_FWD = 0, GPQ_K_STRIDED_INV, GPQ_K_CONTIG_FWD, GPQ_K_CONTIG_INV, GPQ_K_TENSOR_MID,
-       GPQ_K_KEYSWITCH_MID, GPQ_K_POINTWISE, GPQ_K_SMALL, GPQ_K_REFERENCE, GPQ_K_COUNT };
+       GPQ_K_KEYSWITCH_MID, GPQ_K_POINTWISE, GPQ_K_SMALL, GPQ_K_REFERENCE,
+       // the MPI <-> RNS bridge (bridge.hip): rns_decompose, the CRT fast paths, the relinearisation front, its one-pass form, the exact /
+       // masked kernels (bridge_reconstruct, bridge_roundfix, bridge_addround, bridge_exactdiv), he_rs
+       GPQ_K_DECOMPOSE, GPQ_K_RECONSTRUCT, GPQ_K_RELIN_FRONT, GPQ_K_RELIN_TAIL_FUSED, GPQ_K_BRIDGE_EXACT, GPQ_K_RESCALE, GPQ_K_COUNT };
 
 // Constant matrix of the matrix-core CRT fast path for one basis and result width WL (bridge_mfma.hpp)
 struct gpq_recon_mfma {
@@ -109,6 +112,24 @@ struct StageRange {
   ~StageRange() { gpq_range_pop(); }
   StageRange(const StageRange &) = delete;
   StageRange &operator=(const StageRange &) = delete;
+};
+
+// Brackets one kernel launch (or a short run of them) with two events on its stream when profiling is on.
+struct ProfScope {
+  gpq_ctx *c; hipStream_t s; gpq_prof_rec r; bool on;
+  ProfScope(const gpq_ctx *cc, int kernel, hipStream_t st) : c(const_cast<gpq_ctx *>(cc)), s(st), on(cc->prof_on) {
+    if (!on) return;
+    auto get = [&]() { hipEvent_t e; if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+    r.kernel = kernel; r.a = get(); r.b = get();
+    (void)hipEventRecord(r.a, s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, s);
+    c->prof.push_back(r);
+  }
+  ProfScope(const ProfScope &) = delete;
+  ProfScope &operator=(const ProfScope &) = delete;
 };
 
 int gpq_fail(int code, const char *fmt, ...);
