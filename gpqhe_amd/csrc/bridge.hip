@@ -517,7 +517,8 @@ void gpq_bridge_release(gpq_ctx *c) {
   c->bases.clear();
   for (auto &kv : c->relins) {
     (void)hipFree(kv.second.d_pinv);
-    for (void *q : {kv.second.d_bfrag, (void *)kv.second.d_lk, (void *)kv.second.d_pk, (void *)kv.second.d_tkp, (void *)kv.second.d_kf})
+    for (void *q : {kv.second.d_bfrag, (void *)kv.second.d_lk, (void *)kv.second.d_pk, (void *)kv.second.d_tkp, (void *)kv.second.d_kf,
+                    kv.second.d_bfrag_w, (void *)kv.second.d_pk_w, (void *)kv.second.d_tkp_w, (void *)kv.second.d_tabs_w})
       if (q) (void)hipFree(q);
   }
   c->relins.clear();
@@ -664,6 +665,11 @@ int get_relin_front(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables *
   if (lds > kMfmaLdsMax) return GPQ_OK;
   std::vector<int8_t> bf((size_t)NT * KS * 1024, 0);
   std::vector<uint64_t> lk((size_t)8 * KS, 0), pk((size_t)12 * NTp, 0), tkp((size_t)cnt * 64, 0), kf(2, 0);
+  // The same tables with every constant of limb j multiplied by w_j = P^-1 (Pi'/p_j)^-1 mod p_j: with the limbs above P arriving
+  // already multiplied by w_j (ScaledInverse on the key switch's inverse pass) Q's scaled residue is x'_j - (r w_j mod p_j), a
+  // subtraction where the plain tables need a modular multiplication per (coefficient, limb).
+  std::vector<int8_t> bfw;
+  std::vector<uint64_t> pkw((size_t)12 * NTp, 0), tkpw((size_t)cnt * 64, 0), wscale(cnt, 1);
   u128h sum_inv = 0;
   for (unsigned d = 0; d < dimP; ++d) {
     const uint64_t pd = c->p[d];
@@ -681,30 +687,51 @@ int get_relin_front(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables *
   }
   const u128h kfv = (u128h)(uint64_t)sum_inv * 0x8080808080808080ull;
   kf[0] = (uint64_t)kfv; kf[1] = (uint64_t)(kfv >> 64);
-  for (unsigned j = 0; j < cnt; ++j) {
-    const uint64_t pj = c->p[dimP + j];
-    const uint64_t Pm = mod_small(bp->h_P, pj);
-    const uint64_t Pinv = powm(Pm, pj - 2, pj);
-    uint64_t sum_ph = 0;
-    const unsigned nt = j / 4, pq = j % 4;
-    for (unsigned d = 0; d < dimP; ++d) {
-      Big ph(bp->h_phat.begin() + (size_t)d * bp->WP, bp->h_phat.begin() + (size_t)(d + 1) * bp->WP);
-      uint64_t T = mod_small(ph, pj);                                   // (P/p_d) mod p_j
-      sum_ph = (uint64_t)(((u128h)sum_ph + T) % pj);
-      for (unsigned i = 0; i < 8; ++i) {
-        int8_t dig[8];
-        balanced8(T, dig);
-        const unsigned k = 8 * d + i, s = k / 32, h = (k % 32) / 16, tt = k % 16;
-        for (unsigned b = 0; b < 8; ++b) bf[(((size_t)nt * KS + s) * 64 + 32 * h + 8 * pq + b) * 16 + tt] = dig[b];
-        T = (uint64_t)(((u128h)T << 8) % pj);
+  bfw = bf;                                                                // the F columns (row tile NT-1) are the same
+  for (int scaled = 0; scaled < 2; ++scaled) {
+    std::vector<int8_t> &B = scaled ? bfw : bf;
+    std::vector<uint64_t> &PK = scaled ? pkw : pk, &TK = scaled ? tkpw : tkp;
+    for (unsigned j = 0; j < cnt; ++j) {
+      const uint64_t pj = c->p[dimP + j];
+      const uint64_t Pm0 = mod_small(bp->h_P, pj);
+      const uint64_t Pinv = powm(Pm0, pj - 2, pj);
+      const uint64_t wj = (uint64_t)((u128h)Pinv * bq->h_phat_inv[j] % pj);
+      const uint64_t mulw = scaled ? wj : 1;
+      const uint64_t Pm = (uint64_t)((u128h)Pm0 * mulw % pj);
+      wscale[j] = wj;
+      uint64_t sum_ph = 0;
+      const unsigned nt = j / 4, pq = j % 4;
+      for (unsigned d = 0; d < dimP; ++d) {
+        Big ph(bp->h_phat.begin() + (size_t)d * bp->WP, bp->h_phat.begin() + (size_t)(d + 1) * bp->WP);
+        uint64_t T = (uint64_t)((u128h)mod_small(ph, pj) * mulw % pj);   // (P/p_d) [w_j] mod p_j
+        sum_ph = (uint64_t)(((u128h)sum_ph + T) % pj);
+        for (unsigned i = 0; i < 8; ++i) {
+          int8_t dig[8];
+          balanced8(T, dig);
+          const unsigned k = 8 * d + i, s = k / 32, h = (k % 32) / 16, tt = k % 16;
+          for (unsigned b = 0; b < 8; ++b) B[(((size_t)nt * KS + s) * 64 + 32 * h + 8 * pq + b) * 16 + tt] = dig[b];
+          T = (uint64_t)(((u128h)T << 8) % pj);
+        }
       }
+      const uint64_t K = (uint64_t)((u128h)(0x8080808080808080ull % pj) * sum_ph % pj);
+      const uint64_t off = 1ull << 50;
+      PK[3 * (size_t)j] = pj;
+      PK[3 * (size_t)j + 1] = off + (K + pj - off % pj) % pj;
+      PK[3 * (size_t)j + 2] = wj;
+      for (unsigned k = 0; k < 64; ++k) TK[(size_t)j * 64 + k] = (pj - (uint64_t)((u128h)k * Pm % pj)) % pj;
     }
-    const uint64_t K = (uint64_t)((u128h)(0x8080808080808080ull % pj) * sum_ph % pj);
-    const uint64_t off = 1ull << 50;
-    pk[3 * (size_t)j] = pj;
-    pk[3 * (size_t)j + 1] = off + (K + pj - off % pj) % pj;
-    pk[3 * (size_t)j + 2] = (uint64_t)((u128h)Pinv * bq->h_phat_inv[j] % pj);
-    for (unsigned k = 0; k < 64; ++k) tkp[(size_t)j * 64 + k] = (pj - (uint64_t)((u128h)k * Pm % pj)) % pj;
+  }
+  // the context's per-limb table for the key switch's inverse pass: (P/p_d)^-1 on the limbs of P, w_j above
+  std::vector<LimbTab> tw = c->h_tabs;
+  if (!tw.empty()) {
+    auto pair_of = [](uint64_t w, uint64_t p) { return TwS{p - w, p - (uint64_t)(((u128h)w << 31) % p)}; };
+    for (unsigned d = 0; d < dimB; ++d) {
+      LimbTab &e = tw[d];
+      const uint64_t p = e.k.p, sc = d < dimP ? bp->h_phat_inv[d] : wscale[d - dimP];
+      e.ninv = (uint64_t)((u128h)e.ninv * sc % p);
+      e.winv1_ninv = (uint64_t)((u128h)e.winv1_ninv * sc % p);
+      if (d < c->nsplit_tables) { e.ninv_s = pair_of(e.ninv, p); e.winv1_ninv_s = pair_of(e.winv1_ninv, p); }
+    }
   }
   DeviceScope on_device(c->device);
   HIP_TRY(hipMalloc(&rt->d_bfrag, bf.size()));
@@ -717,8 +744,34 @@ int get_relin_front(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables *
   HIP_TRY(hipMemcpy(rt->d_pk, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(rt->d_tkp, tkp.data(), tkp.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(rt->d_kf, kf.data(), kf.size() * 8, hipMemcpyHostToDevice));
+  if (!tw.empty()) {
+    HIP_TRY(hipMalloc(&rt->d_bfrag_w, bfw.size()));
+    HIP_TRY(hipMalloc((void **)&rt->d_pk_w, pkw.size() * 8));
+    HIP_TRY(hipMalloc((void **)&rt->d_tkp_w, tkpw.size() * 8));
+    HIP_TRY(hipMalloc((void **)&rt->d_tabs_w, tw.size() * sizeof(LimbTab)));
+    HIP_TRY(hipMemcpy(rt->d_bfrag_w, bfw.data(), bfw.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(rt->d_pk_w, pkw.data(), pkw.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(rt->d_tkp_w, tkpw.data(), tkpw.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(rt->d_tabs_w, tw.data(), tw.size() * sizeof(LimbTab), hipMemcpyHostToDevice));
+  }
   rt->NT = NT; rt->KS = KS; rt->lds_bytes = lds;
   return GPQ_OK;
+}
+
+// How the key switch of gpq_he_mul / gpq_he_swk may scale its output for the tail that follows: 0 = not at all, 1 = the limbs of P by
+// (P/p_d)^-1 (any tail), 2 = also the limbs above P by w_j (the matrix-core front only: its exact fallbacks read those limbs through
+// the same tables).  *tabs = the per-limb table the inverse pass reads.
+int tail_prescale_mode(gpq_ctx *c, unsigned dimP, unsigned dimB, const LimbTab **tabs, int *mode) {
+  *tabs = nullptr; *mode = 0;
+  if (!can_prescale(c)) return GPQ_OK;
+  gpq_bridge_basis *bp, *bq;
+  gpq_relin_tables *rt;
+  int rc;
+  if ((rc = get_basis(c, 0, dimP, &bp)) || (rc = get_basis(c, dimP, dimB - dimP, &bq)) || (rc = get_relin(c, dimP, dimB, &rt))) return rc;
+  if (c->bridge_mfma && c->logn >= 6 && (rc = get_relin_front(c, dimP, dimB, rt, bp, bq))) return rc;
+  if (c->bridge_mfma && c->logn >= 6 && rt->d_bfrag && rt->d_tabs_w && c->prescale_upper) { *tabs = rt->d_tabs_w; *mode = 2; return GPQ_OK; }
+  *mode = 1;
+  return get_scaled_tabs(c, bp, tabs);
 }
 
 template <int KS, int WL>
@@ -757,7 +810,7 @@ int launch_relin_front(const gpq_ctx *c, unsigned KS, const RelinFrontArgs &f, s
 // launch group are one batch (their chat slabs are adjacent in the workspace), half the launches and twice their size.
 // chat_prescaled: the limbs below dimP already hold chat_d * (P/p_d)^-1 (ScaledInverse on the key switch's inverse pass).
 int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const uint64_t> dbig, unsigned W, unsigned dimP, unsigned dimB,
-               unsigned logql, unsigned polys, void *ws, hipStream_t s, bool chat_prescaled = false) {
+               unsigned logql, unsigned polys, void *ws, hipStream_t s, int chat_prescaled = 0) {
   TailPlan tp;
   int rc = tail_plan(c, W, dimP, dimB, polys, &tp);
   if (rc) return rc;
@@ -781,8 +834,9 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
     // coefficients whose rounding the fixed-point estimates cannot decide.
     unsigned char *flags = (unsigned char *)rhat, *amb = flags + ((size_t)polys << c->logn);   // rhat's place is free in this flow
     const unsigned gpp = c->n >> 6;
-    RelinFrontArgs f{chat, qhat, (const v4i *)rt->d_bfrag, rt->d_lk, rt->d_pk, rt->d_tkp, rt->d_kf, flags, amb,
-                     dimB, dimP, tp.cnt, c->logn, rt->NT, gpp, gpp * polys, nullptr, chat_prescaled ? 1u : 0u};
+    const bool wsc = chat_prescaled == 2;                 // the limbs above P arrive multiplied by w_j: the w-scaled tables, no multiplication in the epilogue
+    RelinFrontArgs f{chat, qhat, (const v4i *)(wsc ? rt->d_bfrag_w : rt->d_bfrag), rt->d_lk, wsc ? rt->d_pk_w : rt->d_pk, wsc ? rt->d_tkp_w : rt->d_tkp, rt->d_kf, flags, amb,
+                     dimB, dimP, tp.cnt, c->logn, rt->NT, gpp, gpp * polys, nullptr, chat_prescaled ? 1u : 0u, wsc ? 1u : 0u};
     // One pass per coefficient (bridge_relin_tail_mfma): the front and the CRT of Q without the round trip of Q's residues.
     const unsigned need = (logql + 63) / 64;
     const int WLf = need <= 7 ? 7 : 14;
@@ -804,7 +858,7 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
       if (rc) return rc;
       // the few coefficients it flagged: round bits settled exactly, Q's residues made for their groups, exact CRT, finish
       ReconExtra only_amb;
-      only_amb.only = amb; only_amb.prescaled = chat_prescaled;
+      only_amb.only = amb; only_amb.prescaled = chat_prescaled != 0;
       if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, only_amb))) return rc;
       RoundFixArgs rf{r, bp->d_phalf, amb, flags, tp.Wr, c->logn};
       { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_roundfix, cgrid, cblock, 0, s, rf); }
@@ -819,7 +873,7 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
     }
     if ((rc = launch_relin_front(c, rt->KS, f, rt->lds_bytes, s))) return rc;
     ReconExtra only_amb;
-    only_amb.only = amb; only_amb.prescaled = chat_prescaled;
+    only_amb.only = amb; only_amb.prescaled = chat_prescaled != 0;
     if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, only_amb))) return rc;
     RoundFixArgs rf{r, bp->d_phalf, amb, flags, tp.Wr, c->logn};
     { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_roundfix, cgrid, cblock, 0, s, rf); }
@@ -840,7 +894,8 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
 
   // r = x mod P from the first dimP limbs, unsigned
   ReconExtra rx;
-  rx.prescaled = chat_prescaled;
+  rx.prescaled = chat_prescaled != 0;
+  if (chat_prescaled == 2) return gpq_fail(GPQ_ERR_INVALID, "relin_tail: w-scaled limbs need the matrix-core front");
   if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, rx))) return rc;
   if ((rc = launch_decompose(c, rhat, r, tp.Wr, dimP, tp.cnt, polys, s))) return rc;
   ExactDivArgs e{c->d_tabs, chat, rhat, qhat, rt->d_pinv, dimB, dimP, tp.cnt, c->logn};
@@ -910,8 +965,8 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
   void *wsK = w; w += align64(gpq_keyswitch_workspace_bytes(c, dimB, m));
   uint64_t *dbig = (uint64_t *)w; w += align64((size_t)m * 3 * W * n * 8);
   void *wsTail = w;
-  gpq_bridge_basis *bA, *bP;
-  if ((rc = get_basis(c, 0, dimA, &bA)) || (rc = get_basis(c, 0, dimP, &bP))) return rc;
+  gpq_bridge_basis *bA;
+  if ((rc = get_basis(c, 0, dimA, &bA))) return rc;
   for (unsigned k0 = 0; k0 < batch; k0 += m) {
     const unsigned polys = batch - k0 < m ? batch - k0 : m;
     const size_t pa = (size_t)polys * dimA * n, pb = (size_t)polys * dimB * n;
@@ -929,7 +984,8 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
     }
     const bool pre = can_prescale(c);      // the inverse passes hand the CRT kernels limbs already multiplied by (P/p_d)^-1
     const LimbTab *tabsA = nullptr, *tabsP = nullptr;
-    if (pre && ((rc = get_scaled_tabs(c, bA, &tabsA)) || (rc = get_scaled_tabs(c, bP, &tabsP)))) return rc;
+    int tail_mode = 0;
+    if (pre && ((rc = get_scaled_tabs(c, bA, &tabsA)) || (rc = tail_prescale_mode(c, dimP, dimB, &tabsP, &tail_mode)))) return rc;
     {
       ScaledInverse scaled(c, tabsA);
       if ((rc = gpq_he_mul_tensor(c, d0h, d1h, d2h, h[0], h[1], square ? h[0] : h[2], square ? h[1] : h[3], dimA, polys, wsT, stream))) return rc;  // :121-136
@@ -955,7 +1011,7 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
     StageRange stage("gpq_he_mul: he_relin tail (CRT, exact division by P, + d)");
     // c0 and c1 as one batch of 2 x polys polynomials: c0hat | c1hat and d0 | d1 are adjacent, the outputs are the caller's two slabs
     if ((rc = relin_tail(c, Two<uint64_t>{out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, polys}, c0hat, Two<const uint64_t>{d0, d1, polys},
-                         W, dimP, dimB, logql, 2 * polys, wsTail, s, pre))) return rc;                             // :67-77
+                         W, dimP, dimB, logql, 2 * polys, wsTail, s, tail_mode))) return rc;                       // :67-77
   }
   return launched("gpq_he_mul");
 }
@@ -983,17 +1039,16 @@ extern "C" int gpq_he_swk(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
     const size_t pb = (size_t)polys * dimB * n;
     uint64_t *d1hat = sB, *c0hat = sB + pb, *c1hat = sB + 2 * pb;
     if ((rc = launch_decompose(c, d1hat, d1 + k0 * bigpoly, W, 0, dimB, polys, s))) return rc;                     // :60
-    const bool pre = can_prescale(c);
     const LimbTab *tabsP = nullptr;
-    gpq_bridge_basis *bP;
-    if (pre && ((rc = get_basis(c, 0, dimP, &bP)) || (rc = get_scaled_tabs(c, bP, &tabsP)))) return rc;
+    int tail_mode = 0;
+    if ((rc = tail_prescale_mode(c, dimP, dimB, &tabsP, &tail_mode))) return rc;
     {
       ScaledInverse scaled(c, tabsP);
       if ((rc = gpq_keyswitch(c, c0hat, c1hat, d1hat, swk0, swk1, dimB, polys, wsK, stream))) return rc;           // :61-65
     }
     // c0 (+ d0) and c1 (no addend) as one batch of 2 x polys polynomials                                           // :68-75
     if ((rc = relin_tail(c, Two<uint64_t>{out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, polys}, c0hat, Two<const uint64_t>{d0 + k0 * bigpoly, nullptr, polys},
-                         W, dimP, dimB, logql, 2 * polys, wsTail, s, pre))) return rc;
+                         W, dimP, dimB, logql, 2 * polys, wsTail, s, tail_mode))) return rc;
   }
   return launched("gpq_he_swk");
 }
@@ -1027,9 +1082,10 @@ extern "C" int gpq_set_fused_tail(gpq_ctx *c, int on) {
 
 // gpq_he_mul / gpq_he_swk let their inverse transforms hand the CRT kernels limbs already multiplied by (P/p_d)^-1 (default on); off = the
 // CRT kernels do that multiplication themselves.  Same results (tests run both).
-extern "C" int gpq_set_prescale(gpq_ctx *c, int on) {
+extern "C" int gpq_set_prescale(gpq_ctx *c, int on) {      // 0: off, 1: the CRT weights only, 2 (default): also w_j on the limbs above P for the relinearisation front
   if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_prescale: null context");
   c->prescale = on != 0;
+  c->prescale_upper = on >= 2;
   return GPQ_OK;
 }
 

@@ -359,6 +359,7 @@ struct RelinFrontArgs {
   // are left alone -- the re-run behind bridge_relin_tail_mfma, which needs yq in memory for the few coefficients it could not finish
   const unsigned char *only;
   unsigned prescaled;        // the limbs below dimP already hold y_d = chat_d * phat_invmp_d (the key switch's inverse pass scaled them: ScaledInverse)
+  unsigned wscaled;          // ... and the limbs above hold chat_j * w_j, bfrag / pk / tkp are the w-scaled tables: yq_j = x'_j - (r w_j mod p_j)
 };
 
 #ifndef GPQ_FRONT_OCC
@@ -493,7 +494,8 @@ __global__ __launch_bounds__(256, (KS <= 4 ? GPQ_FRONT_OCC : 2)) void bridge_rel
         const uint64_t Hl = (uint64_t)H & 0x7ffffffu;
         uint64_t v = (Hl << 32) + (uint64_t)L + kq;
         v = (uint64_t)((int64_t)(-(int)k.c) * Hh + (int64_t)v) + tk[w];     // r mod p_j, lazily: in (0, 4p)
-        const uint64_t yq = canon_fold(mulmod_lazy(xc[w] + (p << 2) - v, wj, k), p, k.c);  // (x - r) in (0, 5p)
+        const uint64_t yq = a.wscaled ? canon_fold(xc[w] + (p << 2) - v, p, k.c)                          // x'_j - r w_j, in (0, 5p)
+                                      : canon_fold(mulmod_lazy(xc[w] + (p << 2) - v, wj, k), p, k.c);  // (x - r) in (0, 5p), times w_j
         if (j < a.cnt) dst[(size_t)j << a.logn] = yq;
 #ifdef GPQ_FRONT_ITEM_BARRIER
         __builtin_amdgcn_sched_barrier(0);
@@ -722,9 +724,9 @@ __global__ __launch_bounds__(256, GPQ_TAIL_WAVES) void bridge_relin_tail_mfma(Re
           uint64_t v = (Hl << 32) + (uint64_t)L + kq;
           v = (uint64_t)((int64_t)(-(int)k.c) * Hh + (int64_t)v) + tk[w];   // r mod p_j, lazily: in (0, 4p)
 #if GPQ_TAIL_WAVES >= 2
-          const uint64_t yq = canon_fold(mulmod_lazy(xc[w] + (p << 2) - v, wj, k), p, k.c);
+          const uint64_t yq = a.wscaled ? canon_fold(xc[w] + (p << 2) - v, p, k.c) : canon_fold(mulmod_lazy(xc[w] + (p << 2) - v, wj, k), p, k.c);
 #else
-          const uint64_t yq = canon_fold(mulmod_lazy(xj[4 * q + w] + (p << 2) - v, wj, k), p, k.c);
+          const uint64_t yq = a.wscaled ? canon_fold(xj[4 * q + w] + (p << 2) - v, p, k.c) : canon_fold(mulmod_lazy(xj[4 * q + w] + (p << 2) - v, wj, k), p, k.c);
 #endif
           yb[w] = (yq ^ 0x8080808080808080ull) & (p ? ~0ull : 0ull);
         }

@@ -51,6 +51,11 @@ struct gpq_relin_tables {
   uint64_t *d_lk = nullptr, *d_pk = nullptr, *d_tkp = nullptr, *d_kf = nullptr;
   unsigned NT = 0, KS = 0;
   size_t lds_bytes = 0;
+  // the same tables for limbs that arrive multiplied by w_j = P^-1 (Pi'/p_j)^-1, and the per-limb table that makes the key switch's
+  // inverse pass deliver them so (bridge.hip: get_relin_front, tail_prescale_mode)
+  void *d_bfrag_w = nullptr;
+  uint64_t *d_pk_w = nullptr, *d_tkp_w = nullptr;
+  gpq::LimbTab *d_tabs_w = nullptr;
 };
 
 struct gpq_ctx {
@@ -83,6 +88,7 @@ struct gpq_ctx {
   std::vector<void *> retired;        // outgrown d_redo buffers: a HIP graph captured earlier may still write them, so they live as long as the context
   bool exact_crt = false;             // force the exact CRT kernel (tests)
   bool prescale = true;               // gpq_he_mul / gpq_he_swk: inverse passes write limbs pre-multiplied by (P/p_d)^-1 for the CRT kernels (gpq_set_prescale)
+  bool prescale_upper = true;         // ... and the limbs above P by w_j for the relinearisation front
   bool fuse_tail = false;             // gpq_set_fused_tail(ctx, 1): the relinearisation tail in one pass per coefficient (bridge_relin_tail_mfma) -- measured 2 % SLOWER
                                       // than the two-kernel form on the whole he_mul (profiles/r03/v3_fused_tail_ab.txt: both are bound by integer VALU work, not by the
                                       // 60 words per coefficient the fusion saves), kept for the parity tests and as the record of the attempt

@@ -121,7 +121,7 @@ class PolyContext:
 
     def set_prescale(self, on):
         """he_mul / he_swk: inverse transforms write limbs pre-multiplied by the CRT weights (default) or not; both exact"""
-        _native.check(self.lib.gpq_set_prescale(self.h, 1 if on else 0), "gpq_set_prescale")
+        _native.check(self.lib.gpq_set_prescale(self.h, int(on)), "gpq_set_prescale")      # 0 / 1 / 2 (True = 1)
 
     def set_exact_crt(self, on):
         _native.check(self.lib.gpq_set_exact_crt(self.h, 1 if on else 0), "gpq_set_exact_crt")

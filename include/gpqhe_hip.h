@@ -201,7 +201,8 @@ int gpq_set_exact_crt(gpq_ctx *ctx, int on);
 /* The tail of he_relin / he_swk as two kernels with Q's residues in memory between them (0, default) or in one pass per coefficient (1:
  * measured 2 % slower on the whole he_mul -- both forms are bound by integer VALU work); same results. */
 int gpq_set_fused_tail(gpq_ctx *ctx, int on);
-/* gpq_he_mul / gpq_he_swk: the inverse transforms hand the CRT kernels limbs already multiplied by (P/p_d)^-1 (1, default) or not (0); same results. */
+/* gpq_he_mul / gpq_he_swk: the inverse transforms hand the kernels that follow limbs already multiplied by their CRT weights -- 2 (default): (P/p_d)^-1 on
+ * the limbs of each basis and w_j = P^-1 (Pi'/p_j)^-1 on the limbs above P for the relinearisation front; 1: the former only; 0: neither.  Same results. */
 int gpq_set_prescale(gpq_ctx *ctx, int on);
 /* rns_decompose is a product of the coefficients' bytes with a fixed matrix (256^k mod p_j) and runs on the matrix cores
  * (v_mfma_i32_32x32x32_i8, exact) by default; 0 selects the integer-VALU kernel instead (the tests cross-check the two). */

@@ -511,7 +511,8 @@ def test_one_pass_relinearisation_tail_equals_the_two_kernel_form(engine_ctx, lo
     outs = []
     try:
         # ... and with / without the inverse transforms pre-multiplying their output by the CRT weights (gpq_set_prescale)
-        for fused, prescale in ((False, True), (True, True), (False, False), (True, False)):
+        # (0 = no scaling, 1 = the CRT weights on the limbs of each basis, 2 = also w_j on the limbs above P for the relinearisation front)
+        for fused, prescale in ((False, 2), (True, 2), (False, 0), (True, 0), (False, 1), (True, 1)):
             g.set_fused_tail(fused)
             g.set_prescale(prescale)
             o0, o1 = torch.empty_like(cts[0]), torch.empty_like(cts[0])
@@ -522,7 +523,7 @@ def test_one_pass_relinearisation_tail_equals_the_two_kernel_form(engine_ctx, lo
             outs.append((o0, o1, s0, s1))
     finally:
         g.set_fused_tail(False)
-        g.set_prescale(True)
+        g.set_prescale(2)
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)

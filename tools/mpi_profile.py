@@ -9,5 +9,5 @@ if os.environ.get("GPQ_BRIDGE_VALU") == "1":      # tool-side switch (tools/gpu_
 if os.environ.get("MPI_FUSED"):
     ctx.set_fused_tail(os.environ["MPI_FUSED"] == "1")
 if os.environ.get("MPI_PRESCALE"):
-    ctx.set_prescale(os.environ["MPI_PRESCALE"] == "1")
+    ctx.set_prescale(int(os.environ["MPI_PRESCALE"]))
 print(he_mul_mpi_rate(torch, gpqhe_amd, ctx, int(os.environ.get("MPI_BATCH", "64")), iters=int(os.environ.get("MPI_ITERS", "6"))))
