@@ -489,6 +489,10 @@ int check(const gpq_ctx *c, unsigned dim, unsigned batch, const char *who) {
   if (!c) return gpq_fail(GPQ_ERR_INVALID, "%s: null context", who);
   if (dim < 1 || dim > c->nprimes) return gpq_fail(GPQ_ERR_INVALID, "%s: dim=%u outside 1..%u", who, dim, c->nprimes);
   if (batch < 1) return gpq_fail(GPQ_ERR_INVALID, "%s: empty batch", who);
+  // kernels launch on the calling thread's current device: it must be the one the context (its tables, the caller's slabs) lives on
+  int dev = -1;
+  if (hipGetDevice(&dev) == hipSuccess && dev != c->device)
+    return gpq_fail(GPQ_ERR_INVALID, "%s: the context lives on device %d but the calling thread's current device is %d (gpq_set_device(gpq_ctx_device(ctx)) first)", who, c->device, dev);
   return GPQ_OK;
 }
 int launched(const char *who) {

@@ -102,6 +102,9 @@ int gpq_free_host(void *hptr);
 /* ---- slab operations ------------------------------------------------------
  * All slabs are device pointers to uint64_t[batch][dim][n] using primes
  * 0..dim-1 of the context.  `stream` is a hipStream_t (NULL = default).
+ * Kernels launch on the calling thread's CURRENT device, which must be the context's (gpq_set_device(gpq_ctx_device(ctx)));
+ * a call from a thread on another device returns GPQ_ERR_INVALID instead of launching there.  A context and the calls on it
+ * are not thread-safe: one host thread per context at a time.
  */
 
 /* ntt / invntt over every limb of every polynomial, in place.

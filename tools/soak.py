@@ -49,6 +49,26 @@ def main():
             for d in range(dim):
                 ins[0][d * o.n:(d + 1) * o.n] = o.p[d] - 1
                 ins[1][d * o.n:(d + 1) * o.n] = 0
+        zero_mode = rng.random() < 0.35                          # the reference's representation of zero (src/ntt.c:47): transforms with residues 0
+        if zero_mode and not (rng.random() < 0.0):
+            nrng = np.random.default_rng(seeds[0])
+            for k in range(batch):
+                for d in range(dim):
+                    if rng.random() < 0.6:
+                        base = (k * dim + d) * o.n
+                        t = o.ntt(ins[0][base:base + o.n], d)
+                        how = rng.choice(["one", "pair", "block", "even", "scatter"])
+                        if how == "one":
+                            t[rng.randrange(o.n)] = 0
+                        elif how == "pair":
+                            j = 2 * rng.randrange(o.n // 2); t[j] = t[j + 1] = 0
+                        elif how == "block":
+                            j = 8 * rng.randrange(o.n // 8); t[j:j + 8] = 0
+                        elif how == "even":
+                            t[0::2] = 0
+                        else:
+                            t[nrng.integers(0, o.n, size=max(2, o.n // 64))] = 0
+                        ins[0][base:base + o.n] = o.invntt(t % np.uint64(o.p[d]), d)
         ev = [o.gen(seeds[5], dim), o.gen(seeds[6], dim)]
         dev = [to_device(v) for v in ins]
         f = dev[0].clone(); g.poly_ntt(f, dim)
@@ -72,7 +92,7 @@ def main():
                     print("MISMATCH", name, "ciphertext", k, dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, seeds=seeds), flush=True)
                     sys.exit(1)
         runs += 1
-        print("ok", dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes), flush=True)
+        print("ok", dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, zero_cases=zero_mode), flush=True)
         g.close()
     print("soak: %d configurations, no mismatch, %.0f s" % (runs, time.time() - t0))
 
