@@ -352,7 +352,7 @@ def cpu_baseline(ctx, host_inputs, gpu_outputs, sample):
 
 ROCPROF_NAMES = {   # how rocprofv3 names the kernels of the default n = 2^16 path (every limb wide-split)
     "tensor_mid": "gpq::tensor_mid8<gpq::TwW, 8>",
-    "keyswitch_mid": "gpq::keyswitch_mid8x2<gpq::TwW, 8>",
+    "keyswitch_mid": "gpq::keyswitch_mid8x2<gpq::TwW, 8, true>",
     "strided_fwd": "gpq::strided_pass<8, 4, false, false, gpq::TwW, 8>",
     "strided_inv": "gpq::strided_pass<8, 4, true, false, gpq::TwW, 8>",
 }

@@ -812,8 +812,15 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
             using TW = decltype(tag);
             KeyswitchArgs ka{a, m.evk0, m.evk1};
             ProfScope prof(c, GPQ_K_KEYSWITCH_MID, s);
-            if (c->low9) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 9>), dim3(c->n >> 11, (polys + 1) / 2, nl), dim3(CONTIG_WAVES * 64), 0, s, ka, polys);
-            else hipLaunchKernelGGL((keyswitch_mid8x2<TW, 8>), dim3(c->n >> 11, (polys + 1) / 2, nl), dim3(CONTIG_WAVES * 64), 0, s, ka, polys);
+            const dim3 block(CONTIG_WAVES * 64);
+            if (polys / 2) {
+              if (c->low9) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 9, true>), dim3(c->n >> 11, polys / 2, nl), block, 0, s, ka, 0u);
+              else hipLaunchKernelGGL((keyswitch_mid8x2<TW, 8, true>), dim3(c->n >> 11, polys / 2, nl), block, 0, s, ka, 0u);
+            }
+            if (polys & 1) {           // the odd last polynomial alone (half the arithmetic of a pair that would be stored once)
+              if (c->low9) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 9, false>), dim3(c->n >> 11, 1, nl), block, 0, s, ka, polys - 1);
+              else hipLaunchKernelGGL((keyswitch_mid8x2<TW, 8, false>), dim3(c->n >> 11, 1, nl), block, 0, s, ka, polys - 1);
+            }
             return (int)GPQ_OK;
           }))) return rc;
       PassArgs b = make_args(c, dim, 2);

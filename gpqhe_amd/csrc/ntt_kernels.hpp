@@ -859,9 +859,9 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void mulpt_mid8(PassArgs a) {
 // Key switch with TWO polynomials of the same limb and tile per workgroup: the key limbs (shared by the batch) and every
 // twiddle group are fetched once for both -- per polynomial the 16-per-lane kernel reads 960 B of twiddle pairs and 256 B
 // of key per lane against 384 B of its own data -- and the four products of a pair run like the tensor stage (2 forward
-// low-halves, 4 inverse ones).  blockIdx.y = pair of polynomials; an odd last polynomial is processed twice and stored once.
-template <typename TW, int LOW>
-__global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid8x2(KeyswitchArgs ka, unsigned polys) {
+// low-halves, 4 inverse ones).  blockIdx.y = pair of polynomials starting at `first`; an odd last polynomial runs alone in the TWO = false instantiation.
+template <typename TW, int LOW, bool TWO = true>
+__global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid8x2(KeyswitchArgs ka, unsigned first) {
   using TT = TwTraits<TW>;
   using L8 = Lane8<LOW>;
   __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
@@ -872,8 +872,8 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid8x2(Keyswit
   const PrimeK k = a.tabs[limb].k;
   const size_t toff = (size_t)limb << a.logn;
   const TW *__restrict__ wf = TT::table(a, false) + toff, *__restrict__ wi = TT::table(a, true) + toff;
-  const unsigned p0 = 2 * blockIdx.y;
-  const bool two = p0 + 1 < polys;
+  const unsigned p0 = first + 2 * blockIdx.y;  // TWO = false: the odd last polynomial of a batch (a single ciphertext is the reference's calling pattern) alone,
+  constexpr bool two = TWO;                    // in its own instantiation -- under a run-time branch the pair form needs 168 registers instead of 116
   const size_t off0 = (size_t)p0 * a.poly_stride + ((size_t)blockIdx.z << a.logn) + wave0;
   const size_t off1 = two ? off0 + a.poly_stride : off0;
   const size_t koff = ((size_t)blockIdx.z << a.logn) + wave0;
@@ -881,42 +881,52 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid8x2(Keyswit
   Tw8<TW, LOW> tw;
   ln.load_h(x0, a.src[0] + off0);
   tw.load_h(ln, wave0, a.logn, wf);
-  ln.load_h(x1, a.src[0] + off1);
+  if constexpr (two) ln.load_h(x1, a.src[0] + off1);
   L8::ct_h(x0, tw.t, k);
-  L8::ct_h(x1, tw.t, k);
+  if constexpr (two) L8::ct_h(x1, tw.t, k);
   tw.load_m(ln, wave0, a.logn, wf);
   ln.h_to_m(x0); L8::ct_m(x0, tw.t, k);
-  ln.h_to_m(x1); L8::ct_m(x1, tw.t, k);
+  if constexpr (two) { ln.h_to_m(x1); L8::ct_m(x1, tw.t, k); }
   tw.load_l(ln, wave0, a.logn, wf);
   ln.m_to_l(x0); L8::ct_l(x0, tw.u, k);
-  ln.m_to_l(x1); L8::ct_l(x1, tw.u, k);
+  if constexpr (two) { ln.m_to_l(x1); L8::ct_l(x1, tw.u, k); }
   ln.load_l(e0, ka.evk0 + koff);
   ln.load_l(e1, ka.evk1 + koff);
   tw.load_l(ln, wave0, a.logn, wi);
   uint64_t y0[8], y1[8];                        // x0 * evk1, x1 * evk1;  x0, x1 become x0 * evk0, x1 * evk0
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const uint64_t u0 = TT::right(x0[e], k), u1 = TT::right(x1[e], k);
+    const uint64_t u0 = TT::right(x0[e], k);
     x0[e] = TT::inv_from4(mulmod_lazy(u0, e0[e], k), k);
     y0[e] = TT::inv_from4(mulmod_lazy(u0, e1[e], k), k);
-    x1[e] = TT::inv_from4(mulmod_lazy(u1, e0[e], k), k);
-    y1[e] = TT::inv_from4(mulmod_lazy(u1, e1[e], k), k);
+  }
+  if constexpr (two) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint64_t u1 = TT::right(x1[e], k);
+      x1[e] = TT::inv_from4(mulmod_lazy(u1, e0[e], k), k);
+      y1[e] = TT::inv_from4(mulmod_lazy(u1, e1[e], k), k);
+    }
   }
   L8::gs_l(x0, tw.u, k); ln.l_to_m(x0);
   L8::gs_l(y0, tw.u, k); ln.l_to_m(y0);
-  L8::gs_l(x1, tw.u, k); ln.l_to_m(x1);
-  L8::gs_l(y1, tw.u, k); ln.l_to_m(y1);
+  if constexpr (two) {
+    L8::gs_l(x1, tw.u, k); ln.l_to_m(x1);
+    L8::gs_l(y1, tw.u, k); ln.l_to_m(y1);
+  }
   tw.load_m(ln, wave0, a.logn, wi);
   L8::gs_hm(x0, tw.t, k); ln.m_to_h(x0);
   L8::gs_hm(y0, tw.t, k); ln.m_to_h(y0);
-  L8::gs_hm(x1, tw.t, k); ln.m_to_h(x1);
-  L8::gs_hm(y1, tw.t, k); ln.m_to_h(y1);
+  if constexpr (two) {
+    L8::gs_hm(x1, tw.t, k); ln.m_to_h(x1);
+    L8::gs_hm(y1, tw.t, k); ln.m_to_h(y1);
+  }
   tw.load_h(ln, wave0, a.logn, wi);
   L8::gs_hm(x0, tw.t, k);
   ln.store_h(a.dst[0] + off0, x0);
   L8::gs_hm(y0, tw.t, k);
   ln.store_h(a.dst[1] + off0, y0);
-  if (two) {
+  if constexpr (two) {
     L8::gs_hm(x1, tw.t, k);
     ln.store_h(a.dst[0] + off1, x1);
     L8::gs_hm(y1, tw.t, k);

@@ -24,7 +24,7 @@ KERNELS = {   # bench.py's kernel names -> mangled-name fragments of the headlin
     "strided_fwd": "strided_passILi8ELi4ELb0ELb0ENS_3TwWELi8E",
     "strided_inv": "strided_passILi8ELi4ELb1ELb0ENS_3TwWELi8E",
     "tensor_mid": "tensor_mid8INS_3TwWELi8E",
-    "keyswitch_mid": "keyswitch_mid8x2INS_3TwWELi8E",
+    "keyswitch_mid": "keyswitch_mid8x2INS_3TwWELi8ELb1E",
     "contig_fwd": "contig_passILb0ENS_3TwWEEE",
     "contig_inv": "contig_passILb1ENS_3TwWEEE",
 }
