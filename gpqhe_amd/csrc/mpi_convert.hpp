@@ -244,6 +244,12 @@ void to_slab_range(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W, u
   const bool direct = mpi_direct();
   for (unsigned i = lo; i < hi; ++i) {
     MPI v = a->coeffs[i];
+    if (direct) {
+      // the integers are 65536 separate heap objects, each with its own limb array: two dependent cache misses per coefficient
+      // unless they are asked for a few coefficients ahead (struct at i + 12, its limbs at i + 6)
+      if (i + 12 < hi) __builtin_prefetch(a->coeffs[i + 12]);
+      if (i + 6 < hi) { const uint64_t *d = ((const MpiView *)a->coeffs[i + 6])->d; __builtin_prefetch(d); __builtin_prefetch(d + 8); }
+    }
     if (direct && !(((const MpiView *)v)->flags & 4)) {          // limbs in place: little-endian magnitude + sign
       const MpiView *m = (const MpiView *)v;
       unsigned nl = m->nlimbs > 0 ? (unsigned)m->nlimbs : 0;
@@ -291,6 +297,10 @@ void from_slab_range(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W,
   unsigned char buf[8 * 64];
   const bool direct = mpi_direct();
   for (unsigned i = lo; i < hi; ++i) {
+    if (direct) {                                             // as in to_slab_range: the destination integers are scattered heap objects
+      if (i + 12 < hi) __builtin_prefetch(r->coeffs[i + 12]);
+      if (i + 6 < hi) { uint64_t *d = ((MpiView *)r->coeffs[i + 6])->d; if (d) { __builtin_prefetch(d, 1); __builtin_prefetch(d + 8, 1); } }
+    }
     uint64_t w[64];
     for (unsigned j = 0; j < W; ++j) w[j] = src[(size_t)j * n + i];
     const bool neg = w[W - 1] >> 63;

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -112,48 +113,70 @@ void copy_range(void *dst, const void *src, unsigned n, unsigned W, unsigned lo,
     die("slab copy failed");
 }
 
-// MPI polynomials -> device big slabs: every host thread converts its range of a polynomial into page-locked memory and sends
-// that range off at once, so conversion of the next range / polynomial overlaps the DMA of the previous one.
+// Transfers go in few, large pieces: a copy of a sixteenth of a polynomial (448 KB) moves at 25 GB/s over PCIe here, a whole polynomial
+// (7 MB) at 53 GB/s -- about 9 us of fixed cost per copy (tools/copy_probe.hip) -- so the ranges the host threads convert are grouped
+// four to a copy: coarse enough for the link, fine enough for conversions and DMA to overlap.
+constexpr unsigned kRangesPerCopy = 4;
+
+// MPI polynomials -> device big slabs: every host thread converts its range of a polynomial into page-locked memory; the thread that
+// finishes the last range of a group of kRangesPerCopy sends the group off, so conversion of the next ranges / polynomial overlaps the DMA.
 // `extra` more tasks (side(0) .. side(extra - 1)) are handed out to the same threads behind the ranges -- the evaluation-key
-// fingerprint of he_mul / he_rot / he_conj, which only reads memory while the conversions compute.
+// fingerprint of a key that is not resident yet, which only reads memory while the conversions compute.
 void upload_polys(const DevBuf *const dst[], const HostBuf *const stage[], const poly_mpi_t *const src[], int count, unsigned n, unsigned W,
                   unsigned extra = 0, const std::function<void(unsigned)> *side = nullptr) {
   if (W < 1 || W > 32) die("coefficients wider than 2047 bits");
   const unsigned nt = n >= 4096 ? workers().width() : 1, per = (n + nt - 1) / nt;
+  const unsigned ranges = (n + per - 1) / per, groups = (ranges + kRangesPerCopy - 1) / kRangesPerCopy;
+  std::vector<std::atomic<unsigned>> done((size_t)count * groups);
+  for (auto &d : done) d.store(0, std::memory_order_relaxed);
   const std::function<void(unsigned)> job = [&](unsigned t) {
     if (t >= nt) { (*side)(t - nt); return; }
     const unsigned lo = t * per, hi = lo + per < n ? lo + per : n;
     if (lo >= hi) return;
     (void)hipSetDevice(g_dev);
+    const unsigned g = t / kRangesPerCopy, first = g * kRangesPerCopy, last = first + kRangesPerCopy < ranges ? first + kRangesPerCopy : ranges;
     for (int i = 0; i < count; ++i) {
       to_slab_range(stage[i]->u64(), src[i], n, W, lo, hi);
-      copy_range(dst[i]->p, stage[i]->p, n, W, lo, hi, hipMemcpyHostToDevice);
+      if (done[(size_t)i * groups + g].fetch_add(1, std::memory_order_acq_rel) + 1 == last - first) {      // the group is complete: one copy for all of it
+        const unsigned glo = first * per, ghi = last * per < n ? last * per : n;
+        copy_range(dst[i]->p, stage[i]->p, n, W, glo, ghi, hipMemcpyHostToDevice);
+      }
     }
   };
   if (nt + extra < 2) job(0); else workers().run(nt + extra, job);
 }
 
-// device big slabs -> the caller's MPIs: the ranges come back one DMA each, in order, an event behind every one; a host thread
-// converts its range as soon as that range has landed while the later ones are still in flight.
-void download_polys(poly_mpi_t *const dst[], const HostBuf *const stage[], const DevBuf *const src[], int count, unsigned n, unsigned W) {
+// device big slabs -> the caller's MPIs: the ranges come back one DMA per group of kRangesPerCopy, in order, an event behind every one; a
+// host thread converts its range as soon as its group has landed while the later ones are still in flight.
+// Phase 1 (download_issue): the copies and their events are queued behind the kernels.  Phase 2 (download_convert): the conversions.
+// Between the two the host threads are free while the device works -- he_mul / he_rot / he_conj verify the evaluation key there.
+void download_issue(const HostBuf *const stage[], const DevBuf *const src[], int count, unsigned n, unsigned W) {
   if (W < 1 || W > 64) die("big slab wider than 64 words");
   const unsigned nt = n >= 4096 ? workers().width() : 1, per = (n + nt - 1) / nt;
-  const unsigned ranges = (n + per - 1) / per;            // the non-empty ones: [t per, min(n, (t + 1) per)), t < ranges <= nt
+  const unsigned ranges = (n + per - 1) / per, groups = (ranges + kRangesPerCopy - 1) / kRangesPerCopy;
   for (int i = 0; i < count; ++i)
-    for (unsigned t = 0; t < ranges; ++t) {
-      const unsigned lo = t * per, hi = lo + per < n ? lo + per : n;
+    for (unsigned g = 0; g < groups; ++g) {
+      const unsigned lo = g * kRangesPerCopy * per, hi = (g + 1) * kRangesPerCopy * per < n ? (g + 1) * kRangesPerCopy * per : n;
       copy_range(stage[i]->p, src[i]->p, n, W, lo, hi, hipMemcpyDeviceToHost);
-      if (hipEventRecord(event_at((size_t)i * ranges + t), nullptr) != hipSuccess) die("hipEventRecord failed");
+      if (hipEventRecord(event_at((size_t)i * groups + g), nullptr) != hipSuccess) die("hipEventRecord failed");
     }
+}
+void download_convert(poly_mpi_t *const dst[], const HostBuf *const stage[], int count, unsigned n, unsigned W) {
+  const unsigned nt = n >= 4096 ? workers().width() : 1, per = (n + nt - 1) / nt;
+  const unsigned ranges = (n + per - 1) / per, groups = (ranges + kRangesPerCopy - 1) / kRangesPerCopy;
   const std::function<void(unsigned)> job = [&](unsigned t) {
     (void)hipSetDevice(g_dev);
     const unsigned lo = t * per, hi = lo + per < n ? lo + per : n;
     for (int i = 0; i < count; ++i) {
-      if (hipEventSynchronize(g_events[(size_t)i * ranges + t]) != hipSuccess) die("download failed");
+      if (hipEventSynchronize(g_events[(size_t)i * groups + t / kRangesPerCopy]) != hipSuccess) die("download failed");
       from_slab_range(dst[i], stage[i]->u64(), n, W, lo, hi);
     }
   };
   if (ranges < 2) job(0); else workers().run(ranges, job);
+}
+void download_polys(poly_mpi_t *const dst[], const HostBuf *const stage[], const DevBuf *const src[], int count, unsigned n, unsigned W) {
+  download_issue(stage, src, count, n, W);
+  download_convert(dst, stage, count, n, W);
 }
 
 // Where the wall time of the last he_mul call went (gpq_mpi_shim_last_timing): conversions + uploads, kernels (HIP events),
@@ -168,9 +191,10 @@ double wall_ms() {
 
 // Evaluation keys are 2 x dim x n words (47 MB at the headline shape) and the same key multiplies many ciphertexts: the device
 // copy is kept, identified by the caller's two pointers, the length and a fingerprint of EVERY word (the reference reads the key
-// it is given on every call, src/he-mult.c:60-64: a key edited in place, in however few words, must multiply as edited).  The
-// fingerprint is computed by the conversion threads next to the ciphertext conversions (KeyPrint: it only reads memory while they
-// compute); gpq_mpi_shim_set_key_check(0) goes back to ~1000 sampled words for callers that never edit a key in place.
+// it is given on every call, src/he-mult.c:60-64: a key edited in place, in however few words, must multiply as edited).  For a
+// key that is resident the fingerprint is computed by the host threads WHILE the device works with the resident copy (they would
+// wait for it otherwise: resident_key / key_still_valid; a mismatch repeats the device work with the fresh key); for a new key, next
+// to the ciphertext conversions.  gpq_mpi_shim_set_key_check(0) goes back to ~1000 sampled words for callers that never edit a key in place.
 struct KeySlot { const uint64_t *h0, *h1; size_t words; uint64_t print; void *d0, *d1; uint64_t used; };
 std::vector<KeySlot> g_keys;
 uint64_t g_key_clock = 0;
@@ -220,6 +244,19 @@ void forget_key_at(const uint64_t *h0, const uint64_t *h1) {          // the hos
   for (size_t i = g_keys.size(); i-- > 0;)
     if (g_keys[i].h0 == h0 || g_keys[i].h1 == h1 || g_keys[i].h0 == h1 || g_keys[i].h1 == h0) drop_key_slot(i);
 }
+// A resident copy of the host key at these addresses and of this length, whatever its fingerprint: he_mul / he_rot / he_conj start
+// the device work with it at once and verify the fingerprint on the host threads WHILE the device works (they would otherwise wait
+// for it); a mismatch -- the key was edited in place since -- uploads the key and runs the device work again.
+KeySlot *resident_key(const he_evk_t *key, size_t words) {
+  for (KeySlot &k : g_keys)
+    if (k.h0 == key->p0.coeffs && k.h1 == key->p1.coeffs && k.words == words) { k.used = ++g_key_clock; return &k; }
+  return nullptr;
+}
+bool key_still_valid(KeySlot *slot, KeyPrint &kp) {
+  if (kp.parts < 2) kp.task(0); else workers().run(kp.parts, kp.task);
+  return kp.value() == slot->print;
+}
+
 void key_on_device(const KeyPrint &kp, uint64_t **d0, uint64_t **d1) {
   const uint64_t *h0 = kp.h0, *h1 = kp.h1;
   const size_t words = kp.words;
@@ -373,22 +410,32 @@ void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t 
   const bool square = ct1->c0.coeffs == ct2->c0.coeffs && ct1->c1.coeffs == ct2->c1.coeffs;
   const double t0 = wall_ms();
   KeyPrint kp(rlk, evk);
-  upload_polys(dd, ss, in, square ? 2 : 4, n, W, kp.parts, &kp.task);
+  KeySlot *spec = resident_key(rlk, evk);                  // a resident copy: used at once, verified while the device works
+  if (spec) upload_polys(dd, ss, in, square ? 2 : 4, n, W);
+  else upload_polys(dd, ss, in, square ? 2 : 4, n, W, kp.parts, &kp.task);
   uint64_t *k0, *k1;
-  key_on_device(kp, &k0, &k1);
+  if (spec) { k0 = (uint64_t *)spec->d0; k1 = (uint64_t *)spec->d1; } else key_on_device(kp, &k0, &k1);
   if (!g_tick[0]) { (void)hipEventCreate(&g_tick[0]); (void)hipEventCreate(&g_tick[1]); }
   (void)hipEventRecord(g_tick[0], nullptr);
   const double t1 = wall_ms();
   uint64_t *const e0 = square ? d0.u64() : d2.u64(), *const e1 = square ? d1.u64() : d3.u64();
-  const int rc = pow2 ? gpq_he_mul(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), e0, e1, k0, k1, W, logql, dimA, dimB, dimP,
-                                   1, ws.p, nullptr)
-                      : gpq_he_mul_general(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), e0, e1, k0, k1, W, qw.data(),
-                                           (unsigned)qw.size(), dimA, dimB, dimP, 1, ws.p, nullptr);
-  if (rc != GPQ_OK) die("he_mul failed");
-  (void)hipEventRecord(g_tick[1], nullptr);
+  auto device_work = [&]() {
+    const int rc = pow2 ? gpq_he_mul(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), e0, e1, k0, k1, W, logql, dimA, dimB, dimP,
+                                     1, ws.p, nullptr)
+                        : gpq_he_mul_general(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), e0, e1, k0, k1, W, qw.data(),
+                                             (unsigned)qw.size(), dimA, dimB, dimP, 1, ws.p, nullptr);
+    if (rc != GPQ_OK) die("he_mul failed");
+    (void)hipEventRecord(g_tick[1], nullptr);
+    download_issue(ss, oo, 2, n, W);
+  };
+  device_work();
   const double t2 = wall_ms();
+  if (spec && !key_still_valid(spec, kp)) {                // edited in place since the upload: the reference reads its key on every call
+    key_on_device(kp, &k0, &k1);
+    device_work();
+  }
   poly_mpi_t *out[2] = {&ct->c0, &ct->c1};
-  download_polys(out, ss, oo, 2, n, W);
+  download_convert(out, ss, 2, n, W);
   const double t3 = wall_ms();
   float dev_ms = 0;
   (void)hipEventElapsedTime(&dev_ms, g_tick[0], g_tick[1]);
@@ -481,18 +528,28 @@ static void automorphism(he_ct_t *ct, const he_evk_t *key, bool conj, unsigned r
   const HostBuf *ss[2] = {&s0, &s1};
   const poly_mpi_t *in[2] = {&ct->c0, &ct->c1};
   KeyPrint kp(key, evk);
-  upload_polys(dd, ss, in, 2, n, W, kp.parts, &kp.task);
+  KeySlot *spec = resident_key(key, evk);
+  if (spec) upload_polys(dd, ss, in, 2, n, W);
+  else upload_polys(dd, ss, in, 2, n, W, kp.parts, &kp.task);
   uint64_t *k0, *k1;
-  key_on_device(kp, &k0, &k1);
-  int rc = conj ? gpq_poly_conj(c, r0.u64(), a0.u64(), W, 1, nullptr) : gpq_poly_rot(c, r0.u64(), a0.u64(), W, rot, 1, nullptr);      // :95-96 / :108-109
-  if (rc == GPQ_OK) rc = conj ? gpq_poly_conj(c, r1.u64(), a1.u64(), W, 1, nullptr) : gpq_poly_rot(c, r1.u64(), a1.u64(), W, rot, 1, nullptr);
-  if (rc == GPQ_OK)                                                                                                                       // :97 / :110
-    rc = pow2 ? gpq_he_swk(c, o0.u64(), o1.u64(), r0.u64(), r1.u64(), k0, k1, W, logql, dimB, dimP, 1, ws.p, nullptr)
-              : gpq_he_swk_general(c, o0.u64(), o1.u64(), r0.u64(), r1.u64(), k0, k1, W, qw.data(), (unsigned)qw.size(), dimB, dimP, 1,
-                                   ws.p, nullptr);
-  if (rc != GPQ_OK) die("he_rot/he_conj failed");
+  if (spec) { k0 = (uint64_t *)spec->d0; k1 = (uint64_t *)spec->d1; } else key_on_device(kp, &k0, &k1);
+  auto device_work = [&]() {
+    int rc = conj ? gpq_poly_conj(c, r0.u64(), a0.u64(), W, 1, nullptr) : gpq_poly_rot(c, r0.u64(), a0.u64(), W, rot, 1, nullptr);      // :95-96 / :108-109
+    if (rc == GPQ_OK) rc = conj ? gpq_poly_conj(c, r1.u64(), a1.u64(), W, 1, nullptr) : gpq_poly_rot(c, r1.u64(), a1.u64(), W, rot, 1, nullptr);
+    if (rc == GPQ_OK)                                                                                                                       // :97 / :110
+      rc = pow2 ? gpq_he_swk(c, o0.u64(), o1.u64(), r0.u64(), r1.u64(), k0, k1, W, logql, dimB, dimP, 1, ws.p, nullptr)
+                : gpq_he_swk_general(c, o0.u64(), o1.u64(), r0.u64(), r1.u64(), k0, k1, W, qw.data(), (unsigned)qw.size(), dimB, dimP, 1,
+                                     ws.p, nullptr);
+    if (rc != GPQ_OK) die("he_rot/he_conj failed");
+    download_issue(ss, oo, 2, n, W);
+  };
+  device_work();
+  if (spec && !key_still_valid(spec, kp)) {
+    key_on_device(kp, &k0, &k1);
+    device_work();
+  }
   poly_mpi_t *out[2] = {&ct->c0, &ct->c1};
-  download_polys(out, ss, oo, 2, n, W);
+  download_convert(out, ss, 2, n, W);
 }
 void he_conj(he_ct_t *ct, const he_evk_t *ck) { automorphism(ct, ck, true, 0); }
 void he_rot(he_ct_t *ct, const int rot, const he_evk_t *rk) { automorphism(ct, &rk[rot], false, (unsigned)rot); }   // rk[rot], :110
