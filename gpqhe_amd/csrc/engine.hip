@@ -492,6 +492,10 @@ int after_launch(const char *who) {
 // clears what it finds set).  An outgrown buffer is retired, not freed: a HIP graph captured earlier may still use it.
 int zero_flags(gpq_ctx *c, size_t count, hipStream_t s, unsigned **out) {
   if (count > c->zflag_cap) {
+    // (growing inside a stream capture would put the allocation into the graph: the first call at a new size runs outside capture, as for the CRT scratch)
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap_status) == hipSuccess && cap_status != hipStreamCaptureStatusNone)
+      return gpq_fail(GPQ_ERR_INVALID, "the first gpq_ntt at a new batch size allocates its zero flags: run it once outside stream capture");
     DeviceScope on_device(c->device);
     unsigned *fresh = nullptr;
     const size_t cap = count < 4096 ? 4096 : count;
