@@ -335,7 +335,8 @@ def cpu_baseline(ctx, host_inputs, gpu_outputs, sample):
     dt = time.perf_counter() - t0
     out = {"value": sample / dt, "unit": "he_mul/s", "cores": 1, "kind": "port",
            "sample": "%d he_mul RNS cores (tensor %d limbs + key-switch %d limbs, n=2^%d) of the same batch, %.1f s" % (sample, DIM_A, DIM_B, LOGN, dt),
-           "bit_exact_vs_gpu": bool(ok)}
+           "bit_exact_vs_gpu": bool(ok),
+           "build": "oracle/gpqhe_oracle.c, gcc -O2 (oracle/Makefile; the survey timed the reference itself at its own -Og: this port is the more generous baseline)"}
     # the same loops with OpenMP over the limbs on every core this process may use (optional, core count stated)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(cores, 16)             # the CPU share of a one-GPU box; more threads than limbs per stage buy nothing anyway
