@@ -75,6 +75,7 @@ SIGNATURES = {
     "gpq_he_mul": (C.c_int, [vp] * 9 + [C.c_uint] * 6 + [vp, vp]),
     "gpq_relin_tail_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
     "gpq_relin_tail": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
+    "gpq_relin_tail_overwriting": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
     "gpq_he_mulpt_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
     "gpq_he_mulpt": (C.c_int, [vp] * 6 + [C.c_uint] * 4 + [vp, vp]),
     "gpq_poly_rot": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, vp]),

@@ -205,12 +205,13 @@ void balanced_digits(const uint64_t *words, size_t nwords, int8_t *out, size_t n
   }
 }
 
-// constant matrix, offsets and multiples of P for bridge_reconstruct_low_mfma<WL> on basis b
-int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out) {
-  auto it = b->mfma.find(WL);
-  if (it != b->mfma.end()) { *out = &it->second; return GPQ_OK; }
-  gpq_recon_mfma t;
-  const unsigned dim = b->dim, NT = (8 * WL + 14 + 31) / 32, ncol = 32 * NT;
+// Constant matrix, offsets and multiples of `Pw` for bridge_reconstruct_low_mfma<WL>: the contraction sum_d y_d * weight_d mod 2^(64 WL)
+// plus the fixed-point columns F = sum_d y_d floor(2^104 / p_d).  For a CRT, weight_d = P/p_d and Pw = P (get_recon_mfma); for the
+// one-product relinearisation tail, weight_d = floor(Pi' 2^104 / p_d) and Pw = Pi' 2^104 (get_tail_direct).
+int build_recon_mfma(gpq_ctx *c, const std::vector<uint64_t> &primes, const std::vector<uint64_t> &weight_inv, const std::vector<Big> &weight,
+                     const Big &Pw, int WL, gpq_recon_mfma *tp) {
+  gpq_recon_mfma &t = *tp;
+  const unsigned dim = (unsigned)primes.size(), NT = (8 * WL + 14 + 31) / 32, ncol = 32 * NT;
   t.KS = (dim + 3) / 4;
   t.lds_bytes = (size_t)t.KS * NT * 1024 + (size_t)t.KS * 64;
   if (t.lds_bytes <= 156 * 1024) {
@@ -220,16 +221,16 @@ int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out
     Big sum_phat(WL, 0);
     u128h sum_inv = 0;
     for (unsigned d = 0; d < dim; ++d) {
-      const uint64_t pd = c->p[b->first + d];
+      const uint64_t pd = primes[d];
       lk[2 * (size_t)d] = pd;
-      lk[2 * (size_t)d + 1] = b->h_phat_inv[d];
-      const uint64_t *ph = &b->h_phat[(size_t)d * b->WP];
-      balanced_digits(ph, (size_t)b->WP < (size_t)WL ? b->WP : WL, beta.data(), beta.size());
+      lk[2 * (size_t)d + 1] = weight_inv[d];
+      const Big &ph = weight[d];
+      balanced_digits(ph.data(), ph.size() < (size_t)WL ? ph.size() : (size_t)WL, beta.data(), beta.size());
       const uint64_t inv = (uint64_t)((((u128h)1) << 104) / pd);                       // < 2^46
       balanced_digits(&inv, 1, phi.data(), 8);
-      uint64_t cy = 0;                                                                   // sum_phat += phat_d mod 2^(64 WL)
+      uint64_t cy = 0;                                                                   // sum_phat += weight_d mod 2^(64 WL)
       for (int j = 0; j < WL; ++j) {
-        const u128h s2 = (u128h)sum_phat[j] + (j < b->WP ? ph[j] : 0) + cy;
+        const u128h s2 = (u128h)sum_phat[j] + ((size_t)j < ph.size() ? ph[j] : 0) + cy;
         sum_phat[j] = (uint64_t)s2; cy = (uint64_t)(s2 >> 64);
       }
       sum_inv += inv;
@@ -245,7 +246,7 @@ int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out
         }
       }
     }
-    // offsets of the signed bytes: 0x8080..80 * sum phat_d (mod 2^(64 WL)) and 0x8080..80 * sum inv_d
+    // offsets of the signed bytes: 0x8080..80 * sum weight_d (mod 2^(64 WL)) and 0x8080..80 * sum inv_d
     Big kcS = sum_phat;
     mul_small(kcS, 0x8080808080808080ull);
     for (int j = 0; j < WL; ++j) kc[j] = (size_t)j < kcS.size() ? kcS[j] : 0;
@@ -255,15 +256,15 @@ int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out
     kc[WL] = (uint64_t)kf; kc[WL + 1] = (uint64_t)(kf >> 64);
     Big mP{0};
     for (unsigned m = 0; m <= 64; ++m) {
-      uint64_t bw = 0;                                                                   // (m P - Kc) mod 2^(64 WL)
+      uint64_t bw = 0;                                                                   // (m Pw - Kc) mod 2^(64 WL)
       for (int j = 0; j < WL; ++j) {
         const u128h d2 = (u128h)((size_t)j < mP.size() ? mP[j] : 0) - kc[j] - bw;
         pm[(size_t)m * WL + j] = (uint64_t)d2; bw = (uint64_t)(d2 >> 64) & 1;
       }
-      Big nxt(std::max(mP.size(), b->h_P.size()) + 1, 0);                                // mP += P
+      Big nxt(std::max(mP.size(), Pw.size()) + 1, 0);                                    // mP += Pw
       uint64_t cy = 0;
       for (size_t j = 0; j < nxt.size(); ++j) {
-        const u128h s2 = (u128h)(j < mP.size() ? mP[j] : 0) + (j < b->h_P.size() ? b->h_P[j] : 0) + cy;
+        const u128h s2 = (u128h)(j < mP.size() ? mP[j] : 0) + (j < Pw.size() ? Pw[j] : 0) + cy;
         nxt[j] = (uint64_t)s2; cy = (uint64_t)(s2 >> 64);
       }
       mP = nxt;
@@ -278,10 +279,28 @@ int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out
     HIP_TRY(hipMemcpy(t.d_kc, kc.data(), kc.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.d_pm, pm.data(), pm.size() * 8, hipMemcpyHostToDevice));
   }
+  return GPQ_OK;
+}
+
+// ... for the CRT over basis b
+int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out) {
+  auto it = b->mfma.find(WL);
+  if (it != b->mfma.end()) { *out = &it->second; return GPQ_OK; }
+  gpq_recon_mfma t;
+  std::vector<uint64_t> primes(b->dim);
+  std::vector<Big> weight(b->dim);
+  for (unsigned d = 0; d < b->dim; ++d) {
+    primes[d] = c->p[b->first + d];
+    weight[d].assign(b->h_phat.begin() + (size_t)d * b->WP, b->h_phat.begin() + (size_t)(d + 1) * b->WP);
+  }
+  if (int rc = build_recon_mfma(c, primes, b->h_phat_inv, weight, b->h_P, WL, &t)) return rc;
   *out = &(b->mfma[WL] = t);
   return GPQ_OK;
 }
 
+template <int WL>
+int launch_low_mfma(const ReconMfmaArgs &a, size_t lds, hipStream_t s);
+int launch_low_mfma16(const ReconMfmaArgs &a, size_t lds, hipStream_t s) { return launch_low_mfma<16>(a, lds, s); }
 template <int WL>
 int launch_low_mfma(const ReconMfmaArgs &a, size_t lds, hipStream_t s) {
   static LdsRaised raised;
@@ -347,7 +366,7 @@ int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, uns
       if (t->d_bfrag) {
         const unsigned gpp = n >> 6;
         ReconMfmaArgs m{slab, bigs, (const v4i *)t->d_bfrag, t->d_lk, t->d_kc, t->d_pm, c->d_redo, tie, b->dim, t->KS, logn, Wout, logq,
-                        slab_dim, slab_first, gpp, gpp * batch, x.addend, x.rflags, x.prescaled ? 1u : 0u};
+                        slab_dim, slab_first, gpp, gpp * batch, x.addend, x.rflags, x.prescaled ? 1u : 0u, 0u, nullptr};
         if (x.fused && x.rflags) *x.fused = true;
         switch (WL) {
           case 1: rc = launch_low_mfma<1>(m, t->lds_bytes, s); break;
@@ -522,7 +541,9 @@ void gpq_bridge_release(gpq_ctx *c) {
   for (auto &kv : c->relins) {
     (void)hipFree(kv.second.d_pinv);
     for (void *q : {kv.second.d_bfrag, (void *)kv.second.d_lk, (void *)kv.second.d_pk, (void *)kv.second.d_tkp, (void *)kv.second.d_kf,
-                    kv.second.d_bfrag_w, (void *)kv.second.d_pk_w, (void *)kv.second.d_tkp_w, (void *)kv.second.d_tabs_w})
+                    kv.second.d_bfrag_w, (void *)kv.second.d_pk_w, (void *)kv.second.d_tkp_w, (void *)kv.second.d_tabs_w,
+                    kv.second.direct.d_bfrag, (void *)kv.second.direct.d_lk, (void *)kv.second.direct.d_kc, (void *)kv.second.direct.d_pm,
+                    (void *)kv.second.d_scale, (void *)kv.second.d_unscale})
       if (q) (void)hipFree(q);
   }
   c->relins.clear();
@@ -762,9 +783,54 @@ int get_relin_front(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables *
   return GPQ_OK;
 }
 
+// Tables of the ONE-PRODUCT relinearisation tail (bridge_reconstruct_low_mfma<16> with frac_bits = 104, bridge_mfma.hpp).  With y_d the
+// residues scaled for the CRT over ALL dimB limbs (Pi_B = P Pi'), x = sum_d y_d Pi_B/p_d - kappa Pi_B and
+//     2^104 x / P = sum_d y_d (Pi' 2^104 / p_d) - kappa Pi' 2^104 :
+// exact integers for the limbs above P (p_j divides Pi'), floors for the limbs of P -- an underestimate by less than dimP 2^60 units of
+// 2^-104.  The low 104 bits of the 16-word sum are the fraction (x mod P)/P that mpi_rdiv rounds on, the bits above floor(x/P); kappa
+// (the multiples of Pi_B the centring of x takes off) comes from the same F columns as in any CRT.  Also: the per-limb table that makes
+// the key switch's inverse pass deliver y_d (ScaledInverse), and the weights Pi_B/p_d mod p_d that take the scaling off again
+// (bridge_limb_scale) for the few groups the exact kernels re-run.
+int get_tail_direct(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables *rt) {
+  if (rt->direct_tried) return GPQ_OK;
+  rt->direct_tried = true;
+  gpq_bridge_basis *bB, *bq;
+  int rc;
+  if (dimB > 60 || dimB - dimP < 4) return GPQ_OK;
+  if ((rc = get_basis(c, 0, dimB, &bB)) || (rc = get_basis(c, dimP, dimB - dimP, &bq))) return rc;
+  if (c->h_tabs.empty()) return GPQ_OK;
+  constexpr int WL = 16;
+  Big num = bq->h_P;                                        // Pi' 2^104
+  num.insert(num.begin(), 0);                               // << 64
+  mul_small(num, 1ull << 40);                               // << 40
+  std::vector<uint64_t> primes(dimB), scale(dimB), unscale(dimB);
+  std::vector<Big> weight(dimB);
+  for (unsigned d = 0; d < dimB; ++d) {
+    primes[d] = c->p[d];
+    Big q = num;
+    (void)divmod_small(q, primes[d]);                       // floor(Pi' 2^104 / p_d): exact for d >= dimP
+    q.resize(WL < (int)q.size() ? q.size() : WL, 0);
+    weight[d] = q;
+    scale[d] = bB->h_phat_inv[d];                           // (Pi_B/p_d)^-1 mod p_d
+    Big ph(bB->h_phat.begin() + (size_t)d * bB->WP, bB->h_phat.begin() + (size_t)(d + 1) * bB->WP);
+    unscale[d] = mod_small(ph, primes[d]);                  // Pi_B/p_d mod p_d
+  }
+  if ((rc = build_recon_mfma(c, primes, scale, weight, num, WL, &rt->direct))) return rc;
+  if (!rt->direct.d_bfrag) return GPQ_OK;
+  const LimbTab *tabs;
+  if ((rc = get_scaled_tabs(c, bB, &tabs))) return rc;
+  rt->d_tabs_direct = tabs;
+  DeviceScope on_device(c->device);
+  HIP_TRY(hipMalloc((void **)&rt->d_scale, dimB * 8));
+  HIP_TRY(hipMalloc((void **)&rt->d_unscale, dimB * 8));
+  HIP_TRY(hipMemcpy(rt->d_scale, scale.data(), dimB * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(rt->d_unscale, unscale.data(), dimB * 8, hipMemcpyHostToDevice));
+  return GPQ_OK;
+}
+
 // How the key switch of gpq_he_mul / gpq_he_swk may scale its output for the tail that follows: 0 = not at all, 1 = the limbs of P by
 // (P/p_d)^-1 (any tail), 2 = also the limbs above P by w_j (the matrix-core front only: its exact fallbacks read those limbs through
-// the same tables).  *tabs = the per-limb table the inverse pass reads.
+// the same tables), 3 = every limb by (Pi_B/p_d)^-1 for the one-product tail.  *tabs = the per-limb table the inverse pass reads.
 int tail_prescale_mode(gpq_ctx *c, unsigned dimP, unsigned dimB, const LimbTab **tabs, int *mode) {
   *tabs = nullptr; *mode = 0;
   if (!can_prescale(c)) return GPQ_OK;
@@ -773,6 +839,10 @@ int tail_prescale_mode(gpq_ctx *c, unsigned dimP, unsigned dimB, const LimbTab *
   int rc;
   if ((rc = get_basis(c, 0, dimP, &bp)) || (rc = get_basis(c, dimP, dimB - dimP, &bq)) || (rc = get_relin(c, dimP, dimB, &rt))) return rc;
   if (c->bridge_mfma && c->logn >= 6 && (rc = get_relin_front(c, dimP, dimB, rt, bp, bq))) return rc;
+  if (c->bridge_mfma && c->logn >= 6 && rt->d_bfrag && c->tail_direct && !c->exact_crt && !c->fuse_tail) {
+    if ((rc = get_tail_direct(c, dimP, dimB, rt))) return rc;
+    if (rt->direct.d_bfrag && rt->d_tabs_direct) { *tabs = rt->d_tabs_direct; *mode = 3; return GPQ_OK; }
+  }
   if (c->bridge_mfma && c->logn >= 6 && rt->d_bfrag && rt->d_tabs_w && c->prescale_upper) { *tabs = rt->d_tabs_w; *mode = 2; return GPQ_OK; }
   *mode = 1;
   return get_scaled_tabs(c, bp, tabs);
@@ -832,6 +902,47 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
   // in place (out IS d) the exact kernel must not park Q over d: Q goes through qc
   const bool in_place = (dbig.a && dbig.a == out.a) || (dbig.b && dbig.b == out.b);
 
+  if (chat_prescaled == 3) {
+    // The limbs carry the CRT weights of the whole basis (ScaledInverse with get_tail_direct's table): ONE product gives floor(x/P), the
+    // rounding decision and the centring of x.  `chat` is the caller's scratch here (c0hat | c1hat of the workspace): the groups of
+    // 64 coefficients the product cannot decide get their weights taken off in place and go through the exact sequence below.
+    uint64_t *chat_rw = const_cast<uint64_t *>(chat);
+    unsigned char *flags = (unsigned char *)rhat, *amb = flags + ((size_t)polys << c->logn);
+    const unsigned char *redo_only = nullptr;
+    const bool direct_ok = !in_place && rt->direct.d_bfrag && W <= 14 && logql <= 896 && c->bridge_mfma;
+    if (direct_ok) {
+      if ((rc = ensure_redo(c, (size_t)polys << c->logn, s))) return rc;
+      const unsigned gpp = c->n >> 6;
+      ReconMfmaArgs m{chat, out, (const v4i *)rt->direct.d_bfrag, rt->direct.d_lk, rt->direct.d_kc, rt->direct.d_pm, c->d_redo, tie, dimB, rt->direct.KS,
+                      c->logn, W, logql, dimB, 0, gpp, gpp * polys, dbig, nullptr, 1u, 104u, amb};
+      {
+        ProfScope prof(c, GPQ_K_RELIN_TAIL_DIRECT, s);
+        if ((rc = launch_low_mfma16(m, rt->direct.lds_bytes, s))) return rc;
+      }
+      redo_only = c->d_redo;
+    }
+    // weights off: for the flagged groups, or -- no product possible (in place, no tables) -- for every coefficient
+    LimbScaleArgs un{c->d_tabs, chat_rw, rt->d_unscale, redo_only, dimB, c->logn};
+    { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_limb_scale, cgrid, cblock, 0, s, un); }
+    if (!direct_ok) return relin_tail(c, out, chat, dbig, W, dimP, dimB, logql, polys, ws, s, 0);
+    // the exact sequence on the flagged groups: front (re-run, writing its flags), r for its ambiguous ones, round bits, Q, finish
+    const unsigned gpp = c->n >> 6;
+    RelinFrontArgs f{chat, qhat, (const v4i *)rt->d_bfrag, rt->d_lk, rt->d_pk, rt->d_tkp, rt->d_kf, flags, amb,
+                     dimB, dimP, tp.cnt, c->logn, rt->NT, gpp, gpp * polys, c->d_redo, 1u, 0u, 0u};
+    if ((rc = launch_relin_front(c, rt->KS, f, rt->lds_bytes, s))) return rc;
+    ReconExtra only_amb;
+    only_amb.only = amb;
+    if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, only_amb))) return rc;
+    RoundFixArgs rf{r, bp->d_phalf, amb, flags, tp.Wr, c->logn};
+    { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_roundfix, cgrid, cblock, 0, s, rf); }
+    ReconExtra q;
+    q.prescaled = true; q.exact_only = true; q.only = c->d_redo; q.big_b = out.b; q.split = out.split;
+    if ((rc = launch_reconstruct(c, bq, out.a, W, qhat, tp.cnt, 0, polys, logql, true, tie, s, -1, q))) return rc;
+    AddRoundArgs ar{out, Two<const uint64_t>{out.a, out.b, out.split}, nullptr, dbig, bp->d_phalf, piq, tie, W, tp.Wr, c->logn, logql, c->d_redo, flags};
+    { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_addround, cgrid, cblock, 0, s, ar); }
+    return launched("relin_tail");
+  }
+
   if (c->bridge_mfma && c->logn >= 6 && (rc = get_relin_front(c, dimP, dimB, rt, bp, bq))) return rc;
   if (c->bridge_mfma && c->logn >= 6 && rt->d_bfrag) {
     // Matrix-core front: Q's (pre-scaled) residues and the round bits straight from chat; the exact kernels only see the
@@ -840,7 +951,7 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
     const unsigned gpp = c->n >> 6;
     const bool wsc = chat_prescaled == 2;                 // the limbs above P arrive multiplied by w_j: the w-scaled tables, no multiplication in the epilogue
     RelinFrontArgs f{chat, qhat, (const v4i *)(wsc ? rt->d_bfrag_w : rt->d_bfrag), rt->d_lk, wsc ? rt->d_pk_w : rt->d_pk, wsc ? rt->d_tkp_w : rt->d_tkp, rt->d_kf, flags, amb,
-                     dimB, dimP, tp.cnt, c->logn, rt->NT, gpp, gpp * polys, nullptr, chat_prescaled ? 1u : 0u, wsc ? 1u : 0u};
+                     dimB, dimP, tp.cnt, c->logn, rt->NT, gpp, gpp * polys, nullptr, 0u, chat_prescaled ? 1u : 0u, wsc ? 1u : 0u};
     // One pass per coefficient (bridge_relin_tail_mfma): the front and the CRT of Q without the round trip of Q's residues.
     const unsigned need = (logql + 63) / 64;
     const int WLf = need <= 7 ? 7 : 14;
@@ -1076,6 +1187,31 @@ extern "C" int gpq_relin_tail(gpq_ctx *c, uint64_t *out, const uint64_t *chat, c
   return relin_tail(c, one_place(out), chat, one_place(d), W, dimP, dimB, logql, batch, workspace, (hipStream_t)stream);
 }
 
+// The same tail for a caller that gives `chat` up as scratch: the CRT weights of the whole basis are put on it in place and the
+// one-product kernel (tail_direct) finishes -- the form gpq_he_mul / gpq_he_swk reach without the extra pass, because their key
+// switch delivers the weighted limbs.  Falls back to gpq_relin_tail's kernels when the product is not available (shape, settings).
+extern "C" int gpq_relin_tail_overwriting(gpq_ctx *c, uint64_t *out, uint64_t *chat, const uint64_t *d, unsigned W, unsigned logql,
+                                          unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream) {
+  int rc = check(c, dimB, batch, "gpq_relin_tail_overwriting");
+  if (rc) return rc;
+  if (!out || !chat || !workspace || !logql || W < (logql + 63) / 64) return gpq_fail(GPQ_ERR_INVALID, "gpq_relin_tail_overwriting: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  gpq_bridge_basis *bp, *bq;
+  gpq_relin_tables *rt;
+  if (dimB <= dimP) return gpq_fail(GPQ_ERR_INVALID, "relin: dimB=%u must exceed dimP=%u", dimB, dimP);
+  if ((rc = get_basis(c, 0, dimP, &bp)) || (rc = get_basis(c, dimP, dimB - dimP, &bq)) || (rc = get_relin(c, dimP, dimB, &rt))) return rc;
+  int mode = 0;
+  if (c->bridge_mfma && c->logn >= 6 && c->tail_direct && !c->exact_crt) {
+    if ((rc = get_relin_front(c, dimP, dimB, rt, bp, bq)) || (rt->d_bfrag && (rc = get_tail_direct(c, dimP, dimB, rt)))) return rc;
+    if (rt->d_bfrag && rt->direct.d_bfrag && rt->d_scale) {
+      LimbScaleArgs sc{c->d_tabs, chat, rt->d_scale, nullptr, dimB, c->logn};
+      hipLaunchKernelGGL(bridge_limb_scale, dim3((c->n + 255) / 256, batch), dim3(256), 0, s, sc);
+      mode = 3;
+    }
+  }
+  return relin_tail(c, one_place(out), chat, one_place(d), W, dimP, dimB, logql, batch, workspace, s, mode);
+}
+
 // The relinearisation tail as one pass per coefficient (default) or as front + CRT kernels with Q's residues in memory between them;
 // bit-identical (tests run both).
 extern "C" int gpq_set_fused_tail(gpq_ctx *c, int on) {
@@ -1086,10 +1222,11 @@ extern "C" int gpq_set_fused_tail(gpq_ctx *c, int on) {
 
 // gpq_he_mul / gpq_he_swk let their inverse transforms hand the CRT kernels limbs already multiplied by (P/p_d)^-1 (default on); off = the
 // CRT kernels do that multiplication themselves.  Same results (tests run both).
-extern "C" int gpq_set_prescale(gpq_ctx *c, int on) {      // 0: off, 1: the CRT weights only, 2 (default): also w_j on the limbs above P for the relinearisation front
+extern "C" int gpq_set_prescale(gpq_ctx *c, int on) {      // 0: off, 1: the CRT weights only, 2: also w_j on the limbs above P for the relinearisation front, 3 (default): the one-product tail
   if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_prescale: null context");
   c->prescale = on != 0;
   c->prescale_upper = on >= 2;
+  c->tail_direct = on >= 3;
   return GPQ_OK;
 }
 

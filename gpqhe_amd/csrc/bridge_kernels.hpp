@@ -403,6 +403,21 @@ __global__ __launch_bounds__(256) void bridge_roundfix(RoundFixArgs a) {
   a.flags[at] = cmp > 0 ? 1 : (cmp < 0 ? 2 : 0);
 }
 
+// chat[poly][d][i] <- chat[poly][d][i] * scale[d] mod p_d, for every coefficient (only == nullptr) or for the groups of 64 coefficients that
+// hold a non-zero entry of `only`: puts the CRT weights of the one-product tail on a raw slab (gpq_relin_tail_overwriting), or takes them
+// off again for the groups its exact fallback re-runs with the kernels that read raw residues.
+struct LimbScaleArgs { const LimbTab *tabs; uint64_t *chat; const uint64_t *scale; const unsigned char *only; unsigned dim, logn; };
+__global__ __launch_bounds__(256) void bridge_limb_scale(LimbScaleArgs a) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;              // blockDim 256 = four groups of 64
+  if (i >= (1u << a.logn)) return;
+  if (a.only && !__builtin_amdgcn_ballot_w64(a.only[((size_t)blockIdx.y << a.logn) + i] != 0)) return;
+  uint64_t *__restrict__ p = a.chat + ((size_t)blockIdx.y * a.dim << a.logn) + i;
+  for (unsigned d = 0; d < a.dim; ++d) {
+    const PrimeK k = a.tabs[d].k;
+    p[(size_t)d << a.logn] = mulmod_canon(p[(size_t)d << a.logn], a.scale[d], k);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // he_genswk's combination (src/he-kem.c:86-99) before the reduction mod P q_L:  x = -t + e + P * sp  per coefficient, with
 // t = swk.p1 * sk (already mod P q_L), e the error, sp the polynomial the key hides (s^2, or the rotated / conjugated s).

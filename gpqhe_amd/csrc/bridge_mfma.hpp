@@ -175,6 +175,12 @@ struct ReconMfmaArgs {
   Two<const uint64_t> addend;    // optional [polys][Wout][n]: d of src/he-mult.c:72-76
   const unsigned char *rflags;   // optional [polys][n]: RF_GT = round the quotient up (mpi_rdiv)
   unsigned prescaled;            // the slab already holds y_d = ahat_d * phat_invmp_d (bridge_relin_front_mfma writes it so)
+  // The whole relinearisation tail as ONE product (WL = 16 only; bridge.hip: tail_direct): with frac_bits = 104 the constant matrix holds
+  // floor(Pi' 2^104 / p_d) for ALL limbs of the key switch's basis, so the columns are 2^104 x / P as a fixed-point number -- the low
+  // 104 bits its fraction (x mod P) / P, the rest floor(x / P): the quotient and the rounding decision of mpi_rdiv come out of the same
+  // contraction that centres x, without the residues of r = x mod P, without the exact division, without a second CRT.
+  unsigned frac_bits;
+  unsigned char *amb_clear;      // optional [polys][n]: cleared (the exact fallback's `amb` array must be 0 outside the groups it re-runs)
 };
 
 // per-coefficient flags of the relinearisation tail: r = x mod P against floor(P/2)
@@ -288,11 +294,11 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
     const u128 F = (((u128)V[WL + 1] << 64) | V[WL]) + (((u128)a.kc[WL + 1] << 64) | a.kc[WL]);
     const uint64_t f1 = (uint64_t)(F >> 64);
     const size_t flag_at = ((size_t)poly << a.logn) + coef0 + lane;
-    const bool ambiguous = ((f1 >> 2) & ((1ull << 38) - 1)) == ((1ull << 37) - 1);   // frac in [1/2 - 2^-38, 1/2)
-    a.redo[flag_at] = ambiguous;
+    bool ambiguous = ((f1 >> 2) & ((1ull << 38) - 1)) == ((1ull << 37) - 1);   // frac in [1/2 - 2^-38, 1/2)
     if (a.tie) a.tie[flag_at] = 0;
+    if (a.amb_clear) a.amb_clear[flag_at] = 0;
+    const unsigned mult = (unsigned)(f1 >> 40) + (unsigned)((f1 >> 39) & 1);       // k, plus one when centring takes P off once more
     if (!ambiguous) {
-      const unsigned mult = (unsigned)(f1 >> 40) + (unsigned)((f1 >> 39) & 1);       // k, plus one when centring takes P off once more
       const uint64_t *__restrict__ P = a.pm + (size_t)mult * WL;
       uint64_t borrow = 0;
 #pragma unroll
@@ -301,6 +307,43 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
         V[j] = (uint64_t)t;
         borrow = (uint64_t)(t >> 64) & 1;
       }
+    }
+    if constexpr (WL == 16) {
+      if (a.frac_bits && !ambiguous) {
+        // V = 2^104 x / P (two's complement, 16 words), underestimated by less than 2^-40 (the constants of the limbs of P are floors, y_d < 2^60):
+        //   fraction f = bits 0..103 = (x mod P) / P;  f >= 1 - 2^-38: the estimate may have borrowed from the integer part -> exact path;
+        //   mpi_rdiv rounds up iff (x mod P) > floor(P/2) iff the true fraction > 1/2 (P is odd):  f >= 1/2 -> up;  f < 1/2 - 2^-38 -> down;  between -> exact path
+        const uint64_t f40 = V[1] & ((1ull << 40) - 1), top38 = f40 >> 2;
+        ambiguous = top38 == ((1ull << 38) - 1) || top38 == ((1ull << 37) - 1);
+        if (!ambiguous) {
+          const uint64_t up_bit = f40 >> 39;
+          uint64_t Q[14];
+#pragma unroll
+          for (int j = 0; j < 14; ++j) Q[j] = (V[j + 1] >> 40) | (V[j + 2] << 24);     // floor(x / P) mod 2^896
+          const uint64_t *addend = a.addend.at(poly, (size_t)a.Wout << a.logn);
+          uint64_t cr = up_bit;
+#pragma unroll
+          for (int j = 0; j < 14; ++j) {
+            const uint64_t dj = (addend && j < (int)a.Wout) ? (addend + coef0 + lane)[(size_t)j << a.logn] : 0;
+            const u128 t = (u128)Q[j] + cr + dj;
+            Q[j] = (uint64_t)t; cr = (uint64_t)(t >> 64);
+          }
+          uint64_t *__restrict__ dst = a.big.at(poly, (size_t)a.Wout << a.logn) + coef0 + lane;
+          const int sw = (int)((a.logq - 1) >> 6);
+          const unsigned up = 63 - ((a.logq - 1) & 63);
+          uint64_t ext = 0;
+#pragma unroll
+          for (int j = 0; j < 14; ++j) if (j == sw) ext = (uint64_t)((int64_t)(Q[j] << up) >> up);
+          const uint64_t qsign = (uint64_t)((int64_t)ext >> 63);
+#pragma unroll
+          for (int j = 0; j < 14; ++j)
+            if (j < (int)a.Wout) dst[(size_t)j << a.logn] = j < sw ? Q[j] : (j == sw ? ext : qsign);
+          for (unsigned j = 14; j < a.Wout; ++j) dst[(size_t)j << a.logn] = qsign;
+        }
+      }
+    }
+    a.redo[flag_at] = ambiguous;
+    if (!ambiguous && !(WL == 16 && a.frac_bits)) {
       if (a.rflags) {                                    // + [r > floor(P/2)] + d   (mod 2^logq: only the low words matter)
         if (!EARLY_D && addend) {
           const uint64_t *__restrict__ dp = addend + coef0 + lane;
@@ -358,6 +401,7 @@ struct RelinFrontArgs {
   // optional [polys][n]: when given, only the groups of 64 coefficients that hold a non-zero entry are processed and flags / amb
   // are left alone -- the re-run behind bridge_relin_tail_mfma, which needs yq in memory for the few coefficients it could not finish
   const unsigned char *only;
+  unsigned only_writes_flags;   // with `only`: write flags / amb for the groups it re-runs after all (behind the one-product tail nothing else has)
   unsigned prescaled;        // the limbs below dimP already hold y_d = chat_d * phat_invmp_d (the key switch's inverse pass scaled them: ScaledInverse)
   unsigned wscaled;          // ... and the limbs above hold chat_j * w_j, bfrag / pk / tkp are the w-scaled tables: yq_j = x'_j - (r w_j mod p_j)
 };
@@ -457,7 +501,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? GPQ_FRONT_OCC : 2)) void bridge_rel
       const bool ambiguous = ((f_hi >> 2) & ((1ull << 38) - 1)) == ((1ull << 37) - 1);
       const unsigned gt = (unsigned)(f_hi >> 39) & 1;
       const size_t flag_at = ((size_t)poly << a.logn) + coef0 + lane;
-      if (!masked) {
+      if (!masked || a.only_writes_flags) {
         a.flags[flag_at] = (unsigned char)(ambiguous ? RF_AMB : (gt ? RF_GT : RF_LT));
         a.amb[flag_at] = ambiguous;
       }

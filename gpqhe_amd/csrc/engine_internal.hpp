@@ -12,7 +12,7 @@ enum { GPQ_K_STRIDED_FWD = 0, GPQ_K_STRIDED_INV, GPQ_K_CONTIG_FWD, GPQ_K_CONTIG_
        GPQ_K_KEYSWITCH_MID, GPQ_K_POINTWISE, GPQ_K_SMALL, GPQ_K_REFERENCE,
        // the MPI <-> RNS bridge (bridge.hip): rns_decompose, the CRT fast paths, the relinearisation front, its one-pass form, the exact /
        // masked kernels (bridge_reconstruct, bridge_roundfix, bridge_addround, bridge_exactdiv), he_rs
-       GPQ_K_DECOMPOSE, GPQ_K_RECONSTRUCT, GPQ_K_RELIN_FRONT, GPQ_K_RELIN_TAIL_FUSED, GPQ_K_BRIDGE_EXACT, GPQ_K_RESCALE, GPQ_K_COUNT };
+       GPQ_K_DECOMPOSE, GPQ_K_RECONSTRUCT, GPQ_K_RELIN_FRONT, GPQ_K_RELIN_TAIL_FUSED, GPQ_K_BRIDGE_EXACT, GPQ_K_RESCALE, GPQ_K_RELIN_TAIL_DIRECT, GPQ_K_COUNT };
 
 // Constant matrix of the matrix-core CRT fast path for one basis and result width WL (bridge_mfma.hpp)
 struct gpq_recon_mfma {
@@ -56,6 +56,12 @@ struct gpq_relin_tables {
   void *d_bfrag_w = nullptr;
   uint64_t *d_pk_w = nullptr, *d_tkp_w = nullptr;
   gpq::LimbTab *d_tabs_w = nullptr;
+  // the one-product tail (bridge.hip: get_tail_direct): constant matrix of floor(Pi' 2^104 / p_d) over all dimB limbs, the per-limb table that
+  // makes the key switch deliver CRT-weighted limbs (owned by the basis), the weights and their inverses for bridge_limb_scale
+  bool direct_tried = false;
+  gpq_recon_mfma direct;
+  const gpq::LimbTab *d_tabs_direct = nullptr;
+  uint64_t *d_scale = nullptr, *d_unscale = nullptr;
 };
 
 struct gpq_ctx {
@@ -89,6 +95,7 @@ struct gpq_ctx {
   bool exact_crt = false;             // force the exact CRT kernel (tests)
   bool prescale = true;               // gpq_he_mul / gpq_he_swk: inverse passes write limbs pre-multiplied by (P/p_d)^-1 for the CRT kernels (gpq_set_prescale)
   bool prescale_upper = true;         // ... and the limbs above P by w_j for the relinearisation front
+  bool tail_direct = true;            // ... or every limb by the weights of the whole basis: the relinearisation tail as ONE product (bridge.hip: get_tail_direct)
   bool fuse_tail = false;             // gpq_set_fused_tail(ctx, 1): the relinearisation tail in one pass per coefficient (bridge_relin_tail_mfma) -- measured 2 % SLOWER
                                       // than the two-kernel form on the whole he_mul (profiles/r03/v3_fused_tail_ab.txt: both are bound by integer VALU work, not by the
                                       // 60 words per coefficient the fusion saves), kept for the parity tests and as the record of the attempt

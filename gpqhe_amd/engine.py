@@ -175,6 +175,15 @@ class PolyContext:
                                               batch, self._ptr(ws), self._stream()), "gpq_relin_tail")
         return out
 
+    def relin_tail_overwriting(self, out, chat, d, W, logql, dimB, dimP):
+        """src/he-mult.c:67-77 with `chat` given up as scratch: the tail as one product over all dimB limbs."""
+        torch = _torch()
+        batch = self._shape(chat, dimB)
+        ws = torch.empty(self.lib.gpq_relin_tail_workspace_bytes(self.h, W, dimB, dimP, batch) // 8 + 8, dtype=torch.int64, device=self._dev)
+        _native.check(self.lib.gpq_relin_tail_overwriting(self.h, self._ptr(out), self._ptr(chat), self._ptr(d) if d is not None else None, W, logql, dimB, dimP,
+                                                          batch, self._ptr(ws), self._stream()), "gpq_relin_tail_overwriting")
+        return out
+
     def he_swk(self, out_c0, out_c1, d0, d1, swk0, swk1, W, logql, dimB, dimP):
         """src/he-automorphism.c:40-85 on big slabs, q_l = 2^logql."""
         torch = _torch()

@@ -204,8 +204,10 @@ int gpq_set_exact_crt(gpq_ctx *ctx, int on);
 /* The tail of he_relin / he_swk as two kernels with Q's residues in memory between them (0, default) or in one pass per coefficient (1:
  * measured 2 % slower on the whole he_mul -- both forms are bound by integer VALU work); same results. */
 int gpq_set_fused_tail(gpq_ctx *ctx, int on);
-/* gpq_he_mul / gpq_he_swk: the inverse transforms hand the kernels that follow limbs already multiplied by their CRT weights -- 2 (default): (P/p_d)^-1 on
- * the limbs of each basis and w_j = P^-1 (Pi'/p_j)^-1 on the limbs above P for the relinearisation front; 1: the former only; 0: neither.  Same results. */
+/* gpq_he_mul / gpq_he_swk: the inverse transforms hand the kernels that follow limbs already multiplied by their CRT weights -- 3 (default): the key
+ * switch's limbs carry the weights of its WHOLE basis and the relinearisation tail is one product (quotient, rounding and centring together);
+ * 2: (P/p_d)^-1 on the limbs of each basis and w_j = P^-1 (Pi'/p_j)^-1 on the limbs above P for the relinearisation front; 1: the former only;
+ * 0: neither.  Same results. */
 int gpq_set_prescale(gpq_ctx *ctx, int on);
 /* rns_decompose is a product of the coefficients' bytes with a fixed matrix (256^k mod p_j) and runs on the matrix cores
  * (v_mfma_i32_32x32x32_i8, exact) by default; 0 selects the integer-VALU kernel instead (the tests cross-check the two). */
@@ -252,6 +254,10 @@ int gpq_he_mul(gpq_ctx *ctx, uint64_t *out_c0, uint64_t *out_c1, const uint64_t 
 size_t gpq_relin_tail_workspace_bytes(gpq_ctx *ctx, unsigned W, unsigned dimB, unsigned dimP, unsigned batch);
 int gpq_relin_tail(gpq_ctx *ctx, uint64_t *out, const uint64_t *chat, const uint64_t *d, unsigned W, unsigned logql,
                    unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream);
+/* The same with `chat` given up as scratch (overwritten): the tail as ONE matrix-core product over all dimB limbs (what gpq_he_mul / gpq_he_swk use
+ * internally, where the key switch already delivers CRT-weighted limbs); same results. */
+int gpq_relin_tail_overwriting(gpq_ctx *ctx, uint64_t *out, uint64_t *chat, const uint64_t *d, unsigned W, unsigned logql,
+                               unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream);
 
 /* he_swk, src/he-automorphism.c:40-85: key-switch d1 with swk and add d0 into c0, big slabs, q_l = 2^logql
  * (the rotation / conjugation permutations of src/poly.c:263-283 are the caller's). */

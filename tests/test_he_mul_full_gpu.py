@@ -75,7 +75,7 @@ def test_he_swk_matches_reference_semantics(engine_ctx, oracle_ctx, logn, logqL,
     assert big_to_ints(to_host(out1), W, n)[0] == e1
 
 
-@pytest.mark.parametrize("mfma", [True, False, "fused"])      # matrix-core front + CRT, integer-VALU kernels, the one-pass tail (gpq_set_fused_tail)
+@pytest.mark.parametrize("mfma", [True, False, "fused", "direct"])      # matrix-core front + CRT, integer-VALU kernels, the one-pass tail (gpq_set_fused_tail), the one-product tail
 @pytest.mark.parametrize("logqL", [120, 200, 438, 610])
 def test_relin_tail_rounding_ties_and_wrap_corner(engine_ctx, oracle_ctx, logqL, mfma):
     """mpi_rdiv rounds up only when the remainder is strictly above floor(P/2) (src/types.c:124): key-switch
@@ -110,13 +110,14 @@ def test_relin_tail_rounding_ties_and_wrap_corner(engine_ctx, oracle_ctx, logqL,
     dvals = [rng.randrange(-(ql // 2), ql // 2) for _ in range(n)]
     exp = ref.he_relin_tail(o, chat, chat, dvals, None, dimP, dimB, ql)
     out = torch.empty(W * n, dtype=torch.int64, device="cuda")
+    tail = g.relin_tail_overwriting if mfma == "direct" else g.relin_tail   # "direct": chat is scratch, the whole tail is one product (gpq_he_mul's form)
     try:
-        g.relin_tail(out, to_device(chat), to_device(ints_to_big(dvals, W)), W, logqL, dimB, dimP)
+        tail(out, to_device(chat), to_device(ints_to_big(dvals, W)), W, logqL, dimB, dimP)
         assert big_to_ints(to_host(out), W, n)[0] == exp[0]
-        g.relin_tail(out, to_device(chat), None, W, logqL, dimB, dimP)
+        tail(out, to_device(chat), None, W, logqL, dimB, dimP)
         assert big_to_ints(to_host(out), W, n)[0] == exp[1]
         inplace = to_device(ints_to_big(dvals, W))               # c0 += d0 in place, as he_swk may be called
-        g.relin_tail(inplace, to_device(chat), inplace, W, logqL, dimB, dimP)
+        tail(inplace, to_device(chat), inplace, W, logqL, dimB, dimP)
         assert big_to_ints(to_host(inplace), W, n)[0] == exp[0]
     finally:
         g.set_bridge_mfma(True)
@@ -512,7 +513,8 @@ def test_one_pass_relinearisation_tail_equals_the_two_kernel_form(engine_ctx, lo
     try:
         # ... and with / without the inverse transforms pre-multiplying their output by the CRT weights (gpq_set_prescale)
         # (0 = no scaling, 1 = the CRT weights on the limbs of each basis, 2 = also w_j on the limbs above P for the relinearisation front)
-        for fused, prescale in ((False, 2), (True, 2), (False, 0), (True, 0), (False, 1), (True, 1)):
+        #  3 = every limb of the key switch by the weights of its whole basis: the relinearisation tail as ONE product)
+        for fused, prescale in ((False, 3), (False, 2), (True, 2), (False, 0), (True, 0), (False, 1), (True, 1)):
             g.set_fused_tail(fused)
             g.set_prescale(prescale)
             o0, o1 = torch.empty_like(cts[0]), torch.empty_like(cts[0])
@@ -523,7 +525,7 @@ def test_one_pass_relinearisation_tail_equals_the_two_kernel_form(engine_ctx, lo
             outs.append((o0, o1, s0, s1))
     finally:
         g.set_fused_tail(False)
-        g.set_prescale(2)
+        g.set_prescale(3)
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
