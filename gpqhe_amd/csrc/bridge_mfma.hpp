@@ -186,6 +186,9 @@ struct ReconMfmaArgs {
 // per-coefficient flags of the relinearisation tail: r = x mod P against floor(P/2)
 constexpr unsigned char RF_GT = 1, RF_LT = 2, RF_AMB = 4;
 
+#ifndef GPQ_RECON_TWO_AHEAD
+#define GPQ_RECON_TWO_AHEAD 16   /* widest WL whose k loop keeps two steps of residues in flight (14: the 16-word form one step only) */
+#endif
 template <int WL>
 __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs a) {
   constexpr int NT = (8 * WL + 14 + 31) / 32;
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
   for (unsigned g = g0; g < a.total_groups; g += gstep) {
     const unsigned poly = g / a.groups_per_poly, coef0 = (g % a.groups_per_poly) << 6;
     const unsigned gn = g + gstep < a.total_groups ? g + gstep : g;          // next group (or this one again: harmless reads)
-    if (!CROSS) { fetch(g, 0, xa); if (WL <= 14) fetch(g, 1, xb); }
+    if (!CROSS) { fetch(g, 0, xa); if (WL <= GPQ_RECON_TWO_AHEAD) fetch(g, 1, xb); }
     v16i acc[2][NT];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
         acc[1][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A1, acc[1][q], 0, 0, 0);
       }
     };
-    if (WL <= 14) {
+    if (WL <= GPQ_RECON_TWO_AHEAD) {
       for (unsigned s = 0; s < a.KS; s += 2) {
         uint64_t x[4];
 #pragma unroll
