@@ -9,5 +9,7 @@ bash tools/gpu_pmc.sh > gpurun_out/r3_pmc.log 2>&1 || { tail gpurun_out/r3_pmc.l
 cp gpurun_out/pmc_summary.json gpurun_out/r3_pmc_summary.json
 rm -rf gpurun_out/prof_r3 && rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r3 -- python3 bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-ntt > gpurun_out/r3_bench_prof.json 2> gpurun_out/r3_prof.err || { tail gpurun_out/r3_prof.err; exit 1; }
 cp $(find gpurun_out/prof_r3 -name "*kernel_stats.csv" | head -1) gpurun_out/r3_kernel_stats.csv
-MPI_BATCH=64 bash tools/gpu_pmc_mpi.sh > gpurun_out/r3_pmc_mpi.txt 2>&1 || { tail gpurun_out/r3_pmc_mpi.txt; exit 1; }
+bash tools/gpu_pmc_mpi.sh > gpurun_out/r3_pmc_mpi.txt 2>&1 || { tail gpurun_out/r3_pmc_mpi.txt; exit 1; }
 tail -30 gpurun_out/r3_pmc_mpi.txt
+bash tools/gpu_r3_probe.sh > /dev/null 2>&1
+bash tools/gpu_r3_mpi.sh final > gpurun_out/r3_mpi_final.log 2>&1; tail -14 gpurun_out/r3_mpi_final.log
