@@ -234,8 +234,12 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6):
     #   rns_decompose     4 x (W in, dimA out) + (W in, dimB out)                                   src/he-mult.c:117-120, :59
     #   CRT (poly_rns2mpi) 3 x (dimA in, W out) for d0, d1, d2 + 2 x (cnt in, W addend in, W out)    :139-141, the tail's CRT of Q (:67-77)
     #   relin front       2 x (dimB in, cnt out)                                                    exact division by P, :70
+    #   one-product tail  2 x (dimB in, W addend in, W out): replaces the relin front and the tail's CRT
     cnt = dimB - dimP
-    words = {"bridge_decompose": 4 * (W + dimA) + (W + dimB), "bridge_reconstruct": 3 * (dimA + W) + 2 * (cnt + 2 * W), "bridge_relin_front": 2 * (dimB + cnt)}
+    if "bridge_relin_tail_direct" in prof:
+        words = {"bridge_decompose": 4 * (W + dimA) + (W + dimB), "bridge_reconstruct": 3 * (dimA + W), "bridge_relin_tail_direct": 2 * (dimB + 2 * W)}
+    else:
+        words = {"bridge_decompose": 4 * (W + dimA) + (W + dimB), "bridge_reconstruct": 3 * (dimA + W) + 2 * (cnt + 2 * W), "bridge_relin_front": 2 * (dimB + cnt)}
     core = {"strided_fwd": 2 * (4 * dimA + dimB), "strided_inv": 2 * (3 * dimA + 2 * dimB), "tensor_mid": 7 * dimA, "keyswitch_mid": 5 * dimB}
     total_ms = sum(v[0] for v in prof.values())
     kernels = {}
@@ -255,7 +259,7 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6):
         roof = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                 "bytes_per_batch": int(words[kname] * 8 * n * batch), "ms_per_batch": bridge[kname]["ms_per_batch"],
                 "note": "the bridge kernel with the largest share of this leg; all launches of the kind together (its launches differ in size); "
-                        "PMC of these kernels: profiles/r03/v5_mpi_pmc.txt"}
+                        "PMC of these kernels: profiles/r03/v12_mpi_pmc.txt"}
     bridge_ms = sum(v["ms_per_batch"] for k, v in kernels.items() if k.startswith("bridge_"))
     return {"shape": "n=2^16, q=2^850 (W=14 words), dimA/dimB/dimP=%d/%d/%d, batch %d" % (dimA, dimB, dimP, batch),
             "ms_per_batch": round(ms, 3), "he_mul_per_s": round(batch / (ms * 1e-3), 1),
