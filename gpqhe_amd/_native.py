@@ -61,6 +61,7 @@ SIGNATURES = {
     "gpq_rns_reconstruct_one": (C.c_int, [vp, C.POINTER(u64), C.c_uint, C.POINTER(u64), C.c_uint]),
     "gpq_set_exact_crt": (C.c_int, [vp, C.c_int]),
     "gpq_set_fused_tail": (C.c_int, [vp, C.c_int]),
+    "gpq_big_transpose": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_int, vp]),
     "gpq_set_prescale": (C.c_int, [vp, C.c_int]),
     "gpq_set_bridge_mfma": (C.c_int, [vp, C.c_int]),
     "gpq_poly_mul_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),

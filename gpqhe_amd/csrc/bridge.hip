@@ -1187,6 +1187,16 @@ extern "C" int gpq_relin_tail(gpq_ctx *c, uint64_t *out, const uint64_t *chat, c
   return relin_tail(c, one_place(out), chat, one_place(d), W, dimP, dimB, logql, batch, workspace, (hipStream_t)stream);
 }
 
+// Big slabs between the kernels' layout (word-major) and rows of W words per coefficient (bridge_big_transpose): what the MPI-typed
+// calls stage host data through.  to_rows = 0: rows -> words, 1: words -> rows.  n >= 64.
+extern "C" int gpq_big_transpose(gpq_ctx *c, uint64_t *dst, const uint64_t *src, unsigned W, unsigned batch, int to_rows, void *stream) {
+  if (!c || !dst || !src || W < 1 || W > 64 || batch < 1 || dst == src) return gpq_fail(GPQ_ERR_INVALID, "gpq_big_transpose: bad arguments");
+  if (c->logn < 6) return gpq_fail(GPQ_ERR_INVALID, "gpq_big_transpose: n >= 64");
+  BigTransposeArgs a{src, dst, W, c->logn, to_rows ? 1u : 0u};
+  hipLaunchKernelGGL(bridge_big_transpose, dim3(c->n >> 6, batch), dim3(64), 0, (hipStream_t)stream, a);
+  return launched("gpq_big_transpose");
+}
+
 // The same tail for a caller that gives `chat` up as scratch: the CRT weights of the whole basis are put on it in place and the
 // one-product kernel (tail_direct) finishes -- the form gpq_he_mul / gpq_he_swk reach without the extra pass, because their key
 // switch delivers the weighted limbs.  Falls back to gpq_relin_tail's kernels when the product is not available (shape, settings).

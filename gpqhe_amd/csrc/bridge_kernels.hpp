@@ -403,6 +403,32 @@ __global__ __launch_bounds__(256) void bridge_roundfix(RoundFixArgs a) {
   a.flags[at] = cmp > 0 ? 1 : (cmp < 0 ? 2 : 0);
 }
 
+// Big slabs between the layout the kernels use -- word j of coefficient i at j*n + i -- and rows of W words per coefficient (i*W + j),
+// the layout a host thread fills or reads as ONE sequential stream (the MPI-typed calls stage through it: gathering 65536 scattered libgcrypt
+// integers into 14 strided streams per thread was most of a call's time).  A 64 x W tile goes through LDS so that both sides move
+// whole cache lines.  to_rows = 0: rows -> words (after an upload), 1: words -> rows (before a download).
+struct BigTransposeArgs { const uint64_t *src; uint64_t *dst; unsigned W, logn, to_rows; };
+__global__ __launch_bounds__(64) void bridge_big_transpose(BigTransposeArgs a) {
+  __shared__ uint64_t tile[64 * 65];                     // up to 64 words per coefficient, padded
+  const unsigned n = 1u << a.logn, i0 = blockIdx.x * 64, lane = threadIdx.x;
+  const size_t poly = (size_t)blockIdx.y * a.W << a.logn;
+  const unsigned total = 64 * a.W;                        // words of the tile
+  if (!a.to_rows) {
+    const uint64_t *__restrict__ rows = a.src + poly + (size_t)i0 * a.W;      // 64 consecutive rows: total contiguous words
+    for (unsigned k = lane; k < total; k += 64) tile[(k / a.W) * 65 + (k % a.W)] = rows[k];
+    __syncthreads();
+    uint64_t *__restrict__ words = a.dst + poly + i0 + lane;
+    for (unsigned j = 0; j < a.W; ++j) words[(size_t)j << a.logn] = tile[lane * 65 + j];
+  } else {
+    const uint64_t *__restrict__ words = a.src + poly + i0 + lane;
+    for (unsigned j = 0; j < a.W; ++j) tile[lane * 65 + j] = words[(size_t)j << a.logn];
+    __syncthreads();
+    uint64_t *__restrict__ rows = a.dst + poly + (size_t)i0 * a.W;
+    for (unsigned k = lane; k < total; k += 64) rows[k] = tile[(k / a.W) * 65 + (k % a.W)];
+  }
+  (void)n;
+}
+
 // chat[poly][d][i] <- chat[poly][d][i] * scale[d] mod p_d, for every coefficient (only == nullptr) or for the groups of 64 coefficients that
 // hold a non-zero entry of `only`: puts the CRT weights of the one-product tail on a raw slab (gpq_relin_tail_overwriting), or takes them
 // off again for the groups its exact fallback re-runs with the kernels that read raw residues.

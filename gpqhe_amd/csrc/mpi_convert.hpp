@@ -239,7 +239,11 @@ unsigned max_bits(const poly_mpi_t *a, unsigned n) {       // widest coefficient
 
 // MPI coefficients -> host big slab [W][n], two's complement.  libgcrypt hands out / takes big-endian magnitude bytes; words are
 // assembled eight bytes at a time (the byte-at-a-time form cost as much as gcry_mpi_print itself).
+// ROWS = false: the device layout, word j of coefficient i at j*n + i (14 write streams per thread);  ROWS = true: one row of W words per
+// coefficient, i*W + j -- one sequential stream, what the MPI-typed calls stage through (the device transposes: bridge_big_transpose)
+template <bool ROWS = false>
 void to_slab_range(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W, unsigned lo, unsigned hi) {
+  const size_t sj = ROWS ? 1 : n, si = ROWS ? W : 1;
   unsigned char buf[8 * 64 + 8];
   const bool direct = mpi_direct();
   for (unsigned i = lo; i < hi; ++i) {
@@ -257,9 +261,9 @@ void to_slab_range(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W, u
       if (nl > W || (nl == W && (m->d[W - 1] >> 63))) die("coefficient does not fit the big slab");
       if (m->sign && nl) {
         uint64_t carry = 1;
-        for (unsigned j = 0; j < W; ++j) { const uint64_t x = ~(j < nl ? m->d[j] : 0) + carry; carry = carry && x == 0; dst[(size_t)j * n + i] = x; }
+        for (unsigned j = 0; j < W; ++j) { const uint64_t x = ~(j < nl ? m->d[j] : 0) + carry; carry = carry && x == 0; dst[j * sj + i * si] = x; }
       } else {
-        for (unsigned j = 0; j < W; ++j) dst[(size_t)j * n + i] = j < nl ? m->d[j] : 0;
+        for (unsigned j = 0; j < W; ++j) dst[j * sj + i * si] = j < nl ? m->d[j] : 0;
       }
       continue;
     }
@@ -284,7 +288,7 @@ void to_slab_range(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W, u
       uint64_t carry = 1;
       for (unsigned j = 0; j < W; ++j) { w[j] = ~w[j] + carry; carry = carry && w[j] == 0; }
     }
-    for (unsigned j = 0; j < W; ++j) dst[(size_t)j * n + i] = w[j];
+    for (unsigned j = 0; j < W; ++j) dst[j * sj + i * si] = w[j];
   }
 }
 void to_slab(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W) {
@@ -293,7 +297,9 @@ void to_slab(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W) {
 }
 
 // host big slab -> existing MPIs (the caller allocated them, src/poly.c:46-51)
+template <bool ROWS = false>
 void from_slab_range(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W, unsigned lo, unsigned hi) {
+  const size_t sj = ROWS ? 1 : n, si = ROWS ? W : 1;
   unsigned char buf[8 * 64];
   const bool direct = mpi_direct();
   for (unsigned i = lo; i < hi; ++i) {
@@ -302,7 +308,7 @@ void from_slab_range(poly_mpi_t *r, const uint64_t *src, unsigned n, unsigned W,
       if (i + 6 < hi) { uint64_t *d = ((MpiView *)r->coeffs[i + 6])->d; if (d) { __builtin_prefetch(d, 1); __builtin_prefetch(d + 8, 1); } }
     }
     uint64_t w[64];
-    for (unsigned j = 0; j < W; ++j) w[j] = src[(size_t)j * n + i];
+    for (unsigned j = 0; j < W; ++j) w[j] = src[j * sj + i * si];
     const bool neg = w[W - 1] >> 63;
     if (neg) {
       uint64_t carry = 1;

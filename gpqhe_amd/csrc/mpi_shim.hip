@@ -106,9 +106,18 @@ hipEvent_t event_at(size_t i) {
   return g_events[i];
 }
 
-// words [lo, hi) of every row of a big slab [W][n]: one strided DMA
+// Host <-> device staging is in ROWS (W words per coefficient, coefficient after coefficient): a host thread fills or reads its range as one
+// sequential stream and the range is one contiguous piece of memory for the DMA; the device turns rows into the kernels' word-major slabs
+// and back (gpq_big_transpose, a few microseconds per polynomial).  Polynomials with fewer than 64 coefficients keep the word-major staging.
+inline bool staged_in_rows(unsigned n) { return n >= 64; }
+// coefficients [lo, hi) of a staged polynomial
 void copy_range(void *dst, const void *src, unsigned n, unsigned W, unsigned lo, unsigned hi, hipMemcpyKind kind) {
-  const size_t pitch = (size_t)n * 8;
+  if (staged_in_rows(n)) {
+    const size_t off = (size_t)lo * W * 8, bytes = (size_t)(hi - lo) * W * 8;
+    if (hipMemcpyAsync((char *)dst + off, (const char *)src + off, bytes, kind, nullptr) != hipSuccess) die("slab copy failed");
+    return;
+  }
+  const size_t pitch = (size_t)n * 8;                       // word-major: words [lo, hi) of every one of the W rows, one strided DMA
   if (hipMemcpy2DAsync((char *)dst + (size_t)lo * 8, pitch, (const char *)src + (size_t)lo * 8, pitch, (size_t)(hi - lo) * 8, W, kind, nullptr) != hipSuccess)
     die("slab copy failed");
 }
@@ -125,6 +134,9 @@ constexpr unsigned kRangesPerCopy = 4;
 void upload_polys(const DevBuf *const dst[], const HostBuf *const stage[], const poly_mpi_t *const src[], int count, unsigned n, unsigned W,
                   unsigned extra = 0, const std::function<void(unsigned)> *side = nullptr) {
   if (W < 1 || W > 32) die("coefficients wider than 2047 bits");
+  const bool rows = staged_in_rows(n);
+  const size_t big = (size_t)W * n * 8;
+  DevBuf landing(rows ? big * count : 8);                   // the rows land here; gpq_big_transpose writes the word-major slabs from it
   const unsigned nt = n >= 4096 ? workers().width() : 1, per = (n + nt - 1) / nt;
   const unsigned ranges = (n + per - 1) / per, groups = (ranges + kRangesPerCopy - 1) / kRangesPerCopy;
   std::vector<std::atomic<unsigned>> done((size_t)count * groups);
@@ -136,32 +148,45 @@ void upload_polys(const DevBuf *const dst[], const HostBuf *const stage[], const
     (void)hipSetDevice(g_dev);
     const unsigned g = t / kRangesPerCopy, first = g * kRangesPerCopy, last = first + kRangesPerCopy < ranges ? first + kRangesPerCopy : ranges;
     for (int i = 0; i < count; ++i) {
-      to_slab_range(stage[i]->u64(), src[i], n, W, lo, hi);
+      if (rows) to_slab_range<true>(stage[i]->u64(), src[i], n, W, lo, hi); else to_slab_range<false>(stage[i]->u64(), src[i], n, W, lo, hi);
       if (done[(size_t)i * groups + g].fetch_add(1, std::memory_order_acq_rel) + 1 == last - first) {      // the group is complete: one copy for all of it
         const unsigned glo = first * per, ghi = last * per < n ? last * per : n;
-        copy_range(dst[i]->p, stage[i]->p, n, W, glo, ghi, hipMemcpyHostToDevice);
+        copy_range(rows ? (char *)landing.p + big * i : (char *)dst[i]->p, stage[i]->p, n, W, glo, ghi, hipMemcpyHostToDevice);
       }
     }
   };
   if (nt + extra < 2) job(0); else workers().run(nt + extra, job);
+  if (rows)
+    for (int i = 0; i < count; ++i)
+      if (gpq_big_transpose(engine(), dst[i]->u64(), (const uint64_t *)((char *)landing.p + big * i), W, 1, 0, nullptr) != GPQ_OK) die("slab transpose failed");
 }
 
-// device big slabs -> the caller's MPIs: the ranges come back one DMA per group of kRangesPerCopy, in order, an event behind every one; a
-// host thread converts its range as soon as its group has landed while the later ones are still in flight.
-// Phase 1 (download_issue): the copies and their events are queued behind the kernels.  Phase 2 (download_convert): the conversions.
+// device big slabs -> the caller's MPIs: the device turns the slabs into rows, the ranges come back one DMA per group of kRangesPerCopy, in
+// order, an event behind every one; a host thread converts its range as soon as its group has landed while the later ones are still in flight.
+// Phase 1 (download_issue): the transposes, the copies and their events are queued behind the kernels.  Phase 2 (download_convert): the conversions.
 // Between the two the host threads are free while the device works -- he_mul / he_rot / he_conj verify the evaluation key there.
 void download_issue(const HostBuf *const stage[], const DevBuf *const src[], int count, unsigned n, unsigned W) {
   if (W < 1 || W > 64) die("big slab wider than 64 words");
+  const bool rows = staged_in_rows(n);
+  const size_t big = (size_t)W * n * 8;
+  DevBuf takeoff(rows ? big * count : 8);                   // stream-ordered: safe to hand back to the pool when this returns
   const unsigned nt = n >= 4096 ? workers().width() : 1, per = (n + nt - 1) / nt;
   const unsigned ranges = (n + per - 1) / per, groups = (ranges + kRangesPerCopy - 1) / kRangesPerCopy;
-  for (int i = 0; i < count; ++i)
+  for (int i = 0; i < count; ++i) {
+    const char *from = (const char *)src[i]->p;
+    if (rows) {
+      if (gpq_big_transpose(engine(), (uint64_t *)((char *)takeoff.p + big * i), src[i]->u64(), W, 1, 1, nullptr) != GPQ_OK) die("slab transpose failed");
+      from = (const char *)takeoff.p + big * i;
+    }
     for (unsigned g = 0; g < groups; ++g) {
       const unsigned lo = g * kRangesPerCopy * per, hi = (g + 1) * kRangesPerCopy * per < n ? (g + 1) * kRangesPerCopy * per : n;
-      copy_range(stage[i]->p, src[i]->p, n, W, lo, hi, hipMemcpyDeviceToHost);
+      copy_range(stage[i]->p, from, n, W, lo, hi, hipMemcpyDeviceToHost);
       if (hipEventRecord(event_at((size_t)i * groups + g), nullptr) != hipSuccess) die("hipEventRecord failed");
     }
+  }
 }
 void download_convert(poly_mpi_t *const dst[], const HostBuf *const stage[], int count, unsigned n, unsigned W) {
+  const bool rows = staged_in_rows(n);
   const unsigned nt = n >= 4096 ? workers().width() : 1, per = (n + nt - 1) / nt;
   const unsigned ranges = (n + per - 1) / per, groups = (ranges + kRangesPerCopy - 1) / kRangesPerCopy;
   const std::function<void(unsigned)> job = [&](unsigned t) {
@@ -169,7 +194,7 @@ void download_convert(poly_mpi_t *const dst[], const HostBuf *const stage[], int
     const unsigned lo = t * per, hi = lo + per < n ? lo + per : n;
     for (int i = 0; i < count; ++i) {
       if (hipEventSynchronize(g_events[(size_t)i * groups + t / kRangesPerCopy]) != hipSuccess) die("download failed");
-      from_slab_range(dst[i], stage[i]->u64(), n, W, lo, hi);
+      if (rows) from_slab_range<true>(dst[i], stage[i]->u64(), n, W, lo, hi); else from_slab_range<false>(dst[i], stage[i]->u64(), n, W, lo, hi);
     }
   };
   if (ranges < 2) job(0); else workers().run(ranges, job);

@@ -254,6 +254,9 @@ int gpq_he_mul(gpq_ctx *ctx, uint64_t *out_c0, uint64_t *out_c1, const uint64_t 
 size_t gpq_relin_tail_workspace_bytes(gpq_ctx *ctx, unsigned W, unsigned dimB, unsigned dimP, unsigned batch);
 int gpq_relin_tail(gpq_ctx *ctx, uint64_t *out, const uint64_t *chat, const uint64_t *d, unsigned W, unsigned logql,
                    unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream);
+/* Big slabs between the kernels' layout (word j of coefficient i at j*n + i) and rows of W words per coefficient (i*W + j), the layout a host
+ * fills or reads sequentially; to_rows = 0: rows -> words, 1: words -> rows.  n >= 64, dst != src, `batch` polynomials one after another. */
+int gpq_big_transpose(gpq_ctx *ctx, uint64_t *dst, const uint64_t *src, unsigned W, unsigned batch, int to_rows, void *stream);
 /* The same with `chat` given up as scratch (overwritten): the tail as ONE matrix-core product over all dimB limbs (what gpq_he_mul / gpq_he_swk use
  * internally, where the key switch already delivers CRT-weighted limbs); same results. */
 int gpq_relin_tail_overwriting(gpq_ctx *ctx, uint64_t *out, uint64_t *chat, const uint64_t *d, unsigned W, unsigned logql,

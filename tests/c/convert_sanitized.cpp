@@ -98,6 +98,26 @@ int main() {
         if (neg != (G.mpi_is_neg(a.coeffs[i]) && G.mpi_get_nbits(a.coeffs[i]) != 0)) { printf("FAIL sign n=%u W=%u i=%u\n", n, W, i); return 1; }
         ++checks;
       }
+      {
+        // the row layout the MPI-typed calls stage through (W words per coefficient): the same words as the word-major slab, transposed,
+        // and a round trip of its own
+        std::vector<uint64_t> rows((size_t)W * n, 0x1111111111111111ull);
+        poly_mpi_t back;
+        back.coeffs = (gpq_MPI *)malloc(n * sizeof(gpq_MPI));
+        for (unsigned i = 0; i < n; ++i) back.coeffs[i] = G.mpi_set_ui(G.mpi_new(0), 7);
+        if (!(n > 2 && G.mpi_get_nbits(a.coeffs[2]) == 64 * W)) {
+          to_slab_range<true>(rows.data(), &a, n, W, 0, n);
+          for (unsigned i = 0; i < n; ++i)
+            for (unsigned j = 0; j < W; ++j)
+              if (rows[(size_t)i * W + j] != slab[(size_t)j * n + i]) { printf("FAIL row layout n=%u W=%u i=%u j=%u\n", n, W, i, j); return 1; }
+          from_slab_range<true>(&back, rows.data(), n, W, 0, n);
+          for (unsigned i = 0; i < n; ++i)
+            if (mpi_cmp(a.coeffs[i], back.coeffs[i]) != 0) { printf("FAIL row roundtrip n=%u W=%u i=%u\n", n, W, i); return 1; }
+          checks += 2 * n;
+        }
+        for (unsigned i = 0; i < n; ++i) G.mpi_release(back.coeffs[i]);
+        free(back.coeffs);
+      }
       from_slab(&r, slab.data(), n, W);
       for (unsigned i = 0; i < n; ++i) {
         if (mpi_cmp(a.coeffs[i], r.coeffs[i]) != 0) { printf("FAIL roundtrip n=%u W=%u i=%u\n", n, W, i); return 1; }
