@@ -282,3 +282,23 @@ def test_poly_mul_general_modulus_exact_at_full_size(engine_ctx, logn):
     r = torch.empty(W * n, dtype=torch.int64, device="cuda")
     g.poly_mul_general(r, to_device(ints_to_big(a, W)), to_device(ints_to_big(s, W)), W, dim, q)
     assert big_to_ints(to_host(r), W, n)[0] == want
+
+
+@pytest.mark.parametrize("logn,W,batch", [(6, 1, 1), (7, 14, 3), (13, 7, 2), (16, 14, 2), (9, 33, 1)])
+def test_big_transpose_between_word_major_and_rows(engine_ctx, logn, W, batch):
+    """gpq_big_transpose: the kernels' layout (word j of coefficient i at j*n + i) <-> rows of W words per coefficient, the layout the
+    MPI-typed calls stage host data through."""
+    import ctypes as C
+    import torch
+    g = engine_ctx(logn, 2)
+    n = g.n
+    rng = np.random.default_rng(logn * 100 + W)
+    words = rng.integers(0, 1 << 63, size=(batch, W, n), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(batch, W, n), dtype=np.uint64)
+    d_words = to_device(words.reshape(-1))
+    d_rows = torch.empty_like(d_words)
+    lib = g.lib
+    assert lib.gpq_big_transpose(g.h, C.c_void_p(d_rows.data_ptr()), C.c_void_p(d_words.data_ptr()), W, batch, 1, g._stream()) == 0
+    assert np.array_equal(to_host(d_rows).reshape(batch, n, W), words.transpose(0, 2, 1))
+    back = torch.empty_like(d_words)
+    assert lib.gpq_big_transpose(g.h, C.c_void_p(back.data_ptr()), C.c_void_p(d_rows.data_ptr()), W, batch, 0, g._stream()) == 0
+    assert torch.equal(back, d_words)
