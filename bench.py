@@ -581,6 +581,7 @@ def main(argv=None):
             del a0, a1, b0, b1, x, d0, d1, d2, c0, c1, wsA, wsB
             torch.cuda.empty_cache()
             out["ntt"].append(ntt_rate(torch, gpqhe_amd, 16, DIM_A, 4 * B))   # launch size matters: 4 GiB slab
+            out["ntt"].append(ntt_rate(torch, gpqhe_amd, 15, 10, 2048))       # configs[1]'s ring at a launch that fills the chip (5 GiB)
             out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, B, iters=3)   # BASELINE configs[2]: he_mul + he_rescale, batch 64
             out["keyswitch_n17"] = keyswitch_n17_rate(torch, gpqhe_amd)
             out["squaring_core"] = squaring_rate(torch, gpqhe_amd, ctx, B)
