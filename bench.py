@@ -378,9 +378,11 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=1, help="2: tensor stage and key-switch stage on separate HIP streams")
     ap.add_argument("--no-scatter-gather", action="store_true", help="N>1: skip the extra step that has the input slabs scattered from "
                     "rank 0 and the outputs gathered back inside the timed region (SURVEY.md 8d config 4)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
-                    "the multi-rank path with several ranks on one GPU)")
+    ap.add_argument("--backend", default="nccl", help="N>1: nccl = slab transfers over RCCL/xGMI, one rank per GPU (the control plane -- barriers, MAX of "
+                    "the timing -- is gloo either way); gloo = everything over gloo, to rehearse several ranks on one GPU")
     ap.add_argument("--sg-deadline", type=float, default=SG_DEADLINE_S, help="seconds the scatter/gather leg may take before every rank gives up (exit status %d)" % SG_FAILED_STATUS)
+    ap.add_argument("--share-gpu", action="store_true", help="testing: with --backend nccl on a node with fewer GPUs than ranks, let ranks share "
+                    "a device -- RCCL refuses that at the first transfer, which rehearses a fabric failure inside the scatter/gather leg")
     ap.add_argument("--sg-stall-rank", type=int, default=-1, help="testing: this rank never enters the scatter/gather leg (rehearses a stalled transfer)")
     return ap.parse_args(argv)
 
@@ -440,11 +442,16 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            if local >= ndev:
+            if local >= ndev and not args.share_gpu:
                 sys.exit("bench.py: rank %d needs cuda:%d but this node shows %d device(s); one rank per GPU over RCCL "
                          "(--backend gloo rehearses several ranks on one GPU)" % (rank, local, ndev))
-            torch.cuda.set_device(local)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+            torch.cuda.set_device(local % ndev)
+            # Control plane (barriers, MAX of the timing, a few bytes) on gloo; the slabs of the scatter/gather leg on an RCCL group
+            # that is only set up at its first transfer, inside that leg's watchdog: the path has no data-path collective
+            # (SURVEY.md 8e), so a fabric problem must not be able to cost the compute-only line.
+            from gpqhe_amd.dist import use_data_group
+            dist.init_process_group(backend="gloo")
+            use_data_group(dist.new_group(backend="nccl"))
         else:
             torch.cuda.set_device(local % ndev)
             dist.init_process_group(backend=args.backend)
@@ -552,7 +559,8 @@ def main(argv=None):
                        "batch_per_gpu": B, "total_batch": total_batch, "chunk": chunk,
                        "parallelism": "ciphertext-per-GPU x%d, no data-path collective" % world,
                        "launcher": "torchrun / external" if os.environ.get("TORCHELASTIC_RUN_ID") else ("self-launched ranks" if world > 1 else "single process"),
-                       "backend": args.backend if world > 1 else None},
+                       "backend": (None if world == 1 else "gloo (control plane) + nccl/RCCL (slab transfers)" if args.backend == "nccl"
+                                   else args.backend)},
             "roofline": {"bound": "hbm", "kernel": kname, "kernel_rocprof": ROCPROF_NAMES.get(kname, kname),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,

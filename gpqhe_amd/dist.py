@@ -4,11 +4,30 @@ The reference has no communication layer at all: ciphertext
 multiplications are independent, so the only multi-GPU structure is a partition
 of the batch.  Nothing is exchanged inside an NTT; the collectives here are the
 optional scatter of input slabs from rank 0, the gather of output slabs back,
-and the MAX-reduce of the timing.  Backend "nccl" (= RCCL over xGMI) on GPUs,
-"gloo" in the CPU tests.
+and the MAX-reduce of the timing.
+
+Two planes.  The CONTROL plane (barriers, the MAX of the timing, small python
+objects) is the default process group and may be plain gloo: it carries a few
+bytes.  The DATA plane (scatter / gather of slabs) is the group handed to
+`use_data_group` -- backend "nccl" (= RCCL over xGMI) on GPUs, created lazily, so
+that a broken fabric can only fail the transfer leg, never the set-up of the
+ranks or the compute-only measurement.  Without `use_data_group` the slabs
+travel over the default group (gloo in the CPU tests: staged through the host).
 """
 import torch
 import torch.distributed as dist
+
+_data = None          # process group of the slab transfers; None = the default group
+
+
+def use_data_group(group):
+    """Slabs travel over `group` from now on (None = the default group again)."""
+    global _data
+    _data = group
+
+
+def data_backend():
+    return dist.get_backend(_data)
 
 
 def shard_range(batch, world, rank):
@@ -22,7 +41,7 @@ def shard_range(batch, world, rank):
 def _wire_device(device):
     """Where a slab sits while it is on the wire: RCCL moves device memory; gloo (CPU tests, and the
     rehearsal of several ranks on one GPU) moves host memory, so device slabs are staged through the host."""
-    return device if dist.get_backend() == "nccl" else torch.device("cpu")
+    return device if data_backend() == "nccl" else torch.device("cpu")
 
 
 def scatter_slab(full, per_ct, batch, src=0, device=None):
@@ -49,9 +68,9 @@ def scatter_slab(full, per_ct, batch, src=0, device=None):
             if r == src:
                 mine.copy_(piece)
             elif rhi > rlo:
-                ops.append(dist.P2POp(dist.isend, piece.contiguous(), r))
+                ops.append(dist.P2POp(dist.isend, piece.contiguous(), r, group=_data))
     elif hi > lo:
-        ops.append(dist.P2POp(dist.irecv, mine, src))
+        ops.append(dist.P2POp(dist.irecv, mine, src, group=_data))
     if ops:
         for w in dist.batch_isend_irecv(ops):  # grouped send/recv: one RCCL group on GPUs
             w.wait()
@@ -76,9 +95,9 @@ def gather_slab(mine, per_ct, batch, dst=0):
             if r == dst:
                 full[rlo * per_ct: rhi * per_ct].copy_(mine)
             elif rhi > rlo:
-                ops.append(dist.P2POp(dist.irecv, full[rlo * per_ct: rhi * per_ct], r))
+                ops.append(dist.P2POp(dist.irecv, full[rlo * per_ct: rhi * per_ct], r, group=_data))
     elif mine.numel():
-        ops.append(dist.P2POp(dist.isend, mine.contiguous(), dst))
+        ops.append(dist.P2POp(dist.isend, mine.contiguous(), dst, group=_data))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
@@ -86,13 +105,16 @@ def gather_slab(mine, per_ct, batch, dst=0):
 
 
 def max_over_ranks(seconds, device=None):
-    """Wall time of the slowest rank (the number bench.py reports)."""
+    """Wall time of the slowest rank (the number bench.py reports); control plane."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device or _default_device())
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def _default_device():
-    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    """Where a shard lands when the caller names no device: the GPU when the slabs travel over RCCL."""
+    return torch.device("cuda", torch.cuda.current_device()) if data_backend() == "nccl" else torch.device("cpu")

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gpqhe_amd.dist import gather_slab, max_over_ranks, scatter_slab, shard_range
+from gpqhe_amd.dist import gather_slab, max_over_ranks, scatter_slab, shard_range, use_data_group
 
 LOGN, DIM, BATCH = 7, 3, 5  # ragged on purpose: 5 ciphertexts over 2 ranks
 
@@ -33,10 +33,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, two_planes=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if two_planes:      # bench.py's arrangement: control plane = default group, slabs over a group of their own
+            use_data_group(dist.new_group(backend="gloo"))
         from oracle.oracle import OracleCtx
         o = OracleCtx(LOGN, DIM)
         per = DIM * o.n
@@ -66,11 +68,13 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(180)
-def test_two_rank_scatter_compute_gather():
+@pytest.mark.parametrize("two_planes", [False, True])
+def test_two_rank_scatter_compute_gather(two_planes):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, _free_port_once(), q)) for r in range(world)]
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, two_planes)) for r in range(world)]
     for p in procs:
         p.start()
     ok, slowest = q.get(timeout=150)
@@ -79,13 +83,3 @@ def test_two_rank_scatter_compute_gather():
         assert p.exitcode == 0
     assert ok, "gathered multi-rank result differs from the single-process result"
     assert slowest == 2.0  # MAX over ranks of (1.0, 2.0)
-
-
-_PORT = None
-
-
-def _free_port_once():
-    global _PORT
-    if _PORT is None:
-        _PORT = _free_port()
-    return _PORT

@@ -141,3 +141,21 @@ def test_a_stalled_scatter_gather_leg_is_a_failure_not_a_success():
     assert out["value"] > 0 and out["n_gpus"] == 2
     sg = out["with_scatter_gather"]
     assert "no result within" in sg["error"] and sg["rank"] == 0 and "scatter" in sg["stage"]
+
+
+@pytest.mark.timeout(600)
+def test_a_failing_rccl_group_costs_the_transfer_leg_only():
+    """--backend nccl keeps barriers and timing on gloo and sets the RCCL group up at the first slab transfer.  Two ranks on the one
+    GPU of this box are something RCCL refuses (or never completes): the compute-only line is still printed in full, the
+    scatter/gather entry carries the error, the exit status is non-zero."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "nccl", "--share-gpu", "--total-batch", "4",
+           "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--no-ntt", "--sg-deadline", "40"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=540, cwd=ROOT)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["n_gpus"] == 2 and out["ranks_seen"] == 2
+    assert "nccl" in out["config"]["backend"] and "gloo" in out["config"]["backend"]
+    assert out["with_scatter_gather"]["error"] and "scatter" in out["with_scatter_gather"]["stage"]
