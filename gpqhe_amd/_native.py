@@ -122,6 +122,10 @@ SIGNATURES = {
     "gpq_mpi_shim_engine": (C.c_void_p, []),
     "gpq_compat_view": (C.c_void_p, [C.c_char_p]),
     "gpq_mpi_shim_resident_keys": (C.c_uint, []),
+    "gpq_mpi_shim_set_poly_slots": (None, [C.c_uint]),
+    "gpq_mpi_shim_resident_polys": (C.c_uint, []),
+    "gpq_mpi_shim_poly_stats": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "gpq_mpi_shim_forget_polys": (None, []),
     "gpq_mpi_shim_set_direct_mpi": (C.c_int, [C.c_int]),
     "gpq_mpi_shim_last_timing": (None, [C.POINTER(C.c_double)]),
     "gpq_fill_rns_chain": (C.c_int, [vp, C.c_uint, vp, C.c_int]),

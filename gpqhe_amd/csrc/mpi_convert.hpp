@@ -155,39 +155,49 @@ class Workers {
   std::mutex mu_;
   std::condition_variable wake_, idle_;
   const std::function<void(unsigned)> *job_ = nullptr;
-  unsigned tasks_ = 0, next_ = 0, open_ = 0;
+  unsigned tasks_ = 0, left_ = 0, open_ = 0;
+  std::vector<char> taken_;
   uint64_t round_ = 0;
 
-  void drain(std::unique_lock<std::mutex> &lk) {       // run tasks of the current round until none is left to take
-    while (next_ < tasks_) {
-      const unsigned t = next_++;
+  // Task t belongs to thread t mod width first: the range of a polynomial a thread wrote in one call (results) is the range it reads
+  // in the next (the check of a resident operand), out of its own cache.  A thread with nothing of its own left takes any task.
+  int pick(unsigned me) {
+    if (!left_) return -1;
+    const unsigned w = width();
+    for (unsigned t = me; t < tasks_; t += w) if (!taken_[t]) return (int)t;
+    for (unsigned t = 0; t < tasks_; ++t) if (!taken_[t]) return (int)t;
+    return -1;
+  }
+  void drain(std::unique_lock<std::mutex> &lk, unsigned me) {       // run tasks of the current round until none is left to take
+    for (int t; (t = pick(me)) >= 0;) {
+      taken_[t] = 1; --left_;
       const std::function<void(unsigned)> *job = job_;
       lk.unlock();
-      (*job)(t);
+      (*job)((unsigned)t);
       lk.lock();
       if (--open_ == 0) idle_.notify_all();
     }
   }
-  void loop() {
+  void loop(unsigned me) {
     std::unique_lock<std::mutex> lk(mu_);
     uint64_t seen = 0;
     for (;;) {
       wake_.wait(lk, [&] { return round_ != seen; });
       seen = round_;
-      drain(lk);
+      drain(lk, me);
     }
   }
 
  public:
   explicit Workers(unsigned helpers) {
-    for (unsigned i = 0; i < helpers; ++i) { th_.emplace_back([this] { loop(); }); th_.back().detach(); }
+    for (unsigned i = 0; i < helpers; ++i) { th_.emplace_back([this, i] { loop(i + 1); }); th_.back().detach(); }
   }
   unsigned width() const { return (unsigned)th_.size() + 1; }
   void run(unsigned tasks, const std::function<void(unsigned)> &f) {     // the caller works too; returns when every task is done
     std::unique_lock<std::mutex> lk(mu_);
-    job_ = &f; tasks_ = tasks; next_ = 0; open_ = tasks; ++round_;
+    job_ = &f; tasks_ = tasks; left_ = tasks; open_ = tasks; taken_.assign(tasks, 0); ++round_;
     wake_.notify_all();
-    drain(lk);
+    drain(lk, 0);
     idle_.wait(lk, [&] { return open_ == 0; });
     job_ = nullptr; tasks_ = 0;
   }
@@ -241,8 +251,10 @@ unsigned max_bits(const poly_mpi_t *a, unsigned n) {       // widest coefficient
 // assembled eight bytes at a time (the byte-at-a-time form cost as much as gcry_mpi_print itself).
 // ROWS = false: the device layout, word j of coefficient i at j*n + i (14 write streams per thread);  ROWS = true: one row of W words per
 // coefficient, i*W + j -- one sequential stream, what the MPI-typed calls stage through (the device transposes: bridge_big_transpose)
+// `misfit`: a coefficient that does not fit W words is reported there (its words are left as they are) instead of ending the program --
+// for the conversions that only CHECK a resident device copy against the caller's integers (mpi_shim.hip, resident polynomials).
 template <bool ROWS = false>
-void to_slab_range(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W, unsigned lo, unsigned hi) {
+void to_slab_range(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W, unsigned lo, unsigned hi, bool *misfit = nullptr) {
   const size_t sj = ROWS ? 1 : n, si = ROWS ? W : 1;
   unsigned char buf[8 * 64 + 8];
   const bool direct = mpi_direct();
@@ -258,7 +270,10 @@ void to_slab_range(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W, u
       const MpiView *m = (const MpiView *)v;
       unsigned nl = m->nlimbs > 0 ? (unsigned)m->nlimbs : 0;
       while (nl && m->d[nl - 1] == 0) --nl;
-      if (nl > W || (nl == W && (m->d[W - 1] >> 63))) die("coefficient does not fit the big slab");
+      if (nl > W || (nl == W && (m->d[W - 1] >> 63))) {
+        if (misfit) { *misfit = true; continue; }
+        die("coefficient does not fit the big slab");
+      }
       if (m->sign && nl) {
         uint64_t carry = 1;
         for (unsigned j = 0; j < W; ++j) { const uint64_t x = ~(j < nl ? m->d[j] : 0) + carry; carry = carry && x == 0; dst[j * sj + i * si] = x; }
@@ -267,7 +282,10 @@ void to_slab_range(uint64_t *dst, const poly_mpi_t *a, unsigned n, unsigned W, u
       }
       continue;
     }
-    if (G.mpi_get_nbits(v) > 64 * W - 1) die("coefficient does not fit the big slab");
+    if (G.mpi_get_nbits(v) > 64 * W - 1) {
+      if (misfit) { *misfit = true; continue; }
+      die("coefficient does not fit the big slab");
+    }
     size_t nw = 0;
     if (G.mpi_print(FMT_USG, buf, 8 * W, &nw, v)) die("gcry_mpi_print failed");
     uint64_t w[64];

@@ -122,6 +122,18 @@ void copy_range(void *dst, const void *src, unsigned n, unsigned W, unsigned lo,
     die("slab copy failed");
 }
 
+// words [lo, hi) of one polynomial: four multiply-xor lanes (the multiply's latency is covered, the loop runs at memory speed)
+uint64_t hash_words(const uint64_t *a, size_t lo, size_t hi) {
+  uint64_t h[4] = {0x9e3779b97f4a7c15ull, 0xbf58476d1ce4e5b9ull, 0x94d049bb133111ebull, 0xcbf29ce484222325ull};
+  size_t i = lo;
+  for (; i + 4 <= hi; i += 4)
+    for (int j = 0; j < 4; ++j) { h[j] = (h[j] ^ a[i + j]) * 0xff51afd7ed558ccdull; h[j] ^= h[j] >> 32; }
+  for (; i < hi; ++i) { h[0] = (h[0] ^ a[i]) * 0xff51afd7ed558ccdull; h[0] ^= h[0] >> 32; }
+  return ((h[0] * 3 + h[1]) * 5 + h[2]) * 7 + h[3];
+}
+// host threads that convert a polynomial of n coefficients (each its own range), and so the pieces its fingerprint is made of
+inline unsigned convert_threads(unsigned n) { return n >= 4096 ? workers().width() : 1; }
+
 // Transfers go in few, large pieces: a copy of a sixteenth of a polynomial (448 KB) moves at 25 GB/s over PCIe here, a whole polynomial
 // (7 MB) at 53 GB/s -- about 9 us of fixed cost per copy (tools/copy_probe.hip) -- so the ranges the host threads convert are grouped
 // four to a copy: coarse enough for the link, fine enough for conversions and DMA to overlap.
@@ -131,13 +143,14 @@ constexpr unsigned kRangesPerCopy = 4;
 // finishes the last range of a group of kRangesPerCopy sends the group off, so conversion of the next ranges / polynomial overlaps the DMA.
 // `extra` more tasks (side(0) .. side(extra - 1)) are handed out to the same threads behind the ranges -- the evaluation-key
 // fingerprint of a key that is not resident yet, which only reads memory while the conversions compute.
+// `prints` (count x convert_threads(n) words, rows staging only): the fingerprint of every converted range, for the resident polynomials below.
 void upload_polys(const DevBuf *const dst[], const HostBuf *const stage[], const poly_mpi_t *const src[], int count, unsigned n, unsigned W,
-                  unsigned extra = 0, const std::function<void(unsigned)> *side = nullptr) {
+                  unsigned extra = 0, const std::function<void(unsigned)> *side = nullptr, uint64_t *prints = nullptr) {
   if (W < 1 || W > 32) die("coefficients wider than 2047 bits");
   const bool rows = staged_in_rows(n);
   const size_t big = (size_t)W * n * 8;
   DevBuf landing(rows ? big * count : 8);                   // the rows land here; gpq_big_transpose writes the word-major slabs from it
-  const unsigned nt = n >= 4096 ? workers().width() : 1, per = (n + nt - 1) / nt;
+  const unsigned nt = convert_threads(n), per = (n + nt - 1) / nt;
   const unsigned ranges = (n + per - 1) / per, groups = (ranges + kRangesPerCopy - 1) / kRangesPerCopy;
   std::vector<std::atomic<unsigned>> done((size_t)count * groups);
   for (auto &d : done) d.store(0, std::memory_order_relaxed);
@@ -149,6 +162,7 @@ void upload_polys(const DevBuf *const dst[], const HostBuf *const stage[], const
     const unsigned g = t / kRangesPerCopy, first = g * kRangesPerCopy, last = first + kRangesPerCopy < ranges ? first + kRangesPerCopy : ranges;
     for (int i = 0; i < count; ++i) {
       if (rows) to_slab_range<true>(stage[i]->u64(), src[i], n, W, lo, hi); else to_slab_range<false>(stage[i]->u64(), src[i], n, W, lo, hi);
+      if (prints && rows) prints[(size_t)i * nt + t] = hash_words(stage[i]->u64(), (size_t)lo * W, (size_t)hi * W);   // just written: in cache
       if (done[(size_t)i * groups + g].fetch_add(1, std::memory_order_acq_rel) + 1 == last - first) {      // the group is complete: one copy for all of it
         const unsigned glo = first * per, ghi = last * per < n ? last * per : n;
         copy_range(rows ? (char *)landing.p + big * i : (char *)dst[i]->p, stage[i]->p, n, W, glo, ghi, hipMemcpyHostToDevice);
@@ -170,7 +184,7 @@ void download_issue(const HostBuf *const stage[], const DevBuf *const src[], int
   const bool rows = staged_in_rows(n);
   const size_t big = (size_t)W * n * 8;
   DevBuf takeoff(rows ? big * count : 8);                   // stream-ordered: safe to hand back to the pool when this returns
-  const unsigned nt = n >= 4096 ? workers().width() : 1, per = (n + nt - 1) / nt;
+  const unsigned nt = convert_threads(n), per = (n + nt - 1) / nt;
   const unsigned ranges = (n + per - 1) / per, groups = (ranges + kRangesPerCopy - 1) / kRangesPerCopy;
   for (int i = 0; i < count; ++i) {
     const char *from = (const char *)src[i]->p;
@@ -185,9 +199,9 @@ void download_issue(const HostBuf *const stage[], const DevBuf *const src[], int
     }
   }
 }
-void download_convert(poly_mpi_t *const dst[], const HostBuf *const stage[], int count, unsigned n, unsigned W) {
+void download_convert(poly_mpi_t *const dst[], const HostBuf *const stage[], int count, unsigned n, unsigned W, uint64_t *prints = nullptr) {
   const bool rows = staged_in_rows(n);
-  const unsigned nt = n >= 4096 ? workers().width() : 1, per = (n + nt - 1) / nt;
+  const unsigned nt = convert_threads(n), per = (n + nt - 1) / nt;
   const unsigned ranges = (n + per - 1) / per, groups = (ranges + kRangesPerCopy - 1) / kRangesPerCopy;
   const std::function<void(unsigned)> job = [&](unsigned t) {
     (void)hipSetDevice(g_dev);
@@ -195,6 +209,7 @@ void download_convert(poly_mpi_t *const dst[], const HostBuf *const stage[], int
     for (int i = 0; i < count; ++i) {
       if (hipEventSynchronize(g_events[(size_t)i * groups + t / kRangesPerCopy]) != hipSuccess) die("download failed");
       if (rows) from_slab_range<true>(dst[i], stage[i]->u64(), n, W, lo, hi); else from_slab_range<false>(dst[i], stage[i]->u64(), n, W, lo, hi);
+      if (prints && rows && lo < hi) prints[(size_t)i * nt + t] = hash_words(stage[i]->u64(), (size_t)lo * W, (size_t)hi * W);
     }
   };
   if (ranges < 2) job(0); else workers().run(ranges, job);
@@ -232,15 +247,6 @@ uint64_t key_print_sampled(const uint64_t *a, const uint64_t *b, size_t words) {
   for (size_t i = 0; i < words; i += step) { mix(a[i]); mix(b[i]); }
   for (size_t i = 0; i < 8 && i < words; ++i) { mix(a[i]); mix(b[i]); mix(a[words - 1 - i]); mix(b[words - 1 - i]); }
   return h;
-}
-// words [lo, hi) of one polynomial: four multiply-xor lanes (the multiply's latency is covered, the loop runs at memory speed)
-uint64_t hash_words(const uint64_t *a, size_t lo, size_t hi) {
-  uint64_t h[4] = {0x9e3779b97f4a7c15ull, 0xbf58476d1ce4e5b9ull, 0x94d049bb133111ebull, 0xcbf29ce484222325ull};
-  size_t i = lo;
-  for (; i + 4 <= hi; i += 4)
-    for (int j = 0; j < 4; ++j) { h[j] = (h[j] ^ a[i + j]) * 0xff51afd7ed558ccdull; h[j] ^= h[j] >> 32; }
-  for (; i < hi; ++i) { h[0] = (h[0] ^ a[i]) * 0xff51afd7ed558ccdull; h[0] ^= h[0] >> 32; }
-  return ((h[0] * 3 + h[1]) * 5 + h[2]) * 7 + h[3];
 }
 struct KeyPrint {                 // fingerprint of a host key, in `parts` pieces that any thread may compute
   const uint64_t *h0, *h1; size_t words; unsigned parts; std::vector<uint64_t> part;
@@ -304,6 +310,125 @@ void key_on_device(const KeyPrint &kp, uint64_t **d0, uint64_t **d1) {
   if (gpq_upload(slot.d0, h0, words * 8, nullptr) != GPQ_OK || gpq_upload(slot.d1, h1, words * 8, nullptr) != GPQ_OK) die("upload failed");
   g_keys.push_back(slot);
   *d0 = (uint64_t *)slot.d0; *d1 = (uint64_t *)slot.d1;
+}
+
+// ---- resident polynomials ----------------------------------------------------------------------------------------------
+// GPQHE's own callers chain the calls on one ciphertext (he_mul(&bn, &bn, &bn, rlk); he_rs(&bn); ... src/he-algo.c:140-160): what one call
+// writes into the caller's integers is what the next one reads back.  Reading 2 x 65536 scattered libgcrypt integers and sending them
+// over PCIe is most of a call (0.7 of 1.9 ms for he_mul), so the device keeps the word-major slab of every polynomial it has seen or
+// produced, identified by the caller's coefficient array, the shape and a fingerprint of EVERY word of every coefficient.  When all
+// operands of a call (and its key) are resident, the device starts from the resident copies at once and the host threads meanwhile do
+// exactly the conversion an upload would have done, into the staging rows, and fingerprint it: a mismatch -- the caller changed the
+// integers since, by any means -- uploads the rows that are then already staged and repeats the device work.  The result can never
+// depend on a stale copy; a program whose operands are always new pays the fingerprint of its results (in cache, a few per cent).
+// Only with the direct integer access (mpi_convert.hpp) and n >= 4096; gpq_mpi_shim_set_poly_slots(0) turns it off.
+struct PolySlot { const gpq_MPI *coeffs; unsigned n, W, parts; uint64_t print; void *d; size_t bytes /* of the buffer: >= W n 8 */; uint64_t used; };
+std::vector<PolySlot> g_polys;
+uint64_t g_poly_clock = 0;
+size_t g_poly_slots = 32;     // 7 MiB each at n = 2^16, 14 words
+uint64_t g_poly_hits = 0, g_poly_stale = 0;
+
+bool poly_cache_on(unsigned n) { return g_poly_slots && n >= 4096 && staged_in_rows(n) && mpi_direct(); }
+uint64_t fold_prints(const uint64_t *part, unsigned parts, unsigned n, unsigned W) {
+  uint64_t h = 0xcbf29ce484222325ull ^ ((uint64_t)n << 32 | W);
+  for (unsigned t = 0; t < parts; ++t) { h = (h ^ part[t]) * 0x100000001b3ull; h ^= h >> 29; }
+  return h;
+}
+void drop_poly_slot(size_t i) {
+  (void)gpq_stream_sync(nullptr);
+  (void)gpq_free(g_polys[i].d);
+  g_polys.erase(g_polys.begin() + i);
+}
+// the resident copy of this polynomial at this shape (W = 0: at whatever width it was kept), or null
+const PolySlot *resident_poly(const poly_mpi_t *p, unsigned n, unsigned W) {
+  for (PolySlot &s : g_polys)
+    if (s.coeffs == p->coeffs && s.n == n && (W == 0 || s.W == W) && s.parts == convert_threads(n)) { s.used = ++g_poly_clock; return &s; }
+  return nullptr;
+}
+// `dev` (word-major, W x n) is what the caller's polynomial holds now: keep a copy (stream-ordered device-to-device copy)
+void remember_poly(const poly_mpi_t *p, unsigned n, unsigned W, uint64_t print, const void *dev) {
+  if (!poly_cache_on(n)) return;
+  const size_t bytes = (size_t)W * n * 8;
+  PolySlot slot{p->coeffs, n, W, convert_threads(n), print, nullptr, bytes, ++g_poly_clock};
+  size_t victim = g_polys.size();
+  for (size_t i = 0; i < g_polys.size(); ++i) if (g_polys[i].coeffs == p->coeffs) victim = i;     // one copy per host polynomial
+  if (victim == g_polys.size() && g_polys.size() >= g_poly_slots) {
+    victim = 0;
+    for (size_t i = 1; i < g_polys.size(); ++i) if (g_polys[i].used < g_polys[victim].used) victim = i;
+  }
+  if (victim < g_polys.size()) {                            // its buffer serves again if it is large enough (he_rs keeps one word less than he_mul: no free / malloc per call)
+    if (g_polys[victim].bytes >= bytes) { slot.d = g_polys[victim].d; slot.bytes = g_polys[victim].bytes; g_polys.erase(g_polys.begin() + victim); }
+    else drop_poly_slot(victim);
+  }
+  if (!slot.d && gpq_malloc(&slot.d, bytes) != GPQ_OK) die("device allocation failed");
+  if (slot.d != dev && hipMemcpyAsync(slot.d, dev, (size_t)W * n * 8, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) die("device copy failed");
+  g_polys.push_back(slot);
+}
+
+// The polynomial operands of one MPI-typed call.  prepare(): either every operand is resident (`resident`, x[i] = the kept slabs, nothing
+// converted yet) or all are converted and uploaded as ever (x[i] = the call's own buffers) and remembered.  After the device work is queued,
+// recheck() -- resident operands only -- converts and fingerprints the caller's integers; operands that differ are uploaded from the rows
+// just staged, x[i] moves to the call's own buffer, and the caller queues the device work again.
+struct Operands {
+  int count; unsigned n, W, nt; bool cache, resident = false; unsigned misfits = 0;
+  const poly_mpi_t *const *src; const DevBuf *const *dst; const HostBuf *const *stage;
+  const uint64_t *x[4]; uint64_t want[4];
+  std::vector<uint64_t> prints;
+  Operands(int count_, const poly_mpi_t *const s[], const DevBuf *const d[], const HostBuf *const st[], unsigned n_, unsigned W_)
+      : count(count_), n(n_), W(W_), nt(convert_threads(n_)), cache(poly_cache_on(n_)), src(s), dst(d), stage(st), prints((size_t)4 * nt, 0) {
+    if (count > 4) die("more than four polynomial operands");
+  }
+  void prepare(bool may_speculate, unsigned extra = 0, const std::function<void(unsigned)> *side = nullptr) {
+    resident = cache && may_speculate;
+    for (int i = 0; i < count && resident; ++i) {
+      const PolySlot *s = resident_poly(src[i], n, W);
+      if (!s) resident = false; else { x[i] = (const uint64_t *)s->d; want[i] = s->print; }
+    }
+    if (resident) return;
+    upload_polys(dst, stage, src, count, n, W, extra, side, cache ? prints.data() : nullptr);
+    for (int i = 0; i < count; ++i) {
+      x[i] = dst[i]->u64();
+      if (cache) remember_poly(src[i], n, W, fold_prints(&prints[(size_t)i * nt], nt, n, W), dst[i]->p);
+    }
+  }
+  bool recheck(unsigned extra = 0, const std::function<void(unsigned)> *side = nullptr) {
+    const unsigned per = (n + nt - 1) / nt;
+    std::atomic<unsigned> misfit{0};
+    const std::function<void(unsigned)> job = [&](unsigned t) {
+      if (t >= nt) { (*side)(t - nt); return; }
+      const unsigned lo = t * per, hi = lo + per < n ? lo + per : n;
+      if (lo >= hi) return;
+      for (int i = 0; i < count; ++i) {
+        bool bad = false;
+        to_slab_range<true>(stage[i]->u64(), src[i], n, W, lo, hi, &bad);
+        if (bad) misfit.fetch_or(1u << i, std::memory_order_relaxed);
+        prints[(size_t)i * nt + t] = hash_words(stage[i]->u64(), (size_t)lo * W, (size_t)hi * W);
+      }
+    };
+    if (nt + extra < 2) job(0); else workers().run(nt + extra, job);
+    g_poly_hits += count;
+    bool again = false;
+    for (int i = 0; i < count; ++i) {
+      const uint64_t now = fold_prints(&prints[(size_t)i * nt], nt, n, W);
+      const bool unfit = misfit.load() >> i & 1;
+      if (now == want[i] && !unfit) continue;
+      ++g_poly_stale; --g_poly_hits;
+      again = true;
+      if (unfit) { misfits |= 1u << i; continue; }           // wider than the kept copy: the caller decides (he_mul ends the program, he_rs widens)
+      DevBuf landing((size_t)W * n * 8);                     // the caller's integers as they are now: rows already staged by the check
+      copy_range(landing.p, stage[i]->p, n, W, 0, n, hipMemcpyHostToDevice);
+      if (gpq_big_transpose(engine(), dst[i]->u64(), (const uint64_t *)landing.p, W, 1, 0, nullptr) != GPQ_OK) die("slab transpose failed");
+      x[i] = dst[i]->u64();
+      remember_poly(src[i], n, W, now, dst[i]->p);
+    }
+    return again;
+  }
+};
+// the results of a call went into the caller's integers (download_convert with prints): keep the device slabs they came from
+void remember_results(poly_mpi_t *const out[], const DevBuf *const dev[], int count, unsigned n, unsigned W, const std::vector<uint64_t> &prints) {
+  if (!poly_cache_on(n)) return;
+  const unsigned nt = convert_threads(n);
+  for (int i = 0; i < count; ++i) remember_poly(out[i], n, W, fold_prints(&prints[(size_t)i * nt], nt, n, W), dev[i]->p);
 }
 
 // The MPI-typed entry points share the staging buffers, the buffer pools, the key cache and the worker threads: one call at a
@@ -426,41 +551,48 @@ void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t 
   const unsigned W = logql / 64 + 1;
   const size_t big = (size_t)W * n, evk = (size_t)dimB * n;
   const poly_mpi_t *in[4] = {&ct1->c0, &ct1->c1, &ct2->c0, &ct2->c1};
-  HostBuf s0(big * 8), s1(big * 8), s2(big * 8), s3(big * 8);
+  HostBuf s0(big * 8), s1(big * 8), s2(big * 8), s3(big * 8), t0s(big * 8), t1s(big * 8);
   DevBuf d0(big * 8), d1(big * 8), d2(big * 8), d3(big * 8), o0(big * 8), o1(big * 8),
       ws(pow2 ? gpq_he_mul_workspace_bytes(c, W, dimA, dimB, dimP, 1) : gpq_he_general_workspace_bytes(c, W, dimA, dimB, dimP, 1));
   const DevBuf *dd[4] = {&d0, &d1, &d2, &d3}, *oo[2] = {&o0, &o1};
-  const HostBuf *ss[4] = {&s0, &s1, &s2, &s3};
+  const HostBuf *ss[4] = {&s0, &s1, &s2, &s3}, *ts[2] = {&t0s, &t1s};   // results come back into rows of their own: ss may still be filling (recheck)
   // he_mul(&ct, &ct, &ct, rlk), src/he-algo.c:151: one ciphertext on both sides -- convert and upload it once, square on the device
   const bool square = ct1->c0.coeffs == ct2->c0.coeffs && ct1->c1.coeffs == ct2->c1.coeffs;
   const double t0 = wall_ms();
   KeyPrint kp(rlk, evk);
   KeySlot *spec = resident_key(rlk, evk);                  // a resident copy: used at once, verified while the device works
-  if (spec) upload_polys(dd, ss, in, square ? 2 : 4, n, W);
-  else upload_polys(dd, ss, in, square ? 2 : 4, n, W, kp.parts, &kp.task);
+  Operands ops(square ? 2 : 4, in, dd, ss, n, W);
+  if (spec) ops.prepare(true); else ops.prepare(false, kp.parts, &kp.task);
   uint64_t *k0, *k1;
   if (spec) { k0 = (uint64_t *)spec->d0; k1 = (uint64_t *)spec->d1; } else key_on_device(kp, &k0, &k1);
   if (!g_tick[0]) { (void)hipEventCreate(&g_tick[0]); (void)hipEventCreate(&g_tick[1]); }
   (void)hipEventRecord(g_tick[0], nullptr);
   const double t1 = wall_ms();
-  uint64_t *const e0 = square ? d0.u64() : d2.u64(), *const e1 = square ? d1.u64() : d3.u64();
   auto device_work = [&]() {
-    const int rc = pow2 ? gpq_he_mul(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), e0, e1, k0, k1, W, logql, dimA, dimB, dimP,
-                                     1, ws.p, nullptr)
-                        : gpq_he_mul_general(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), e0, e1, k0, k1, W, qw.data(),
+    const uint64_t *const a0 = ops.x[0], *const a1 = ops.x[1], *const e0 = square ? a0 : ops.x[2], *const e1 = square ? a1 : ops.x[3];
+    const int rc = pow2 ? gpq_he_mul(c, o0.u64(), o1.u64(), a0, a1, e0, e1, k0, k1, W, logql, dimA, dimB, dimP, 1, ws.p, nullptr)
+                        : gpq_he_mul_general(c, o0.u64(), o1.u64(), a0, a1, e0, e1, k0, k1, W, qw.data(),
                                              (unsigned)qw.size(), dimA, dimB, dimP, 1, ws.p, nullptr);
     if (rc != GPQ_OK) die("he_mul failed");
     (void)hipEventRecord(g_tick[1], nullptr);
-    download_issue(ss, oo, 2, n, W);
+    download_issue(ts, oo, 2, n, W);
   };
   device_work();
   const double t2 = wall_ms();
-  if (spec && !key_still_valid(spec, kp)) {                // edited in place since the upload: the reference reads its key on every call
+  bool again = false;
+  if (ops.resident) {                                      // operands and key are checked against the caller's memory while the device works
+    again = ops.recheck(kp.parts, &kp.task);
+    if (ops.misfits) die("coefficient does not fit the big slab");
+    if (kp.value() != spec->print) { key_on_device(kp, &k0, &k1); again = true; }
+  } else if (spec && !key_still_valid(spec, kp)) {         // edited in place since the upload: the reference reads its key on every call
     key_on_device(kp, &k0, &k1);
-    device_work();
+    again = true;
   }
+  if (again) device_work();
   poly_mpi_t *out[2] = {&ct->c0, &ct->c1};
-  download_convert(out, ss, 2, n, W);
+  std::vector<uint64_t> oprints((size_t)2 * ops.nt, 0);
+  download_convert(out, ts, 2, n, W, oprints.data());
+  remember_results(out, oo, 2, n, W, oprints);
   const double t3 = wall_ms();
   float dev_ms = 0;
   (void)hipEventElapsedTime(&dev_ms, g_tick[0], g_tick[1]);
@@ -482,22 +614,49 @@ static void rescale_common(he_ct_t *ct, bool divide) {
   const bool pow2 = is_pow2(qw) && (!divide || is_pow2(dw));
   const unsigned logql = G.mpi_get_nbits(hectx.q[lnew]) - 1;
   const unsigned s = divide ? G.mpi_get_nbits(hectx.p) - 1 : 0;
-  unsigned bits = max_bits(&ct->c0, n), b1 = max_bits(&ct->c1, n);
-  if (b1 > bits) bits = b1;
-  if (logql + 1 > bits) bits = logql + 1;
-  const unsigned W = bits / 64 + 1;
-  const size_t big = (size_t)W * n;
-  HostBuf s0(big * 8), s1(big * 8);
-  DevBuf d0(big * 8), d1(big * 8), scratch(192 * 8);
-  const DevBuf *dd[2] = {&d0, &d1};
-  const HostBuf *ss[2] = {&s0, &s1};
   const poly_mpi_t *in[2] = {&ct->c0, &ct->c1};
-  upload_polys(dd, ss, in, 2, n, W);
-  const int rc = pow2 ? gpq_he_rs(c, d0.u64(), d1.u64(), W, s, logql, 1, nullptr)                                  // :45-48 / :64-65
-                      : gpq_he_rs_general(c, d0.u64(), d1.u64(), W, divide ? dw[0] : 1ull, qw.data(), (unsigned)qw.size(), 1, scratch.p, nullptr);
-  if (rc != GPQ_OK) die("he_rs failed");
   poly_mpi_t *out[2] = {&ct->c0, &ct->c1};
-  download_polys(out, ss, dd, 2, n, W);
+  const unsigned Wout = logql / 64 + 1;                    // the results are centred mod q_lnew: they fit the width he_mul uses at that level
+  // One pass at W words per coefficient; with `kept`, from the resident copies of both polynomials (returns false if one of them
+  // turned out wider than its copy: the caller measures the integers and runs again)
+  auto pass = [&](unsigned W, bool kept) -> bool {
+    const size_t big = (size_t)W * n;
+    HostBuf s0(big * 8), s1(big * 8), t0s(big * 8), t1s(big * 8);
+    DevBuf d0(big * 8), d1(big * 8), scratch(192 * 8);
+    const DevBuf *dd[2] = {&d0, &d1};
+    const HostBuf *ss[2] = {&s0, &s1}, *ts[2] = {&t0s, &t1s};
+    Operands ops(2, in, dd, ss, n, W);
+    ops.prepare(kept);
+    const unsigned Wdown = Wout < W ? Wout : W;
+    auto device_work = [&]() {
+      for (int i = 0; i < 2; ++i)                            // gpq_he_rs works in place: a resident copy is copied, not lent
+        if (ops.x[i] != dd[i]->u64() && hipMemcpyAsync(dd[i]->p, ops.x[i], big * 8, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) die("device copy failed");
+      const int rc = pow2 ? gpq_he_rs(c, d0.u64(), d1.u64(), W, s, logql, 1, nullptr)                                  // :45-48 / :64-65
+                          : gpq_he_rs_general(c, d0.u64(), d1.u64(), W, divide ? dw[0] : 1ull, qw.data(), (unsigned)qw.size(), 1, scratch.p, nullptr);
+      if (rc != GPQ_OK) die("he_rs failed");
+      download_issue(ts, dd, 2, n, Wdown);                   // the low Wdown words of every coefficient (word-major: the first rows)
+    };
+    device_work();
+    if (ops.resident && ops.recheck()) {
+      if (ops.misfits) return false;
+      device_work();
+    }
+    std::vector<uint64_t> oprints((size_t)2 * ops.nt, 0);
+    download_convert(out, ts, 2, n, Wdown, oprints.data());
+    remember_results(out, dd, 2, n, Wdown, oprints);
+    return true;
+  };
+  bool done = false;
+  if (poly_cache_on(n)) {
+    const PolySlot *k0 = resident_poly(in[0], n, 0), *k1 = resident_poly(in[1], n, 0);
+    if (k0 && k1 && k0->W == k1->W && k0->W >= Wout) done = pass(k0->W, true);
+  }
+  if (!done) {
+    unsigned bits = max_bits(&ct->c0, n), b1 = max_bits(&ct->c1, n);
+    if (b1 > bits) bits = b1;
+    if (logql + 1 > bits) bits = logql + 1;
+    pass(bits / 64 + 1, false);
+  }
   ct->l = lnew;
   if (divide) { ct->nu /= hectx.Delta; ct->B = ct->B / hectx.Delta + hectx.bnd.Brs; }             // :37-38
 }
@@ -518,18 +677,29 @@ void he_mulpt(struct he_ct *dest, const struct he_ct *src, const struct he_pt *p
   if (logql + 1 > bits) bits = logql + 1;
   const unsigned W = bits / 64 + 1;
   const size_t big = (size_t)W * n;
-  HostBuf s0(big * 8), s1(big * 8), s2(big * 8);
+  HostBuf s0(big * 8), s1(big * 8), s2(big * 8), t0s(big * 8), t1s(big * 8);
   DevBuf d0(big * 8), d1(big * 8), dm(big * 8), o0(big * 8), o1(big * 8),
       ws(gpq_he_mulpt_workspace_bytes(c, dim, 1) + gpq_poly_mul_general_workspace_bytes(c, dim, 1));
   const DevBuf *dd[3] = {&d0, &d1, &dm}, *oo[2] = {&o0, &o1};
-  const HostBuf *ss[3] = {&s0, &s1, &s2};
+  const HostBuf *ss[3] = {&s0, &s1, &s2}, *ts[2] = {&t0s, &t1s};
   const poly_mpi_t *in[3] = {&src->c0, &src->c1, &pt->m};
-  upload_polys(dd, ss, in, 3, n, W);
-  const int rc = pow2 ? gpq_he_mulpt(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), dm.u64(), W, logql, dim, 1, ws.p, nullptr)
-                      : gpq_he_mulpt_general(c, o0.u64(), o1.u64(), d0.u64(), d1.u64(), dm.u64(), W, qw.data(), (unsigned)qw.size(), dim, 1, ws.p, nullptr);
-  if (rc != GPQ_OK) die("he_mulpt failed");
+  Operands ops(3, in, dd, ss, n, W);
+  ops.prepare(true);
+  auto device_work = [&]() {
+    const int rc = pow2 ? gpq_he_mulpt(c, o0.u64(), o1.u64(), ops.x[0], ops.x[1], ops.x[2], W, logql, dim, 1, ws.p, nullptr)
+                        : gpq_he_mulpt_general(c, o0.u64(), o1.u64(), ops.x[0], ops.x[1], ops.x[2], W, qw.data(), (unsigned)qw.size(), dim, 1, ws.p, nullptr);
+    if (rc != GPQ_OK) die("he_mulpt failed");
+    download_issue(ts, oo, 2, n, W);
+  };
+  device_work();
+  if (ops.resident && ops.recheck()) {
+    if (ops.misfits) die("coefficient does not fit the big slab");
+    device_work();
+  }
   poly_mpi_t *out[2] = {&dest->c0, &dest->c1};
-  download_polys(out, ss, oo, 2, n, W);
+  std::vector<uint64_t> oprints((size_t)2 * ops.nt, 0);
+  download_convert(out, ts, 2, n, W, oprints.data());
+  remember_results(out, oo, 2, n, W, oprints);
   dest->l = l; dest->nu = nu; dest->B = B;                                                      // :162-164
 }
 
@@ -546,35 +716,43 @@ static void automorphism(he_ct_t *ct, const he_evk_t *key, bool conj, unsigned r
   const unsigned dimB = (nbq + nbPqL + polyctx.logn) / 59 + 1, dimP = hectx.dim;                // src/he-automorphism.c:52
   const unsigned W = logql / 64 + 1;
   const size_t big = (size_t)W * n, evk = (size_t)dimB * n;
-  HostBuf s0(big * 8), s1(big * 8);
+  HostBuf s0(big * 8), s1(big * 8), t0s(big * 8), t1s(big * 8);
   DevBuf a0(big * 8), a1(big * 8), r0(big * 8), r1(big * 8), o0(big * 8), o1(big * 8),
       ws(pow2 ? gpq_he_swk_workspace_bytes(c, W, dimB, dimP, 1) : gpq_he_general_workspace_bytes(c, W, 0, dimB, dimP, 1));
   const DevBuf *dd[2] = {&a0, &a1}, *oo[2] = {&o0, &o1};
-  const HostBuf *ss[2] = {&s0, &s1};
+  const HostBuf *ss[2] = {&s0, &s1}, *ts[2] = {&t0s, &t1s};
   const poly_mpi_t *in[2] = {&ct->c0, &ct->c1};
   KeyPrint kp(key, evk);
   KeySlot *spec = resident_key(key, evk);
-  if (spec) upload_polys(dd, ss, in, 2, n, W);
-  else upload_polys(dd, ss, in, 2, n, W, kp.parts, &kp.task);
+  Operands ops(2, in, dd, ss, n, W);
+  if (spec) ops.prepare(true); else ops.prepare(false, kp.parts, &kp.task);
   uint64_t *k0, *k1;
   if (spec) { k0 = (uint64_t *)spec->d0; k1 = (uint64_t *)spec->d1; } else key_on_device(kp, &k0, &k1);
   auto device_work = [&]() {
-    int rc = conj ? gpq_poly_conj(c, r0.u64(), a0.u64(), W, 1, nullptr) : gpq_poly_rot(c, r0.u64(), a0.u64(), W, rot, 1, nullptr);      // :95-96 / :108-109
-    if (rc == GPQ_OK) rc = conj ? gpq_poly_conj(c, r1.u64(), a1.u64(), W, 1, nullptr) : gpq_poly_rot(c, r1.u64(), a1.u64(), W, rot, 1, nullptr);
+    int rc = conj ? gpq_poly_conj(c, r0.u64(), ops.x[0], W, 1, nullptr) : gpq_poly_rot(c, r0.u64(), ops.x[0], W, rot, 1, nullptr);      // :95-96 / :108-109
+    if (rc == GPQ_OK) rc = conj ? gpq_poly_conj(c, r1.u64(), ops.x[1], W, 1, nullptr) : gpq_poly_rot(c, r1.u64(), ops.x[1], W, rot, 1, nullptr);
     if (rc == GPQ_OK)                                                                                                                       // :97 / :110
       rc = pow2 ? gpq_he_swk(c, o0.u64(), o1.u64(), r0.u64(), r1.u64(), k0, k1, W, logql, dimB, dimP, 1, ws.p, nullptr)
                 : gpq_he_swk_general(c, o0.u64(), o1.u64(), r0.u64(), r1.u64(), k0, k1, W, qw.data(), (unsigned)qw.size(), dimB, dimP, 1,
                                      ws.p, nullptr);
     if (rc != GPQ_OK) die("he_rot/he_conj failed");
-    download_issue(ss, oo, 2, n, W);
+    download_issue(ts, oo, 2, n, W);
   };
   device_work();
-  if (spec && !key_still_valid(spec, kp)) {
+  bool again = false;
+  if (ops.resident) {
+    again = ops.recheck(kp.parts, &kp.task);
+    if (ops.misfits) die("coefficient does not fit the big slab");
+    if (kp.value() != spec->print) { key_on_device(kp, &k0, &k1); again = true; }
+  } else if (spec && !key_still_valid(spec, kp)) {
     key_on_device(kp, &k0, &k1);
-    device_work();
+    again = true;
   }
+  if (again) device_work();
   poly_mpi_t *out[2] = {&ct->c0, &ct->c1};
-  download_convert(out, ss, 2, n, W);
+  std::vector<uint64_t> oprints((size_t)2 * ops.nt, 0);
+  download_convert(out, ts, 2, n, W, oprints.data());
+  remember_results(out, oo, 2, n, W, oprints);
 }
 void he_conj(he_ct_t *ct, const he_evk_t *ck) { automorphism(ct, ck, true, 0); }
 void he_rot(he_ct_t *ct, const int rot, const he_evk_t *rk) { automorphism(ct, &rk[rot], false, (unsigned)rot); }   // rk[rot], :110
@@ -707,10 +885,33 @@ void gpq_mpi_shim_forget_keys(void) {
   g_keys.clear();
 }
 
+// Resident polynomials (see PolySlot above): how many device copies of the caller's polynomials are kept between calls (default 32, 7 MiB each at
+// n = 2^16 and 14 words; 0 = none: every call converts and uploads its operands before the device starts, as up to round 2).
+void gpq_mpi_shim_set_poly_slots(unsigned slots) {
+  SHIM_CALL();
+  g_poly_slots = slots;
+  while (g_polys.size() > g_poly_slots) {
+    size_t victim = 0;
+    for (size_t i = 1; i < g_polys.size(); ++i) if (g_polys[i].used < g_polys[victim].used) victim = i;
+    drop_poly_slot(victim);
+  }
+}
+unsigned gpq_mpi_shim_resident_polys(void) { SHIM_CALL(); return (unsigned)g_polys.size(); }
+// operands served from a resident copy that the check confirmed / that the check found changed (uploaded again, device work repeated)
+void gpq_mpi_shim_poly_stats(uint64_t *confirmed, uint64_t *stale) { SHIM_CALL(); if (confirmed) *confirmed = g_poly_hits; if (stale) *stale = g_poly_stale; }
+void gpq_mpi_shim_forget_polys(void) {
+  SHIM_CALL();
+  (void)gpq_stream_sync(nullptr);
+  for (PolySlot &k : g_polys) (void)gpq_free(k.d);
+  g_polys.clear();
+}
+
 // frees the device buffers the MPI-typed calls keep between calls, and the engine context
 void gpq_mpi_shim_release(void) {
   SHIM_CALL();
   (void)gpq_stream_sync(nullptr);
+  for (PolySlot &k : g_polys) (void)gpq_free(k.d);
+  g_polys.clear();
   for (auto &kv : g_pool) for (void *q : kv.second) (void)gpq_free(q);
   g_pool.clear();
   for (auto &kv : g_pinned) for (void *q : kv.second) (void)hipHostFree(q);

@@ -170,6 +170,18 @@ unsigned gpq_mpi_shim_resident_keys(void);
  * in place, after a probe through libgcrypt's public API has confirmed the layout in this process (3x faster calls at n = 2^16);
  * 0 goes through gcry_mpi_print / gcry_mpi_scan for every coefficient.  Returns 1 if the direct path is in use afterwards. */
 int gpq_mpi_shim_set_direct_mpi(int on);
+/* Resident polynomials.  GPQHE chains its calls on one ciphertext (he_mul(&bn, &bn, &bn, rlk); he_rs(&bn); ..., src/he-algo.c:140-160):
+ * the device keeps the slab of every polynomial the MPI-typed calls have read or written (`slots` of them, default 32, least recently
+ * used out; 0 = none), identified by the caller's coefficient array, the shape and a fingerprint of every word of every coefficient.
+ * When all operands of a call are resident the device starts from them at once, and the conversion threads meanwhile convert and
+ * fingerprint the caller's integers exactly as an upload would; operands the caller changed since are uploaded from the rows then
+ * already staged and the device work runs again.  Results never depend on a stale copy; only with the direct integer access
+ * (gpq_mpi_shim_set_direct_mpi) and n >= 4096. */
+void gpq_mpi_shim_set_poly_slots(unsigned slots);
+unsigned gpq_mpi_shim_resident_polys(void);
+/* operands served from a resident copy that the check confirmed / found changed (uploaded again, device work repeated) */
+void gpq_mpi_shim_poly_stats(uint64_t *confirmed, uint64_t *stale);
+void gpq_mpi_shim_forget_polys(void);
 /* Drops the device copies of the evaluation keys.  Never needed with the default key check; he_genrlk / he_genck / he_genrk drop
  * the copy of the key they write themselves. */
 void gpq_mpi_shim_forget_keys(void);

@@ -30,6 +30,8 @@ MPI gcry_mpi_set_ui(MPI w, unsigned long u);
 MPI gcry_mpi_copy(const MPI a);
 void gcry_mpi_mul(MPI w, MPI u, MPI v);
 void gcry_mpi_add(MPI w, MPI u, MPI v);
+void gcry_mpi_add_ui(MPI w, MPI u, unsigned long v);
+MPI gcry_mpi_set(MPI w, const MPI u);
 void gcry_mpi_div(MPI q, MPI r, MPI dividend, MPI divisor, int round);
 void gcry_mpi_mul_ui(MPI w, MPI u, unsigned long v);
 void gcry_mpi_lshift(MPI x, MPI a, unsigned int n);
@@ -429,8 +431,67 @@ static int hemultime(unsigned logn, unsigned logq)
     for (unsigned i = 0; i < polyctx.n; i++) if (gcry_mpi_cmp(x.c0.coeffs[i], y.c0.coeffs[i]) || gcry_mpi_cmp(x.c1.coeffs[i], y.c1.coeffs[i])) same = 0;
     printf("direct mpi access: %s, print/scan path %s (%.2f ms per call that way)\n", direct ? "in use" : "NOT in use", same ? "identical" : "DIFFERS", slow);
   }
+  {
+    /* resident polynomials: the device keeps the slabs of polynomials it has seen or produced and starts from them while the host
+     * threads check them against the caller's integers -- whatever the caller does to its integers between two calls, the result
+     * must be what a library without that memory computes (gpq_mpi_shim_set_poly_slots(0)) */
+    he_ct_t u, v, w;
+    poly_mpi_t *qs[6] = {&u.c0, &u.c1, &v.c0, &v.c1, &w.c0, &w.c1};
+    for (int i = 0; i < 6; i++) poly_alloc(qs[i]);
+    uint64_t ok0 = 0, stale0 = 0, ok1 = 0, stale1 = 0;
+    int bad = 0;
+#define SAME_CT(x, y) ({ int same_ = 1; for (unsigned i_ = 0; i_ < polyctx.n; i_++) if (gcry_mpi_cmp((x).c0.coeffs[i_], (y).c0.coeffs[i_]) || gcry_mpi_cmp((x).c1.coeffs[i_], (y).c1.coeffs[i_])) same_ = 0; same_; })
+    he_mul(&u, &ct1, &ct2, &rlk);                             /* operands resident (the calls above), unchanged */
+    gpq_mpi_shim_poly_stats(&ok0, &stale0);
+    gpq_mpi_shim_set_poly_slots(0);
+    he_mul(&v, &ct1, &ct2, &rlk);
+    gpq_mpi_shim_set_poly_slots(32);
+    if (!SAME_CT(u, v)) { bad = 1; printf("resident polynomials: unchanged operands DIFFER from a fresh upload\n"); }
+    he_mul(&u, &ct1, &ct2, &rlk);                             /* slots were emptied: uploads, remembers */
+    /* one coefficient changed by one / one sign flipped / one integer object replaced by an equal one / one overwritten with a small value */
+    for (int edit = 0; edit < 4; edit++) {
+      MPI *c = &ct1.c0.coeffs[(12345 + 977 * edit) % polyctx.n];
+      if (edit == 0) gcry_mpi_add_ui(*c, *c, 1);
+      if (edit == 1) { c = &ct2.c1.coeffs[4242 % polyctx.n]; gcry_mpi_neg(*c, *c); }
+      if (edit == 2) { MPI t = gcry_mpi_copy(*c); gcry_mpi_release(*c); *c = t; }
+      if (edit == 3) { c = &ct1.c1.coeffs[7 % polyctx.n]; gcry_mpi_set_ui(*c, 3); }
+      gpq_mpi_shim_poly_stats(&ok0, &stale0);
+      he_mul(&w, &ct1, &ct2, &rlk);
+      gpq_mpi_shim_poly_stats(&ok1, &stale1);
+      gpq_mpi_shim_set_poly_slots(0);
+      he_mul(&v, &ct1, &ct2, &rlk);
+      gpq_mpi_shim_set_poly_slots(32);
+      const int changed = !SAME_CT(w, u), expect_change = edit != 2;
+      if (!SAME_CT(w, v) || changed != expect_change || (stale1 - stale0) != (uint64_t)expect_change) {
+        bad = 1;
+        printf("resident polynomials: edit %d -- result %s a fresh upload, %s the product before the edit, %llu operand(s) found changed\n", edit,
+               SAME_CT(w, v) ? "equals" : "DIFFERS from", changed ? "differs from" : "equals", (unsigned long long)(stale1 - stale0));
+      }
+      he_mul(&u, &ct1, &ct2, &rlk);
+    }
+    /* the chain of src/he-algo.c:140-160 on one ciphertext: square, rescale, square, rescale, rotate-free -- with and without the memory */
+    for (int pass = 0; pass < 2; pass++) {
+      he_ct_t *c = pass ? &w : &v;
+      gpq_mpi_shim_set_poly_slots(pass ? 32 : 0);
+      for (unsigned i = 0; i < polyctx.n; i++) { gcry_mpi_set(c->c0.coeffs[i], ct1.c0.coeffs[i]); gcry_mpi_set(c->c1.coeffs[i], ct1.c1.coeffs[i]); }
+      c->l = hectx.L; c->nu = 1.0; c->B = 1.0;
+      for (int step = 0; step < 3; step++) {
+        he_mul(c, c, c, &rlk);
+        if (step == 1) gcry_mpi_add_ui(c->c1.coeffs[99], c->c1.coeffs[99], 5);     /* the caller touches the result between two calls */
+        he_rescale(c);
+        if (step == 0) he_moddown(c);
+      }
+    }
+    gpq_mpi_shim_set_poly_slots(32);
+    if (!SAME_CT(v, w) || v.l != w.l) { bad = 1; printf("resident polynomials: the chained calls DIFFER from the same chain with fresh uploads\n"); }
+    gpq_mpi_shim_poly_stats(&ok1, &stale1);
+    printf("resident polynomials: %s (%u resident, %llu operands confirmed, %llu found changed and uploaded again)\n", bad ? "MISMATCH" : "edits and chains identical to fresh uploads",
+           gpq_mpi_shim_resident_polys(), (unsigned long long)ok1, (unsigned long long)stale1);
+  }
   enum { CALLS = 50 };
   double tm[CALLS], tsq[CALLS], trs[CALLS], part[8];
+  /* (a) operands the library has never seen (gpq_mpi_shim_set_poly_slots(0): every call converts and uploads before the device starts) */
+  gpq_mpi_shim_set_poly_slots(0);
   for (int i = 0; i < 3; i++) he_mul(&ct, &ct1, &ct2, &rlk);
   for (int i = 0; i < CALLS; i++) { const double t0 = now_ms(); he_mul(&ct, &ct1, &ct2, &rlk); tm[i] = now_ms() - t0; }
   gpq_mpi_shim_last_timing(part);
@@ -438,13 +499,31 @@ static int hemultime(unsigned logn, unsigned logq)
   for (int i = 0; i < CALLS; i++) { const double t0 = now_ms(); he_mul(&ct, &ct1, &ct1, &rlk); tsq[i] = now_ms() - t0; }
   gpq_mpi_shim_last_timing(part + 4);
   ct.l = hectx.L; he_rescale(&ct);                            /* first call at this shape allocates the staging buffers */
-  for (int i = 0; i < CALLS; i++) { ct.l = hectx.L; const double t0 = now_ms(); he_rescale(&ct); trs[i] = now_ms() - t0; }
+  for (int i = 0; i < CALLS; i++) {                           /* a full-size ciphertext every time (rescaling the same one again and again would time ever smaller integers) */
+    for (unsigned k = 0; k < polyctx.n; k++) { gcry_mpi_set(ct.c0.coeffs[k], ct1.c0.coeffs[k]); gcry_mpi_set(ct.c1.coeffs[k], ct1.c1.coeffs[k]); }
+    ct.l = hectx.L;
+    const double t0 = now_ms(); he_rescale(&ct); trs[i] = now_ms() - t0;
+  }
   qsort(tm, CALLS, sizeof *tm, cmp_double); qsort(tsq, CALLS, sizeof *tsq, cmp_double); qsort(trs, CALLS, sizeof *trs, cmp_double);
   printf("he_mul(MPI) n=2^%u logq=%u dims %u/%u: %.1f ms per call; he_rescale %.1f ms\n", logn, logq, hectx.dim, hectx.dimevk, tm[CALLS / 2], trs[CALLS / 2]);
   printf("  %d calls each: he_mul p50 %.2f p95 %.2f min %.2f max %.2f ms; squaring p50 %.2f p95 %.2f ms; he_rescale p50 %.2f p95 %.2f ms\n", CALLS,
          tm[CALLS / 2], tm[CALLS * 95 / 100], tm[0], tm[CALLS - 1], tsq[CALLS / 2], tsq[CALLS * 95 / 100], trs[CALLS / 2], trs[CALLS * 95 / 100]);
   printf("  last he_mul: convert+upload %.2f ms, kernels %.2f ms, download+convert %.2f ms, call %.2f ms\n", part[0], part[1], part[2], part[3]);
   printf("  squaring he_mul(&ct, &a, &a): %.1f ms per call (convert+upload %.2f ms, kernels %.2f ms, download+convert %.2f ms)\n", tsq[CALLS / 2], part[4], part[5], part[6]);
+  /* (b) chained calls, GPQHE's own pattern (src/he-algo.c:140-160): the operands of a call are what an earlier call wrote or read */
+  gpq_mpi_shim_set_poly_slots(32);
+  for (int i = 0; i < 3; i++) he_mul(&ct, &ct1, &ct2, &rlk);
+  for (int i = 0; i < CALLS; i++) { const double t0 = now_ms(); he_mul(&ct, &ct1, &ct2, &rlk); tm[i] = now_ms() - t0; }
+  gpq_mpi_shim_last_timing(part);
+  ct.l = hectx.L;
+  he_mul(&ct, &ct, &ct, &rlk);
+  for (int i = 0; i < CALLS; i++) { const double t0 = now_ms(); he_mul(&ct, &ct, &ct, &rlk); tsq[i] = now_ms() - t0; }     /* x -> x^2 -> x^4 ... on one ciphertext */
+  gpq_mpi_shim_last_timing(part + 4);
+  for (int i = 0; i < CALLS; i++) { ct.l = hectx.L; he_mul(&ct, &ct1, &ct2, &rlk); const double t0 = now_ms(); he_rescale(&ct); trs[i] = now_ms() - t0; }
+  qsort(tm, CALLS, sizeof *tm, cmp_double); qsort(tsq, CALLS, sizeof *tsq, cmp_double); qsort(trs, CALLS, sizeof *trs, cmp_double);
+  printf("  chained (operands resident, checked while the device works): he_mul p50 %.2f p95 %.2f ms; he_mul(&ct, &ct, &ct) p50 %.2f p95 %.2f ms; he_rescale of a product p50 %.2f p95 %.2f ms\n",
+         tm[CALLS / 2], tm[CALLS * 95 / 100], tsq[CALLS / 2], tsq[CALLS * 95 / 100], trs[CALLS / 2], trs[CALLS * 95 / 100]);
+  printf("  last chained he_mul: before the device starts %.2f ms, kernels %.2f ms, check+download+convert %.2f ms, call %.2f ms\n", part[0], part[1], part[2], part[3]);
   return 0;
 }
 

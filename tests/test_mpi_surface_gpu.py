@@ -337,3 +337,10 @@ def test_reference_signature_he_mul_at_the_headline_shape_keeps_its_key_on_the_d
     t = re.search(r"convert\+upload ([0-9.]+) ms, kernels ([0-9.]+) ms, download\+convert ([0-9.]+) ms, call ([0-9.]+) ms", res.stdout)
     parts = [float(v) for v in t.groups()]
     assert 0.1 < parts[1] < 5 and parts[0] + parts[2] <= parts[3] * 1.05 and parts[3] < 200
+    # resident polynomials (round 3): one coefficient changed by one, a sign flipped, an integer object replaced, a coefficient overwritten,
+    # a result touched between two chained calls -- every product equals the one of a library that uploads everything afresh
+    assert "resident polynomials: edits and chains identical to fresh uploads" in res.stdout, res.stdout
+    r = re.search(r"(\d+) operands confirmed, (\d+) found changed", res.stdout)
+    assert r and int(r.group(1)) > 0 and int(r.group(2)) == 4, res.stdout
+    ch = re.search(r"chained .*he_mul p50 ([0-9.]+) .*he_mul\(&ct, &ct, &ct\) p50 ([0-9.]+) .*he_rescale of a product p50 ([0-9.]+)", res.stdout)
+    assert ch and all(0.05 < float(v) < 200 for v in ch.groups()), res.stdout
