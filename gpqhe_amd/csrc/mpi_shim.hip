@@ -512,23 +512,47 @@ void poly_mul(poly_mpi_t *r, const poly_mpi_t *a, const poly_mpi_t *b, const uns
   const unsigned n = polyctx.n;
   const std::vector<uint64_t> qw = words_of(q, "poly_mul: the modulus must be positive");
   const unsigned nbq = G.mpi_get_nbits(q);
-  unsigned bits = max_bits(a, n), bb = max_bits(b, n);
-  if (bb > bits) bits = bb;
-  if (nbq > bits) bits = nbq;
-  const unsigned W = bits / 64 + 1;
-  if (W > 32) die("poly_mul: coefficients wider than 2047 bits");
-  const size_t big = (size_t)W * n;
-  HostBuf s0(big * 8), s1(big * 8);
-  DevBuf da(big * 8), db(big * 8), dr(big * 8), ws(gpq_poly_mul_general_workspace_bytes(c, dim, 1));
-  const DevBuf *dd[2] = {&da, &db}, *oo[1] = {&dr};
-  const HostBuf *ss[2] = {&s0, &s1};
   const poly_mpi_t *in[2] = {a, b};
-  upload_polys(dd, ss, in, 2, n, W);
-  const int rc = is_pow2(qw) ? gpq_poly_mul(c, dr.u64(), da.u64(), db.u64(), W, dim, nbq - 1, 1, ws.p, nullptr)
-                             : gpq_poly_mul_general(c, dr.u64(), da.u64(), db.u64(), W, dim, qw.data(), (unsigned)qw.size(), 1, ws.p, nullptr);
-  if (rc != GPQ_OK) die("poly_mul failed");   // q = P*q_L in he_genswk (src/he-kem.c:95) takes the general path
   poly_mpi_t *out[1] = {r};
-  download_polys(out, ss, oo, 1, n, W);
+  const bool pow2 = is_pow2(qw), same = a->coeffs == b->coeffs;
+  // one pass at W words per coefficient; with `kept`, from the resident copies of both operands (false: one of them has outgrown its copy)
+  auto pass = [&](unsigned W, bool kept) -> bool {
+    if (W > 32) die("poly_mul: coefficients wider than 2047 bits");
+    const size_t big = (size_t)W * n;
+    HostBuf s0(big * 8), s1(big * 8), t0s(big * 8);
+    DevBuf da(big * 8), db(big * 8), dr(big * 8), ws(gpq_poly_mul_general_workspace_bytes(c, dim, 1));
+    const DevBuf *dd[2] = {&da, &db}, *oo[1] = {&dr};
+    const HostBuf *ss[2] = {&s0, &s1}, *ts[1] = {&t0s};
+    Operands ops(same ? 1 : 2, in, dd, ss, n, W);
+    ops.prepare(kept);
+    auto device_work = [&]() {
+      const uint64_t *xa = ops.x[0], *xb = same ? xa : ops.x[1];
+      const int rc = pow2 ? gpq_poly_mul(c, dr.u64(), xa, xb, W, dim, nbq - 1, 1, ws.p, nullptr)
+                          : gpq_poly_mul_general(c, dr.u64(), xa, xb, W, dim, qw.data(), (unsigned)qw.size(), 1, ws.p, nullptr);
+      if (rc != GPQ_OK) die("poly_mul failed");   // q = P*q_L in he_genswk (src/he-kem.c:95) takes the general path
+      download_issue(ts, oo, 1, n, W);
+    };
+    device_work();
+    if (ops.resident && ops.recheck()) {
+      if (ops.misfits) return false;
+      device_work();
+    }
+    std::vector<uint64_t> oprints((size_t)ops.nt, 0);
+    download_convert(out, ts, 1, n, W, oprints.data());
+    remember_results(out, oo, 1, n, W, oprints);
+    return true;
+  };
+  bool done = false;
+  if (poly_cache_on(n)) {                                   // he_dec multiplies a chained ciphertext's c1 with the same secret key every time
+    const PolySlot *ka = resident_poly(a, n, 0), *kb = resident_poly(b, n, 0);
+    if (ka && kb && ka->W == kb->W && ka->W >= nbq / 64 + 1) done = pass(ka->W, true);
+  }
+  if (!done) {
+    unsigned bits = max_bits(a, n), bb = max_bits(b, n);
+    if (bb > bits) bits = bb;
+    if (nbq > bits) bits = nbq;
+    pass(bits / 64 + 1, false);
+  }
 }
 
 // src/he-mult.c:88-156

@@ -484,6 +484,16 @@ static int hemultime(unsigned logn, unsigned logq)
     }
     gpq_mpi_shim_set_poly_slots(32);
     if (!SAME_CT(v, w) || v.l != w.l) { bad = 1; printf("resident polynomials: the chained calls DIFFER from the same chain with fresh uploads\n"); }
+    /* poly_mul as he_dec calls it (src/he-enc.c): a chained ciphertext's c1 times the same small polynomial, twice with the memory, once without */
+    for (unsigned i = 0; i < polyctx.n; i++) gcry_mpi_set_ui(u.c0.coeffs[i], (unsigned long)(splitmix64(&st) % 3));
+    poly_mul(&u.c1, &w.c1, &u.c0, hectx.dim, hectx.q[w.l]);
+    poly_mul(&u.c1, &w.c1, &u.c0, hectx.dim, hectx.q[w.l]);
+    gcry_mpi_add_ui(w.c1.coeffs[5], w.c1.coeffs[5], 1);
+    poly_mul(&u.c1, &w.c1, &u.c0, hectx.dim, hectx.q[w.l]);
+    gpq_mpi_shim_set_poly_slots(0);
+    poly_mul(&v.c1, &w.c1, &u.c0, hectx.dim, hectx.q[w.l]);
+    gpq_mpi_shim_set_poly_slots(32);
+    for (unsigned i = 0; i < polyctx.n; i++) if (gcry_mpi_cmp(u.c1.coeffs[i], v.c1.coeffs[i])) { bad = 1; printf("resident polynomials: poly_mul DIFFERS from a fresh upload at %u\n", i); break; }
     gpq_mpi_shim_poly_stats(&ok1, &stale1);
     printf("resident polynomials: %s (%u resident, %llu operands confirmed, %llu found changed and uploaded again)\n", bad ? "MISMATCH" : "edits and chains identical to fresh uploads",
            gpq_mpi_shim_resident_polys(), (unsigned long long)ok1, (unsigned long long)stale1);
