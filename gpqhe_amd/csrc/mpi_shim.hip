@@ -322,7 +322,9 @@ void key_on_device(const KeyPrint &kp, uint64_t **d0, uint64_t **d1) {
 // integers since, by any means -- uploads the rows that are then already staged and repeats the device work.  The result can never
 // depend on a stale copy; a program whose operands are always new pays the fingerprint of its results (in cache, a few per cent).
 // Only with the direct integer access (mpi_convert.hpp) and n >= 4096; gpq_mpi_shim_set_poly_slots(0) turns it off.
-struct PolySlot { const gpq_MPI *coeffs; unsigned n, W, parts; uint64_t print; void *d; size_t bytes /* of the buffer: >= W n 8 */; uint64_t used; };
+// `trusted`: a polynomial the caller changed behind the library's back last time (he_add and friends run on the host) is converted and
+// uploaded before the device starts next time, as if unknown -- a wrong guess costs a repeated device pass -- until a call finds it unchanged.
+struct PolySlot { const gpq_MPI *coeffs; unsigned n, W, parts; uint64_t print; void *d; size_t bytes /* of the buffer: >= W n 8 */; uint64_t used; bool trusted; };
 std::vector<PolySlot> g_polys;
 uint64_t g_poly_clock = 0;
 size_t g_poly_slots = 32;     // 7 MiB each at n = 2^16, 14 words
@@ -346,12 +348,14 @@ const PolySlot *resident_poly(const poly_mpi_t *p, unsigned n, unsigned W) {
   return nullptr;
 }
 // `dev` (word-major, W x n) is what the caller's polynomial holds now: keep a copy (stream-ordered device-to-device copy)
-void remember_poly(const poly_mpi_t *p, unsigned n, unsigned W, uint64_t print, const void *dev) {
+void remember_poly(const poly_mpi_t *p, unsigned n, unsigned W, uint64_t print, const void *dev, bool ours = false) {
   if (!poly_cache_on(n)) return;
   const size_t bytes = (size_t)W * n * 8;
-  PolySlot slot{p->coeffs, n, W, convert_threads(n), print, nullptr, bytes, ++g_poly_clock};
+  PolySlot slot{p->coeffs, n, W, convert_threads(n), print, nullptr, bytes, ++g_poly_clock, true};
   size_t victim = g_polys.size();
   for (size_t i = 0; i < g_polys.size(); ++i) if (g_polys[i].coeffs == p->coeffs) victim = i;     // one copy per host polynomial
+  if (victim < g_polys.size() && !ours)                     // read from the caller: trusted unless it differs from what was kept for it
+    slot.trusted = g_polys[victim].n == n && g_polys[victim].W == W && g_polys[victim].print == print;
   if (victim == g_polys.size() && g_polys.size() >= g_poly_slots) {
     victim = 0;
     for (size_t i = 1; i < g_polys.size(); ++i) if (g_polys[i].used < g_polys[victim].used) victim = i;
@@ -382,7 +386,7 @@ struct Operands {
     resident = cache && may_speculate;
     for (int i = 0; i < count && resident; ++i) {
       const PolySlot *s = resident_poly(src[i], n, W);
-      if (!s) resident = false; else { x[i] = (const uint64_t *)s->d; want[i] = s->print; }
+      if (!s || !s->trusted) resident = false; else { x[i] = (const uint64_t *)s->d; want[i] = s->print; }
     }
     if (resident) return;
     upload_polys(dst, stage, src, count, n, W, extra, side, cache ? prints.data() : nullptr);
@@ -428,7 +432,7 @@ struct Operands {
 void remember_results(poly_mpi_t *const out[], const DevBuf *const dev[], int count, unsigned n, unsigned W, const std::vector<uint64_t> &prints) {
   if (!poly_cache_on(n)) return;
   const unsigned nt = convert_threads(n);
-  for (int i = 0; i < count; ++i) remember_poly(out[i], n, W, fold_prints(&prints[(size_t)i * nt], nt, n, W), dev[i]->p);
+  for (int i = 0; i < count; ++i) remember_poly(out[i], n, W, fold_prints(&prints[(size_t)i * nt], nt, n, W), dev[i]->p, true);
 }
 
 // The MPI-typed entry points share the staging buffers, the buffer pools, the key cache and the worker threads: one call at a
@@ -545,7 +549,7 @@ void poly_mul(poly_mpi_t *r, const poly_mpi_t *a, const poly_mpi_t *b, const uns
   bool done = false;
   if (poly_cache_on(n)) {                                   // he_dec multiplies a chained ciphertext's c1 with the same secret key every time
     const PolySlot *ka = resident_poly(a, n, 0), *kb = resident_poly(b, n, 0);
-    if (ka && kb && ka->W == kb->W && ka->W >= nbq / 64 + 1) done = pass(ka->W, true);
+    if (ka && kb && ka->trusted && kb->trusted && ka->W == kb->W && ka->W >= nbq / 64 + 1) done = pass(ka->W, true);
   }
   if (!done) {
     unsigned bits = max_bits(a, n), bb = max_bits(b, n);
@@ -673,7 +677,7 @@ static void rescale_common(he_ct_t *ct, bool divide) {
   bool done = false;
   if (poly_cache_on(n)) {
     const PolySlot *k0 = resident_poly(in[0], n, 0), *k1 = resident_poly(in[1], n, 0);
-    if (k0 && k1 && k0->W == k1->W && k0->W >= Wout) done = pass(k0->W, true);
+    if (k0 && k1 && k0->trusted && k1->trusted && k0->W == k1->W && k0->W >= Wout) done = pass(k0->W, true);
   }
   if (!done) {
     unsigned bits = max_bits(&ct->c0, n), b1 = max_bits(&ct->c1, n);

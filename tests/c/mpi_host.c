@@ -494,6 +494,22 @@ static int hemultime(unsigned logn, unsigned logq)
     poly_mul(&v.c1, &w.c1, &u.c0, hectx.dim, hectx.q[w.l]);
     gpq_mpi_shim_set_poly_slots(32);
     for (unsigned i = 0; i < polyctx.n; i++) if (gcry_mpi_cmp(u.c1.coeffs[i], v.c1.coeffs[i])) { bad = 1; printf("resident polynomials: poly_mul DIFFERS from a fresh upload at %u\n", i); break; }
+    {
+      /* a polynomial the caller keeps changing behind the library's back (he_add and friends run on the host) is not guessed at again:
+       * after the first wrong guess its calls convert and upload before the device starts, until one finds it unchanged */
+      uint64_t s0 = 0, s1 = 0, c0 = 0, c1 = 0;
+      he_mul(&u, &ct1, &ct2, &rlk);
+      he_mul(&u, &ct1, &ct2, &rlk);
+      gpq_mpi_shim_poly_stats(&c0, &s0);
+      for (int k = 0; k < 3; k++) { gcry_mpi_add_ui(ct2.c0.coeffs[k], ct2.c0.coeffs[k], 1); he_mul(&u, &ct1, &ct2, &rlk); }
+      gpq_mpi_shim_poly_stats(&c1, &s1);
+      if (s1 - s0 != 1) { bad = 1; printf("resident polynomials: %llu wrong guesses for an operand changed three times in a row (one expected)\n", (unsigned long long)(s1 - s0)); }
+      he_mul(&u, &ct1, &ct2, &rlk);                           /* unchanged this time: converted and uploaded, trusted again ... */
+      gpq_mpi_shim_poly_stats(&c0, &s0);
+      he_mul(&v, &ct1, &ct2, &rlk);                           /* ... and served from the device copies */
+      gpq_mpi_shim_poly_stats(&c1, &s1);
+      if (c1 - c0 != 4 || s1 != s0 || !SAME_CT(u, v)) { bad = 1; printf("resident polynomials: trust not regained (%llu confirmed, %llu changed)\n", (unsigned long long)(c1 - c0), (unsigned long long)(s1 - s0)); }
+    }
     gpq_mpi_shim_poly_stats(&ok1, &stale1);
     printf("resident polynomials: %s (%u resident, %llu operands confirmed, %llu found changed and uploaded again)\n", bad ? "MISMATCH" : "edits and chains identical to fresh uploads",
            gpq_mpi_shim_resident_polys(), (unsigned long long)ok1, (unsigned long long)stale1);

@@ -341,6 +341,6 @@ def test_reference_signature_he_mul_at_the_headline_shape_keeps_its_key_on_the_d
     # a result touched between two chained calls -- every product equals the one of a library that uploads everything afresh
     assert "resident polynomials: edits and chains identical to fresh uploads" in res.stdout, res.stdout
     r = re.search(r"(\d+) operands confirmed, (\d+) found changed", res.stdout)
-    assert r and int(r.group(1)) > 0 and int(r.group(2)) == 5, res.stdout
+    assert r and int(r.group(1)) > 0 and int(r.group(2)) == 6, res.stdout
     ch = re.search(r"chained .*he_mul p50 ([0-9.]+) .*he_mul\(&ct, &ct, &ct\) p50 ([0-9.]+) .*he_rescale of a product p50 ([0-9.]+)", res.stdout)
     assert ch and all(0.05 < float(v) < 200 for v in ch.groups()), res.stdout
