@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <cmath>
@@ -230,12 +231,14 @@ double wall_ms() {
 }
 
 // Evaluation keys are 2 x dim x n words (47 MB at the headline shape) and the same key multiplies many ciphertexts: the device
-// copy is kept, identified by the caller's two pointers, the length and a fingerprint of EVERY word (the reference reads the key
-// it is given on every call, src/he-mult.c:60-64: a key edited in place, in however few words, must multiply as edited).  For a
-// key that is resident the fingerprint is computed by the host threads WHILE the device works with the resident copy (they would
-// wait for it otherwise: resident_key / key_still_valid; a mismatch repeats the device work with the fresh key); for a new key, next
-// to the ciphertext conversions.  gpq_mpi_shim_set_key_check(0) goes back to ~1000 sampled words for callers that never edit a key in place.
-struct KeySlot { const uint64_t *h0, *h1; size_t words; uint64_t print; void *d0, *d1; uint64_t used; };
+// copy is kept, identified by the caller's two pointers and a fingerprint of EVERY word, limb by limb (the reference reads the key
+// it is given on every call, src/he-mult.c:60-64: a key edited in place, in however few words, must multiply as edited).  A call at a
+// lower level reads fewer limbs of the same key (dimB shrinks with q_l, :51): the resident copy serves every prefix of itself, checked
+// over just the limbs in use -- one copy per key, not one per level.  For a key that is resident the fingerprint is computed by the host
+// threads WHILE the device works with the resident copy (they would wait for it otherwise: resident_key / key_still_valid; a mismatch
+// repeats the device work with the fresh key); for a new key, next to the ciphertext conversions.  gpq_mpi_shim_set_key_check(0) goes
+// back to ~1000 sampled words (of the exact length in use) for callers that never edit a key in place.
+struct KeySlot { const uint64_t *h0, *h1; unsigned limbs, n; bool full; std::vector<uint64_t> print; void *d0, *d1; size_t cap_words; uint64_t used; };
 std::vector<KeySlot> g_keys;
 uint64_t g_key_clock = 0;
 size_t g_key_slots = 16;      // resident keys (rlk, ck, the rotation keys in use): 45 MiB each at the headline shape; gpq_mpi_shim_set_key_slots
@@ -248,22 +251,24 @@ uint64_t key_print_sampled(const uint64_t *a, const uint64_t *b, size_t words) {
   for (size_t i = 0; i < 8 && i < words; ++i) { mix(a[i]); mix(b[i]); mix(a[words - 1 - i]); mix(b[words - 1 - i]); }
   return h;
 }
-struct KeyPrint {                 // fingerprint of a host key, in `parts` pieces that any thread may compute
-  const uint64_t *h0, *h1; size_t words; unsigned parts; std::vector<uint64_t> part;
+struct KeyPrint {                 // fingerprint of the first `limbs` limbs of a host key: one piece per limb, any thread may compute any piece
+  const uint64_t *h0, *h1; unsigned limbs, n; bool full; unsigned parts; std::vector<uint64_t> part;
   std::function<void(unsigned)> task;
-  KeyPrint(const he_evk_t *key, size_t w) : h0(key->p0.coeffs), h1(key->p1.coeffs), words(w) {
-    parts = (g_key_check_full && words >= 65536) ? 2 * workers().width() : 1;
+  KeyPrint(const he_evk_t *key, unsigned limbs_, unsigned n_) : h0(key->p0.coeffs), h1(key->p1.coeffs), limbs(limbs_), n(n_), full(g_key_check_full) {
+    parts = full ? limbs : 1;
     part.assign(parts, 0);
     task = [this](unsigned t) {
-      if (!g_key_check_full) { part[t] = key_print_sampled(h0, h1, words); return; }
-      const size_t lo = words * t / parts, hi = words * (t + 1) / parts;
+      if (!full) { part[t] = key_print_sampled(h0, h1, (size_t)limbs * n); return; }
+      const size_t lo = (size_t)t * n, hi = lo + n;
       part[t] = hash_words(h0, lo, hi) * 0x100000001b3ull + hash_words(h1, lo, hi);
     };
   }
-  uint64_t value() const {
-    uint64_t h = 0xcbf29ce484222325ull ^ words;
-    for (uint64_t v : part) { h = (h ^ v) * 0x100000001b3ull; h ^= h >> 29; }
-    return h;
+  size_t words() const { return (size_t)limbs * n; }
+  bool covered_by(const KeySlot &k) const {                 // the slot's shape can serve this request at all
+    return k.h0 == h0 && k.h1 == h1 && k.n == n && k.full == full && (full ? k.limbs >= limbs : k.limbs == limbs);
+  }
+  bool matches(const KeySlot &k) const {                    // ... and (part[] computed) holds the words the caller holds now
+    return covered_by(k) && std::equal(part.begin(), part.end(), k.print.begin());
   }
 };
 void drop_key_slot(size_t i) {
@@ -275,35 +280,34 @@ void forget_key_at(const uint64_t *h0, const uint64_t *h1) {          // the hos
   for (size_t i = g_keys.size(); i-- > 0;)
     if (g_keys[i].h0 == h0 || g_keys[i].h1 == h1 || g_keys[i].h0 == h1 || g_keys[i].h1 == h0) drop_key_slot(i);
 }
-// A resident copy of the host key at these addresses and of this length, whatever its fingerprint: he_mul / he_rot / he_conj start
-// the device work with it at once and verify the fingerprint on the host threads WHILE the device works (they would otherwise wait
-// for it); a mismatch -- the key was edited in place since -- uploads the key and runs the device work again.
-KeySlot *resident_key(const he_evk_t *key, size_t words) {
+// A resident copy of the host key at these addresses that covers the limbs in use, whatever its fingerprint: he_mul / he_rot / he_conj
+// start the device work with it at once and verify the fingerprint on the host threads WHILE the device works (they would otherwise
+// wait for it); a mismatch -- the key was edited in place since -- uploads the key and runs the device work again.
+KeySlot *resident_key(const KeyPrint &kp) {
   for (KeySlot &k : g_keys)
-    if (k.h0 == key->p0.coeffs && k.h1 == key->p1.coeffs && k.words == words) { k.used = ++g_key_clock; return &k; }
+    if (kp.covered_by(k)) { k.used = ++g_key_clock; return &k; }
   return nullptr;
 }
 bool key_still_valid(KeySlot *slot, KeyPrint &kp) {
   if (kp.parts < 2) kp.task(0); else workers().run(kp.parts, kp.task);
-  return kp.value() == slot->print;
+  return kp.matches(*slot);
 }
 
 void key_on_device(const KeyPrint &kp, uint64_t **d0, uint64_t **d1) {
   const uint64_t *h0 = kp.h0, *h1 = kp.h1;
-  const size_t words = kp.words;
-  const uint64_t print = kp.value();
+  const size_t words = kp.words();
   for (KeySlot &k : g_keys)
-    if (k.h0 == h0 && k.h1 == h1 && k.words == words && k.print == print) { k.used = ++g_key_clock; *d0 = (uint64_t *)k.d0; *d1 = (uint64_t *)k.d1; return; }
-  KeySlot slot{h0, h1, words, print, nullptr, nullptr, ++g_key_clock};
+    if (kp.matches(k)) { k.used = ++g_key_clock; *d0 = (uint64_t *)k.d0; *d1 = (uint64_t *)k.d1; return; }
+  KeySlot slot{h0, h1, kp.limbs, kp.n, kp.full, kp.part, nullptr, nullptr, words, ++g_key_clock};
   size_t victim = g_keys.size();
-  for (size_t i = 0; i < g_keys.size(); ++i)               // same host key at another state / length, else the least recently used
-    if (g_keys[i].h0 == h0 && g_keys[i].h1 == h1 && g_keys[i].words == words) victim = i;
+  for (size_t i = 0; i < g_keys.size(); ++i)               // same host key in another state / at another length, else the least recently used
+    if (g_keys[i].h0 == h0 && g_keys[i].h1 == h1) victim = i;
   if (victim == g_keys.size() && g_keys.size() >= g_key_slots) {
     victim = 0;
     for (size_t i = 1; i < g_keys.size(); ++i) if (g_keys[i].used < g_keys[victim].used) victim = i;
   }
   if (victim < g_keys.size()) {
-    if (g_keys[victim].words == words) { slot.d0 = g_keys[victim].d0; slot.d1 = g_keys[victim].d1; g_keys.erase(g_keys.begin() + victim); }
+    if (g_keys[victim].cap_words >= words) { slot.d0 = g_keys[victim].d0; slot.d1 = g_keys[victim].d1; slot.cap_words = g_keys[victim].cap_words; g_keys.erase(g_keys.begin() + victim); }
     else drop_key_slot(victim);
   }
   if (!slot.d0 && (gpq_malloc(&slot.d0, words * 8) != GPQ_OK || gpq_malloc(&slot.d1, words * 8) != GPQ_OK)) die("device allocation failed");
@@ -369,12 +373,12 @@ void remember_poly(const poly_mpi_t *p, unsigned n, unsigned W, uint64_t print, 
   g_polys.push_back(slot);
 }
 
-// The polynomial operands of one MPI-typed call.  prepare(): either every operand is resident (`resident`, x[i] = the kept slabs, nothing
-// converted yet) or all are converted and uploaded as ever (x[i] = the call's own buffers) and remembered.  After the device work is queued,
-// recheck() -- resident operands only -- converts and fingerprints the caller's integers; operands that differ are uploaded from the rows
-// just staged, x[i] moves to the call's own buffer, and the caller queues the device work again.
+// The polynomial operands of one MPI-typed call.  prepare(): an operand with a trusted resident copy is taken from it (x[i] = the kept slab,
+// nothing converted yet); the others are converted and uploaded as ever (x[i] = the call's own buffers) and remembered.  After the device
+// work is queued, recheck() converts and fingerprints the caller's integers of the operands that were taken from their copies; those that
+// differ are uploaded from the rows just staged, x[i] moves to the call's own buffer, and the caller queues the device work again.
 struct Operands {
-  int count; unsigned n, W, nt; bool cache, resident = false; unsigned misfits = 0;
+  int count; unsigned n, W, nt; bool cache, resident = false; unsigned kept = 0 /* operands served from their resident copies */, misfits = 0;
   const poly_mpi_t *const *src; const DevBuf *const *dst; const HostBuf *const *stage;
   const uint64_t *x[4]; uint64_t want[4];
   std::vector<uint64_t> prints;
@@ -383,16 +387,27 @@ struct Operands {
     if (count > 4) die("more than four polynomial operands");
   }
   void prepare(bool may_speculate, unsigned extra = 0, const std::function<void(unsigned)> *side = nullptr) {
-    resident = cache && may_speculate;
-    for (int i = 0; i < count && resident; ++i) {
-      const PolySlot *s = resident_poly(src[i], n, W);
-      if (!s || !s->trusted) resident = false; else { x[i] = (const uint64_t *)s->d; want[i] = s->print; }
+    kept = 0;
+    if (cache && may_speculate)
+      for (int i = 0; i < count; ++i) {
+        const PolySlot *s = resident_poly(src[i], n, W);
+        if (s && s->trusted) { x[i] = (const uint64_t *)s->d; want[i] = s->print; kept |= 1u << i; }
+      }
+    resident = kept != 0;
+    // the operands without a (trusted) resident copy are converted and uploaded before the device starts, as ever
+    const poly_mpi_t *usrc[4]; const DevBuf *udst[4]; const HostBuf *ustage[4]; int idx[4], m = 0;
+    for (int i = 0; i < count; ++i)
+      if (!(kept >> i & 1)) { usrc[m] = src[i]; udst[m] = dst[i]; ustage[m] = stage[i]; idx[m++] = i; }
+    if (!m) {
+      if (extra) workers().run(extra, *side);
+      return;
     }
-    if (resident) return;
-    upload_polys(dst, stage, src, count, n, W, extra, side, cache ? prints.data() : nullptr);
-    for (int i = 0; i < count; ++i) {
+    std::vector<uint64_t> uprints((size_t)m * nt, 0);
+    upload_polys(udst, ustage, usrc, m, n, W, extra, side, cache ? uprints.data() : nullptr);
+    for (int k = 0; k < m; ++k) {
+      const int i = idx[k];
       x[i] = dst[i]->u64();
-      if (cache) remember_poly(src[i], n, W, fold_prints(&prints[(size_t)i * nt], nt, n, W), dst[i]->p);
+      if (cache) remember_poly(src[i], n, W, fold_prints(&uprints[(size_t)k * nt], nt, n, W), dst[i]->p);
     }
   }
   bool recheck(unsigned extra = 0, const std::function<void(unsigned)> *side = nullptr) {
@@ -403,6 +418,7 @@ struct Operands {
       const unsigned lo = t * per, hi = lo + per < n ? lo + per : n;
       if (lo >= hi) return;
       for (int i = 0; i < count; ++i) {
+        if (!(kept >> i & 1)) continue;
         bool bad = false;
         to_slab_range<true>(stage[i]->u64(), src[i], n, W, lo, hi, &bad);
         if (bad) misfit.fetch_or(1u << i, std::memory_order_relaxed);
@@ -410,9 +426,10 @@ struct Operands {
       }
     };
     if (nt + extra < 2) job(0); else workers().run(nt + extra, job);
-    g_poly_hits += count;
     bool again = false;
     for (int i = 0; i < count; ++i) {
+      if (!(kept >> i & 1)) continue;
+      ++g_poly_hits;
       const uint64_t now = fold_prints(&prints[(size_t)i * nt], nt, n, W);
       const bool unfit = misfit.load() >> i & 1;
       if (now == want[i] && !unfit) continue;
@@ -577,7 +594,7 @@ void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t 
   const unsigned dimP = hectx.dim;                                                             // hectx.P, src/precomp.c:401-404
   if (gpq_ctx_pbits(c, dimP) != G.mpi_get_nbits(hectx.P)) die("he_mul: hectx.P is not the product of the first hectx.dim primes");
   const unsigned W = logql / 64 + 1;
-  const size_t big = (size_t)W * n, evk = (size_t)dimB * n;
+  const size_t big = (size_t)W * n;
   const poly_mpi_t *in[4] = {&ct1->c0, &ct1->c1, &ct2->c0, &ct2->c1};
   HostBuf s0(big * 8), s1(big * 8), s2(big * 8), s3(big * 8), t0s(big * 8), t1s(big * 8);
   DevBuf d0(big * 8), d1(big * 8), d2(big * 8), d3(big * 8), o0(big * 8), o1(big * 8),
@@ -587,8 +604,8 @@ void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t 
   // he_mul(&ct, &ct, &ct, rlk), src/he-algo.c:151: one ciphertext on both sides -- convert and upload it once, square on the device
   const bool square = ct1->c0.coeffs == ct2->c0.coeffs && ct1->c1.coeffs == ct2->c1.coeffs;
   const double t0 = wall_ms();
-  KeyPrint kp(rlk, evk);
-  KeySlot *spec = resident_key(rlk, evk);                  // a resident copy: used at once, verified while the device works
+  KeyPrint kp(rlk, dimB, n);
+  KeySlot *spec = resident_key(kp);                  // a resident copy: used at once, verified while the device works
   Operands ops(square ? 2 : 4, in, dd, ss, n, W);
   if (spec) ops.prepare(true); else ops.prepare(false, kp.parts, &kp.task);
   uint64_t *k0, *k1;
@@ -611,7 +628,7 @@ void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t 
   if (ops.resident) {                                      // operands and key are checked against the caller's memory while the device works
     again = ops.recheck(kp.parts, &kp.task);
     if (ops.misfits) die("coefficient does not fit the big slab");
-    if (kp.value() != spec->print) { key_on_device(kp, &k0, &k1); again = true; }
+    if (!kp.matches(*spec)) { key_on_device(kp, &k0, &k1); again = true; }
   } else if (spec && !key_still_valid(spec, kp)) {         // edited in place since the upload: the reference reads its key on every call
     key_on_device(kp, &k0, &k1);
     again = true;
@@ -743,15 +760,15 @@ static void automorphism(he_ct_t *ct, const he_evk_t *key, bool conj, unsigned r
   const unsigned nbq = G.mpi_get_nbits(hectx.q[l]), logql = nbq - 1, nbPqL = G.mpi_get_nbits(hectx.PqL);
   const unsigned dimB = (nbq + nbPqL + polyctx.logn) / 59 + 1, dimP = hectx.dim;                // src/he-automorphism.c:52
   const unsigned W = logql / 64 + 1;
-  const size_t big = (size_t)W * n, evk = (size_t)dimB * n;
+  const size_t big = (size_t)W * n;
   HostBuf s0(big * 8), s1(big * 8), t0s(big * 8), t1s(big * 8);
   DevBuf a0(big * 8), a1(big * 8), r0(big * 8), r1(big * 8), o0(big * 8), o1(big * 8),
       ws(pow2 ? gpq_he_swk_workspace_bytes(c, W, dimB, dimP, 1) : gpq_he_general_workspace_bytes(c, W, 0, dimB, dimP, 1));
   const DevBuf *dd[2] = {&a0, &a1}, *oo[2] = {&o0, &o1};
   const HostBuf *ss[2] = {&s0, &s1}, *ts[2] = {&t0s, &t1s};
   const poly_mpi_t *in[2] = {&ct->c0, &ct->c1};
-  KeyPrint kp(key, evk);
-  KeySlot *spec = resident_key(key, evk);
+  KeyPrint kp(key, dimB, n);
+  KeySlot *spec = resident_key(kp);
   Operands ops(2, in, dd, ss, n, W);
   if (spec) ops.prepare(true); else ops.prepare(false, kp.parts, &kp.task);
   uint64_t *k0, *k1;
@@ -771,7 +788,7 @@ static void automorphism(he_ct_t *ct, const he_evk_t *key, bool conj, unsigned r
   if (ops.resident) {
     again = ops.recheck(kp.parts, &kp.task);
     if (ops.misfits) die("coefficient does not fit the big slab");
-    if (kp.value() != spec->print) { key_on_device(kp, &k0, &k1); again = true; }
+    if (!kp.matches(*spec)) { key_on_device(kp, &k0, &k1); again = true; }
   } else if (spec && !key_still_valid(spec, kp)) {
     key_on_device(kp, &k0, &k1);
     again = true;

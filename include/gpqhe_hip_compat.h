@@ -160,10 +160,11 @@ void gpq_mpi_shim_last_timing(double ms[4]);
 /* Number of evaluation keys the MPI-typed calls keep on the device between calls (default 16, least recently used out; lowering
  * the number evicts at once). */
 void gpq_mpi_shim_set_key_slots(unsigned slots);
-/* How a resident key is recognised: by the caller's two pointers, the length and a fingerprint of EVERY word (full != 0, the
+/* How a resident key is recognised: by the caller's two pointers and a fingerprint of EVERY word, limb by limb (full != 0, the
  * default: a key edited in place multiplies as edited, like the reference, which reads its key on every call), computed by the
- * conversion threads beside the ciphertext conversions; or of ~1000 sampled words (full == 0), for programs that never edit a key
- * in place. */
+ * conversion threads while the device works; a call at a lower level, which reads fewer limbs of the same key (src/he-mult.c:51),
+ * is served by the same copy, checked over the limbs it reads.  Or by ~1000 sampled words of the exact length in use (full == 0),
+ * for programs that never edit a key in place. */
 void gpq_mpi_shim_set_key_check(int full);
 unsigned gpq_mpi_shim_resident_keys(void);
 /* How coefficients cross between libgcrypt integers and big slabs: on != 0 (default) reads and writes the limbs of `struct gcry_mpi`
@@ -173,9 +174,9 @@ int gpq_mpi_shim_set_direct_mpi(int on);
 /* Resident polynomials.  GPQHE chains its calls on one ciphertext (he_mul(&bn, &bn, &bn, rlk); he_rs(&bn); ..., src/he-algo.c:140-160):
  * the device keeps the slab of every polynomial the MPI-typed calls have read or written (`slots` of them, default 32, least recently
  * used out; 0 = none), identified by the caller's coefficient array, the shape and a fingerprint of every word of every coefficient.
- * When all operands of a call are resident the device starts from them at once, and the conversion threads meanwhile convert and
- * fingerprint the caller's integers exactly as an upload would; operands the caller changed since are uploaded from the rows then
- * already staged and the device work runs again.  Results never depend on a stale copy; only with the direct integer access
+ * Operands that are resident are not converted before the device starts: the device works from the copies at once, and the conversion
+ * threads meanwhile convert and fingerprint the caller's integers exactly as an upload would; operands the caller changed since are
+ * uploaded from the rows then already staged and the device work runs again (and such an operand is converted up front next time).  Results never depend on a stale copy; only with the direct integer access
  * (gpq_mpi_shim_set_direct_mpi) and n >= 4096. */
 void gpq_mpi_shim_set_poly_slots(unsigned slots);
 unsigned gpq_mpi_shim_resident_polys(void);

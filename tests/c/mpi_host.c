@@ -247,6 +247,9 @@ static int hemul(const char *path)
   printf("he_mulpt %u %.17g %.17g\n", prod.l, prod.nu, prod.B);
   for (unsigned i = 0; i < polyctx.n; i++) print_mpi(prod.c0.coeffs[i]);
   for (unsigned i = 0; i < polyctx.n; i++) print_mpi(prod.c1.coeffs[i]);
+  uint64_t confirmed = 0, changed = 0;
+  gpq_mpi_shim_poly_stats(&confirmed, &changed);             /* operands the chain took from the device copies of earlier results */
+  printf("resident %llu %llu\n", (unsigned long long)confirmed, (unsigned long long)changed);
   return 0;
 }
 

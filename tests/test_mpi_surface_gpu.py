@@ -92,6 +92,9 @@ def test_crt_bridge_through_reference_signatures(mpi_host, oracle_ctx):
 @pytest.mark.parametrize("logn,qL,Delta", [
     (7, 1 << 120, 1 << 30),                       # the reference's test family: powers of two (tests/gpqhe.c:1349-1352)
     (7, 1000003 ** 5 * 1048573, 1000003),         # Delta and every q_l odd: the general-modulus kernels
+    (12, 1 << 109, 1 << 30),                      # tests/gpqhe.c's default parameters; n >= 4096: threaded conversions, every call of the chain
+                                                  # works on the device copies of what the call before wrote (resident polynomials)
+    (12, 1000003 ** 4 * 1048573, 1000003),        # the same with odd moduli (100 bits: the security table allows 109 at n = 2^12, src/precomp.c:53-117)
 ])
 def test_he_chain_with_real_mpis(mpi_host, oracle_ctx, tmp_path, logn, qL, Delta):
     """he_mul -> he_rescale -> he_moddown -> he_mul(&ct,&ct,&ct) -> he_rot -> he_conj -> he_mulpt on real libgcrypt MPIs."""
@@ -185,6 +188,12 @@ def test_he_chain_with_real_mpis(mpi_host, oracle_ctx, tmp_path, logn, qL, Delta
     dim_pt = int((ql.bit_length() + 10.0 + logn) / 59 + 1)
     v0, v1 = ref.he_mulpt(o, (u0, u1), m, dim_pt, 0, ql=ql)
     assert _ints(lines[base + 1:base + 1 + n]) == v0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == v1
+    # he_rescale, he_moddown, the squaring (its key is the resident rlk, a prefix of it at this level) and he_mulpt took their ciphertext
+    # (2 polynomials each) from the device copies the call before left; he_rot / he_conj meet their keys for the first time and upload
+    # everything -- at n >= 4096; smaller rings always convert and upload
+    base += 1 + 2 * n
+    tag, confirmed, changed = lines[base].split()
+    assert tag == "resident" and int(changed) == 0 and int(confirmed) == (8 if logn >= 12 else 0)
 
 
 def _splitmix(state):
