@@ -661,6 +661,15 @@ static void rescale_common(he_ct_t *ct, bool divide) {
   const unsigned s = divide ? G.mpi_get_nbits(hectx.p) - 1 : 0;
   const poly_mpi_t *in[2] = {&ct->c0, &ct->c1};
   poly_mpi_t *out[2] = {&ct->c0, &ct->c1};
+  if (logql == 0) {
+    // q_0 = 1 (logq a multiple of logDelta, e.g. 850 = 17 x 50): mpi_smod (src/types.c:108-113) takes r = x mod 1 = 0, finds 0 >= floor(1/2)
+    // and subtracts q -- every coefficient of the reference's result is -1, whatever the ciphertext was.  No device work in that.
+    for (int k = 0; k < 2; ++k)
+      for (unsigned i = 0; i < n; ++i) { G.mpi_set_ui(out[k]->coeffs[i], 1); G.mpi_neg(out[k]->coeffs[i], out[k]->coeffs[i]); }
+    ct->l = lnew;
+    if (divide) { ct->nu /= hectx.Delta; ct->B = ct->B / hectx.Delta + hectx.bnd.Brs; }
+    return;
+  }
   const unsigned Wout = logql / 64 + 1;                    // the results are centred mod q_lnew: they fit the width he_mul uses at that level
   // One pass at W words per coefficient; with `kept`, from the resident copies of both polynomials (returns false if one of them
   // turned out wider than its copy: the caller measures the integers and runs again)

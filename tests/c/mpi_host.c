@@ -553,6 +553,28 @@ static int hemultime(unsigned logn, unsigned logq)
   printf("  chained (operands resident, checked while the device works): he_mul p50 %.2f p95 %.2f ms; he_mul(&ct, &ct, &ct) p50 %.2f p95 %.2f ms; he_rescale of a product p50 %.2f p95 %.2f ms\n",
          tm[CALLS / 2], tm[CALLS * 95 / 100], tsq[CALLS / 2], tsq[CALLS * 95 / 100], trs[CALLS / 2], trs[CALLS * 95 / 100]);
   printf("  last chained he_mul: before the device starts %.2f ms, kernels %.2f ms, check+download+convert %.2f ms, call %.2f ms\n", part[0], part[1], part[2], part[3]);
+  /* (c) the whole ladder, as he_inv / he_exp walk it (src/he-algo.c:140-160): square and rescale from level L down to level 1 on one
+   * ciphertext; the second descent is timed (the first builds the per-level device tables), once with and once without the memory */
+  for (int mem = 1; mem >= 0; mem--) {
+    gpq_mpi_shim_set_poly_slots(mem ? 32 : 0);
+    double total = 0;
+    for (int pass = 0; pass < 2; pass++) {
+      for (unsigned k = 0; k < polyctx.n; k++) { gcry_mpi_set(ct.c0.coeffs[k], ct1.c0.coeffs[k]); gcry_mpi_set(ct.c1.coeffs[k], ct1.c1.coeffs[k]); }
+      ct.l = hectx.L; ct.nu = 1.0; ct.B = 1.0;
+      const double t0 = now_ms();
+      while (ct.l > 0) { he_mul(&ct, &ct, &ct, &rlk); he_rescale(&ct); }
+      total = now_ms() - t0;
+    }
+    printf("  ladder of %u x (he_mul(&ct, &ct, &ct) + he_rescale), level %u -> 0, %s: %.1f ms\n", hectx.L, hectx.L, mem ? "operands resident" : "every call uploads", total);
+    if (gcry_mpi_get_nbits(hectx.q[0]) == 1) {               /* q_0 = 1: mpi_smod by 1 makes every coefficient -1 (src/types.c:108-113) */
+      MPI m1 = gcry_mpi_new(0);
+      gcry_mpi_set_ui(m1, 1); gcry_mpi_neg(m1, m1);
+      int all = 1;
+      for (unsigned k = 0; k < polyctx.n; k++) if (gcry_mpi_cmp(ct.c0.coeffs[k], m1) || gcry_mpi_cmp(ct.c1.coeffs[k], m1)) all = 0;
+      printf("  level 0 has q_0 = 1: every coefficient %s\n", all ? "is -1, as mpi_smod by 1 leaves it" : "SHOULD be -1");
+    }
+  }
+  gpq_mpi_shim_set_poly_slots(32);
   return 0;
 }
 
