@@ -353,3 +353,6 @@ def test_reference_signature_he_mul_at_the_headline_shape_keeps_its_key_on_the_d
     assert r and int(r.group(1)) > 0 and int(r.group(2)) == 6, res.stdout
     ch = re.search(r"chained .*he_mul p50 ([0-9.]+) .*he_mul\(&ct, &ct, &ct\) p50 ([0-9.]+) .*he_rescale of a product p50 ([0-9.]+)", res.stdout)
     assert ch and all(0.05 < float(v) < 200 for v in ch.groups()), res.stdout
+    # the square + rescale ladder down to level 0, where q_0 = 2^(850 - 17 * 50) = 1 and the reference's mpi_smod leaves -1 everywhere
+    assert len(re.findall(r"ladder of 17 x .* ([0-9.]+) ms", res.stdout)) == 2, res.stdout
+    assert res.stdout.count("level 0 has q_0 = 1: every coefficient is -1") == 2, res.stdout
