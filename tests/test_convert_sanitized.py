@@ -35,3 +35,24 @@ def test_conversions_and_context_helpers_under_asan_and_ubsan(binary):
     assert "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stderr
     word = r.stdout.split()
     assert word[0] == "ok" and int(word[1]) > 80000
+
+
+@pytest.mark.timeout(400)
+def test_conversion_threads_under_tsan(tmp_path):
+    """The same program under ThreadSanitizer: the conversion pool (tasks that keep to their thread, the caller working beside its helpers)
+    and the threaded conversions race-free."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    out = str(tmp_path / "convert_tsan")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c", "convert_sanitized.cpp"), "-ldl", "-l:libgcrypt.so.20", "-pthread", "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and ("sanitize" in r.stderr or "tsan" in r.stderr or "libgcrypt" in r.stderr):
+        pytest.skip("sanitizer runtime or libgcrypt runtime not installed: " + r.stderr.splitlines()[-1])
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([out], capture_output=True, text=True, timeout=380)
+    if "FATAL: ThreadSanitizer" in r.stderr and "mmap" in r.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory here: " + r.stderr.splitlines()[0])
+    assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
+    assert r.stdout.split()[0] == "ok"
+
