@@ -241,7 +241,7 @@ double wall_ms() {
 struct KeySlot { const uint64_t *h0, *h1; unsigned limbs, n; bool full; std::vector<uint64_t> print; void *d0, *d1; size_t cap_words; uint64_t used; };
 std::vector<KeySlot> g_keys;
 uint64_t g_key_clock = 0;
-size_t g_key_slots = 16;      // resident keys (rlk, ck, the rotation keys in use): 45 MiB each at the headline shape; gpq_mpi_shim_set_key_slots
+size_t g_key_slots = 64;      // resident keys (rlk, ck, the rotation keys in use): 45 MiB each at the headline shape (2.9 GB of the 288 GB when all are in use); gpq_mpi_shim_set_key_slots
 bool g_key_check_full = true; // gpq_mpi_shim_set_key_check
 uint64_t key_print_sampled(const uint64_t *a, const uint64_t *b, size_t words) {
   uint64_t h = 0xcbf29ce484222325ull;
@@ -910,7 +910,7 @@ void he_genrk(he_evk_t *rk, const poly_mpi_t *sk) {                             
 // [2] downloads and slab -> MPI conversions (includes waiting for [1]), [3] the whole call
 void gpq_mpi_shim_last_timing(double ms[4]) { for (int i = 0; i < 4; ++i) ms[i] = g_last_ms[i]; }
 
-// How many evaluation keys stay on the device between calls (default 16; he_rot over many rotation keys -- the gemv of
+// How many evaluation keys stay on the device between calls (default 64; he_rot over many rotation keys -- the gemv of
 // src/he-algo.c:63-85 walks rk[0..slots) -- wants as many as it cycles through: 45 MiB each at n = 2^16, 45 limbs).
 void gpq_mpi_shim_set_key_slots(unsigned slots) {
   SHIM_CALL();

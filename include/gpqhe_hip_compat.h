@@ -157,7 +157,7 @@ void gpq_dropin_reset(void);
 /* Wall milliseconds of the last he_mul(he_ct_t *, ...) call: [0] MPI -> slab conversions + uploads, [1] device kernels (HIP
  * events), [2] downloads + slab -> MPI conversions (includes waiting for [1]), [3] the whole call. */
 void gpq_mpi_shim_last_timing(double ms[4]);
-/* Number of evaluation keys the MPI-typed calls keep on the device between calls (default 16, least recently used out; lowering
+/* Number of evaluation keys the MPI-typed calls keep on the device between calls (default 64, least recently used out; lowering
  * the number evicts at once). */
 void gpq_mpi_shim_set_key_slots(unsigned slots);
 /* How a resident key is recognised: by the caller's two pointers and a fingerprint of EVERY word, limb by limb (full != 0, the

@@ -415,7 +415,7 @@ static int hemultime(unsigned logn, unsigned logq)
     const unsigned before = gpq_mpi_shim_resident_keys();
     gpq_mpi_shim_set_key_slots(1);
     const unsigned one = gpq_mpi_shim_resident_keys();
-    gpq_mpi_shim_set_key_slots(16);
+    gpq_mpi_shim_set_key_slots(64);
     printf("key cache: resident %u, after set_key_slots(1) %u\n", before, one);
   }
   {
