@@ -333,8 +333,10 @@ std::vector<PolySlot> g_polys;
 uint64_t g_poly_clock = 0;
 size_t g_poly_slots = 32;     // 7 MiB each at n = 2^16, 14 words
 uint64_t g_poly_hits = 0, g_poly_stale = 0;
+std::vector<const void *> g_poly_pinned;   // resident slabs the MPI-typed call in progress reads from: not to be evicted or reused before it returns
 
-bool poly_cache_on(unsigned n) { return g_poly_slots && n >= 4096 && staged_in_rows(n) && mpi_direct(); }
+bool g_poly_bypass = false;   // gpq_mpi_shim_poly_bypass: calls neither consult nor update the resident polynomials (they stay as they are)
+bool poly_cache_on(unsigned n) { return g_poly_slots && !g_poly_bypass && n >= 4096 && staged_in_rows(n) && mpi_direct(); }
 uint64_t fold_prints(const uint64_t *part, unsigned parts, unsigned n, unsigned W) {
   uint64_t h = 0xcbf29ce484222325ull ^ ((uint64_t)n << 32 | W);
   for (unsigned t = 0; t < parts; ++t) { h = (h ^ part[t]) * 0x100000001b3ull; h ^= h >> 29; }
@@ -361,8 +363,12 @@ void remember_poly(const poly_mpi_t *p, unsigned n, unsigned W, uint64_t print, 
   if (victim < g_polys.size() && !ours)                     // read from the caller: trusted unless it differs from what was kept for it
     slot.trusted = g_polys[victim].n == n && g_polys[victim].W == W && g_polys[victim].print == print;
   if (victim == g_polys.size() && g_polys.size() >= g_poly_slots) {
-    victim = 0;
-    for (size_t i = 1; i < g_polys.size(); ++i) if (g_polys[i].used < g_polys[victim].used) victim = i;
+    // the least recently used goes -- but never a copy the call in progress is reading from (Operands::kept): with few slots the
+    // operands of one call can be all there is, and then the newcomer is simply not kept
+    auto pinned = [](const void *d) { for (const void *q : g_poly_pinned) if (q == d) return true; return false; };
+    for (size_t i = 0; i < g_polys.size(); ++i)
+      if (!pinned(g_polys[i].d) && (victim == g_polys.size() || g_polys[i].used < g_polys[victim].used)) victim = i;
+    if (victim == g_polys.size()) return;
   }
   if (victim < g_polys.size()) {                            // its buffer serves again if it is large enough (he_rs keeps one word less than he_mul: no free / malloc per call)
     if (g_polys[victim].bytes >= bytes) { slot.d = g_polys[victim].d; slot.bytes = g_polys[victim].bytes; g_polys.erase(g_polys.begin() + victim); }
@@ -386,12 +392,15 @@ struct Operands {
       : count(count_), n(n_), W(W_), nt(convert_threads(n_)), cache(poly_cache_on(n_)), src(s), dst(d), stage(st), prints((size_t)4 * nt, 0) {
     if (count > 4) die("more than four polynomial operands");
   }
+  ~Operands() { g_poly_pinned.clear(); }                    // one call at a time (SHIM_CALL), one Operands per call
+  Operands(const Operands &) = delete;
+  Operands &operator=(const Operands &) = delete;
   void prepare(bool may_speculate, unsigned extra = 0, const std::function<void(unsigned)> *side = nullptr) {
     kept = 0;
     if (cache && may_speculate)
       for (int i = 0; i < count; ++i) {
         const PolySlot *s = resident_poly(src[i], n, W);
-        if (s && s->trusted) { x[i] = (const uint64_t *)s->d; want[i] = s->print; kept |= 1u << i; }
+        if (s && s->trusted) { x[i] = (const uint64_t *)s->d; want[i] = s->print; kept |= 1u << i; g_poly_pinned.push_back(s->d); }
       }
     resident = kept != 0;
     // the operands without a (trusted) resident copy are converted and uploaded before the device starts, as ever
@@ -953,6 +962,8 @@ void gpq_mpi_shim_set_poly_slots(unsigned slots) {
 unsigned gpq_mpi_shim_resident_polys(void) { SHIM_CALL(); return (unsigned)g_polys.size(); }
 // operands served from a resident copy that the check confirmed / that the check found changed (uploaded again, device work repeated)
 void gpq_mpi_shim_poly_stats(uint64_t *confirmed, uint64_t *stale) { SHIM_CALL(); if (confirmed) *confirmed = g_poly_hits; if (stale) *stale = g_poly_stale; }
+// testing: while on, the MPI-typed calls convert and upload everything and remember nothing, without touching what is resident
+void gpq_mpi_shim_poly_bypass(int on) { SHIM_CALL(); g_poly_bypass = on != 0; }
 void gpq_mpi_shim_forget_polys(void) {
   SHIM_CALL();
   (void)gpq_stream_sync(nullptr);

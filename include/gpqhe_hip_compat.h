@@ -183,6 +183,8 @@ unsigned gpq_mpi_shim_resident_polys(void);
 /* operands served from a resident copy that the check confirmed / found changed (uploaded again, device work repeated) */
 void gpq_mpi_shim_poly_stats(uint64_t *confirmed, uint64_t *stale);
 void gpq_mpi_shim_forget_polys(void);
+/* testing: while on, calls neither consult nor update the resident polynomials (which stay as they are) */
+void gpq_mpi_shim_poly_bypass(int on);
 /* Drops the device copies of the evaluation keys.  Never needed with the default key check; he_genrlk / he_genck / he_genrk drop
  * the copy of the key they write themselves. */
 void gpq_mpi_shim_forget_keys(void);

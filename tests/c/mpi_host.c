@@ -7,6 +7,7 @@
  *   mpi_host crt                         rns_decompose per limb, rns_reconstruct per coefficient, poly_rns2mpi (tests/crt.c:76-109)
  *   mpi_host polymulmono <logn>          poly_mul of a dense polynomial by -3 x^5 at a size that takes the threaded conversions
  *   mpi_host keygen <logn> <logq>        he_genrlk / he_genck / he_genrk with deterministic stand-ins for the reference's samplers
+ *   mpi_host residentfuzz <logn> <logq> <logDelta> <steps> <seed>   random walk over the calls, resident polynomials vs fresh uploads
  *   mpi_host hemultime <logn> <logq>     wall time of he_mul / he_rescale through the MPI-typed symbols (conversions and copies included)
  *   mpi_host hemul  <in.txt>             he_mul on ciphertexts read as hex, then he_rs, then he_moddown
  *   mpi_host ctxcheck <logn> <logq> <Delta>   every field hectx_init / polyctx_init fill, for comparison with the restated formulas
@@ -578,6 +579,125 @@ static int hemultime(unsigned logn, unsigned logq)
   return 0;
 }
 
+/* Random walk over the MPI-typed calls with the resident polynomials in play: every step runs once on a ciphertext the library may hold
+ * copies of and once, with gpq_mpi_shim_poly_bypass, on its twin that is always converted and uploaded afresh; after every step the two must be
+ * the same integers.  Steps: he_mul with every aliasing pattern, he_rescale, he_moddown, he_rot, he_conj, he_mulpt, host-side edits of a
+ * ciphertext (as he_add and friends do), copies between ciphertexts, a smaller number of slots (evictions), a rewritten key. */
+static void fill_key(he_evk_t *k, uint64_t seed)
+{
+  struct rns_ctx *r = polyctx.rns;
+  for (unsigned d = 0; d < hectx.dimevk; d++, r = r->next)
+    for (unsigned i = 0; i < polyctx.n; i++) {
+      k->p0.coeffs[(size_t)d * polyctx.n + i] = splitmix64(&seed) % r->p;
+      k->p1.coeffs[(size_t)d * polyctx.n + i] = splitmix64(&seed) % r->p;
+    }
+}
+
+static int residentfuzz(unsigned logn, unsigned logq, unsigned logDelta, unsigned steps, uint64_t seed)
+{
+  MPI q = pow2(logq);
+  he_ctx_init(logn, q, 1ull << logDelta);
+  enum { K = 4 };
+  he_ct_t x[K], y[K];                                         /* y[i] is the twin of x[i] */
+  const unsigned n = polyctx.n;
+  uint64_t st = seed;
+  unsigned char *buf = malloc(logq / 8 + 16);
+  for (int i = 0; i < K; i++) {
+    poly_alloc(&x[i].c0); poly_alloc(&x[i].c1); poly_alloc(&y[i].c0); poly_alloc(&y[i].c1);
+    poly_mpi_t *ps[2] = {&x[i].c0, &x[i].c1}, *pt[2] = {&y[i].c0, &y[i].c1};
+    for (int h = 0; h < 2; h++)
+      for (unsigned k = 0; k < n; k++) {
+        const unsigned nb = (logq - 2) / 8;
+        for (unsigned b = 0; b < nb; b += 8) { uint64_t v = splitmix64(&st); memcpy(buf + b, &v, 8); }
+        MPI t = NULL;
+        gcry_mpi_scan(&t, 5, buf, nb, NULL);
+        if (splitmix64(&st) & 1) gcry_mpi_neg(t, t);
+        gcry_mpi_release(ps[h]->coeffs[k]); ps[h]->coeffs[k] = t;
+        gcry_mpi_set(pt[h]->coeffs[k], t);
+      }
+    x[i].l = y[i].l = hectx.L; x[i].nu = y[i].nu = 1.0; x[i].B = y[i].B = 1.0;
+  }
+  he_evk_t keys[4];                                           /* rlk, rk[1], rk[2], ck */
+  for (int i = 0; i < 4; i++) {
+    keys[i].p0.coeffs = malloc((size_t)hectx.dimevk * n * 8); keys[i].p1.coeffs = malloc((size_t)hectx.dimevk * n * 8);
+    fill_key(&keys[i], 7000 + i);
+  }
+  he_evk_t rk[3] = {{{NULL}, {NULL}}, keys[1], keys[2]};
+  he_pt_t pt;
+  poly_alloc(&pt.m);
+  pt.nu = 1024.0;
+  for (unsigned i = 0; i < n; i++) { gcry_mpi_set_ui(pt.m.coeffs[i], (unsigned long)(splitmix64(&st) >> 40)); if (i & 1) gcry_mpi_neg(pt.m.coeffs[i], pt.m.coeffs[i]); }
+  unsigned count[12] = {0};
+#define TWIN(call_x, call_y) do { call_x; gpq_mpi_shim_poly_bypass(1); call_y; gpq_mpi_shim_poly_bypass(0); } while (0)
+  for (unsigned step = 0; step < steps; step++) {
+    const unsigned op = (unsigned)(splitmix64(&st) % 12), a = (unsigned)(splitmix64(&st) % K), b = (unsigned)(splitmix64(&st) % K), d = (unsigned)(splitmix64(&st) % K);
+    int touched = -1;
+    if (op <= 2) {                                            /* he_mul: dst may be a, b, both or neither */
+      if (x[a].l != x[b].l || x[a].l == 0) continue;
+      TWIN(he_mul(&x[d], &x[a], &x[b], &keys[0]), he_mul(&y[d], &y[a], &y[b], &keys[0]));
+      touched = (int)d;
+    } else if (op == 3) {
+      if (x[a].l < 2) continue;
+      TWIN(he_rescale(&x[a]), he_rescale(&y[a]));
+      touched = (int)a;
+    } else if (op == 4) {
+      if (x[a].l < 2) continue;
+      TWIN(he_moddown(&x[a]), he_moddown(&y[a]));
+      touched = (int)a;
+    } else if (op == 5) {
+      if (x[a].l == 0) continue;
+      const int r = 1 + (int)(b & 1);
+      TWIN(he_rot(&x[a], r, rk), he_rot(&y[a], r, rk));
+      touched = (int)a;
+    } else if (op == 6) {
+      if (x[a].l == 0) continue;
+      TWIN(he_conj(&x[a], &keys[3]), he_conj(&y[a], &keys[3]));
+      touched = (int)a;
+    } else if (op == 7) {
+      if (x[a].l == 0) continue;
+      TWIN(he_mulpt(&x[d], &x[a], &pt), he_mulpt(&y[d], &y[a], &pt));
+      touched = (int)d;
+    } else if (op == 8) {                                     /* the host changes a ciphertext behind the library's back */
+      const unsigned k = (unsigned)(splitmix64(&st) % n), how = (unsigned)(splitmix64(&st) % 4);
+      poly_mpi_t *px = (splitmix64(&st) & 1) ? &x[a].c0 : &x[a].c1, *py = px == &x[a].c0 ? &y[a].c0 : &y[a].c1;
+      if (how == 0) { gcry_mpi_add_ui(px->coeffs[k], px->coeffs[k], 1); gcry_mpi_add_ui(py->coeffs[k], py->coeffs[k], 1); }
+      if (how == 1) { gcry_mpi_neg(px->coeffs[k], px->coeffs[k]); gcry_mpi_neg(py->coeffs[k], py->coeffs[k]); }
+      if (how == 2) { gcry_mpi_set_ui(px->coeffs[k], 5); gcry_mpi_set_ui(py->coeffs[k], 5); }
+      if (how == 3) { MPI t = gcry_mpi_copy(px->coeffs[k]); gcry_mpi_release(px->coeffs[k]); px->coeffs[k] = t; }
+    } else if (op == 9) {                                     /* x[d] = x[a] */
+      if (a == d) continue;
+      for (unsigned k = 0; k < n; k++) {
+        gcry_mpi_set(x[d].c0.coeffs[k], x[a].c0.coeffs[k]); gcry_mpi_set(x[d].c1.coeffs[k], x[a].c1.coeffs[k]);
+        gcry_mpi_set(y[d].c0.coeffs[k], y[a].c0.coeffs[k]); gcry_mpi_set(y[d].c1.coeffs[k], y[a].c1.coeffs[k]);
+      }
+      x[d].l = x[a].l; y[d].l = y[a].l;
+    } else if (op == 10) {
+      gpq_mpi_shim_set_poly_slots(2 + (unsigned)(splitmix64(&st) % 7));
+    } else {                                                  /* a key rewritten in place, in one word or in all */
+      he_evk_t *k = &keys[splitmix64(&st) % 4];
+      if (splitmix64(&st) & 1) fill_key(k, splitmix64(&st));
+      else { const size_t at = splitmix64(&st) % ((size_t)hectx.dimevk * n); k->p1.coeffs[at] = k->p1.coeffs[at] > 9 ? k->p1.coeffs[at] - 9 : k->p1.coeffs[at] + 9; }
+    }
+    count[op]++;
+    if (touched >= 0) {
+      if (x[touched].l != y[touched].l) { printf("step %u op %u: levels differ\n", step, op); return 1; }
+      for (unsigned k = 0; k < n; k++)
+        if (gcry_mpi_cmp(x[touched].c0.coeffs[k], y[touched].c0.coeffs[k]) || gcry_mpi_cmp(x[touched].c1.coeffs[k], y[touched].c1.coeffs[k])) {
+          printf("step %u op %u (a %u b %u d %u, level %u): coefficient %u differs from the twin computed from fresh uploads\n", step, op, a, b, d, x[touched].l, k);
+          return 1;
+        }
+    }
+    /* ladders run out of levels: put a spent ciphertext back on top now and then (both twins alike) */
+    if (x[a].l < 2 && (splitmix64(&st) & 1)) { x[a].l = y[a].l = hectx.L; }
+  }
+  uint64_t confirmed = 0, changed = 0;
+  gpq_mpi_shim_poly_stats(&confirmed, &changed);
+  printf("residentfuzz ok: %u steps (mul %u rs %u moddown %u rot %u conj %u mulpt %u edit %u copy %u slots %u key %u), %llu operands confirmed, %llu found changed\n", steps,
+         count[0] + count[1] + count[2], count[3], count[4], count[5], count[6], count[7], count[8], count[9], count[10], count[11],
+         (unsigned long long)confirmed, (unsigned long long)changed);
+  return 0;
+}
+
 /* hectx_init / polyctx_init / poly_*_alloc of the library (weak definitions), printed field by field for the Python side to compare
  * with the restated formulas (src/precomp.c:266-293, :328-450) and with the dims SURVEY.md 8c captured from the reference */
 static int ctxcheck(unsigned logn, unsigned logq, unsigned long long Delta)
@@ -629,5 +749,6 @@ int main(int argc, char **argv)
   if (argc >= 3 && !strcmp(argv[1], "polymulmono")) return polymulmono(atoi(argv[2]));
   if (argc >= 4 && !strcmp(argv[1], "keygen")) return keygen(atoi(argv[2]), atoi(argv[3]));
   if (argc >= 4 && !strcmp(argv[1], "hemultime")) return hemultime(atoi(argv[2]), atoi(argv[3]));
+  if (argc >= 7 && !strcmp(argv[1], "residentfuzz")) return residentfuzz(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), strtoull(argv[6], NULL, 10));
   return 2;
 }

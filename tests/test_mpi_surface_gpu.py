@@ -356,3 +356,17 @@ def test_reference_signature_he_mul_at_the_headline_shape_keeps_its_key_on_the_d
     # the square + rescale ladder down to level 0, where q_0 = 2^(850 - 17 * 50) = 1 and the reference's mpi_smod leaves -1 everywhere
     assert len(re.findall(r"ladder of 17 x .* ([0-9.]+) ms", res.stdout)) == 2, res.stdout
     assert res.stdout.count("level 0 has q_0 = 1: every coefficient is -1") == 2, res.stdout
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("logn,logq,logDelta,steps,seed", [(12, 109, 20, 400, 1), (12, 109, 30, 300, 2), (13, 200, 25, 250, 3)])
+def test_random_walk_with_resident_polynomials_equals_fresh_uploads(mpi_host, logn, logq, logDelta, steps, seed):
+    """`mpi_host residentfuzz`: a random walk over he_mul (every aliasing pattern) / he_rescale / he_moddown / he_rot / he_conj / he_mulpt,
+    host-side edits of ciphertexts between calls, copies, evictions and keys rewritten in place.  Every step runs on a ciphertext the
+    library may hold device copies of and on a twin that is always converted and uploaded afresh: the integers must never differ."""
+    import re
+    res = subprocess.run([mpi_host, "residentfuzz", str(logn), str(logq), str(logDelta), str(steps), str(seed)], capture_output=True, text=True, timeout=850)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    m = re.search(r"residentfuzz ok: (\d+) steps .* (\d+) operands confirmed, (\d+) found changed", res.stdout)
+    assert m and int(m.group(2)) > 20 and int(m.group(3)) > 0, res.stdout[-2000:]
+
