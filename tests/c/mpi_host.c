@@ -627,10 +627,10 @@ static int residentfuzz(unsigned logn, unsigned logq, unsigned logDelta, unsigne
   poly_alloc(&pt.m);
   pt.nu = 1024.0;
   for (unsigned i = 0; i < n; i++) { gcry_mpi_set_ui(pt.m.coeffs[i], (unsigned long)(splitmix64(&st) >> 40)); if (i & 1) gcry_mpi_neg(pt.m.coeffs[i], pt.m.coeffs[i]); }
-  unsigned count[12] = {0};
+  unsigned count[13] = {0};
 #define TWIN(call_x, call_y) do { call_x; gpq_mpi_shim_poly_bypass(1); call_y; gpq_mpi_shim_poly_bypass(0); } while (0)
   for (unsigned step = 0; step < steps; step++) {
-    const unsigned op = (unsigned)(splitmix64(&st) % 12), a = (unsigned)(splitmix64(&st) % K), b = (unsigned)(splitmix64(&st) % K), d = (unsigned)(splitmix64(&st) % K);
+    const unsigned op = (unsigned)(splitmix64(&st) % 13), a = (unsigned)(splitmix64(&st) % K), b = (unsigned)(splitmix64(&st) % K), d = (unsigned)(splitmix64(&st) % K);
     int touched = -1;
     if (op <= 2) {                                            /* he_mul: dst may be a, b, both or neither */
       if (x[a].l != x[b].l || x[a].l == 0) continue;
@@ -671,6 +671,10 @@ static int residentfuzz(unsigned logn, unsigned logq, unsigned logDelta, unsigne
         gcry_mpi_set(y[d].c0.coeffs[k], y[a].c0.coeffs[k]); gcry_mpi_set(y[d].c1.coeffs[k], y[a].c1.coeffs[k]);
       }
       x[d].l = x[a].l; y[d].l = y[a].l;
+    } else if (op == 12) {                                    /* poly_mul as he_dec / he_enc call it: one polynomial of a times one of b, mod q of d's level, into d */
+      if (x[d].l == 0) continue;
+      TWIN(poly_mul(&x[d].c0, &x[a].c1, &x[b].c0, hectx.dimevk, hectx.q[x[d].l]), poly_mul(&y[d].c0, &y[a].c1, &y[b].c0, hectx.dimevk, hectx.q[y[d].l]));
+      touched = (int)d;
     } else if (op == 10) {
       gpq_mpi_shim_set_poly_slots(2 + (unsigned)(splitmix64(&st) % 7));
     } else {                                                  /* a key rewritten in place, in one word or in all */
@@ -692,8 +696,8 @@ static int residentfuzz(unsigned logn, unsigned logq, unsigned logDelta, unsigne
   }
   uint64_t confirmed = 0, changed = 0;
   gpq_mpi_shim_poly_stats(&confirmed, &changed);
-  printf("residentfuzz ok: %u steps (mul %u rs %u moddown %u rot %u conj %u mulpt %u edit %u copy %u slots %u key %u), %llu operands confirmed, %llu found changed\n", steps,
-         count[0] + count[1] + count[2], count[3], count[4], count[5], count[6], count[7], count[8], count[9], count[10], count[11],
+  printf("residentfuzz ok: %u steps (mul %u rs %u moddown %u rot %u conj %u mulpt %u edit %u copy %u slots %u key %u poly_mul %u), %llu operands confirmed, %llu found changed\n", steps,
+         count[0] + count[1] + count[2], count[3], count[4], count[5], count[6], count[7], count[8], count[9], count[10], count[11], count[12],
          (unsigned long long)confirmed, (unsigned long long)changed);
   return 0;
 }
