@@ -268,7 +268,7 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6):
             "bridge_algo_bytes_per_he_mul": int(sum(words.values()) * 8 * n), "kernels": kernels, "roofline": roof}
 
 
-def keyswitch_n17_rate(torch, gpqhe_amd, batch=16, iters=3):
+def keyswitch_n17_rate(torch, gpqhe_amd, batch=64, iters=3):
     """BASELINE configs[4] shape: the key-switch inner product (he_swk loop, src/he-automorphism.c:59-67) at n = 2^17, 44 limbs."""
     logn, dim = 17, 44
     ctx = gpqhe_amd.PolyContext(logn, dim)
