@@ -62,6 +62,7 @@ SIGNATURES = {
     "gpq_set_exact_crt": (C.c_int, [vp, C.c_int]),
     "gpq_set_fused_tail": (C.c_int, [vp, C.c_int]),
     "gpq_big_transpose": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_int, vp]),
+    "gpq_big_addsub": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_int, vp]),
     "gpq_set_prescale": (C.c_int, [vp, C.c_int]),
     "gpq_set_bridge_mfma": (C.c_int, [vp, C.c_int]),
     "gpq_poly_mul_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint]),
@@ -136,7 +137,7 @@ SIGNATURES = {
 # exercised from C (tests/c/dropin_host.c)
 EXPORTED_ONLY = ["montgomery_reduce", "barrett_reduce",
                  # MPI-typed surface: driven from C with real libgcrypt MPIs (tests/c/mpi_host.c)
-                 "rns_decompose", "rns_reconstruct", "poly_rns2mpi", "poly_mul", "he_mul", "he_rs", "he_rescale", "he_moddown", "he_mulpt", "he_conj", "he_rot", "he_genrlk", "he_genck", "he_genrk",
+                 "rns_decompose", "rns_reconstruct", "poly_rns2mpi", "poly_mul", "he_mul", "he_rs", "he_rescale", "he_moddown", "he_mulpt", "he_add", "he_sub", "he_addpt", "he_subpt", "he_neg", "he_conj", "he_rot", "he_genrlk", "he_genck", "he_genrk",
                  ]
 # libgpqhe_hip_ctx.so (ctx_compat.hip): context construction / storage names for hosts that are not GPQHE; driven from C
 CTX_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgpqhe_hip_ctx.so")

@@ -1197,6 +1197,14 @@ extern "C" int gpq_big_transpose(gpq_ctx *c, uint64_t *dst, const uint64_t *src,
   return launched("gpq_big_transpose");
 }
 
+// out = a + b / a - b / -a on `polys` big slabs of W words (two's complement, wrapping): the arithmetic of src/he-add.c before its mpi_smod
+extern "C" int gpq_big_addsub(gpq_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, unsigned W, unsigned polys, int mode, void *stream) {
+  if (!c || !out || !a || (mode != 2 && !b) || W < 1 || W > 64 || polys < 1 || mode < 0 || mode > 2) return gpq_fail(GPQ_ERR_INVALID, "gpq_big_addsub: bad arguments");
+  BigAddSubArgs k{out, a, b, W, c->logn, (unsigned)mode};
+  hipLaunchKernelGGL(bridge_big_addsub, dim3((c->n + 255) / 256, polys), dim3(256), 0, (hipStream_t)stream, k);
+  return launched("gpq_big_addsub");
+}
+
 // The same tail for a caller that gives `chat` up as scratch: the CRT weights of the whole basis are put on it in place and the
 // one-product kernel (tail_direct) finishes -- the form gpq_he_mul / gpq_he_swk reach without the extra pass, because their key
 // switch delivers the weighted limbs.  Falls back to gpq_relin_tail's kernels when the product is not available (shape, settings).

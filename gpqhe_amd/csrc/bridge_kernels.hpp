@@ -429,6 +429,27 @@ __global__ __launch_bounds__(64) void bridge_big_transpose(BigTransposeArgs a) {
   (void)n;
 }
 
+// out = a + b (mode 0), a - b (mode 1), -a (mode 2) on big slabs: W-word two's complement per coefficient, word-major, wrapping at 2^(64 W).
+// The additive calls of the reference (he_add / he_sub / he_addpt / he_subpt / he_neg, src/he-add.c:32-140) are this followed by the
+// centring mpi_smod the rescale kernels already do; one thread per coefficient carries through its W words, every word plane of a
+// wavefront is one contiguous run of memory.  out may be a or b.
+struct BigAddSubArgs { uint64_t *out; const uint64_t *a, *b; unsigned W, logn, mode; };
+__global__ __launch_bounds__(256) void bridge_big_addsub(BigAddSubArgs k) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (1u << k.logn)) return;
+  const size_t base = ((size_t)blockIdx.y * k.W << k.logn) + i;
+  unsigned carry = k.mode ? 1u : 0u;                       // a - b = a + ~b + 1,  -a = 0 + ~a + 1
+  for (unsigned j = 0; j < k.W; ++j) {
+    const size_t at = base + ((size_t)j << k.logn);
+    const uint64_t x = k.mode == 2 ? 0ull : k.a[at];
+    uint64_t y = k.mode == 2 ? k.a[at] : k.b[at];
+    if (k.mode) y = ~y;
+    const uint64_t s1 = x + y, s2 = s1 + carry;
+    carry = (s1 < x) | (s2 < s1);
+    k.out[at] = s2;
+  }
+}
+
 // chat[poly][d][i] <- chat[poly][d][i] * scale[d] mod p_d, for every coefficient (only == nullptr) or for the groups of 64 coefficients that
 // hold a non-zero entry of `only`: puts the CRT weights of the one-product tail on a raw slab (gpq_relin_tail_overwriting), or takes them
 // off again for the groups its exact fallback re-runs with the kernels that read raw residues.

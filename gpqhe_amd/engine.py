@@ -145,6 +145,13 @@ class PolyContext:
                       "gpq_poly_mul_general")
         return r
 
+    def big_addsub(self, out, a, b, W, mode):
+        """out = a + b (mode 0), a - b (1), -a (2) on big slabs of W words, wrapping: src/he-add.c:32-140 before its mpi_smod."""
+        polys = a.numel() // (W * self.n)
+        _native.check(self.lib.gpq_big_addsub(self.h, self._ptr(out), self._ptr(a), self._ptr(b) if b is not None else None, W, polys, mode, self._stream()),
+                      "gpq_big_addsub")
+        return out
+
     def he_rs(self, c0, c1, W, logDelta, logql):
         """src/he-rescale.c:33-54 with Delta = 2^logDelta, q_l = 2^logql, in place."""
         batch = c0.numel() // (W * self.n)

@@ -257,6 +257,10 @@ int gpq_relin_tail(gpq_ctx *ctx, uint64_t *out, const uint64_t *chat, const uint
 /* Big slabs between the kernels' layout (word j of coefficient i at j*n + i) and rows of W words per coefficient (i*W + j), the layout a host
  * fills or reads sequentially; to_rows = 0: rows -> words, 1: words -> rows.  n >= 64, dst != src, `batch` polynomials one after another. */
 int gpq_big_transpose(gpq_ctx *ctx, uint64_t *dst, const uint64_t *src, unsigned W, unsigned batch, int to_rows, void *stream);
+/* out = a + b (mode 0), a - b (mode 1), -a (mode 2; b unused) on `polys` big slabs of W words per coefficient (two's complement,
+ * wrapping at 2^(64 W); out may alias a or b): the arithmetic of he_add / he_sub / he_addpt / he_subpt / he_neg before their mpi_smod
+ * (src/he-add.c:32-140); gpq_he_rs with logDelta = 0 (or gpq_he_rs_general with delta = 1) is that mpi_smod. */
+int gpq_big_addsub(gpq_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, unsigned W, unsigned polys, int mode, void *stream);
 /* The same with `chat` given up as scratch (overwritten): the tail as ONE matrix-core product over all dimB limbs (what gpq_he_mul / gpq_he_swk use
  * internally, where the key switch already delivers CRT-weighted limbs); same results. */
 int gpq_relin_tail_overwriting(gpq_ctx *ctx, uint64_t *out, uint64_t *chat, const uint64_t *d, unsigned W, unsigned logql,

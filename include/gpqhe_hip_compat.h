@@ -125,6 +125,13 @@ void he_rs(struct he_ct *ct);                                                   
 void he_rescale(struct he_ct *ct);                                                      /* north-star name of he_rs */
 void he_moddown(he_ct_t *ct);                                                           /* src/gpqhe.h:137  */
 void he_mulpt(struct he_ct *dest, const struct he_ct *src, const struct he_pt *pt);     /* src/gpqhe.h:148  */
+/* src/he-add.c:32-140 (decl src/gpqhe.h:140-144): big-integer work only, but interleaved with every product in GPQHE's algorithms
+ * (src/he-algo.c:146-155) -- on the device they keep a chain's ciphertexts resident.  A GPQHE build that wants them drops he-add.c. */
+void he_add(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2);                       /* src/gpqhe.h:140  */
+void he_sub(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2);                       /* src/gpqhe.h:141  */
+void he_addpt(he_ct_t *dest, const he_ct_t *src, const he_pt_t *pt);                    /* src/gpqhe.h:142  */
+void he_subpt(he_ct_t *dest, const he_ct_t *src, const he_pt_t *pt);                    /* src/gpqhe.h:143  */
+void he_neg(he_ct_t *ct);                                                               /* src/gpqhe.h:144  */
 void he_conj(he_ct_t *ct, const he_evk_t *ck);                                          /* src/gpqhe.h:151  */
 void he_rot(he_ct_t *ct, const int rot, const he_evk_t *rk);                            /* src/gpqhe.h:152  */
 /* Key generation, src/he-kem.c:120-170 (decl src/gpqhe.h:131-133).  The randomness comes from the host program's own

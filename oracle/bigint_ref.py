@@ -181,3 +181,25 @@ def he_mulpt(o, ct, m, dim, logql, ql=None):
         prod = _np.concatenate([o.rns_mul(ch[d * n:(d + 1) * n], mh[d * n:(d + 1) * n], d) for d in range(dim)])
         out.append(poly_rns2mpi(_limbs(o.ntt_slab(prod, dim, inverse=True), dim, n), basis, ql))
     return out
+
+
+# src/he-add.c:32-140 -- (c0, c1) pairs of coefficient lists; every result is mpi_smod'ed by q_l (:43-44, :67-68, :91-94, :114-117, :134-137)
+def he_add(ct1, ct2, ql):
+    return tuple([mpi_smod((x + y) % ql, ql) for x, y in zip(a, b)] for a, b in zip(ct1, ct2))          # mpi_addm, :41-42
+
+
+def he_sub(ct1, ct2, ql):
+    return tuple([mpi_smod((x - y) % ql, ql) for x, y in zip(a, b)] for a, b in zip(ct1, ct2))          # mpi_subm, :65-66
+
+
+def he_addpt(ct, m, ql):
+    return [mpi_smod((x + y) % ql, ql) for x, y in zip(ct[0], m)], [mpi_smod(x % ql, ql) for x in ct[1]]  # :89-90
+
+
+def he_subpt(ct, m, ql):
+    return [mpi_smod((x - y) % ql, ql) for x, y in zip(ct[0], m)], [mpi_smod(x % ql, ql) for x in ct[1]]  # :112-113
+
+
+def he_neg(ct, ql):
+    return tuple([mpi_smod(-x, ql) for x in c] for c in ct)                                               # :132-135
+

@@ -32,6 +32,8 @@ MPI gcry_mpi_copy(const MPI a);
 void gcry_mpi_mul(MPI w, MPI u, MPI v);
 void gcry_mpi_add(MPI w, MPI u, MPI v);
 void gcry_mpi_add_ui(MPI w, MPI u, unsigned long v);
+void gcry_mpi_addm(MPI w, MPI u, MPI v, MPI m);
+void gcry_mpi_sub(MPI w, MPI u, MPI v);
 MPI gcry_mpi_set(MPI w, const MPI u);
 void gcry_mpi_div(MPI q, MPI r, MPI dividend, MPI divisor, int round);
 void gcry_mpi_mul_ui(MPI w, MPI u, unsigned long v);
@@ -248,6 +250,30 @@ static int hemul(const char *path)
   printf("he_mulpt %u %.17g %.17g\n", prod.l, prod.nu, prod.B);
   for (unsigned i = 0; i < polyctx.n; i++) print_mpi(prod.c0.coeffs[i]);
   for (unsigned i = 0; i < polyctx.n; i++) print_mpi(prod.c1.coeffs[i]);
+  /* src/he-add.c: he_add, he_sub, he_addpt, he_subpt, he_neg on the same chain (he_inv's pattern, src/he-algo.c:146-155) */
+  he_ct_t sum;
+  poly_alloc(&sum.c0); poly_alloc(&sum.c1);
+  ct.l = prod.l;
+  he_add(&sum, &prod, &ct);
+  printf("he_add %u %.17g %.17g\n", sum.l, sum.nu, sum.B);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(sum.c0.coeffs[i]);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(sum.c1.coeffs[i]);
+  he_sub(&sum, &sum, &prod);                                 /* output aliases the first operand */
+  printf("he_sub %u\n", sum.l);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(sum.c0.coeffs[i]);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(sum.c1.coeffs[i]);
+  he_addpt(&sum, &prod, &pt);
+  printf("he_addpt %u %.17g %.17g\n", sum.l, sum.nu, sum.B);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(sum.c0.coeffs[i]);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(sum.c1.coeffs[i]);
+  he_subpt(&sum, &sum, &pt);
+  printf("he_subpt %u\n", sum.l);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(sum.c0.coeffs[i]);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(sum.c1.coeffs[i]);
+  he_neg(&sum);
+  printf("he_neg %u\n", sum.l);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(sum.c0.coeffs[i]);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(sum.c1.coeffs[i]);
   uint64_t confirmed = 0, changed = 0;
   gpq_mpi_shim_poly_stats(&confirmed, &changed);             /* operands the chain took from the device copies of earlier results */
   printf("resident %llu %llu\n", (unsigned long long)confirmed, (unsigned long long)changed);
@@ -554,6 +580,41 @@ static int hemultime(unsigned logn, unsigned logq)
   printf("  chained (operands resident, checked while the device works): he_mul p50 %.2f p95 %.2f ms; he_mul(&ct, &ct, &ct) p50 %.2f p95 %.2f ms; he_rescale of a product p50 %.2f p95 %.2f ms\n",
          tm[CALLS / 2], tm[CALLS * 95 / 100], tsq[CALLS / 2], tsq[CALLS * 95 / 100], trs[CALLS / 2], trs[CALLS * 95 / 100]);
   printf("  last chained he_mul: before the device starts %.2f ms, kernels %.2f ms, check+download+convert %.2f ms, call %.2f ms\n", part[0], part[1], part[2], part[3]);
+  {
+    /* the additive calls in a chain (he_inv's iteration: he_mul, he_rs, he_addpt, he_mul, he_rs, src/he-algo.c:151-155) */
+    he_pt_t one;
+    poly_alloc(&one.m);
+    one.nu = 1.0;
+    gcry_mpi_set_ui(one.m.coeffs[0], 1ul << 20);
+    double tadd[CALLS], tapt[CALLS], tneg[CALLS];
+    he_ct_t acc;
+    poly_alloc(&acc.c0); poly_alloc(&acc.c1);
+    ct.l = hectx.L; he_mul(&ct, &ct1, &ct2, &rlk);
+    he_add(&acc, &ct, &ct); he_addpt(&acc, &ct, &one); he_neg(&acc);
+    for (int i = 0; i < CALLS; i++) {
+      he_mul(&ct, &ct1, &ct2, &rlk);
+      double t0 = now_ms(); he_add(&acc, &acc, &ct); tadd[i] = now_ms() - t0;
+      t0 = now_ms(); he_addpt(&acc, &acc, &one); tapt[i] = now_ms() - t0;
+      t0 = now_ms(); he_neg(&acc); tneg[i] = now_ms() - t0;
+    }
+    qsort(tadd, CALLS, sizeof *tadd, cmp_double); qsort(tapt, CALLS, sizeof *tapt, cmp_double); qsort(tneg, CALLS, sizeof *tneg, cmp_double);
+    {
+      /* what the same he_add costs where the reference runs it: 2n x (mpi_addm, mpi_mod, mpi_cmp, mpi_sub) in libgcrypt on the host (src/he-add.c:40-45) */
+      MPI qh = gcry_mpi_new(0);
+      gcry_mpi_rshift(qh, hectx.q[hectx.L], 1);
+      const double t0 = now_ms();
+      for (unsigned i = 0; i < polyctx.n; i++)
+        for (int h = 0; h < 2; h++) {
+          MPI r = h ? acc.c1.coeffs[i] : acc.c0.coeffs[i];
+          gcry_mpi_addm(r, h ? ct1.c1.coeffs[i] : ct1.c0.coeffs[i], h ? ct2.c1.coeffs[i] : ct2.c0.coeffs[i], hectx.q[hectx.L]);
+          gcry_mpi_mod(r, r, hectx.q[hectx.L]);
+          if (gcry_mpi_cmp(r, qh) >= 0) gcry_mpi_sub(r, r, hectx.q[hectx.L]);
+        }
+      printf("  (libgcrypt on the host, the reference's way: one he_add %.1f ms)\n", now_ms() - t0);
+    }
+    printf("  additive calls in a chain (src/he-add.c): he_add p50 %.2f p95 %.2f ms; he_addpt p50 %.2f p95 %.2f ms; he_neg p50 %.2f p95 %.2f ms\n",
+           tadd[CALLS / 2], tadd[CALLS * 95 / 100], tapt[CALLS / 2], tapt[CALLS * 95 / 100], tneg[CALLS / 2], tneg[CALLS * 95 / 100]);
+  }
   /* (c) the whole ladder, as he_inv / he_exp walk it (src/he-algo.c:140-160): square and rescale from level L down to level 1 on one
    * ciphertext; the second descent is timed (the first builds the per-level device tables), once with and once without the memory */
   for (int mem = 1; mem >= 0; mem--) {
@@ -627,10 +688,10 @@ static int residentfuzz(unsigned logn, unsigned logq, unsigned logDelta, unsigne
   poly_alloc(&pt.m);
   pt.nu = 1024.0;
   for (unsigned i = 0; i < n; i++) { gcry_mpi_set_ui(pt.m.coeffs[i], (unsigned long)(splitmix64(&st) >> 40)); if (i & 1) gcry_mpi_neg(pt.m.coeffs[i], pt.m.coeffs[i]); }
-  unsigned count[13] = {0};
+  unsigned count[16] = {0};
 #define TWIN(call_x, call_y) do { call_x; gpq_mpi_shim_poly_bypass(1); call_y; gpq_mpi_shim_poly_bypass(0); } while (0)
   for (unsigned step = 0; step < steps; step++) {
-    const unsigned op = (unsigned)(splitmix64(&st) % 13), a = (unsigned)(splitmix64(&st) % K), b = (unsigned)(splitmix64(&st) % K), d = (unsigned)(splitmix64(&st) % K);
+    const unsigned op = (unsigned)(splitmix64(&st) % 16), a = (unsigned)(splitmix64(&st) % K), b = (unsigned)(splitmix64(&st) % K), d = (unsigned)(splitmix64(&st) % K);
     int touched = -1;
     if (op <= 2) {                                            /* he_mul: dst may be a, b, both or neither */
       if (x[a].l != x[b].l || x[a].l == 0) continue;
@@ -675,6 +736,20 @@ static int residentfuzz(unsigned logn, unsigned logq, unsigned logDelta, unsigne
       if (x[d].l == 0) continue;
       TWIN(poly_mul(&x[d].c0, &x[a].c1, &x[b].c0, hectx.dimevk, hectx.q[x[d].l]), poly_mul(&y[d].c0, &y[a].c1, &y[b].c0, hectx.dimevk, hectx.q[y[d].l]));
       touched = (int)d;
+    } else if (op == 13) {                                    /* src/he-add.c: he_add / he_sub, any aliasing */
+      if (x[a].l != x[b].l || x[a].l == 0) continue;
+      if (splitmix64(&st) & 1) TWIN(he_add(&x[d], &x[a], &x[b]), he_add(&y[d], &y[a], &y[b]));
+      else TWIN(he_sub(&x[d], &x[a], &x[b]), he_sub(&y[d], &y[a], &y[b]));
+      touched = (int)d;
+    } else if (op == 14) {                                    /* he_addpt / he_subpt */
+      if (x[a].l == 0) continue;
+      if (splitmix64(&st) & 1) TWIN(he_addpt(&x[d], &x[a], &pt), he_addpt(&y[d], &y[a], &pt));
+      else TWIN(he_subpt(&x[d], &x[a], &pt), he_subpt(&y[d], &y[a], &pt));
+      touched = (int)d;
+    } else if (op == 15) {
+      if (x[a].l == 0) continue;
+      TWIN(he_neg(&x[a]), he_neg(&y[a]));
+      touched = (int)a;
     } else if (op == 10) {
       gpq_mpi_shim_set_poly_slots(2 + (unsigned)(splitmix64(&st) % 7));
     } else {                                                  /* a key rewritten in place, in one word or in all */
@@ -696,8 +771,8 @@ static int residentfuzz(unsigned logn, unsigned logq, unsigned logDelta, unsigne
   }
   uint64_t confirmed = 0, changed = 0;
   gpq_mpi_shim_poly_stats(&confirmed, &changed);
-  printf("residentfuzz ok: %u steps (mul %u rs %u moddown %u rot %u conj %u mulpt %u edit %u copy %u slots %u key %u poly_mul %u), %llu operands confirmed, %llu found changed\n", steps,
-         count[0] + count[1] + count[2], count[3], count[4], count[5], count[6], count[7], count[8], count[9], count[10], count[11], count[12],
+  printf("residentfuzz ok: %u steps (mul %u rs %u moddown %u rot %u conj %u mulpt %u edit %u copy %u slots %u key %u poly_mul %u add/sub %u addpt/subpt %u neg %u), %llu operands confirmed, %llu found changed\n", steps,
+         count[0] + count[1] + count[2], count[3], count[4], count[5], count[6], count[7], count[8], count[9], count[10], count[11], count[12], count[13], count[14], count[15],
          (unsigned long long)confirmed, (unsigned long long)changed);
   return 0;
 }

@@ -188,12 +188,37 @@ def test_he_chain_with_real_mpis(mpi_host, oracle_ctx, tmp_path, logn, qL, Delta
     dim_pt = int((ql.bit_length() + 10.0 + logn) / 59 + 1)
     v0, v1 = ref.he_mulpt(o, (u0, u1), m, dim_pt, 0, ql=ql)
     assert _ints(lines[base + 1:base + 1 + n]) == v0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == v1
+    # src/he-add.c on the same chain: ct still holds he_conj's result (u), prod the he_mulpt result (v)
+    base += 1 + 2 * n
+    hdr = lines[base].split()
+    assert hdr[0] == "he_add" and int(hdr[1]) == level - 2 and float(hdr[2]) == 2048.0 and float(hdr[3]) == 3.0 * 1024.0 + 3.0
+    a0, a1 = ref.he_add((v0, v1), (u0, u1), ql)
+    assert _ints(lines[base + 1:base + 1 + n]) == a0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == a1
+    base += 1 + 2 * n
+    assert lines[base].split() == ["he_sub", str(level - 2)]
+    b0, b1 = ref.he_sub((a0, a1), (v0, v1), ql)
+    assert _ints(lines[base + 1:base + 1 + n]) == b0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == b1
+    base += 1 + 2 * n
+    hdr = lines[base].split()
+    assert hdr[0] == "he_addpt" and int(hdr[1]) == level - 2 and float(hdr[2]) == 2048.0 and float(hdr[3]) == 3.0 * 1024.0
+    p0, p1 = ref.he_addpt((v0, v1), m, ql)
+    assert _ints(lines[base + 1:base + 1 + n]) == p0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == p1
+    base += 1 + 2 * n
+    assert lines[base].split() == ["he_subpt", str(level - 2)]
+    s0_, s1_ = ref.he_subpt((p0, p1), m, ql)
+    assert _ints(lines[base + 1:base + 1 + n]) == s0_ and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == s1_
+    base += 1 + 2 * n
+    assert lines[base].split() == ["he_neg", str(level - 2)]
+    n0, n1 = ref.he_neg((s0_, s1_), ql)
+    assert _ints(lines[base + 1:base + 1 + n]) == n0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == n1
     # he_rescale, he_moddown, the squaring (its key is the resident rlk, a prefix of it at this level) and he_mulpt took their ciphertext
     # (2 polynomials each) from the device copies the call before left; he_rot / he_conj meet their keys for the first time and upload
     # everything -- at n >= 4096; smaller rings always convert and upload
     base += 1 + 2 * n
     tag, confirmed, changed = lines[base].split()
-    assert tag == "resident" and int(changed) == 0 and int(confirmed) == (8 if logn >= 12 else 0)
+    # ... and so did the five additive calls where q_l is a power of two (4 + 4 + 3 + 3 + 2 polynomials; the plaintext is resident since he_mulpt)
+    assert tag == "resident" and int(changed) == 0
+    assert int(confirmed) == (0 if logn < 12 else 8 + 16 if qL & (qL - 1) == 0 else 8)
 
 
 def _splitmix(state):
