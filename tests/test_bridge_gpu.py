@@ -302,3 +302,44 @@ def test_big_transpose_between_word_major_and_rows(engine_ctx, logn, W, batch):
     back = torch.empty_like(d_words)
     assert lib.gpq_big_transpose(g.h, C.c_void_p(back.data_ptr()), C.c_void_p(d_rows.data_ptr()), W, batch, 0, g._stream()) == 0
     assert torch.equal(back, d_words)
+
+
+@pytest.mark.parametrize("logn,W,polys", [(6, 1, 1), (8, 2, 3), (13, 7, 2), (16, 14, 2)])
+def test_big_addsub_is_wrapping_twos_complement_arithmetic(engine_ctx, logn, W, polys):
+    """gpq_big_addsub: a + b, a - b, -a on W-word two's complement slabs (the arithmetic of src/he-add.c:32-140 before its mpi_smod), with the
+    carries that run through every word: all-ones + 1, 0 - 1, the most negative value, aliasing of out with either operand."""
+    import torch
+    g = engine_ctx(logn, 2)
+    n = g.n
+    rng = random.Random(logn * 31 + W)
+    mod = 1 << (64 * W)
+
+    def ints(seed_edges):
+        v = [rng.randrange(mod) for _ in range(polys * n)]
+        v[:6] = seed_edges
+        return v
+
+    a = ints([mod - 1, 0, 1 << (64 * W - 1), (1 << (64 * W - 1)) - 1, 1, mod - 1])
+    b = ints([1, 1, 1 << (64 * W - 1), 1, mod - 1, mod - 1])
+
+    def slab(v):        # word-major per polynomial
+        out = np.empty((polys, W, n), dtype=np.uint64)
+        for k in range(polys):
+            for j in range(W):
+                out[k, j] = [(v[k * n + i] >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for i in range(n)]
+        return to_device(out.reshape(-1))
+
+    def back(t):
+        w = to_host(t).reshape(polys, W, n)
+        return [sum(int(w[k, j, i]) << (64 * j) for j in range(W)) for k in range(polys) for i in range(n)]
+
+    da, db = slab(a), slab(b)
+    out = torch.empty_like(da)
+    assert back(g.big_addsub(out, da, db, W, 0)) == [(x + y) % mod for x, y in zip(a, b)]
+    assert back(g.big_addsub(out, da, db, W, 1)) == [(x - y) % mod for x, y in zip(a, b)]
+    assert back(g.big_addsub(out, da, None, W, 2)) == [(-x) % mod for x in a]
+    t = da.clone()
+    assert back(g.big_addsub(t, t, db, W, 1)) == [(x - y) % mod for x, y in zip(a, b)]       # out aliases a
+    t = db.clone()
+    assert back(g.big_addsub(t, da, t, W, 0)) == [(x + y) % mod for x, y in zip(a, b)]       # out aliases b
+
