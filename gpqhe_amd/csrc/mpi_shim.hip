@@ -771,7 +771,8 @@ void he_mulpt(struct he_ct *dest, const struct he_ct *src, const struct he_pt *p
 // product (he_inv: he_addpt between two he_mul, src/he-algo.c:146-155), each is 2n libgcrypt calls on the host (tens of milliseconds at
 // n = 2^16), and a ciphertext the host has added to is one the device copies no longer match.  On the device they are one carry chain
 // per coefficient and the centring the rescale kernels already do, on operands that are resident after the call before.
-// kind 0: ct = a + b; 1: ct = a - b; 2: ct = a + pt; 3: ct = a - pt; 4: ct = -a (in place)
+// kind 0: ct = a + b; 1: ct = a - b; 2: ct = a + pt; 3: ct = a - pt; 4: ct = -a (in place); 5: ct = a exactly (he_copy_ct, src/he-mem.c:88-97:
+// no reduction -- 2n mpi_set on the host otherwise, and a copy the device knows nothing about)
 static void additive(he_ct_t *ct, const he_ct_t *a, const he_ct_t *b, const he_pt_t *pt, int kind) {
   SHIM_CALL();
   need_gcrypt();
@@ -779,21 +780,22 @@ static void additive(he_ct_t *ct, const he_ct_t *a, const he_ct_t *b, const he_p
   if (kind < 2 && a->l != b->l) die("he_add / he_sub: operands at different levels");              // assert at src/he-add.c:35, :59
   gpq_ctx *c = engine();
   const unsigned n = polyctx.n, l = a->l;
-  const double nu = kind == 4 ? a->nu : kind < 2 ? (a->nu >= b->nu ? a->nu : b->nu) : (a->nu >= pt->nu ? a->nu : pt->nu);   // :37, :61, :84, :107
-  const double B = kind == 4 ? a->B : kind < 2 ? a->B + b->B : a->B;                                                     // :38, :62, :85, :108
-  const std::vector<uint64_t> qw = words_of(hectx.q[l], "he_add: q_l must be positive");
+  const double nu = kind >= 4 ? a->nu : kind < 2 ? (a->nu >= b->nu ? a->nu : b->nu) : (a->nu >= pt->nu ? a->nu : pt->nu);   // :37, :61, :84, :107
+  const double B = kind >= 4 ? a->B : kind < 2 ? a->B + b->B : a->B;                                                     // :38, :62, :85, :108
+  // a copy never looks at q_l (src/he-mem.c:88-97 copies whatever level the source claims)
+  const std::vector<uint64_t> qw = kind == 5 ? std::vector<uint64_t>{2} : words_of(hectx.q[l], "he_add: q_l must be positive");
   const bool pow2 = is_pow2(qw);
-  const unsigned nbq = G.mpi_get_nbits(hectx.q[l]), logql = nbq - 1;
+  const unsigned nbq = kind == 5 ? 2 : G.mpi_get_nbits(hectx.q[l]), logql = nbq - 1;
   poly_mpi_t *out[2] = {&ct->c0, &ct->c1};
-  const int count = kind == 4 ? 2 : kind < 2 ? 4 : 3;
+  const int count = kind >= 4 ? 2 : kind < 2 ? 4 : 3;
   const poly_mpi_t *in[4] = {&a->c0, &a->c1, kind < 2 ? &b->c0 : kind < 4 ? &pt->m : nullptr, kind < 2 ? &b->c1 : nullptr};
-  if (logql == 0) {                                         // q_l = 1: mpi_smod leaves -1 everywhere (see he_rs)
+  if (logql == 0 && kind != 5) {                            // q_l = 1: mpi_smod leaves -1 everywhere (see he_rs)
     for (int k = 0; k < 2; ++k)
       for (unsigned i = 0; i < n; ++i) { G.mpi_set_ui(out[k]->coeffs[i], 1); G.mpi_neg(out[k]->coeffs[i], out[k]->coeffs[i]); }
     ct->l = l; ct->nu = nu; ct->B = B;
     return;
   }
-  const unsigned Wout = logql / 64 + 1;                    // the results are centred mod q_l
+  const unsigned Wout = kind == 5 ? 64 : logql / 64 + 1;    // the results are centred mod q_l (a copy keeps every word)
   auto pass = [&](unsigned W, bool kept) -> bool {
     if (W > 32) die("he_add: coefficients wider than 2047 bits");
     const size_t big = (size_t)W * n;
@@ -805,6 +807,12 @@ static void additive(he_ct_t *ct, const he_ct_t *a, const he_ct_t *b, const he_p
     ops.prepare(kept);
     auto device_work = [&]() {
       int rc;
+      if (kind == 5) {
+        if (hipMemcpyAsync(o0.p, ops.x[0], big * 8, hipMemcpyDeviceToDevice, nullptr) != hipSuccess ||
+            hipMemcpyAsync(o1.p, ops.x[1], big * 8, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) die("device copy failed");
+        download_issue(ts, oo, 2, n, W);
+        return;
+      }
       if (kind == 4) {
         rc = gpq_big_addsub(c, o0.u64(), ops.x[0], nullptr, W, 1, 2, nullptr);
         if (rc == GPQ_OK) rc = gpq_big_addsub(c, o1.u64(), ops.x[1], nullptr, W, 1, 2, nullptr);
@@ -831,14 +839,14 @@ static void additive(he_ct_t *ct, const he_ct_t *a, const he_ct_t *b, const he_p
     return true;
   };
   bool done = false;
-  if (pow2 && poly_cache_on(n)) {                           // wrapping sums are harmless below a power of two; any other q_l measures its operands first
+  if ((pow2 || kind == 5) && poly_cache_on(n)) {            // wrapping sums are harmless below a power of two; any other q_l measures its operands first
     unsigned W = 0;
     bool all = true;
     for (int i = 0; i < count && all; ++i) {
       const PolySlot *k = resident_poly(in[i], n, 0);
       if (!k || !k->trusted || (W && k->W != W)) all = false; else W = k->W;
     }
-    if (all && W >= Wout) done = pass(W, true);
+    if (all && (W >= Wout || kind == 5)) done = pass(W, true);
   }
   if (!done) {
     unsigned bits = nbq;
@@ -852,6 +860,7 @@ void he_sub(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2) { additive(ct, 
 void he_addpt(he_ct_t *dest, const he_ct_t *src, const he_pt_t *pt) { additive(dest, src, nullptr, pt, 2); }
 void he_subpt(he_ct_t *dest, const he_ct_t *src, const he_pt_t *pt) { additive(dest, src, nullptr, pt, 3); }
 void he_neg(he_ct_t *ct) { additive(ct, ct, nullptr, nullptr, 4); }
+void he_copy_ct(he_ct_t *dest, const he_ct_t *src) { if (dest != src) additive(dest, src, nullptr, nullptr, 5); }      // src/he-mem.c:88-97
 
 // he_rot / he_conj, src/he-automorphism.c:87-115: permute both polynomials, then he_swk (:40-85) in place
 static void automorphism(he_ct_t *ct, const he_evk_t *key, bool conj, unsigned rot) {

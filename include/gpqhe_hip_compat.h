@@ -132,6 +132,10 @@ void he_sub(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2);               
 void he_addpt(he_ct_t *dest, const he_ct_t *src, const he_pt_t *pt);                    /* src/gpqhe.h:142  */
 void he_subpt(he_ct_t *dest, const he_ct_t *src, const he_pt_t *pt);                    /* src/gpqhe.h:143  */
 void he_neg(he_ct_t *ct);                                                               /* src/gpqhe.h:144  */
+/* src/he-mem.c:88-97: 2n mpi_set on the host in the reference; here the copy's device slab is a copy of the source's, so the calls that
+ * follow on the copy (he_gemv: he_copy_ct, he_rot, he_mulpt, he_add per diagonal, src/he-algo.c:66-78) start on the device.  Optional
+ * (guard the one function in he-mem.c). */
+void he_copy_ct(struct he_ct *dest, const struct he_ct *src);
 void he_conj(he_ct_t *ct, const he_evk_t *ck);                                          /* src/gpqhe.h:151  */
 void he_rot(he_ct_t *ct, const int rot, const he_evk_t *rk);                            /* src/gpqhe.h:152  */
 /* Key generation, src/he-kem.c:120-170 (decl src/gpqhe.h:131-133).  The randomness comes from the host program's own

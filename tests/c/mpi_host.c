@@ -274,6 +274,13 @@ static int hemul(const char *path)
   printf("he_neg %u\n", sum.l);
   for (unsigned i = 0; i < polyctx.n; i++) print_mpi(sum.c0.coeffs[i]);
   for (unsigned i = 0; i < polyctx.n; i++) print_mpi(sum.c1.coeffs[i]);
+  he_ct_t cp;
+  poly_alloc(&cp.c0); poly_alloc(&cp.c1);
+  sum.nu = 6.5; sum.B = 7.25;
+  he_copy_ct(&cp, &sum);                                     /* src/he-mem.c:88-97 */
+  int same = cp.l == sum.l && cp.nu == 6.5 && cp.B == 7.25;
+  for (unsigned i = 0; i < polyctx.n; i++) if (gcry_mpi_cmp(cp.c0.coeffs[i], sum.c0.coeffs[i]) || gcry_mpi_cmp(cp.c1.coeffs[i], sum.c1.coeffs[i])) same = 0;
+  printf("he_copy_ct %s\n", same ? "identical" : "DIFFERS");
   uint64_t confirmed = 0, changed = 0;
   gpq_mpi_shim_poly_stats(&confirmed, &changed);             /* operands the chain took from the device copies of earlier results */
   printf("resident %llu %llu\n", (unsigned long long)confirmed, (unsigned long long)changed);
@@ -612,6 +619,17 @@ static int hemultime(unsigned logn, unsigned logq)
         }
       printf("  (libgcrypt on the host, the reference's way: one he_add %.1f ms)\n", now_ms() - t0);
     }
+    {
+      double tcp[CALLS];
+      he_ct_t cp;
+      poly_alloc(&cp.c0); poly_alloc(&cp.c1);
+      he_copy_ct(&cp, &acc);
+      for (int i = 0; i < CALLS; i++) { he_neg(&acc); const double t0 = now_ms(); he_copy_ct(&cp, &acc); tcp[i] = now_ms() - t0; }
+      qsort(tcp, CALLS, sizeof *tcp, cmp_double);
+      const double t0 = now_ms();
+      for (unsigned i = 0; i < polyctx.n; i++) { gcry_mpi_set(cp.c0.coeffs[i], acc.c0.coeffs[i]); gcry_mpi_set(cp.c1.coeffs[i], acc.c1.coeffs[i]); }
+      printf("  he_copy_ct of a chained ciphertext p50 %.2f p95 %.2f ms (2n mpi_set on the host, the reference's way: %.1f ms)\n", tcp[CALLS / 2], tcp[CALLS * 95 / 100], now_ms() - t0);
+    }
     printf("  additive calls in a chain (src/he-add.c): he_add p50 %.2f p95 %.2f ms; he_addpt p50 %.2f p95 %.2f ms; he_neg p50 %.2f p95 %.2f ms\n",
            tadd[CALLS / 2], tadd[CALLS * 95 / 100], tapt[CALLS / 2], tapt[CALLS * 95 / 100], tneg[CALLS / 2], tneg[CALLS * 95 / 100]);
   }
@@ -725,7 +743,11 @@ static int residentfuzz(unsigned logn, unsigned logq, unsigned logDelta, unsigne
       if (how == 1) { gcry_mpi_neg(px->coeffs[k], px->coeffs[k]); gcry_mpi_neg(py->coeffs[k], py->coeffs[k]); }
       if (how == 2) { gcry_mpi_set_ui(px->coeffs[k], 5); gcry_mpi_set_ui(py->coeffs[k], 5); }
       if (how == 3) { MPI t = gcry_mpi_copy(px->coeffs[k]); gcry_mpi_release(px->coeffs[k]); px->coeffs[k] = t; }
-    } else if (op == 9) {                                     /* x[d] = x[a] */
+    } else if (op == 9 && (splitmix64(&st) & 1)) {            /* x[d] = x[a] through he_copy_ct (src/he-mem.c:88-97) */
+      if (a == d) continue;
+      TWIN(he_copy_ct(&x[d], &x[a]), he_copy_ct(&y[d], &y[a]));
+      touched = (int)d;
+    } else if (op == 9) {                                     /* x[d] = x[a] on the host, behind the library's back */
       if (a == d) continue;
       for (unsigned k = 0; k < n; k++) {
         gcry_mpi_set(x[d].c0.coeffs[k], x[a].c0.coeffs[k]); gcry_mpi_set(x[d].c1.coeffs[k], x[a].c1.coeffs[k]);

@@ -211,6 +211,9 @@ def test_he_chain_with_real_mpis(mpi_host, oracle_ctx, tmp_path, logn, qL, Delta
     assert lines[base].split() == ["he_neg", str(level - 2)]
     n0, n1 = ref.he_neg((s0_, s1_), ql)
     assert _ints(lines[base + 1:base + 1 + n]) == n0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == n1
+    base += 1 + 2 * n
+    assert lines[base].split() == ["he_copy_ct", "identical"]                                # src/he-mem.c:88-97: l, nu, B and every integer
+    base -= 2 * n                                                                             # (one line, no integers: undo the stride below)
     # he_rescale, he_moddown, the squaring (its key is the resident rlk, a prefix of it at this level) and he_mulpt took their ciphertext
     # (2 polynomials each) from the device copies the call before left; he_rot / he_conj meet their keys for the first time and upload
     # everything -- at n >= 4096; smaller rings always convert and upload
@@ -218,7 +221,7 @@ def test_he_chain_with_real_mpis(mpi_host, oracle_ctx, tmp_path, logn, qL, Delta
     tag, confirmed, changed = lines[base].split()
     # ... and so did the five additive calls where q_l is a power of two (4 + 4 + 3 + 3 + 2 polynomials; the plaintext is resident since he_mulpt)
     assert tag == "resident" and int(changed) == 0
-    assert int(confirmed) == (0 if logn < 12 else 8 + 16 if qL & (qL - 1) == 0 else 8)
+    assert int(confirmed) == (0 if logn < 12 else 8 + 16 + 2 if qL & (qL - 1) == 0 else 8 + 2)       # + he_copy_ct's two polynomials (any modulus)
 
 
 def _splitmix(state):
