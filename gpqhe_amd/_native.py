@@ -137,7 +137,7 @@ SIGNATURES = {
 # exercised from C (tests/c/dropin_host.c)
 EXPORTED_ONLY = ["montgomery_reduce", "barrett_reduce",
                  # MPI-typed surface: driven from C with real libgcrypt MPIs (tests/c/mpi_host.c)
-                 "rns_decompose", "rns_reconstruct", "poly_rns2mpi", "poly_mul", "he_mul", "he_rs", "he_rescale", "he_moddown", "he_mulpt", "he_add", "he_sub", "he_addpt", "he_subpt", "he_neg", "he_copy_ct", "he_conj", "he_rot", "he_genrlk", "he_genck", "he_genrk",
+                 "rns_decompose", "rns_reconstruct", "poly_rns2mpi", "poly_mul", "he_mul", "he_rs", "he_rescale", "he_moddown", "he_mulpt", "he_add", "he_sub", "he_addpt", "he_subpt", "he_neg", "he_copy_ct", "he_dec", "he_conj", "he_rot", "he_genrlk", "he_genck", "he_genrk",
                  ]
 # libgpqhe_hip_ctx.so (ctx_compat.hip): context construction / storage names for hosts that are not GPQHE; driven from C
 CTX_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgpqhe_hip_ctx.so")

@@ -585,6 +585,74 @@ void poly_mul(poly_mpi_t *r, const poly_mpi_t *a, const poly_mpi_t *b, const uns
   }
 }
 
+// src/he-encrypt.c:105-125: m = c1 * sk + c0, centred mod q_l.  The reference multiplies through poly_mul and then adds and centres with
+// 2n libgcrypt calls on the host; here the product never leaves the device before the sum is centred, and a chained ciphertext (and the
+// secret key after its first use) is resident.
+void he_dec(struct he_pt *pt, const struct he_ct *ct, const poly_mpi_t *sk) {
+  SHIM_CALL();
+  need_gcrypt();
+  if (&hectx == nullptr || !hectx.q) die("`hectx` is not initialised (hectx_init first)");
+  gpq_ctx *c = engine();
+  const unsigned n = polyctx.n, l = ct->l;
+  const std::vector<uint64_t> qw = words_of(hectx.q[l], "he_dec: q_l must be positive");
+  const bool pow2 = is_pow2(qw);
+  const unsigned nbq = G.mpi_get_nbits(hectx.q[l]), logql = nbq - 1, dim = nbq / 59 + 1;        // :113
+  const poly_mpi_t *in[3] = {&ct->c1, sk, &ct->c0};
+  poly_mpi_t *out[1] = {&pt->m};
+  pt->nu = ct->nu;                                                                               // :108
+  if (logql == 0) {                                         // q_l = 1: mpi_smod leaves -1 everywhere (see he_rs)
+    for (unsigned i = 0; i < n; ++i) { G.mpi_set_ui(pt->m.coeffs[i], 1); G.mpi_neg(pt->m.coeffs[i], pt->m.coeffs[i]); }
+    return;
+  }
+  const unsigned Wout = logql / 64 + 1;
+  auto pass = [&](unsigned W, bool kept) -> bool {
+    if (W > 32) die("he_dec: coefficients wider than 2047 bits");
+    const size_t big = (size_t)W * n;
+    HostBuf s0(big * 8), s1(big * 8), s2(big * 8), t0s(big * 8);
+    DevBuf d0(big * 8), d1(big * 8), d2(big * 8), dr(big * 8), dz(big * 8), ws(gpq_poly_mul_general_workspace_bytes(c, dim, 1)), scratch(192 * 8);
+    const DevBuf *dd[3] = {&d0, &d1, &d2}, *oo[1] = {&dr};
+    const HostBuf *ss[3] = {&s0, &s1, &s2}, *ts[1] = {&t0s};
+    Operands ops(3, in, dd, ss, n, W);
+    ops.prepare(kept);
+    const unsigned Wdown = Wout < W ? Wout : W;
+    auto device_work = [&]() {
+      int rc = pow2 ? gpq_poly_mul(c, dr.u64(), ops.x[0], ops.x[1], W, dim, logql, 1, ws.p, nullptr)                                   // :115
+                    : gpq_poly_mul_general(c, dr.u64(), ops.x[0], ops.x[1], W, dim, qw.data(), (unsigned)qw.size(), 1, ws.p, nullptr);
+      if (rc == GPQ_OK) rc = gpq_big_addsub(c, dr.u64(), dr.u64(), ops.x[2], W, 1, 0, nullptr);                                       // :117
+      if (rc == GPQ_OK && hipMemsetAsync(dz.p, 0, big * 8, nullptr) != hipSuccess) die("device memset failed");                       // the centring kernels take a pair
+      if (rc == GPQ_OK)                                                                                                                // :118
+        rc = pow2 ? gpq_he_rs(c, dr.u64(), dz.u64(), W, 0, logql, 1, nullptr)
+                  : gpq_he_rs_general(c, dr.u64(), dz.u64(), W, 1ull, qw.data(), (unsigned)qw.size(), 1, scratch.p, nullptr);
+      if (rc != GPQ_OK) die("he_dec failed");
+      download_issue(ts, oo, 1, n, Wdown);
+    };
+    device_work();
+    if (ops.resident && ops.recheck()) {
+      if (ops.misfits) return false;
+      device_work();
+    }
+    std::vector<uint64_t> oprints((size_t)ops.nt, 0);
+    download_convert(out, ts, 1, n, Wdown, oprints.data());
+    remember_results(out, oo, 1, n, Wdown, oprints);
+    return true;
+  };
+  bool done = false;
+  if (pow2 && poly_cache_on(n)) {
+    unsigned W = 0;
+    bool all = true;
+    for (int i = 0; i < 3 && all; ++i) {
+      const PolySlot *k = resident_poly(in[i], n, 0);
+      if (!k || !k->trusted || (W && k->W != W)) all = false; else W = k->W;
+    }
+    if (all && W >= Wout) done = pass(W, true);
+  }
+  if (!done) {
+    unsigned bits = nbq;
+    for (int i = 0; i < 3; ++i) { const unsigned bi = max_bits(in[i], n); if (bi > bits) bits = bi; }
+    pass((bits + 1) / 64 + 1, false);
+  }
+}
+
 // src/he-mult.c:88-156
 void he_mul(he_ct_t *ct, const he_ct_t *ct1, const he_ct_t *ct2, const he_evk_t *rlk) {
   SHIM_CALL();

@@ -136,6 +136,9 @@ void he_neg(he_ct_t *ct);                                                       
  * follow on the copy (he_gemv: he_copy_ct, he_rot, he_mulpt, he_add per diagonal, src/he-algo.c:66-78) start on the device.  Optional
  * (guard the one function in he-mem.c). */
 void he_copy_ct(struct he_ct *dest, const struct he_ct *src);
+/* src/he-encrypt.c:105-125 (decl src/gpqhe.h:130): m = c1 * sk + c0 centred mod q_l -- the caller of poly_mul at the end of every
+ * computation; the sum and its centring stay on the device (2n libgcrypt calls on the host in the reference).  Optional. */
+void he_dec(struct he_pt *pt, const struct he_ct *ct, const poly_mpi_t *sk);
 void he_conj(he_ct_t *ct, const he_evk_t *ck);                                          /* src/gpqhe.h:151  */
 void he_rot(he_ct_t *ct, const int rot, const he_evk_t *rk);                            /* src/gpqhe.h:152  */
 /* Key generation, src/he-kem.c:120-170 (decl src/gpqhe.h:131-133).  The randomness comes from the host program's own

@@ -203,3 +203,19 @@ def he_subpt(ct, m, ql):
 def he_neg(ct, ql):
     return tuple([mpi_smod(-x, ql) for x in c] for c in ct)                                               # :132-135
 
+
+def he_dec_sparse(ct, sk_terms, ql):
+    """src/he-encrypt.c:105-125 for a secret key given by its non-zero terms {index: value}: m = c1 * sk + c0, every coefficient
+    mpi_smod'ed by q_l (:117-118).  The product is the negacyclic one of poly_mul (src/poly.c:84-107), written out term by term."""
+    c0, c1 = ct
+    n = len(c0)
+    prod = [0] * n
+    for j, v in sk_terms.items():
+        for i in range(n):
+            k = i + j
+            if k < n:
+                prod[k] += c1[i] * v
+            else:
+                prod[k - n] -= c1[i] * v
+    return [mpi_smod((mpi_smod(p % ql, ql) + c) % ql, ql) for p, c in zip(prod, c0)]
+

@@ -281,6 +281,17 @@ static int hemul(const char *path)
   int same = cp.l == sum.l && cp.nu == 6.5 && cp.B == 7.25;
   for (unsigned i = 0; i < polyctx.n; i++) if (gcry_mpi_cmp(cp.c0.coeffs[i], sum.c0.coeffs[i]) || gcry_mpi_cmp(cp.c1.coeffs[i], sum.c1.coeffs[i])) same = 0;
   printf("he_copy_ct %s\n", same ? "identical" : "DIFFERS");
+  poly_mpi_t sk;                                             /* a sparse secret key: 1 - x^5 + x^(n-1) */
+  poly_alloc(&sk);
+  gcry_mpi_set_ui(sk.coeffs[0], 1); gcry_mpi_set_ui(sk.coeffs[5], 1); gcry_mpi_neg(sk.coeffs[5], sk.coeffs[5]); gcry_mpi_set_ui(sk.coeffs[polyctx.n - 1], 1);
+  he_pt_t dec;
+  poly_alloc(&dec.m);
+  he_dec(&dec, &cp, &sk);                                    /* src/he-encrypt.c:105-125 */
+  printf("he_dec %.17g\n", dec.nu);
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(dec.m.coeffs[i]);
+  he_dec(&dec, &cp, &sk);                                    /* again: the ciphertext and the key are resident now */
+  printf("he_dec again\n");
+  for (unsigned i = 0; i < polyctx.n; i++) print_mpi(dec.m.coeffs[i]);
   uint64_t confirmed = 0, changed = 0;
   gpq_mpi_shim_poly_stats(&confirmed, &changed);             /* operands the chain took from the device copies of earlier results */
   printf("resident %llu %llu\n", (unsigned long long)confirmed, (unsigned long long)changed);

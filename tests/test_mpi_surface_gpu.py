@@ -213,7 +213,15 @@ def test_he_chain_with_real_mpis(mpi_host, oracle_ctx, tmp_path, logn, qL, Delta
     assert _ints(lines[base + 1:base + 1 + n]) == n0 and _ints(lines[base + 1 + n:base + 1 + 2 * n]) == n1
     base += 1 + 2 * n
     assert lines[base].split() == ["he_copy_ct", "identical"]                                # src/he-mem.c:88-97: l, nu, B and every integer
-    base -= 2 * n                                                                             # (one line, no integers: undo the stride below)
+    # he_dec (src/he-encrypt.c:105-125) of the copy with the sparse key 1 - x^5 + x^(n-1), twice (the second time everything is resident)
+    want = ref.he_dec_sparse((n0, n1), {0: 1, 5: -1, n - 1: 1}, ql)
+    base += 1
+    assert lines[base].split() == ["he_dec", "6.5"]
+    assert _ints(lines[base + 1:base + 1 + n]) == want
+    base += 1 + n
+    assert lines[base].split() == ["he_dec", "again"]
+    assert _ints(lines[base + 1:base + 1 + n]) == want
+    base -= n                                                                                 # (n integers behind the last header: the stride below adds 1 + 2 n)
     # he_rescale, he_moddown, the squaring (its key is the resident rlk, a prefix of it at this level) and he_mulpt took their ciphertext
     # (2 polynomials each) from the device copies the call before left; he_rot / he_conj meet their keys for the first time and upload
     # everything -- at n >= 4096; smaller rings always convert and upload
@@ -221,7 +229,8 @@ def test_he_chain_with_real_mpis(mpi_host, oracle_ctx, tmp_path, logn, qL, Delta
     tag, confirmed, changed = lines[base].split()
     # ... and so did the five additive calls where q_l is a power of two (4 + 4 + 3 + 3 + 2 polynomials; the plaintext is resident since he_mulpt)
     assert tag == "resident" and int(changed) == 0
-    assert int(confirmed) == (0 if logn < 12 else 8 + 16 + 2 if qL & (qL - 1) == 0 else 8 + 2)       # + he_copy_ct's two polynomials (any modulus)
+    # + he_copy_ct's two polynomials (any modulus) + he_dec's three the second time (the first time the key is new and the call measures and uploads)
+    assert int(confirmed) == (0 if logn < 12 else 8 + 16 + 2 + 3 if qL & (qL - 1) == 0 else 8 + 2)
 
 
 def _splitmix(state):
