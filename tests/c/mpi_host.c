@@ -717,10 +717,15 @@ static int residentfuzz(unsigned logn, unsigned logq, unsigned logDelta, unsigne
   poly_alloc(&pt.m);
   pt.nu = 1024.0;
   for (unsigned i = 0; i < n; i++) { gcry_mpi_set_ui(pt.m.coeffs[i], (unsigned long)(splitmix64(&st) >> 40)); if (i & 1) gcry_mpi_neg(pt.m.coeffs[i], pt.m.coeffs[i]); }
-  unsigned count[16] = {0};
+  unsigned count[17] = {0};
+  poly_mpi_t sk;                                              /* a dense ternary secret key */
+  poly_alloc(&sk);
+  for (unsigned i = 0; i < n; i++) { const unsigned t = (unsigned)(splitmix64(&st) % 3); gcry_mpi_set_ui(sk.coeffs[i], t ? 1 : 0); if (t == 2) gcry_mpi_neg(sk.coeffs[i], sk.coeffs[i]); }
+  he_pt_t dx, dy;
+  poly_alloc(&dx.m); poly_alloc(&dy.m);
 #define TWIN(call_x, call_y) do { call_x; gpq_mpi_shim_poly_bypass(1); call_y; gpq_mpi_shim_poly_bypass(0); } while (0)
   for (unsigned step = 0; step < steps; step++) {
-    const unsigned op = (unsigned)(splitmix64(&st) % 16), a = (unsigned)(splitmix64(&st) % K), b = (unsigned)(splitmix64(&st) % K), d = (unsigned)(splitmix64(&st) % K);
+    const unsigned op = (unsigned)(splitmix64(&st) % 17), a = (unsigned)(splitmix64(&st) % K), b = (unsigned)(splitmix64(&st) % K), d = (unsigned)(splitmix64(&st) % K);
     int touched = -1;
     if (op <= 2) {                                            /* he_mul: dst may be a, b, both or neither */
       if (x[a].l != x[b].l || x[a].l == 0) continue;
@@ -783,6 +788,11 @@ static int residentfuzz(unsigned logn, unsigned logq, unsigned logDelta, unsigne
       if (x[a].l == 0) continue;
       TWIN(he_neg(&x[a]), he_neg(&y[a]));
       touched = (int)a;
+    } else if (op == 16) {                                    /* he_dec (src/he-encrypt.c:105-125) */
+      if (x[a].l == 0) continue;
+      TWIN(he_dec(&dx, &x[a], &sk), he_dec(&dy, &y[a], &sk));
+      for (unsigned k = 0; k < n; k++)
+        if (gcry_mpi_cmp(dx.m.coeffs[k], dy.m.coeffs[k])) { printf("step %u he_dec (a %u, level %u): coefficient %u differs from the twin computed from fresh uploads\n", step, a, x[a].l, k); return 1; }
     } else if (op == 10) {
       gpq_mpi_shim_set_poly_slots(2 + (unsigned)(splitmix64(&st) % 7));
     } else {                                                  /* a key rewritten in place, in one word or in all */
@@ -804,8 +814,8 @@ static int residentfuzz(unsigned logn, unsigned logq, unsigned logDelta, unsigne
   }
   uint64_t confirmed = 0, changed = 0;
   gpq_mpi_shim_poly_stats(&confirmed, &changed);
-  printf("residentfuzz ok: %u steps (mul %u rs %u moddown %u rot %u conj %u mulpt %u edit %u copy %u slots %u key %u poly_mul %u add/sub %u addpt/subpt %u neg %u), %llu operands confirmed, %llu found changed\n", steps,
-         count[0] + count[1] + count[2], count[3], count[4], count[5], count[6], count[7], count[8], count[9], count[10], count[11], count[12], count[13], count[14], count[15],
+  printf("residentfuzz ok: %u steps (mul %u rs %u moddown %u rot %u conj %u mulpt %u edit %u copy %u slots %u key %u poly_mul %u add/sub %u addpt/subpt %u neg %u dec %u), %llu operands confirmed, %llu found changed\n", steps,
+         count[0] + count[1] + count[2], count[3], count[4], count[5], count[6], count[7], count[8], count[9], count[10], count[11], count[12], count[13], count[14], count[15], count[16],
          (unsigned long long)confirmed, (unsigned long long)changed);
   return 0;
 }
