@@ -644,6 +644,42 @@ static int hemultime(unsigned logn, unsigned logq)
     printf("  additive calls in a chain (src/he-add.c): he_add p50 %.2f p95 %.2f ms; he_addpt p50 %.2f p95 %.2f ms; he_neg p50 %.2f p95 %.2f ms\n",
            tadd[CALLS / 2], tadd[CALLS * 95 / 100], tapt[CALLS / 2], tapt[CALLS * 95 / 100], tneg[CALLS / 2], tneg[CALLS * 95 / 100]);
   }
+  {
+    /* he_inv's own call sequence (src/he-algo.c:130-165) with 8 iterations: every call it makes is one of this library's symbols, so the
+     * reference's he_inv, unchanged, runs like this -- on ciphertexts that never leave the device between calls */
+    he_pt_t one, two;
+    poly_alloc(&one.m); poly_alloc(&two.m);
+    one.nu = two.nu = 1.0;
+    gcry_mpi_set_ui(one.m.coeffs[0], 1); gcry_mpi_lshift(one.m.coeffs[0], one.m.coeffs[0], 50);
+    gcry_mpi_set_ui(two.m.coeffs[0], 2); gcry_mpi_lshift(two.m.coeffs[0], two.m.coeffs[0], 50);
+    he_ct_t tmp, an, bn, inv;
+    poly_mpi_t *ps2[8] = {&tmp.c0, &tmp.c1, &an.c0, &an.c1, &bn.c0, &bn.c1, &inv.c0, &inv.c1};
+    for (int i = 0; i < 8; i++) poly_alloc(ps2[i]);
+    for (int mem = 1; mem >= 0; mem--) {
+      gpq_mpi_shim_set_poly_slots(mem ? 32 : 0);
+      double total = 0;
+      for (int pass = 0; pass < 2; pass++) {                  /* the second pass is timed (the first builds the per-level tables) */
+        ct1.l = hectx.L;
+        const double t0 = now_ms();
+        he_copy_ct(&tmp, &ct1);
+        he_neg(&tmp);
+        he_addpt(&an, &tmp, &two);
+        he_moddown(&an);
+        he_addpt(&bn, &tmp, &one);
+        for (int it = 0; it < 8; it++) {
+          he_mul(&bn, &bn, &bn, &rlk);
+          he_rs(&bn);
+          he_addpt(&tmp, &bn, &one);
+          he_mul(&an, &an, &tmp, &rlk);
+          he_rs(&an);
+        }
+        he_copy_ct(&inv, &an);
+        total = now_ms() - t0;
+      }
+      printf("  he_inv's call sequence, 8 iterations (45 calls, level %u -> %u), %s: %.1f ms\n", hectx.L, inv.l, mem ? "operands resident" : "every call uploads", total);
+    }
+    gpq_mpi_shim_set_poly_slots(32);
+  }
   /* (c) the whole ladder, as he_inv / he_exp walk it (src/he-algo.c:140-160): square and rescale from level L down to level 1 on one
    * ciphertext; the second descent is timed (the first builds the per-level device tables), once with and once without the memory */
   for (int mem = 1; mem >= 0; mem--) {
