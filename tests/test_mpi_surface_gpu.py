@@ -393,6 +393,9 @@ def test_reference_signature_he_mul_at_the_headline_shape_keeps_its_key_on_the_d
     # the square + rescale ladder down to level 0, where q_0 = 2^(850 - 17 * 50) = 1 and the reference's mpi_smod leaves -1 everywhere
     assert len(re.findall(r"ladder of 17 x .* ([0-9.]+) ms", res.stdout)) == 2, res.stdout
     assert res.stdout.count("level 0 has q_0 = 1: every coefficient is -1") == 2, res.stdout
+    # the additive calls, he_copy_ct and he_inv's whole call sequence (src/he-algo.c:130-165) on resident ciphertexts
+    assert re.search(r"additive calls in a chain .*he_add p50 ([0-9.]+)", res.stdout) and re.search(r"he_copy_ct of a chained ciphertext p50", res.stdout), res.stdout
+    assert len(re.findall(r"he_inv's call sequence, 8 iterations \(45 calls, level 17 -> 8\)", res.stdout)) == 2, res.stdout
 
 
 @pytest.mark.timeout(900)
