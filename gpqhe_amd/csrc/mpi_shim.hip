@@ -215,10 +215,6 @@ void download_convert(poly_mpi_t *const dst[], const HostBuf *const stage[], int
   };
   if (ranges < 2) job(0); else workers().run(ranges, job);
 }
-void download_polys(poly_mpi_t *const dst[], const HostBuf *const stage[], const DevBuf *const src[], int count, unsigned n, unsigned W) {
-  download_issue(stage, src, count, n, W);
-  download_convert(dst, stage, count, n, W);
-}
 
 // Where the wall time of the last he_mul call went (gpq_mpi_shim_last_timing): conversions + uploads, kernels (HIP events),
 // downloads + conversions, whole call.
