@@ -167,6 +167,24 @@ def power_state(torch, step, seconds=2.5):
         return None
 
 
+def copy_rate(torch, mib=2048, iters=10):
+    """Bytes read + written per second by a plain device-to-device copy: what a streaming kernel can reach on THIS device (0.6 of the
+    nominal 8 TB/s on the pool's MI355X) -- the yardstick beside `roofline.peak` for the kernels that are HBM-bound."""
+    a = torch.empty(mib * 1024 * 1024 // 8, dtype=torch.int64, device="cuda")
+    a.random_()
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return {"GBps": round(2 * a.numel() * 8 / ms / 1e6, 1), "how": "torch Tensor.copy_ of %d MiB, device to device, read + written bytes" % mib}
+
+
 def ntt_rate(torch, gpqhe_amd, logn, dim, batch, iters=20):
     """Second half of BASELINE's metric: NTT GB/s = 16*n bytes per limb per direction
     (read + write once) over a forward+inverse pair, HIP-event timed."""
@@ -584,6 +602,10 @@ def main(argv=None):
                 vi = valu_issue(value / world, pw["sclk_MHz"])
                 if vi is not None:
                     out["valu_issue"] = vi
+            cr = copy_rate(torch)
+            out["copy_rate"] = cr
+            for rec in out["kernels"].values():               # every kernel's algorithmic rate against that of a plain copy
+                rec["of_copy_rate"] = round(rec["algo_GBps"] / cr["GBps"], 3)
             # NTT GB/s at the headline ring (n=2^16, 30 limbs) and at BASELINE configs[1] (n=2^15, 10 limbs)
             out["ntt"] = [ntt_rate(torch, gpqhe_amd, 16, DIM_A, B), ntt_rate(torch, gpqhe_amd, 15, 10, 64)]
             del a0, a1, b0, b1, x, d0, d1, d2, c0, c1, wsA, wsB
