@@ -187,12 +187,11 @@ void download_issue(const HostBuf *const stage[], const DevBuf *const src[], int
   DevBuf takeoff(rows ? big * count : 8);                   // stream-ordered: safe to hand back to the pool when this returns
   const unsigned nt = convert_threads(n), per = (n + nt - 1) / nt;
   const unsigned ranges = (n + per - 1) / per, groups = (ranges + kRangesPerCopy - 1) / kRangesPerCopy;
-  for (int i = 0; i < count; ++i) {
-    const char *from = (const char *)src[i]->p;
-    if (rows) {
+  if (rows)                                                 // all the transposes first: the DMA of the first polynomial then runs without a kernel queued between its copies and the next's
+    for (int i = 0; i < count; ++i)
       if (gpq_big_transpose(engine(), (uint64_t *)((char *)takeoff.p + big * i), src[i]->u64(), W, 1, 1, nullptr) != GPQ_OK) die("slab transpose failed");
-      from = (const char *)takeoff.p + big * i;
-    }
+  for (int i = 0; i < count; ++i) {
+    const char *from = rows ? (const char *)takeoff.p + big * i : (const char *)src[i]->p;
     for (unsigned g = 0; g < groups; ++g) {
       const unsigned lo = g * kRangesPerCopy * per, hi = (g + 1) * kRangesPerCopy * per < n ? (g + 1) * kRangesPerCopy * per : n;
       copy_range(stage[i]->p, from, n, W, lo, hi, hipMemcpyDeviceToHost);
