@@ -35,6 +35,13 @@ extern "C" void sample_uniform(poly_mpi_t *r, const gpq_MPI q) __attribute__((we
 
 #include "mpi_convert.hpp"
 
+// Every copy, kernel and event of the MPI-typed calls goes to the legacy null stream (stream argument nullptr), from the calling thread and
+// from the conversion threads alike: that ONE stream is what orders a range's upload before the transposes and kernels that read it, and a
+// pooled buffer's reuse behind its last reader.  With per-thread default streams nullptr would mean a different stream in every thread.
+#if defined(HIP_API_PER_THREAD_DEFAULT_STREAM)
+#error "mpi_shim.hip relies on the legacy (process-wide) null stream: build without -fgpu-default-stream=per-thread"
+#endif
+
 namespace {
 
 int g_dev = 0;             // device of the engine context: HIP's current device is per thread, the workers set it for their copies
