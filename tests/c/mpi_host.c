@@ -645,6 +645,36 @@ static int hemultime(unsigned logn, unsigned logq)
            tadd[CALLS / 2], tadd[CALLS * 95 / 100], tapt[CALLS / 2], tapt[CALLS * 95 / 100], tneg[CALLS / 2], tneg[CALLS * 95 / 100]);
   }
   {
+    /* he_gemv's per-diagonal calls (src/he-algo.c:66-78) on a chained ciphertext: he_copy_ct, he_rot, he_mulpt (a new plaintext every time:
+     * he_ecd runs on the host), he_add */
+    he_evk_t rk[3];
+    for (int i = 1; i < 3; i++) {
+      rk[i].p0.coeffs = malloc((size_t)hectx.dimevk * polyctx.n * 8); rk[i].p1.coeffs = malloc((size_t)hectx.dimevk * polyctx.n * 8);
+      struct rns_ctx *rr = polyctx.rns;
+      for (unsigned d = 0; d < hectx.dimevk; d++, rr = rr->next)
+        for (unsigned k = 0; k < polyctx.n; k++) { rk[i].p0.coeffs[(size_t)d * polyctx.n + k] = splitmix64(&st) % rr->p; rk[i].p1.coeffs[(size_t)d * polyctx.n + k] = splitmix64(&st) % rr->p; }
+    }
+    rk[0].p0.coeffs = rk[0].p1.coeffs = NULL;
+    he_pt_t diag;
+    poly_alloc(&diag.m);
+    diag.nu = 1024.0;
+    he_ct_t rot, sum;
+    poly_alloc(&rot.c0); poly_alloc(&rot.c1); poly_alloc(&sum.c0); poly_alloc(&sum.c1);
+    double trot[CALLS], tmpt[CALLS];
+    ct1.l = hectx.L;
+    he_copy_ct(&sum, &ct1);
+    for (int i = -2; i < CALLS; i++) {
+      for (unsigned k = 0; k < polyctx.n; k += 64) gcry_mpi_set_ui(diag.m.coeffs[k], (unsigned long)(splitmix64(&st) >> 24));   /* "he_ecd": a plaintext the library has not seen */
+      he_copy_ct(&rot, &ct1);
+      double t0 = now_ms(); he_rot(&rot, 1 + (i & 1), rk); if (i >= 0) trot[i] = now_ms() - t0;
+      t0 = now_ms(); he_mulpt(&rot, &rot, &diag); if (i >= 0) tmpt[i] = now_ms() - t0;
+      he_add(&sum, &sum, &rot);
+    }
+    qsort(trot, CALLS, sizeof *trot, cmp_double); qsort(tmpt, CALLS, sizeof *tmpt, cmp_double);
+    printf("  he_gemv's per-diagonal calls in a chain: he_rot p50 %.2f p95 %.2f ms; he_mulpt with a new plaintext p50 %.2f p95 %.2f ms\n",
+           trot[CALLS / 2], trot[CALLS * 95 / 100], tmpt[CALLS / 2], tmpt[CALLS * 95 / 100]);
+  }
+  {
     /* he_inv's own call sequence (src/he-algo.c:130-165) with 8 iterations: every call it makes is one of this library's symbols, so the
      * reference's he_inv, unchanged, runs like this -- on ciphertexts that never leave the device between calls */
     he_pt_t one, two;
