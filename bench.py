@@ -309,6 +309,50 @@ def keyswitch_n17_rate(torch, gpqhe_amd, batch=64, iters=3):
             "algo_GBps": round(algo / (ms * 1e-3) / 1e9, 1)}
 
 
+def reference_signature_latency(timeout_s=150):
+    """Batch-1 wall times through GPQHE's own signatures with real libgcrypt integers (the reference's only calling pattern): builds
+    tests/c/mpi_host.c against the in-tree library and parses its `hemultime 16 850` report.  A child process (this one holds the GPU
+    already; nothing is exec'ed over it).  None when gcc / libgcrypt's runtime are not there."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(root, "gpqhe_amd")
+    if shutil.which("gcc") is None or not os.path.exists(os.path.join(lib, "libgpqhe_hip_ctx.so")):
+        return None
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "mpi_host")
+        cc = ["gcc", "-O1", "-std=gnu11", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "mpi_host.c"), "-L", lib,
+              "-lgpqhe_hip", "-lgpqhe_hip_ctx", "-l:libgcrypt.so.20", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+        try:
+            if subprocess.run(cc, capture_output=True, text=True, timeout=120).returncode != 0:
+                return None
+            r = subprocess.run([exe, "hemultime", "16", "850"], capture_output=True, text=True, timeout=timeout_s)
+        except (OSError, subprocess.TimeoutExpired):
+            return None
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+    t = r.stdout
+    out = {"shape": "n=2^16, q=2^850, Delta=2^50 (17 levels), one ciphertext per call, libgcrypt integers in and out", "unit": "ms per call, p50 of 50",
+           "note": "host-bound (16 conversion threads over scattered libgcrypt integers, PCIe): these move by +-30 % with the CPU load of the box; profiles/r03/v13_hemultime_resident.txt",
+           "parity_lines": [ln.strip() for ln in t.splitlines() if ln.startswith(("key cache:", "resident polynomials:", "direct mpi access:"))]}
+
+    def grab(key, pattern, cast=float):
+        m = re.search(pattern, t)
+        if m:
+            out[key] = cast(m.group(1)) if m.lastindex == 1 else [cast(g) for g in m.groups()]
+    grab("new_operands[he_mul,squaring,he_rescale]", r"50 calls each: he_mul p50 ([0-9.]+) .*?squaring p50 ([0-9.]+) .*?he_rescale p50 ([0-9.]+)")
+    grab("chained[he_mul,he_mul(ct,ct,ct),he_rescale]", r"chained .*?he_mul p50 ([0-9.]+) .*?he_mul\(&ct, &ct, &ct\) p50 ([0-9.]+) .*?he_rescale of a product p50 ([0-9.]+)")
+    grab("chained[he_add,he_addpt,he_neg]", r"additive calls in a chain .*?he_add p50 ([0-9.]+) .*?he_addpt p50 ([0-9.]+) .*?he_neg p50 ([0-9.]+)")
+    grab("chained[he_rot,he_mulpt_new_plaintext]", r"per-diagonal calls in a chain: he_rot p50 ([0-9.]+) .*?new plaintext p50 ([0-9.]+)")
+    grab("chained_he_copy_ct", r"he_copy_ct of a chained ciphertext p50 ([0-9.]+)")
+    grab("he_inv_sequence_45_calls_ms[resident,every_call_uploads]", r"he_inv's call sequence.*?operands resident: ([0-9.]+) ms\n.*?every call uploads: ([0-9.]+) ms")
+    grab("ladder_17x(he_mul+he_rescale)_ms[resident,every_call_uploads]", r"ladder of 17 x .*?operands resident: ([0-9.]+) ms\n(?:.*\n)?.*?every call uploads: ([0-9.]+) ms")
+    grab("libgcrypt_host_he_add_ms", r"one he_add ([0-9.]+) ms")
+    return out
+
+
 def squaring_rate(torch, gpqhe_amd, ctx, batch, iters=5):
     """The RNS core of a SQUARING, he_mul(&ct, &ct, &ct, rlk) (src/he-algo.c:151; he_exp / he_inv square repeatedly): the tensor stage
     with both operands the same slabs runs two forward transforms instead of four (tensor_sq_mid8); key switch unchanged."""
@@ -615,6 +659,9 @@ def main(argv=None):
             out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, B, iters=3)   # BASELINE configs[2]: he_mul + he_rescale, batch 64
             out["keyswitch_n17"] = keyswitch_n17_rate(torch, gpqhe_amd)
             out["squaring_core"] = squaring_rate(torch, gpqhe_amd, ctx, B)
+            rs = reference_signature_latency()
+            if rs is not None:
+                out["reference_signature"] = rs
     if dist is not None and not args.no_scatter_gather:
         # BASELINE configs[3] with the transfers inside the timed region: rank 0 owns the whole batch, every rank works on its
         # shard, results return to rank 0.  A root-GPU scatter is bound by one xGMI link per peer.  This leg is
