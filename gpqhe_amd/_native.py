@@ -127,6 +127,7 @@ SIGNATURES = {
     "gpq_mpi_shim_resident_polys": (C.c_uint, []),
     "gpq_mpi_shim_poly_stats": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gpq_mpi_shim_forget_polys": (None, []),
+    "gpq_mpi_shim_set_conversion_threads": (C.c_uint, [C.c_uint]),
     "gpq_mpi_shim_poly_bypass": (None, [C.c_int]),
     "gpq_mpi_shim_set_direct_mpi": (C.c_int, [C.c_int]),
     "gpq_mpi_shim_last_timing": (None, [C.POINTER(C.c_double)]),

@@ -202,10 +202,12 @@ class Workers {
     job_ = nullptr; tasks_ = 0;
   }
 };
+unsigned g_workers_wanted = 0;   // gpq_mpi_shim_set_conversion_threads, before the first MPI-typed call; 0 = min(hardware threads, 16)
 Workers &workers() {       // never destroyed: its threads wait detached and vanish with the process
   static Workers *w = [] {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt > 16) nt = 16;
+    unsigned nt = g_workers_wanted ? g_workers_wanted : std::thread::hardware_concurrency();
+    if (!g_workers_wanted && nt > 16) nt = 16;            // the conversions are bound by memory latency on scattered heap objects: more threads help until the
+    if (nt > 64) nt = 64;                                 // host's memory system is busy; 16 is what a one-GPU share of a node usually has
     if (nt < 1) nt = 1;
     return new Workers(nt - 1);
   }();

@@ -1125,6 +1125,9 @@ void gpq_mpi_shim_set_poly_slots(unsigned slots) {
     drop_poly_slot(victim);
   }
 }
+// Host threads that convert between libgcrypt integers and slabs (default: the hardware threads, at most 16; up to 64).  Takes effect only
+// before the first MPI-typed call of the process (the pool is started once); returns the number in use afterwards.
+unsigned gpq_mpi_shim_set_conversion_threads(unsigned threads) { SHIM_CALL(); g_workers_wanted = threads; return workers().width(); }
 unsigned gpq_mpi_shim_resident_polys(void) { SHIM_CALL(); return (unsigned)g_polys.size(); }
 // operands served from a resident copy that the check confirmed / that the check found changed (uploaded again, device work repeated)
 void gpq_mpi_shim_poly_stats(uint64_t *confirmed, uint64_t *stale) { SHIM_CALL(); if (confirmed) *confirmed = g_poly_hits; if (stale) *stale = g_poly_stale; }

@@ -199,6 +199,9 @@ void gpq_mpi_shim_poly_stats(uint64_t *confirmed, uint64_t *stale);
 void gpq_mpi_shim_forget_polys(void);
 /* testing: while on, calls neither consult nor update the resident polynomials (which stay as they are) */
 void gpq_mpi_shim_poly_bypass(int on);
+/* Host threads converting between libgcrypt integers and slabs: default min(hardware threads, 16), at most 64.  Only before the first
+ * MPI-typed call of the process; returns the number in use. */
+unsigned gpq_mpi_shim_set_conversion_threads(unsigned threads);
 /* Drops the device copies of the evaluation keys.  Never needed with the default key check; he_genrlk / he_genck / he_genrk drop
  * the copy of the key they write themselves. */
 void gpq_mpi_shim_forget_keys(void);

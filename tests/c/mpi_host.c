@@ -8,7 +8,7 @@
  *   mpi_host polymulmono <logn>          poly_mul of a dense polynomial by -3 x^5 at a size that takes the threaded conversions
  *   mpi_host keygen <logn> <logq>        he_genrlk / he_genck / he_genrk with deterministic stand-ins for the reference's samplers
  *   mpi_host residentfuzz <logn> <logq> <logDelta> <steps> <seed>   random walk over the calls, resident polynomials vs fresh uploads
- *   mpi_host hemultime <logn> <logq>     wall time of he_mul / he_rescale through the MPI-typed symbols (conversions and copies included)
+ *   mpi_host hemultime <logn> <logq> [threads]   wall time of he_mul / he_rescale through the MPI-typed symbols (conversions and copies included)
  *   mpi_host hemul  <in.txt>             he_mul on ciphertexts read as hex, then he_rs, then he_moddown
  *   mpi_host ctxcheck <logn> <logq> <Delta>   every field hectx_init / polyctx_init fill, for comparison with the restated formulas
  *
@@ -936,6 +936,7 @@ int main(int argc, char **argv)
   if (argc >= 3 && !strcmp(argv[1], "hemul")) return hemul(argv[2]);
   if (argc >= 3 && !strcmp(argv[1], "polymulmono")) return polymulmono(atoi(argv[2]));
   if (argc >= 4 && !strcmp(argv[1], "keygen")) return keygen(atoi(argv[2]), atoi(argv[3]));
+  if (argc >= 5 && !strcmp(argv[1], "hemultime")) printf("conversion threads: %u\n", gpq_mpi_shim_set_conversion_threads((unsigned)atoi(argv[4])));
   if (argc >= 4 && !strcmp(argv[1], "hemultime")) return hemultime(atoi(argv[2]), atoi(argv[3]));
   if (argc >= 7 && !strcmp(argv[1], "residentfuzz")) return residentfuzz(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), strtoull(argv[6], NULL, 10));
   return 2;
