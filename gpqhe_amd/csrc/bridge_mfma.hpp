@@ -186,8 +186,13 @@ struct ReconMfmaArgs {
 // per-coefficient flags of the relinearisation tail: r = x mod P against floor(P/2)
 constexpr unsigned char RF_GT = 1, RF_LT = 2, RF_AMB = 4;
 
-#ifndef GPQ_RECON_TWO_AHEAD
-#define GPQ_RECON_TWO_AHEAD 16   /* widest WL whose k loop keeps two steps of residues in flight (14: the 16-word form one step only) */
+// k steps of residues a wave keeps in flight.  The kernel is bound by bytes in flight, not by arithmetic (two waves per SIMD at its register
+// count: 8 waves x AHEAD x 2 KB per CU against latency x bandwidth): every further step is 8 VGPRs.
+#ifndef GPQ_RECON_AHEAD
+#define GPQ_RECON_AHEAD 2        /* WL <= 14 */
+#endif
+#ifndef GPQ_RECON_AHEAD16
+#define GPQ_RECON_AHEAD16 2      /* WL = 16 (the one-product tail) */
 #endif
 template <int WL>
 __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs a) {
@@ -203,8 +208,9 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
   const unsigned r = lane & 31, h = lane >> 5;
   const unsigned g0 = blockIdx.x * 8 + wave, gstep = gridDim.x * 8;
   // residues of k step s of group g: limbs 4s+2h, 4s+2h+1 of coefficients r (tile 0) and 32+r (tile 1); padding limbs and
-  // steps past the end read the last limb.  Two steps are kept in flight (xa, xb), across the group boundary too.
-  uint64_t xa[4], xb[4];
+  // steps past the end read the last limb.  AH steps are kept in flight (xq), across the group boundary too where the registers allow (CROSS).
+  constexpr int AH = WL <= 14 ? GPQ_RECON_AHEAD : GPQ_RECON_AHEAD16;
+  uint64_t xq[AH][4];
   auto fetch = [&](unsigned g, unsigned s, uint64_t (&xn)[4]) {
     const unsigned poly = g / a.groups_per_poly, coef0 = (g % a.groups_per_poly) << 6;
     const uint64_t *__restrict__ src = a.slab + (((size_t)poly * a.slab_dim + a.slab_first) << a.logn) + coef0 + r;
@@ -216,11 +222,17 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
     }
   };
   constexpr bool CROSS = WL <= 10;      // fetch the next group's first steps under this group's epilogue (registers allowing)
-  if (CROSS && g0 < a.total_groups) { fetch(g0, 0, xa); fetch(g0, 1, xb); }
+  if (CROSS && g0 < a.total_groups) {
+#pragma unroll
+    for (int j = 0; j < AH; ++j) fetch(g0, j, xq[j]);
+  }
   for (unsigned g = g0; g < a.total_groups; g += gstep) {
     const unsigned poly = g / a.groups_per_poly, coef0 = (g % a.groups_per_poly) << 6;
     const unsigned gn = g + gstep < a.total_groups ? g + gstep : g;          // next group (or this one again: harmless reads)
-    if (!CROSS) { fetch(g, 0, xa); if (WL <= GPQ_RECON_TWO_AHEAD) fetch(g, 1, xb); }
+    if (!CROSS) {
+#pragma unroll
+      for (int j = 0; j < AH; ++j) fetch(g, j, xq[j]);
+    }
     v16i acc[2][NT];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -249,27 +261,16 @@ __global__ __launch_bounds__(512) void bridge_reconstruct_low_mfma(ReconMfmaArgs
         acc[1][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A1, acc[1][q], 0, 0, 0);
       }
     };
-    if (WL <= GPQ_RECON_TWO_AHEAD) {
-      for (unsigned s = 0; s < a.KS; s += 2) {
-        uint64_t x[4];
+    for (unsigned s = 0; s < a.KS; s += AH) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = xa[e];
-        if (s + 2 < a.KS) fetch(g, s + 2, xa); else if (CROSS) fetch(gn, 0, xa);
-        step(s, x);
-        if (s + 1 < a.KS) {
+      for (int j = 0; j < AH; ++j) {
+        if (s + j < a.KS) {
+          uint64_t x[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = xb[e];
+          for (int e = 0; e < 4; ++e) x[e] = xq[j][e];
+          if (s + j + AH < a.KS) fetch(g, s + j + AH, xq[j]); else if (CROSS) fetch(gn, j, xq[j]);     // (slot j opens the next group with its step j)
+          step(s + j, x);
         }
-        if (s + 3 < a.KS) fetch(g, s + 3, xb); else if (CROSS) fetch(gn, 1, xb);
-        if (s + 1 < a.KS) step(s + 1, x);
-      }
-    } else {                                               // WL = 16: one step ahead only (registers)
-      for (unsigned s = 0; s < a.KS; ++s) {
-        uint64_t x[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = xa[e];
-        if (s + 1 < a.KS) fetch(g, s + 1, xa);
-        step(s, x);
       }
     }
     // epilogue: this lane finishes coefficient coef0 + lane (tile h, column r)
