@@ -60,6 +60,8 @@ SIGNATURES = {
     "gpq_rns_reconstruct": (C.c_int, [vp, vp, C.c_uint, vp, C.c_uint, C.c_uint, C.c_uint, vp]),
     "gpq_rns_reconstruct_one": (C.c_int, [vp, C.POINTER(u64), C.c_uint, C.POINTER(u64), C.c_uint]),
     "gpq_set_exact_crt": (C.c_int, [vp, C.c_int]),
+    "gpq_set_stream_bridge": (C.c_int, [vp, C.c_int]),
+    "gpq_debug_force_redo": (C.c_int, [vp, C.c_uint]),
     "gpq_set_fused_tail": (C.c_int, [vp, C.c_int]),
     "gpq_big_transpose": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_int, vp]),
     "gpq_big_addsub": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_int, vp]),

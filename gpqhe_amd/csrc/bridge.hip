@@ -5,6 +5,7 @@
 #include "engine_internal.hpp"
 #include "bridge_kernels.hpp"
 #include "bridge_mfma.hpp"
+#include "bridge_stream.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -186,9 +187,14 @@ struct ScaledInverse {
 };
 inline bool can_prescale(const gpq_ctx *c) { return c->prescale && c->logn > 12 && !c->h_tabs.empty(); }   // the two-pass transforms only (small rings: gpq_invntt)
 
+// grid of a masked kernel of `threads` threads: over the waves of the launch that wrote its mask (FlagScope), or over (n, polys)
+inline dim3 masked_grid(const FlagScope &sc, unsigned threads, unsigned n, unsigned polys) {
+  if (sc.wave_any) return dim3((sc.waves + threads / 64 - 1) / (threads / 64));
+  return dim3((n + threads - 1) / threads, polys);
+}
 template <int WP>
 void launch_exact(const ReconstructArgs &a, unsigned n, unsigned batch, hipStream_t s) {
-  hipLaunchKernelGGL((bridge_reconstruct<WP>), dim3((n + 127) / 128, batch), dim3(128), 0, s, a);
+  hipLaunchKernelGGL((bridge_reconstruct<WP>), masked_grid(a.scope, 128, n, batch), dim3(128), 0, s, a);
 }
 template <int WL>
 void launch_low(const ReconstructArgs &a, unsigned WPstride, unsigned char *redo, unsigned n, unsigned batch, hipStream_t s) {
@@ -209,10 +215,10 @@ void balanced_digits(const uint64_t *words, size_t nwords, int8_t *out, size_t n
 // plus the fixed-point columns F = sum_d y_d floor(2^104 / p_d).  For a CRT, weight_d = P/p_d and Pw = P (get_recon_mfma); for the
 // one-product relinearisation tail, weight_d = floor(Pi' 2^104 / p_d) and Pw = Pi' 2^104 (get_tail_direct).
 int build_recon_mfma(gpq_ctx *c, const std::vector<uint64_t> &primes, const std::vector<uint64_t> &weight_inv, const std::vector<Big> &weight,
-                     const Big &Pw, int WL, gpq_recon_mfma *tp) {
+                     const Big &Pw, int WL, gpq_recon_mfma *tp, unsigned KSpad = 0) {
   gpq_recon_mfma &t = *tp;
   const unsigned dim = (unsigned)primes.size(), NT = (8 * WL + 14 + 31) / 32, ncol = 32 * NT;
-  t.KS = (dim + 3) / 4;
+  t.KS = std::max((dim + 3) / 4, KSpad);                 // (KSpad: zero rows up to the k steps a bridge_stream.hpp instantiation runs)
   t.lds_bytes = (size_t)t.KS * NT * 1024 + (size_t)t.KS * 64;
   if (t.lds_bytes <= 156 * 1024) {
     std::vector<int8_t> bf((size_t)t.KS * NT * 1024, 0);
@@ -283,8 +289,10 @@ int build_recon_mfma(gpq_ctx *c, const std::vector<uint64_t> &primes, const std:
 }
 
 // ... for the CRT over basis b
-int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out) {
-  auto it = b->mfma.find(WL);
+int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out, unsigned KSpad = 0) {
+  if (KSpad <= (b->dim + 3) / 4) KSpad = 0;
+  const int key = WL + 1000 * (int)KSpad;
+  auto it = b->mfma.find(key);
   if (it != b->mfma.end()) { *out = &it->second; return GPQ_OK; }
   gpq_recon_mfma t;
   std::vector<uint64_t> primes(b->dim);
@@ -293,8 +301,8 @@ int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out
     primes[d] = c->p[b->first + d];
     weight[d].assign(b->h_phat.begin() + (size_t)d * b->WP, b->h_phat.begin() + (size_t)(d + 1) * b->WP);
   }
-  if (int rc = build_recon_mfma(c, primes, b->h_phat_inv, weight, b->h_P, WL, &t)) return rc;
-  *out = &(b->mfma[WL] = t);
+  if (int rc = build_recon_mfma(c, primes, b->h_phat_inv, weight, b->h_P, WL, &t, KSpad)) return rc;
+  *out = &(b->mfma[key] = t);
   return GPQ_OK;
 }
 
@@ -323,6 +331,7 @@ struct ReconExtra {
   uint64_t *big_b = nullptr;      // the polynomials from `split` on are written here instead (Two<>, bridge_kernels.hpp)
   unsigned split = ~0u;
   bool exact_only = false;        // skip the fast paths: the exact kernel alone (restricted by `only`)
+  FlagScope scope = kNoScope;     // with `only` and exact_only: the bridge_stream.hpp launch that wrote the mask
 };
 
 // per-coefficient "redo exactly" flags of the fast CRT paths
@@ -348,7 +357,7 @@ int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, uns
   const unsigned logn = logn_override < 0 ? c->logn : (unsigned)logn_override, n = 1u << logn;
   const Two<uint64_t> bigs{big, x.big_b, x.split};
   ReconstructArgs a{c->d_tabs, slab, bigs, b->d_phat, b->d_phat_inv, b->d_pmult, b->d_phalf, tie, x.only, b->d_inv128,
-                    b->dim, logn, Wout, logq, b->first, slab_dim, slab_first, centre ? 1u : 0u, x.prescaled ? 1u : 0u};
+                    b->dim, logn, Wout, logq, b->first, slab_dim, slab_first, centre ? 1u : 0u, x.prescaled ? 1u : 0u, x.scope};
   if (x.fused) *x.fused = false;
   // fast path: centred result modulo a power of two that needs fewer words than P has
   const unsigned need = (logq + 63) / 64;
@@ -390,6 +399,7 @@ int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, uns
     else if (need <= 14) launch_low<14>(a, b->WP, c->d_redo, n, batch, s);   // q up to 2^896 (headline 2^850)
     else launch_low<16>(a, b->WP, c->d_redo, n, batch, s);
     a.only = c->d_redo;   // exact kernel below redoes only the flagged coefficients
+    a.scope = kNoScope;   // (the fast kernels above leave no per-wave words)
   }
   ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s);
   switch (b->WP) {
@@ -413,13 +423,15 @@ void balanced8(uint64_t v, int8_t out[8]) {
 constexpr size_t kMfmaLdsMax = 96 * 1024;   // of the CU's 160 KB: one workgroup always fits, two when the tables are small
 
 // constant matrix of bridge_decompose_mfma for the primes limb0 .. limb0+dim-1 and W-word inputs
-int get_decomp_mfma(gpq_ctx *c, unsigned limb0, unsigned dim, unsigned W, gpq_decomp_mfma **out) {
-  const auto key = std::make_pair(std::make_pair(limb0, dim), W);
+int get_decomp_mfma(gpq_ctx *c, unsigned limb0, unsigned dim, unsigned W, gpq_decomp_mfma **out, unsigned KSforce = 0) {
+  const unsigned KSnat = W <= 4 ? 1 : W <= 8 ? 2 : W <= 16 ? 4 : 8;
+  if (KSforce <= KSnat) KSforce = 0;
+  const auto key = std::make_pair(std::make_pair(limb0, dim), W + 1000 * KSforce);
   auto it = c->decomps.find(key);
   if (it != c->decomps.end()) { *out = &it->second; return GPQ_OK; }
   gpq_decomp_mfma t;
   const unsigned KB = 8 * W;
-  t.KS = W <= 4 ? 1 : W <= 8 ? 2 : W <= 16 ? 4 : 8;
+  t.KS = KSforce ? KSforce : KSnat;                      // (KSforce: zero columns up to the k steps a bridge_stream.hpp instantiation runs)
   t.NT = (dim + 3) / 4;
   t.lds_bytes = (size_t)t.NT * t.KS * 1024 + (size_t)t.NT * 96;
   if (t.lds_bytes <= kMfmaLdsMax) {
@@ -504,6 +516,93 @@ int launch_decompose(gpq_ctx *c, uint64_t *slab, const BigSources &big, unsigned
   return GPQ_OK;
 }
 
+// rns_decompose of the coefficients marked in `only` alone (integer-VALU kernel; the exact fallback behind bridge_crt_decompose)
+int launch_decompose_masked(gpq_ctx *c, uint64_t *slab, const uint64_t *big, unsigned W, unsigned limb0, unsigned dim, unsigned batch,
+                            const unsigned char *only, const FlagScope &scope, hipStream_t s) {
+  ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s);
+  DecomposeArgs a{c->d_tabs, one_source(big), slab, W, dim, c->logn, limb0, only, scope};
+  const dim3 grid = masked_grid(scope, 256, c->n, batch), block(256);
+  if (W <= 4) hipLaunchKernelGGL((bridge_decompose<4>), grid, block, 0, s, a);
+  else if (W <= 7) hipLaunchKernelGGL((bridge_decompose<7>), grid, block, 0, s, a);
+  else if (W <= 14) hipLaunchKernelGGL((bridge_decompose<14>), grid, block, 0, s, a);
+  else if (W <= 16) hipLaunchKernelGGL((bridge_decompose<16>), grid, block, 0, s, a);
+  else if (W <= 32) hipLaunchKernelGGL((bridge_decompose<32>), grid, block, 0, s, a);
+  else return gpq_fail(GPQ_ERR_UNSUPPORTED, "decompose: W=%u words (max 32)", W);
+  return GPQ_OK;
+}
+
+// ---- bridge_stream.hpp: launchers ----
+constexpr unsigned kStreamBlocks = 256, kStreamWaves = 8;          // one 8-wave workgroup per CU, persistent over the groups
+constexpr size_t kStreamLdsMax = 156 * 1024;
+
+int ensure_wave_any(gpq_ctx *c, hipStream_t s) {
+  if (c->d_wave_any) return GPQ_OK;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return gpq_fail(GPQ_ERR_INVALID, "the first call allocates scratch: run it once outside stream capture");
+  DeviceScope on_device(c->device);
+  HIP_TRY(hipMalloc((void **)&c->d_wave_any, kStreamBlocks * kStreamWaves * sizeof(unsigned)));
+  HIP_TRY(hipMemset(c->d_wave_any, 0, kStreamBlocks * kStreamWaves * sizeof(unsigned)));
+  return GPQ_OK;
+}
+inline unsigned stream_blocks(unsigned total_groups) {
+  const unsigned need = (total_groups + kStreamWaves - 1) / kStreamWaves;
+  return need < kStreamBlocks ? need : kStreamBlocks;
+}
+inline bool stream_fast_ok(const gpq_ctx *c, const gpq_bridge_basis *b, unsigned logq) {   // launch_reconstruct's conditions for the fast CRT path
+  const unsigned need = (logq + 63) / 64;
+  return logq && !c->exact_crt && c->bridge_mfma && c->logn >= 6 && b->dim >= 4 && need + 1 < (unsigned)b->WP && b->pbits >= 160;
+}
+
+template <int WL, int KS, int KSD, int R>
+int launch_crt_decompose_t(const CrtDecomposeArgs &a, size_t lds, unsigned blocks, hipStream_t s) {
+  static LdsRaised raised;
+  if (int rc = raised.raise(reinterpret_cast<const void *>(&bridge_crt_decompose<WL, KS, KSD, R>), (int)kStreamLdsMax)) return rc;
+  hipLaunchKernelGGL((bridge_crt_decompose<WL, KS, KSD, R>), dim3(blocks), dim3(512), lds, s, a);
+  return GPQ_OK;
+}
+
+// src/he-mult.c:140 + :59 -- poly_rns2mpi(d2hat) mod 2^logq and rns_decompose of it over dimB limbs in one kernel; `scratch` = W words per
+// coefficient for the coefficients the exact kernels redo.  *done = false: shape or settings outside the instantiations (caller runs the two kernels).
+int crt_decompose_stream(gpq_ctx *c, gpq_bridge_basis *bA, uint64_t *out, const uint64_t *slab, uint64_t *scratch, unsigned W, unsigned dimA,
+                         unsigned dimB, unsigned logq, unsigned polys, hipStream_t s, bool *done) {
+  *done = false;
+  const unsigned need = (logq + 63) / 64;
+  if (!c->stream_bridge || !stream_fast_ok(c, bA, logq) || W < need || dimB < 4) return GPQ_OK;
+  int WL, KS, KSD;
+  if (W <= 7 && dimA <= 16) { WL = 7; KS = 4; KSD = 2; }
+  else if (W <= 14 && dimA <= 32) { WL = 14; KS = 8; KSD = 4; }
+  else return GPQ_OK;
+  gpq_recon_mfma *tr;
+  gpq_decomp_mfma *td;
+  int rc;
+  if ((rc = get_recon_mfma(c, bA, WL, &tr, KS)) || (rc = get_decomp_mfma(c, 0, dimB, W, &td, KSD))) return rc;
+  if (!tr->d_bfrag || !td->d_bfrag || tr->KS != (unsigned)KS || td->KS != (unsigned)KSD) return GPQ_OK;
+  const unsigned NT = (8 * WL + 14 + 31) / 32;
+  const size_t lds = (size_t)KS * NT * 1024 + (size_t)td->NT * KSD * 1024 + (size_t)65 * WL * 8;
+  if (lds > kStreamLdsMax) return GPQ_OK;
+  if ((rc = ensure_redo(c, (size_t)polys << c->logn, s)) || (rc = ensure_wave_any(c, s))) return rc;
+  const unsigned groups = (c->n >> 6) * polys, blocks = stream_blocks(groups);
+  const size_t slab_bytes = ((size_t)polys * dimA << c->logn) * 8;
+  if (slab_bytes >= 0xfffff000ull) return GPQ_OK;
+  CrtDecomposeArgs a{slab, slab_bytes, out, (const v4i *)tr->d_bfrag, tr->d_kc, tr->d_pm, (const v4i *)td->d_bfrag, td->d_pk, c->d_redo, c->d_wave_any,
+                     dimA, dimB, td->NT, c->logn, logq, W, groups, c->debug_force_redo};
+  {
+    ProfScope prof(c, GPQ_K_CRT_DECOMPOSE, s);
+    if (WL == 7) rc = launch_crt_decompose_t<7, 4, 2, 4>(a, lds, blocks, s);
+    else rc = launch_crt_decompose_t<14, 8, 4, 4>(a, lds, blocks, s);
+    if (rc) return rc;
+  }
+  // the coefficients in the CRT's window: exact CRT into the scratch words, integer-VALU decompose of those
+  const FlagScope scope{c->d_wave_any, blocks * kStreamWaves, groups};
+  ReconExtra ex;
+  ex.prescaled = true; ex.exact_only = true; ex.only = c->d_redo; ex.scope = scope;
+  if ((rc = launch_reconstruct(c, bA, scratch, W, slab, dimA, 0, polys, logq, true, nullptr, s, -1, ex))) return rc;
+  if ((rc = launch_decompose_masked(c, out, scratch, W, 0, dimB, polys, c->d_redo, scope, s))) return rc;
+  *done = true;
+  return GPQ_OK;
+}
+
 int check(const gpq_ctx *c, unsigned dim, unsigned batch, const char *who) {
   if (!c) return gpq_fail(GPQ_ERR_INVALID, "%s: null context", who);
   if (dim < 1 || dim > c->nprimes) return gpq_fail(GPQ_ERR_INVALID, "%s: dim=%u outside 1..%u", who, dim, c->nprimes);
@@ -535,6 +634,8 @@ void gpq_bridge_release(gpq_ctx *c) {
   }
   if (c->d_redo) (void)hipFree(c->d_redo);
   c->d_redo = nullptr; c->redo_cap = 0;
+  if (c->d_wave_any) (void)hipFree(c->d_wave_any);
+  c->d_wave_any = nullptr;
   for (void *old : c->retired) (void)hipFree(old);
   c->retired.clear();
   c->bases.clear();
@@ -545,6 +646,9 @@ void gpq_bridge_release(gpq_ctx *c) {
                     kv.second.direct.d_bfrag, (void *)kv.second.direct.d_lk, (void *)kv.second.direct.d_kc, (void *)kv.second.direct.d_pm,
                     (void *)kv.second.d_scale, (void *)kv.second.d_unscale})
       if (q) (void)hipFree(q);
+    for (auto &m : kv.second.direct_padded)
+      for (void *q : {m.second.d_bfrag, (void *)m.second.d_lk, (void *)m.second.d_kc, (void *)m.second.d_pm})
+        if (q) (void)hipFree(q);
   }
   c->relins.clear();
   for (auto &kv : c->decomps) { if (kv.second.d_bfrag) (void)hipFree(kv.second.d_bfrag); if (kv.second.d_pk) (void)hipFree(kv.second.d_pk); }
@@ -867,6 +971,7 @@ int launch_relin_front_t(const RelinFrontArgs &a, size_t lds, hipStream_t s) {
   if (per_cu < 1) per_cu = 1;
   unsigned blocks = 256 * per_cu;
   if (blocks > (a.total_groups + 3) / 4) blocks = (a.total_groups + 3) / 4;
+  if (a.scope.wave_any) blocks = (a.scope.waves + 3) / 4;     // wave w of this launch = wave w of the launch that wrote the mask
   hipLaunchKernelGGL((bridge_relin_front_mfma<KS>), dim3(blocks), dim3(256), lds, s, a);
   return GPQ_OK;
 }
@@ -879,12 +984,94 @@ int launch_relin_front(const gpq_ctx *c, unsigned KS, const RelinFrontArgs &f, s
   }
 }
 
+// The addend of the relinearisation tail as LIMBS (he_mul: d0hat | d1hat, src/he-mult.c:139,141 never leave RNS form before the tail):
+// [polys][dimA][n] weighted for the CRT over bA; scratch = [polys][W][n] words for the coefficients the exact kernels redo (or for all of
+// them when the streaming kernel does not cover the shape).
+struct TailD { const uint64_t *hat; gpq_bridge_basis *bA; unsigned dimA; uint64_t *scratch; };
+
+template <int KST, int WLD, int KSD, bool DCRT, int R>
+int launch_tail_stream_t(const TailStreamArgs &a, size_t lds, unsigned blocks, hipStream_t s) {
+  static LdsRaised raised;
+  if (int rc = raised.raise(reinterpret_cast<const void *>(&bridge_tail_stream<KST, WLD, KSD, DCRT, R>), (int)kStreamLdsMax)) return rc;
+  hipLaunchKernelGGL((bridge_tail_stream<KST, WLD, KSD, DCRT, R>), dim3(blocks), dim3(512), lds, s, a);
+  return GPQ_OK;
+}
+
+// get_tail_direct's matrix zero-padded to KST k steps
+int get_tail_direct_padded(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables *rt, unsigned KST, gpq_recon_mfma **out) {
+  if (KST <= (dimB + 3) / 4) { *out = &rt->direct; return GPQ_OK; }
+  auto it = rt->direct_padded.find(KST);
+  if (it != rt->direct_padded.end()) { *out = &it->second; return GPQ_OK; }
+  gpq_bridge_basis *bB, *bq;
+  int rc;
+  if ((rc = get_basis(c, 0, dimB, &bB)) || (rc = get_basis(c, dimP, dimB - dimP, &bq))) return rc;
+  Big num = bq->h_P;                                        // Pi' 2^104 (as get_tail_direct)
+  num.insert(num.begin(), 0);
+  mul_small(num, 1ull << 40);
+  std::vector<uint64_t> primes(dimB), scale(dimB);
+  std::vector<Big> weight(dimB);
+  for (unsigned d = 0; d < dimB; ++d) {
+    primes[d] = c->p[d];
+    Big q = num;
+    (void)divmod_small(q, primes[d]);
+    q.resize(16 < q.size() ? q.size() : 16, 0);
+    weight[d] = q;
+    scale[d] = bB->h_phat_inv[d];
+  }
+  gpq_recon_mfma t;
+  if ((rc = build_recon_mfma(c, primes, scale, weight, num, 16, &t, KST))) return rc;
+  *out = &(rt->direct_padded[KST] = t);
+  return GPQ_OK;
+}
+
+// The one-product tail as a stream (bridge_stream.hpp), with the addend's CRT in the same kernel when it comes as limbs.  *scope = the
+// launch's per-wave words for the masked kernels behind it; *done = false: not covered (shape, settings).
+int tail_stream(gpq_ctx *c, gpq_relin_tables *rt, Two<uint64_t> out, const uint64_t *chat, Two<const uint64_t> dbig, const TailD *dh, unsigned W,
+                unsigned dimP, unsigned dimB, unsigned logql, unsigned polys, unsigned char *tie, unsigned char *amb, hipStream_t s, FlagScope *scope, bool *done) {
+  *done = false;
+  const unsigned need = (logql + 63) / 64;
+  if (!c->stream_bridge || W > 14 || W < need || logql > 896) return GPQ_OK;
+  int KST, WLD = 0, KSD = 0;
+  if (dh) {
+    if (!stream_fast_ok(c, dh->bA, logql)) return GPQ_OK;
+    if (dimB <= 32 && dh->dimA <= 16 && need <= 7) { KST = 8; WLD = 7; KSD = 4; }
+    else if (dimB <= 48 && dh->dimA <= 32 && need <= 14) { KST = 12; WLD = 14; KSD = 8; }
+    else return GPQ_OK;
+  } else {
+    if (dimB <= 24) KST = 6; else if (dimB <= 48) KST = 12; else return GPQ_OK;
+  }
+  gpq_recon_mfma *tt, *td = nullptr;
+  int rc;
+  if ((rc = get_tail_direct_padded(c, dimP, dimB, rt, KST, &tt))) return rc;
+  if (dh && (rc = get_recon_mfma(c, dh->bA, WLD, &td, KSD))) return rc;
+  if (!tt->d_bfrag || tt->KS != (unsigned)KST || (dh && (!td->d_bfrag || td->KS != (unsigned)KSD))) return GPQ_OK;
+  const unsigned NTD = dh ? (8 * WLD + 14 + 31) / 32 : 0;
+  const size_t lds = (size_t)KST * 5 * 1024 + (size_t)KSD * NTD * 1024 + (size_t)65 * 16 * 8 + (size_t)65 * WLD * 8;
+  if (lds > kStreamLdsMax) return GPQ_OK;
+  if ((rc = ensure_redo(c, (size_t)polys << c->logn, s)) || (rc = ensure_wave_any(c, s))) return rc;
+  const unsigned groups = (c->n >> 6) * polys, blocks = stream_blocks(groups);
+  const size_t chat_bytes = ((size_t)polys * dimB << c->logn) * 8, dhat_bytes = dh ? ((size_t)polys * dh->dimA << c->logn) * 8 : 0;
+  if (chat_bytes >= 0xfffff000ull || dhat_bytes >= 0xfffff000ull) return GPQ_OK;
+  TailStreamArgs a{chat, dh ? dh->hat : nullptr, chat_bytes, dhat_bytes, dbig, out, (const v4i *)tt->d_bfrag, tt->d_kc, tt->d_pm,
+                   dh ? (const v4i *)td->d_bfrag : nullptr, dh ? td->d_kc : nullptr, dh ? td->d_pm : nullptr,
+                   c->d_redo, tie, amb, c->d_wave_any, dimB, dh ? dh->dimA : 0u, c->logn, W, logql, groups, c->debug_force_redo};
+  ProfScope prof(c, GPQ_K_TAIL_STREAM, s);
+  if (dh && KST == 8) rc = launch_tail_stream_t<8, 7, 4, true, 4>(a, lds, blocks, s);
+  else if (dh) rc = launch_tail_stream_t<12, 14, 8, true, 4>(a, lds, blocks, s);
+  else if (KST == 6) rc = launch_tail_stream_t<6, 7, 4, false, 3>(a, lds, blocks, s);
+  else rc = launch_tail_stream_t<12, 14, 8, false, 4>(a, lds, blocks, s);
+  if (rc) return rc;
+  *scope = FlagScope{c->d_wave_any, blocks * kStreamWaves, groups};
+  *done = true;
+  return GPQ_OK;
+}
+
 // src/he-mult.c:67-77 (d != null: c = rdiv(c,P) + d) and src/he-automorphism.c:68-76, for q_l = 2^logql.
 // `polys` polynomials of chat; the first `split` of them go to out.a (+ addend d.a), the rest to out.b (+ d.b): c0 and c1 of a
 // launch group are one batch (their chat slabs are adjacent in the workspace), half the launches and twice their size.
 // chat_prescaled: the limbs below dimP already hold chat_d * (P/p_d)^-1 (ScaledInverse on the key switch's inverse pass).
 int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const uint64_t> dbig, unsigned W, unsigned dimP, unsigned dimB,
-               unsigned logql, unsigned polys, void *ws, hipStream_t s, int chat_prescaled = 0) {
+               unsigned logql, unsigned polys, void *ws, hipStream_t s, int chat_prescaled = 0, const TailD *dh = nullptr) {
   TailPlan tp;
   int rc = tail_plan(c, W, dimP, dimB, polys, &tp);
   if (rc) return rc;
@@ -910,7 +1097,18 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
     unsigned char *flags = (unsigned char *)rhat, *amb = flags + ((size_t)polys << c->logn);
     const unsigned char *redo_only = nullptr;
     const bool direct_ok = !in_place && rt->direct.d_bfrag && W <= 14 && logql <= 896 && c->bridge_mfma;
-    if (direct_ok) {
+    FlagScope scope = kNoScope;
+    bool streamed = false;
+    if (direct_ok && (rc = tail_stream(c, rt, out, chat, dbig, dh, W, dimP, dimB, logql, polys, tie, amb, s, &scope, &streamed))) return rc;
+    if (dh) {
+      // the addend as words: for the flagged coefficients only behind the streaming kernel (exact CRT), for all of them otherwise
+      ReconExtra dx;
+      dx.prescaled = true;
+      if (streamed) { dx.exact_only = true; dx.only = c->d_redo; dx.scope = scope; }
+      if ((rc = launch_reconstruct(c, dh->bA, dh->scratch, W, dh->hat, dh->dimA, 0, polys, logql, true, nullptr, s, -1, dx))) return rc;
+      dbig = Two<const uint64_t>{dh->scratch, dh->scratch + (size_t)out.split * W * n, out.split};
+    }
+    if (direct_ok && !streamed) {
       if ((rc = ensure_redo(c, (size_t)polys << c->logn, s))) return rc;
       const unsigned gpp = c->n >> 6;
       ReconMfmaArgs m{chat, out, (const v4i *)rt->direct.d_bfrag, rt->direct.d_lk, rt->direct.d_kc, rt->direct.d_pm, c->d_redo, tie, dimB, rt->direct.KS,
@@ -919,27 +1117,27 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
         ProfScope prof(c, GPQ_K_RELIN_TAIL_DIRECT, s);
         if ((rc = launch_low_mfma16(m, rt->direct.lds_bytes, s))) return rc;
       }
-      redo_only = c->d_redo;
     }
+    if (direct_ok) redo_only = c->d_redo;
     // weights off: for the flagged groups, or -- no product possible (in place, no tables) -- for every coefficient
-    LimbScaleArgs un{c->d_tabs, chat_rw, rt->d_unscale, redo_only, dimB, c->logn};
-    { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_limb_scale, cgrid, cblock, 0, s, un); }
+    LimbScaleArgs un{c->d_tabs, chat_rw, rt->d_unscale, redo_only, dimB, c->logn, scope};
+    { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_limb_scale, masked_grid(scope, 256, c->n, polys), cblock, 0, s, un); }
     if (!direct_ok) return relin_tail(c, out, chat, dbig, W, dimP, dimB, logql, polys, ws, s, 0);
     // the exact sequence on the flagged groups: front (re-run, writing its flags), r for its ambiguous ones, round bits, Q, finish
     const unsigned gpp = c->n >> 6;
     RelinFrontArgs f{chat, qhat, (const v4i *)rt->d_bfrag, rt->d_lk, rt->d_pk, rt->d_tkp, rt->d_kf, flags, amb,
-                     dimB, dimP, tp.cnt, c->logn, rt->NT, gpp, gpp * polys, c->d_redo, 1u, 0u, 0u};
+                     dimB, dimP, tp.cnt, c->logn, rt->NT, gpp, gpp * polys, c->d_redo, 1u, 0u, 0u, scope};
     if ((rc = launch_relin_front(c, rt->KS, f, rt->lds_bytes, s))) return rc;
     ReconExtra only_amb;
-    only_amb.only = amb;
+    only_amb.only = amb; only_amb.scope = scope;
     if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, only_amb))) return rc;
-    RoundFixArgs rf{r, bp->d_phalf, amb, flags, tp.Wr, c->logn};
-    { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_roundfix, cgrid, cblock, 0, s, rf); }
+    RoundFixArgs rf{r, bp->d_phalf, amb, flags, tp.Wr, c->logn, scope};
+    { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_roundfix, masked_grid(scope, 256, c->n, polys), cblock, 0, s, rf); }
     ReconExtra q;
-    q.prescaled = true; q.exact_only = true; q.only = c->d_redo; q.big_b = out.b; q.split = out.split;
+    q.prescaled = true; q.exact_only = true; q.only = c->d_redo; q.big_b = out.b; q.split = out.split; q.scope = scope;
     if ((rc = launch_reconstruct(c, bq, out.a, W, qhat, tp.cnt, 0, polys, logql, true, tie, s, -1, q))) return rc;
-    AddRoundArgs ar{out, Two<const uint64_t>{out.a, out.b, out.split}, nullptr, dbig, bp->d_phalf, piq, tie, W, tp.Wr, c->logn, logql, c->d_redo, flags};
-    { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_addround, cgrid, cblock, 0, s, ar); }
+    AddRoundArgs ar{out, Two<const uint64_t>{out.a, out.b, out.split}, nullptr, dbig, bp->d_phalf, piq, tie, W, tp.Wr, c->logn, logql, c->d_redo, flags, scope};
+    { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_addround, masked_grid(scope, 256, c->n, polys), cblock, 0, s, ar); }
     return launched("relin_tail");
   }
 
@@ -1106,27 +1304,38 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
       if ((rc = gpq_he_mul_tensor(c, d0h, d1h, d2h, h[0], h[1], square ? h[0] : h[2], square ? h[1] : h[3], dimA, polys, wsT, stream))) return rc;  // :121-136
     }
     uint64_t *d0 = dbig, *d1 = dbig + polys * bigpoly, *d2 = dbig + 2 * polys * bigpoly;
-    // poly_rns2mpi of d0, d2, d1 (:139-141): the three slabs are adjacent on both sides, one launch
-    {
-      StageRange stage("gpq_he_mul: poly_rns2mpi d0,d1,d2 (CRT)");
-      ReconExtra rx;
-      rx.prescaled = pre;
-      if ((rc = launch_reconstruct(c, bA, d0, W, d0h, dimA, 0, 3 * polys, logql, true, nullptr, s, -1, rx))) return rc;
-    }
-    // he_relin, :40-85
     uint64_t *d2hat = sB, *c0hat = sB + pb, *c1hat = sB + 2 * pb;
-    {
+    // With the one-product tail and bridge_stream.hpp, d0, d1, d2 (:139-141) never exist as words: d2hat goes CRT -> rns_decompose (:59) in
+    // one kernel, d0hat | d1hat enter the tail as limbs.  Otherwise: poly_rns2mpi of the three adjacent slabs in one launch, rns_decompose of d2.
+    const bool limbs_addend = pre && tail_mode == 3 && c->stream_bridge;
+    bool fused = false;
+    if (limbs_addend) {
+      StageRange stage("gpq_he_mul: poly_rns2mpi d2 -> he_relin rns_decompose (one kernel)");
+      if ((rc = crt_decompose_stream(c, bA, d2hat, d2h, d2, W, dimA, dimB, logql, polys, s, &fused))) return rc;
+    }
+    if (!fused) {
+      {
+        StageRange stage("gpq_he_mul: poly_rns2mpi d0,d1,d2 (CRT)");
+        ReconExtra rx;
+        rx.prescaled = pre;
+        if (limbs_addend) rc = launch_reconstruct(c, bA, d2, W, d2h, dimA, 0, polys, logql, true, nullptr, s, -1, rx);
+        else rc = launch_reconstruct(c, bA, d0, W, d0h, dimA, 0, 3 * polys, logql, true, nullptr, s, -1, rx);
+        if (rc) return rc;
+      }
       StageRange stage("gpq_he_mul: he_relin rns_decompose d2");
       if ((rc = launch_decompose(c, d2hat, d2, W, 0, dimB, polys, s))) return rc;                                  // :59
     }
+    // he_relin, :40-85
     {
       ScaledInverse scaled(c, tabsP);
       if ((rc = gpq_keyswitch(c, c0hat, c1hat, d2hat, rlk0, rlk1, dimB, polys, wsK, stream))) return rc;           // :60-64
     }
     StageRange stage("gpq_he_mul: he_relin tail (CRT, exact division by P, + d)");
     // c0 and c1 as one batch of 2 x polys polynomials: c0hat | c1hat and d0 | d1 are adjacent, the outputs are the caller's two slabs
-    if ((rc = relin_tail(c, Two<uint64_t>{out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, polys}, c0hat, Two<const uint64_t>{d0, d1, polys},
-                         W, dimP, dimB, logql, 2 * polys, wsTail, s, tail_mode))) return rc;                       // :67-77
+    const TailD dh{d0h, bA, dimA, d0};
+    if ((rc = relin_tail(c, Two<uint64_t>{out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, polys}, c0hat,
+                         limbs_addend ? Two<const uint64_t>{nullptr, nullptr, polys} : Two<const uint64_t>{d0, d1, polys},
+                         W, dimP, dimB, logql, 2 * polys, wsTail, s, tail_mode, limbs_addend ? &dh : nullptr))) return rc;   // :67-77
   }
   return launched("gpq_he_mul");
 }
@@ -1245,6 +1454,21 @@ extern "C" int gpq_set_prescale(gpq_ctx *c, int on) {      // 0: off, 1: the CRT
   c->prescale = on != 0;
   c->prescale_upper = on >= 2;
   c->tail_direct = on >= 3;
+  return GPQ_OK;
+}
+
+// gpq_he_mul / gpq_he_swk: bridge_stream.hpp's fused streaming kernels (default) or round 3's separate CRT / decompose / tail kernels.
+// Same words either way (tests run both).
+extern "C" int gpq_set_stream_bridge(gpq_ctx *c, int on) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_stream_bridge: null context");
+  c->stream_bridge = on != 0;
+  return GPQ_OK;
+}
+
+// Tests: bridge_stream.hpp's kernels also hand every coefficient whose index is a multiple of `every` to the exact kernels behind them (0: off).
+extern "C" int gpq_debug_force_redo(gpq_ctx *c, unsigned every) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_debug_force_redo: null context");
+  c->debug_force_redo = every;
   return GPQ_OK;
 }
 

@@ -30,6 +30,30 @@ struct Two {
 };
 template <typename T> inline Two<T> one_place(T *a) { return Two<T>{a, nullptr, ~0u}; }
 
+// What a fast kernel of bridge_stream.hpp leaves for the masked kernels behind it: one word per wave of ITS launch, non-zero when that
+// wave flagged a coefficient; wave w of the producer owned the groups of 64 coefficients w, w + waves, w + 2 waves, ...  A masked kernel
+// given a scope is launched as ceil(waves / (its threads / 64)) workgroups: its wave w returns at once when word w is 0 (the common
+// case: 2^-38 of the coefficients are ever flagged) and otherwise walks the producer wave's groups, still checking its per-coefficient mask.
+struct FlagScope {
+  const unsigned *wave_any;
+  unsigned waves, total_groups;
+};
+constexpr FlagScope kNoScope{nullptr, 0u, 0u};
+
+// body(poly, i) for the coefficients of a masked kernel: the scope's groups, or the classic grid (n / threads, polys)
+template <class Body>
+__device__ __forceinline__ void scoped_or_grid(const FlagScope &sc, unsigned logn, unsigned threads, Body body) {
+  if (sc.wave_any) {
+    const unsigned wv = blockIdx.x * (threads >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wv >= sc.waves || !sc.wave_any[wv]) return;
+    const unsigned lg = logn - 6;
+    for (unsigned g = wv; g < sc.total_groups; g += sc.waves) body(g >> lg, ((g & ((1u << lg) - 1)) << 6) + lane);
+  } else {
+    const unsigned i = blockIdx.x * threads + threadIdx.x;
+    if (i < (1u << logn)) body(blockIdx.y, i);
+  }
+}
+
 
 constexpr uint64_t M59 = (1ull << 59) - 1;
 
@@ -64,16 +88,17 @@ struct DecomposeArgs {
   BigSources big;           // [polys][W][n]
   uint64_t *slab;           // [polys][dim][n]: limb d of the output is prime limb0 + d
   unsigned W, dim, logn, limb0;
+  const unsigned char *only;   // optional [polys][n]: when given, coefficients with 0 are skipped
+  FlagScope scope;
 };
 
 template <int MAXW>
 __global__ __launch_bounds__(256) void bridge_decompose(DecomposeArgs a) {
   constexpr int ND = (64 * MAXW + 58) / 59;             // 59-bit digits, the top one signed
   constexpr int TOPBITS = 64 * MAXW - 59 * (ND - 1);
-  const unsigned n = 1u << a.logn;
-  const unsigned i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t *__restrict__ src = a.big.at(blockIdx.y, (size_t)a.W << a.logn) + i;
+  scoped_or_grid(a.scope, a.logn, 256, [&](unsigned poly, unsigned i) {
+  if (a.only && !a.only[((size_t)poly << a.logn) + i]) return;
+  const uint64_t *__restrict__ src = a.big.at(poly, (size_t)a.W << a.logn) + i;
   uint64_t w[MAXW + 1];
 #pragma unroll
   for (int j = 0; j < MAXW; ++j) w[j] = j < (int)a.W ? src[(size_t)j << a.logn] : 0;
@@ -94,7 +119,7 @@ __global__ __launch_bounds__(256) void bridge_decompose(DecomposeArgs a) {
   }
   // top digit as a signed number of TOPBITS bits
   const int64_t top = ((int64_t)(dg[ND - 1] << (64 - TOPBITS))) >> (64 - TOPBITS);
-  uint64_t *__restrict__ dst = a.slab + ((size_t)blockIdx.y * a.dim << a.logn) + i;
+  uint64_t *__restrict__ dst = a.slab + ((size_t)poly * a.dim << a.logn) + i;
   for (unsigned d = 0; d < a.dim; ++d) {
     const PrimeK k = a.tabs[a.limb0 + d].k;
     uint64_t r = top < 0 ? (uint64_t)top + k.p : (uint64_t)top;     // [0, p + 2^58)
@@ -102,6 +127,7 @@ __global__ __launch_bounds__(256) void bridge_decompose(DecomposeArgs a) {
     for (int t = ND - 2; t >= 0; --t) r = horner59(r, dg[t], k);
     dst[(size_t)d << a.logn] = canon4(r, k);
   }
+  });
 }
 
 // ---------------------------------------------------------------------------
@@ -128,15 +154,14 @@ struct ReconstructArgs {
   unsigned slab_dim, slab_first;    // the slab has slab_dim limbs per polynomial; read limbs slab_first ..
   unsigned centre;             // 0: leave the result in [0, P)
   unsigned prescaled;          // the slab already holds y_d (bridge_relin_front_mfma writes Q's residues so)
+  FlagScope scope;             // with `only`: the launch that wrote it (bridge_stream.hpp); bridge_reconstruct alone reads it
 };
 
 template <int WP>
 __global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
-  const unsigned n = 1u << a.logn;
-  const unsigned i = blockIdx.x * 128 + threadIdx.x;
-  if (i >= n) return;
-  if (a.only && !a.only[((size_t)blockIdx.y << a.logn) + i]) return;
-  const uint64_t *__restrict__ src = a.slab + (((size_t)blockIdx.y * a.slab_dim + a.slab_first) << a.logn) + i;
+  scoped_or_grid(a.scope, a.logn, 128, [&](unsigned poly, unsigned i) {
+  if (a.only && !a.only[((size_t)poly << a.logn) + i]) return;
+  const uint64_t *__restrict__ src = a.slab + (((size_t)poly * a.slab_dim + a.slab_first) << a.logn) + i;
   uint64_t S[WP + 1];
 #pragma unroll
   for (int j = 0; j <= WP; ++j) S[j] = 0;
@@ -180,7 +205,7 @@ __global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
       any |= (uint64_t)t;
       borrow = (uint64_t)(t >> 64) & 1;
     }
-    if (a.tie) a.tie[((size_t)blockIdx.y << a.logn) + i] = !borrow && !any;
+    if (a.tie) a.tie[((size_t)poly << a.logn) + i] = !borrow && !any;
     if (!borrow) {
       const uint64_t *__restrict__ mp = a.pmult + (size_t)5 * (WP + 1);
       uint64_t b2 = 0;
@@ -193,7 +218,7 @@ __global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
     }
   }
   // mpi_smod(., 2^logq, 2^(logq-1)): keep logq bits, sign-extend from bit logq-1
-  uint64_t *__restrict__ dst = a.big.at(blockIdx.y, (size_t)a.Wout << a.logn) + i;
+  uint64_t *__restrict__ dst = a.big.at(poly, (size_t)a.Wout << a.logn) + i;
   const uint64_t sext = (uint64_t)((int64_t)S[WP] >> 63);
   uint64_t qsign = 0;
   if (a.logq) {
@@ -218,6 +243,7 @@ __global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
   }
   const uint64_t fill = a.logq ? qsign : sext;
   for (unsigned j = WP + 1; j < a.Wout; ++j) dst[(size_t)j << a.logn] = fill;
+  });
 }
 
 // ---------------------------------------------------------------------------
@@ -337,18 +363,18 @@ struct AddRoundArgs {
   unsigned W, Wr, logn, logql;
   const unsigned char *only;   // optional [polys][n]: when given, coefficients with 0 are skipped
   const unsigned char *rflags; // optional [polys][n]: r against floor(P/2) as RF_GT / RF_LT bits instead of the words of r
+  FlagScope scope;             // with `only`: the launch that wrote it
 };
 
 __global__ __launch_bounds__(256) void bridge_addround(AddRoundArgs a) {
-  const unsigned i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= (1u << a.logn)) return;
-  if (a.only && !a.only[((size_t)blockIdx.y << a.logn) + i]) return;
+  scoped_or_grid(a.scope, a.logn, 256, [&](unsigned poly, unsigned i) {
+  if (a.only && !a.only[((size_t)poly << a.logn) + i]) return;
   int cmp = 0;
   if (a.rflags) {
-    const unsigned char f = a.rflags[((size_t)blockIdx.y << a.logn) + i];
+    const unsigned char f = a.rflags[((size_t)poly << a.logn) + i];
     cmp = (f & 1) ? 1 : ((f & 2) ? -1 : 0);
   } else {
-    const uint64_t *__restrict__ r = a.r + ((size_t)blockIdx.y * a.Wr << a.logn) + i;
+    const uint64_t *__restrict__ r = a.r + ((size_t)poly * a.Wr << a.logn) + i;
     // compare r with floor(P/2), most significant word first
     for (int j = (int)a.Wr - 1; j >= 0 && cmp == 0; --j) {
       const uint64_t rv = r[(size_t)j << a.logn], hv = a.phalf[j];
@@ -356,11 +382,11 @@ __global__ __launch_bounds__(256) void bridge_addround(AddRoundArgs a) {
     }
   }
   uint64_t carry = cmp > 0;                               // mpi_rdiv: round up when r > floor(P/2)
-  const bool fix = a.tie[((size_t)blockIdx.y << a.logn) + i] && cmp < 0;
+  const bool fix = a.tie[((size_t)poly << a.logn) + i] && cmp < 0;
   const size_t stride = (size_t)a.W << a.logn;
-  uint64_t *outp = a.out.at(blockIdx.y, stride) + i;
-  const uint64_t *qcp = a.qc.at(blockIdx.y, stride) + i;
-  const uint64_t *dbase = a.d.at(blockIdx.y, stride);
+  uint64_t *outp = a.out.at(poly, stride) + i;
+  const uint64_t *qcp = a.qc.at(poly, stride) + i;
+  const uint64_t *dbase = a.d.at(poly, stride);
   const uint64_t *dp = dbase ? dbase + i : nullptr;
   const unsigned sb = a.logql - 1;
   uint64_t qsign = 0;
@@ -378,6 +404,7 @@ __global__ __launch_bounds__(256) void bridge_addround(AddRoundArgs a) {
     }
     outp[o] = v;
   }
+  });
 }
 
 // Round bits of the coefficients bridge_relin_front_mfma could not decide (RF_AMB): r, made exactly by
@@ -388,19 +415,20 @@ struct RoundFixArgs {
   const unsigned char *amb;    // [polys][n]
   unsigned char *flags;        // [polys][n]
   unsigned Wr, logn;
+  FlagScope scope;             // the launch whose flagged groups `amb` lies in
 };
 __global__ __launch_bounds__(256) void bridge_roundfix(RoundFixArgs a) {
-  const unsigned i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= (1u << a.logn)) return;
-  const size_t at = ((size_t)blockIdx.y << a.logn) + i;
+  scoped_or_grid(a.scope, a.logn, 256, [&](unsigned poly, unsigned i) {
+  const size_t at = ((size_t)poly << a.logn) + i;
   if (!a.amb[at]) return;
-  const uint64_t *__restrict__ r = a.r + ((size_t)blockIdx.y * a.Wr << a.logn) + i;
+  const uint64_t *__restrict__ r = a.r + ((size_t)poly * a.Wr << a.logn) + i;
   int cmp = 0;
   for (int j = (int)a.Wr - 1; j >= 0 && cmp == 0; --j) {
     const uint64_t rv = r[(size_t)j << a.logn], hv = a.phalf[j];
     cmp = rv > hv ? 1 : (rv < hv ? -1 : 0);
   }
   a.flags[at] = cmp > 0 ? 1 : (cmp < 0 ? 2 : 0);
+  });
 }
 
 // Big slabs between the layout the kernels use -- word j of coefficient i at j*n + i -- and rows of W words per coefficient (i*W + j),
@@ -453,16 +481,16 @@ __global__ __launch_bounds__(256) void bridge_big_addsub(BigAddSubArgs k) {
 // chat[poly][d][i] <- chat[poly][d][i] * scale[d] mod p_d, for every coefficient (only == nullptr) or for the groups of 64 coefficients that
 // hold a non-zero entry of `only`: puts the CRT weights of the one-product tail on a raw slab (gpq_relin_tail_overwriting), or takes them
 // off again for the groups its exact fallback re-runs with the kernels that read raw residues.
-struct LimbScaleArgs { const LimbTab *tabs; uint64_t *chat; const uint64_t *scale; const unsigned char *only; unsigned dim, logn; };
+struct LimbScaleArgs { const LimbTab *tabs; uint64_t *chat; const uint64_t *scale; const unsigned char *only; unsigned dim, logn; FlagScope scope; };
 __global__ __launch_bounds__(256) void bridge_limb_scale(LimbScaleArgs a) {
-  const unsigned i = blockIdx.x * 256 + threadIdx.x;              // blockDim 256 = four groups of 64
-  if (i >= (1u << a.logn)) return;
-  if (a.only && !__builtin_amdgcn_ballot_w64(a.only[((size_t)blockIdx.y << a.logn) + i] != 0)) return;
-  uint64_t *__restrict__ p = a.chat + ((size_t)blockIdx.y * a.dim << a.logn) + i;
+  scoped_or_grid(a.scope, a.logn, 256, [&](unsigned poly, unsigned i) {     // a wave = one group of 64 either way
+  if (a.only && !__builtin_amdgcn_ballot_w64(a.only[((size_t)poly << a.logn) + i] != 0)) return;
+  uint64_t *__restrict__ p = a.chat + ((size_t)poly * a.dim << a.logn) + i;
   for (unsigned d = 0; d < a.dim; ++d) {
     const PrimeK k = a.tabs[d].k;
     p[(size_t)d << a.logn] = mulmod_canon(p[(size_t)d << a.logn], a.scale[d], k);
   }
+  });
 }
 
 // ---------------------------------------------------------------------------

@@ -408,6 +408,8 @@ struct RelinFrontArgs {
   unsigned only_writes_flags;   // with `only`: write flags / amb for the groups it re-runs after all (behind the one-product tail nothing else has)
   unsigned prescaled;        // the limbs below dimP already hold y_d = chat_d * phat_invmp_d (the key switch's inverse pass scaled them: ScaledInverse)
   unsigned wscaled;          // ... and the limbs above hold chat_j * w_j, bfrag / pk / tkp are the w-scaled tables: yq_j = x'_j - (r w_j mod p_j)
+  FlagScope scope;           // with `only`: the launch that wrote it (bridge_stream.hpp); the grid is then scope.waves / 4 workgroups, so that
+                             // wave w of this launch walks the groups of the producer's wave w
 };
 
 #ifndef GPQ_FRONT_OCC
@@ -416,6 +418,11 @@ struct RelinFrontArgs {
 template <int KS>
 __global__ __launch_bounds__(256, (KS <= 4 ? GPQ_FRONT_OCC : 2)) void bridge_relin_front_mfma(RelinFrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (a.scope.wave_any) {                                  // nothing flagged by the four producer waves this workgroup stands for: done (uniform)
+    unsigned flagged = 0;
+    for (unsigned k = 0; k < 4; ++k) if (blockIdx.x * 4 + k < a.scope.waves) flagged |= a.scope.wave_any[blockIdx.x * 4 + k];
+    if (!flagged) return;
+  }
   v4i *Bl = reinterpret_cast<v4i *>(smem);
   const unsigned nB = a.NT * KS * 64;
   uint64_t *lkl = reinterpret_cast<uint64_t *>(smem + (size_t)nB * 16);                 // 8 KS words
@@ -445,7 +452,8 @@ __global__ __launch_bounds__(256, (KS <= 4 ? GPQ_FRONT_OCC : 2)) void bridge_rel
   const unsigned g0 = blockIdx.x * 4 + wave, gstep = gridDim.x * 4;
   const bool masked = a.only != nullptr;
   if (!masked && g0 < a.total_groups) load_raw(g0);
-  for (unsigned g = g0; g < a.total_groups; g += gstep) {
+  const bool idle = a.scope.wave_any && (g0 >= a.scope.waves || !a.scope.wave_any[g0]);      // the producer's wave g0 flagged nothing
+  for (unsigned g = idle ? a.total_groups : g0; g < a.total_groups; g += gstep) {
     const unsigned poly = g / a.groups_per_poly, coef0 = (g % a.groups_per_poly) << 6;
     if (masked) {
       if (!__builtin_amdgcn_ballot_w64(a.only[((size_t)poly << a.logn) + coef0 + lane] != 0)) continue;

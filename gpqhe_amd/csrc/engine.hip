@@ -375,7 +375,7 @@ namespace {
 static const char *const kKernelNames[GPQ_K_COUNT] = {"strided_fwd", "strided_inv", "contig_fwd", "contig_inv",
                                                       "tensor_mid", "keyswitch_mid", "pointwise", "small_ntt", "reference_redo",
                                                       "bridge_decompose", "bridge_reconstruct", "bridge_relin_front", "bridge_relin_tail_fused", "bridge_exact_paths", "bridge_rescale",
-                                                      "bridge_relin_tail_direct"};
+                                                      "bridge_relin_tail_direct", "bridge_crt_decompose", "bridge_tail_stream"};
 
 int check_shape(const gpq_ctx *c, unsigned dim, unsigned batch, const char *who) {
   if (!c) return gpq_fail(GPQ_ERR_INVALID, "%s: null context", who);

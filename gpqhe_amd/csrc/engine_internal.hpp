@@ -12,7 +12,9 @@ enum { GPQ_K_STRIDED_FWD = 0, GPQ_K_STRIDED_INV, GPQ_K_CONTIG_FWD, GPQ_K_CONTIG_
        GPQ_K_KEYSWITCH_MID, GPQ_K_POINTWISE, GPQ_K_SMALL, GPQ_K_REFERENCE,
        // the MPI <-> RNS bridge (bridge.hip): rns_decompose, the CRT fast paths, the relinearisation front, its one-pass form, the exact /
        // masked kernels (bridge_reconstruct, bridge_roundfix, bridge_addround, bridge_exactdiv), he_rs
-       GPQ_K_DECOMPOSE, GPQ_K_RECONSTRUCT, GPQ_K_RELIN_FRONT, GPQ_K_RELIN_TAIL_FUSED, GPQ_K_BRIDGE_EXACT, GPQ_K_RESCALE, GPQ_K_RELIN_TAIL_DIRECT, GPQ_K_COUNT };
+       GPQ_K_DECOMPOSE, GPQ_K_RECONSTRUCT, GPQ_K_RELIN_FRONT, GPQ_K_RELIN_TAIL_FUSED, GPQ_K_BRIDGE_EXACT, GPQ_K_RESCALE, GPQ_K_RELIN_TAIL_DIRECT,
+       // bridge_stream.hpp: CRT(d2hat) -> rns_decompose in one kernel; the one-product tail with its addend's CRT in the same kernel
+       GPQ_K_CRT_DECOMPOSE, GPQ_K_TAIL_STREAM, GPQ_K_COUNT };
 
 // Constant matrix of the matrix-core CRT fast path for one basis and result width WL (bridge_mfma.hpp)
 struct gpq_recon_mfma {
@@ -60,6 +62,7 @@ struct gpq_relin_tables {
   // makes the key switch deliver CRT-weighted limbs (owned by the basis), the weights and their inverses for bridge_limb_scale
   bool direct_tried = false;
   gpq_recon_mfma direct;
+  std::map<unsigned, gpq_recon_mfma> direct_padded;   // the same matrix zero-padded to KS k steps (bridge_stream.hpp's instantiations)
   const gpq::LimbTab *d_tabs_direct = nullptr;
   uint64_t *d_scale = nullptr, *d_unscale = nullptr;
 };
@@ -92,6 +95,9 @@ struct gpq_ctx {
   unsigned char *d_redo = nullptr;    // per-coefficient "redo exactly" flags of the fast CRT path
   size_t redo_cap = 0;
   std::vector<void *> retired;        // outgrown d_redo buffers: a HIP graph captured earlier may still write them, so they live as long as the context
+  unsigned *d_wave_any = nullptr;     // one word per wave of the last bridge_stream.hpp launch: did it flag a coefficient (FlagScope)
+  unsigned debug_force_redo = 0;      // tests (gpq_debug_force_redo)
+  bool stream_bridge = true;          // gpq_he_mul / gpq_he_swk: bridge_stream.hpp's fused streaming kernels (gpq_set_stream_bridge(ctx, 0): round 3's separate kernels)
   bool exact_crt = false;             // force the exact CRT kernel (tests)
   bool prescale = true;               // gpq_he_mul / gpq_he_swk: inverse passes write limbs pre-multiplied by (P/p_d)^-1 for the CRT kernels (gpq_set_prescale)
   bool prescale_upper = true;         // ... and the limbs above P by w_j for the relinearisation front

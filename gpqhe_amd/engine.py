@@ -116,12 +116,26 @@ class PolyContext:
         _native.check(self.lib.gpq_set_bridge_mfma(self.h, 1 if on else 0), "gpq_set_bridge_mfma")
 
     def set_fused_tail(self, on):
-        """relinearisation tail in one pass per coefficient (default) or as front + CRT kernels; both exact, the tests compare them"""
+        """with set_prescale(2): relinearisation tail in one pass per coefficient (1) or as front + CRT kernels (0, the default: the
+        one-pass form measured 2 % slower); both exact, the tests compare them"""
         _native.check(self.lib.gpq_set_fused_tail(self.h, 1 if on else 0), "gpq_set_fused_tail")
 
-    def set_prescale(self, on):
-        """he_mul / he_swk: inverse transforms write limbs pre-multiplied by the CRT weights (default) or not; both exact"""
-        _native.check(self.lib.gpq_set_prescale(self.h, int(on)), "gpq_set_prescale")      # 0 / 1 / 2 (True = 1)
+    PRESCALE_DEFAULT = 3
+
+    def set_prescale(self, mode):
+        """he_mul / he_swk: what the inverse transforms pre-multiply for the kernels behind them -- 3 (default, also True): the weights of the
+        key switch's whole basis, the relinearisation tail is one product; 2: per-basis CRT weights + w_j for the relinearisation front;
+        1: per-basis CRT weights; 0 / False: nothing.  All exact; the tests compare them."""
+        mode = self.PRESCALE_DEFAULT if mode is True else int(mode)
+        _native.check(self.lib.gpq_set_prescale(self.h, mode), "gpq_set_prescale")
+
+    def set_stream_bridge(self, on):
+        """he_mul / he_swk: the fused streaming bridge kernels (default) or round 3's separate kernels; same words"""
+        _native.check(self.lib.gpq_set_stream_bridge(self.h, 1 if on else 0), "gpq_set_stream_bridge")
+
+    def debug_force_redo(self, every):
+        """tests: the streaming bridge kernels also flag every coefficient whose index is a multiple of `every` (0: off)"""
+        _native.check(self.lib.gpq_debug_force_redo(self.h, int(every)), "gpq_debug_force_redo")
 
     def set_exact_crt(self, on):
         _native.check(self.lib.gpq_set_exact_crt(self.h, 1 if on else 0), "gpq_set_exact_crt")

@@ -201,7 +201,13 @@ int gpq_rns_reconstruct(gpq_ctx *ctx, uint64_t *big, unsigned Wout, const uint64
  * (rare) coefficients whose rounding it cannot decide with the exact full-width kernel; this forces the
  * exact kernel for everything (used by the tests to cross-check the two). */
 int gpq_set_exact_crt(gpq_ctx *ctx, int on);
-/* The tail of he_relin / he_swk as two kernels with Q's residues in memory between them (0, default) or in one pass per coefficient (1:
+/* gpq_he_mul / gpq_he_swk: 1 (default) = the bridge as streaming kernels (gpqhe_amd/csrc/bridge_stream.hpp): poly_rns2mpi(d2) -> rns_decompose
+ * (src/he-mult.c:140, :59) in one kernel, and the relinearisation tail (:67-77) as one product that makes its addend d0 / d1 (:139, :141) from the
+ * limbs on the spot -- d0, d1, d2 never exist as words; 0 = round 3's separate CRT, decompose and tail kernels.  Same words (the tests run both). */
+int gpq_set_stream_bridge(gpq_ctx *ctx, int on);
+/* Tests: the streaming kernels also flag every coefficient whose index is a multiple of `every` for the exact kernels behind them (0 = off). */
+int gpq_debug_force_redo(gpq_ctx *ctx, unsigned every);
+/* With gpq_set_prescale(ctx, 2): the tail of he_relin / he_swk as two kernels with Q's residues in memory between them (0, default) or in one pass per coefficient (1:
  * measured 2 % slower on the whole he_mul -- both forms are bound by integer VALU work); same results. */
 int gpq_set_fused_tail(gpq_ctx *ctx, int on);
 /* gpq_he_mul / gpq_he_swk: the inverse transforms hand the kernels that follow limbs already multiplied by their CRT weights -- 3 (default): the key

@@ -10,4 +10,6 @@ if os.environ.get("MPI_FUSED"):
     ctx.set_fused_tail(os.environ["MPI_FUSED"] == "1")
 if os.environ.get("MPI_PRESCALE"):
     ctx.set_prescale(int(os.environ["MPI_PRESCALE"]))
+if os.environ.get("MPI_STREAM"):
+    ctx.set_stream_bridge(os.environ["MPI_STREAM"] == "1")
 print(he_mul_mpi_rate(torch, gpqhe_amd, ctx, int(os.environ.get("MPI_BATCH", "64")), iters=int(os.environ.get("MPI_ITERS", "6"))))
