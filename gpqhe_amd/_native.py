@@ -33,6 +33,7 @@ SIGNATURES = {
     "gpq_copy": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "gpq_stream_sync": (C.c_int, [vp]),
     "gpq_device_count": (C.c_int, []),
+    "gpq_probe_stream": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint, vp]),
     "gpq_set_device": (C.c_int, [C.c_int]),
     "gpq_stream_create": (C.c_int, [C.POINTER(vp)]),
     "gpq_stream_destroy": (C.c_int, [vp]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "gpq_set_exact_crt": (C.c_int, [vp, C.c_int]),
     "gpq_set_stream_bridge": (C.c_int, [vp, C.c_int]),
     "gpq_debug_force_redo": (C.c_int, [vp, C.c_uint]),
+    "gpq_set_lazy_decompose": (C.c_int, [vp, C.c_int]),
     "gpq_set_fused_tail": (C.c_int, [vp, C.c_int]),
     "gpq_big_transpose": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_int, vp]),
     "gpq_big_addsub": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_int, vp]),

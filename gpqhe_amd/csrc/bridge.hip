@@ -215,10 +215,11 @@ void balanced_digits(const uint64_t *words, size_t nwords, int8_t *out, size_t n
 // plus the fixed-point columns F = sum_d y_d floor(2^104 / p_d).  For a CRT, weight_d = P/p_d and Pw = P (get_recon_mfma); for the
 // one-product relinearisation tail, weight_d = floor(Pi' 2^104 / p_d) and Pw = Pi' 2^104 (get_tail_direct).
 int build_recon_mfma(gpq_ctx *c, const std::vector<uint64_t> &primes, const std::vector<uint64_t> &weight_inv, const std::vector<Big> &weight,
-                     const Big &Pw, int WL, gpq_recon_mfma *tp, unsigned KSpad = 0) {
+                     const Big &Pw, int WL, gpq_recon_mfma *tp, unsigned KSpad = 0, unsigned fcol0 = 0) {
   gpq_recon_mfma &t = *tp;
   const unsigned dim = (unsigned)primes.size(), NT = (8 * WL + 14 + 31) / 32, ncol = 32 * NT;
   t.KS = std::max((dim + 3) / 4, KSpad);                 // (KSpad: zero rows up to the k steps a bridge_stream.hpp instantiation runs)
+  if (!fcol0) fcol0 = 8u * WL;                           // first of the 14 fixed-point columns (the addend's rows inside the tail's product: 144)
   t.lds_bytes = (size_t)t.KS * NT * 1024 + (size_t)t.KS * 64;
   if (t.lds_bytes <= 156 * 1024) {
     std::vector<int8_t> bf((size_t)t.KS * NT * 1024, 0);
@@ -245,7 +246,7 @@ int build_recon_mfma(gpq_ctx *c, const std::vector<uint64_t> &primes, const std:
         for (unsigned col = 0; col < ncol; ++col) {
           int8_t v = 0;
           if (col < 8u * WL) { if (col >= i) v = beta[col - i]; }
-          else { const unsigned m = col - 8u * WL; if (m >= i && m - i < 8 && m < 14) v = phi[m - i]; }
+          else if (col >= fcol0) { const unsigned m = col - fcol0; if (m >= i && m - i < 8 && m < 14) v = phi[m - i]; }
           if (!v) continue;
           const unsigned nt = col / 32, lane = 32 * h + col % 32;
           bf[(((size_t)s * NT + nt) * 64 + lane) * 16 + tt] = v;
@@ -302,6 +303,32 @@ int get_recon_mfma(gpq_ctx *c, gpq_bridge_basis *b, int WL, gpq_recon_mfma **out
     weight[d].assign(b->h_phat.begin() + (size_t)d * b->WP, b->h_phat.begin() + (size_t)(d + 1) * b->WP);
   }
   if (int rc = build_recon_mfma(c, primes, b->h_phat_inv, weight, b->h_P, WL, &t, KSpad)) return rc;
+  *out = &(b->mfma[key] = t);
+  return GPQ_OK;
+}
+
+// Rows that put poly_rns2mpi(dhat) INSIDE the one-product relinearisation tail (bridge_stream.hpp, DCRT): the CRT over basis b with every
+// weight shifted up by the tail's 104 fraction bits -- weight_d = (P/p_d) 2^104, P_w = P 2^104, all modulo 2^1024 -- and the fixed-point
+// columns for its own multiple of P at 144 .. 157 (the tail's are 128 .. 141).  Padded to KSpad k steps.
+int get_addend_rows(gpq_ctx *c, gpq_bridge_basis *b, unsigned KSpad, gpq_recon_mfma **out) {
+  const int key = 100016 + 1000 * (int)KSpad;
+  auto it = b->mfma.find(key);
+  if (it != b->mfma.end()) { *out = &it->second; return GPQ_OK; }
+  auto shifted = [](const Big &v) {                      // v * 2^104
+    Big r = v;
+    r.insert(r.begin(), 0);
+    mul_small(r, 1ull << 40);
+    return r;
+  };
+  std::vector<uint64_t> primes(b->dim);
+  std::vector<Big> weight(b->dim);
+  for (unsigned d = 0; d < b->dim; ++d) {
+    primes[d] = c->p[b->first + d];
+    weight[d] = shifted(Big(b->h_phat.begin() + (size_t)d * b->WP, b->h_phat.begin() + (size_t)(d + 1) * b->WP));
+    weight[d].resize(weight[d].size() < 16 ? 16 : weight[d].size(), 0);
+  }
+  gpq_recon_mfma t;
+  if (int rc = build_recon_mfma(c, primes, b->h_phat_inv, weight, shifted(b->h_P), 16, &t, KSpad, 144)) return rc;
   *out = &(b->mfma[key] = t);
   return GPQ_OK;
 }
@@ -483,12 +510,13 @@ int launch_decompose_mfma_t(const DecomposeMfmaArgs &a, size_t lds, hipStream_t 
   return GPQ_OK;
 }
 
-int launch_decompose(gpq_ctx *c, uint64_t *slab, const BigSources &big, unsigned W, unsigned limb0, unsigned dim, unsigned batch, hipStream_t s);
-int launch_decompose(gpq_ctx *c, uint64_t *slab, const uint64_t *big, unsigned W, unsigned limb0, unsigned dim, unsigned batch, hipStream_t s) {
-  return launch_decompose(c, slab, one_source(big), W, limb0, dim, batch, s);
+int launch_decompose(gpq_ctx *c, uint64_t *slab, const BigSources &big, unsigned W, unsigned limb0, unsigned dim, unsigned batch, hipStream_t s, bool lazy = false);
+int launch_decompose(gpq_ctx *c, uint64_t *slab, const uint64_t *big, unsigned W, unsigned limb0, unsigned dim, unsigned batch, hipStream_t s, bool lazy = false) {
+  return launch_decompose(c, slab, one_source(big), W, limb0, dim, batch, s, lazy);
 }
-// `batch` polynomials in all, `big.per` from each source slab in turn, written one after another to `slab`
-int launch_decompose(gpq_ctx *c, uint64_t *slab, const BigSources &big, unsigned W, unsigned limb0, unsigned dim, unsigned batch, hipStream_t s) {
+// `batch` polynomials in all, `big.per` from each source slab in turn, written one after another to `slab`.  lazy: the residues may stay in
+// (0, 3p) (matrix-core kernel only; for slabs that go straight into a two-pass forward transform: gpq_he_mul's own decompositions)
+int launch_decompose(gpq_ctx *c, uint64_t *slab, const BigSources &big, unsigned W, unsigned limb0, unsigned dim, unsigned batch, hipStream_t s, bool lazy) {
   ProfScope prof(c, GPQ_K_DECOMPOSE, s);
   if (c->bridge_mfma && c->logn >= 6 && W <= 32 && dim >= 4) {
     gpq_decomp_mfma *t;
@@ -496,7 +524,7 @@ int launch_decompose(gpq_ctx *c, uint64_t *slab, const BigSources &big, unsigned
     if (rc) return rc;
     if (t->d_bfrag) {
       const unsigned gpp = c->n >> 6;
-      DecomposeMfmaArgs m{big, slab, (const v4i *)t->d_bfrag, t->d_pk, W, dim, c->logn, t->NT, gpp, gpp * batch};
+      DecomposeMfmaArgs m{big, slab, (const v4i *)t->d_bfrag, t->d_pk, W, dim, c->logn, t->NT, gpp, gpp * batch, lazy ? 1u : 0u};
       switch (t->KS) {
         case 1: return launch_decompose_mfma_t<1>(m, t->lds_bytes, s);
         case 2: return launch_decompose_mfma_t<2>(m, t->lds_bytes, s);
@@ -586,7 +614,7 @@ int crt_decompose_stream(gpq_ctx *c, gpq_bridge_basis *bA, uint64_t *out, const 
   const size_t slab_bytes = ((size_t)polys * dimA << c->logn) * 8;
   if (slab_bytes >= 0xfffff000ull) return GPQ_OK;
   CrtDecomposeArgs a{slab, slab_bytes, out, (const v4i *)tr->d_bfrag, tr->d_kc, tr->d_pm, (const v4i *)td->d_bfrag, td->d_pk, c->d_redo, c->d_wave_any,
-                     dimA, dimB, td->NT, c->logn, logq, W, groups, c->debug_force_redo};
+                     dimA, dimB, td->NT, c->logn, logq, W, groups, c->debug_force_redo, (c->lazy_decompose && c->logn > 12) ? 1u : 0u};
   {
     ProfScope prof(c, GPQ_K_CRT_DECOMPOSE, s);
     if (WL == 7) rc = launch_crt_decompose_t<7, 4, 2, 4>(a, lds, blocks, s);
@@ -989,11 +1017,11 @@ int launch_relin_front(const gpq_ctx *c, unsigned KS, const RelinFrontArgs &f, s
 // them when the streaming kernel does not cover the shape).
 struct TailD { const uint64_t *hat; gpq_bridge_basis *bA; unsigned dimA; uint64_t *scratch; };
 
-template <int KST, int WLD, int KSD, bool DCRT, int R>
+template <int KST, int KSD, bool DCRT, int R>
 int launch_tail_stream_t(const TailStreamArgs &a, size_t lds, unsigned blocks, hipStream_t s) {
   static LdsRaised raised;
-  if (int rc = raised.raise(reinterpret_cast<const void *>(&bridge_tail_stream<KST, WLD, KSD, DCRT, R>), (int)kStreamLdsMax)) return rc;
-  hipLaunchKernelGGL((bridge_tail_stream<KST, WLD, KSD, DCRT, R>), dim3(blocks), dim3(512), lds, s, a);
+  if (int rc = raised.raise(reinterpret_cast<const void *>(&bridge_tail_stream<KST, KSD, DCRT, R>), (int)kStreamLdsMax)) return rc;
+  hipLaunchKernelGGL((bridge_tail_stream<KST, KSD, DCRT, R>), dim3(blocks), dim3(512), lds, s, a);
   return GPQ_OK;
 }
 
@@ -1031,11 +1059,11 @@ int tail_stream(gpq_ctx *c, gpq_relin_tables *rt, Two<uint64_t> out, const uint6
   *done = false;
   const unsigned need = (logql + 63) / 64;
   if (!c->stream_bridge || W > 14 || W < need || logql > 896) return GPQ_OK;
-  int KST, WLD = 0, KSD = 0;
+  int KST, KSD = 0;
   if (dh) {
     if (!stream_fast_ok(c, dh->bA, logql)) return GPQ_OK;
-    if (dimB <= 32 && dh->dimA <= 16 && need <= 7) { KST = 8; WLD = 7; KSD = 4; }
-    else if (dimB <= 48 && dh->dimA <= 32 && need <= 14) { KST = 12; WLD = 14; KSD = 8; }
+    if (dimB <= 32 && dh->dimA <= 16) { KST = 8; KSD = 4; }
+    else if (dimB <= 48 && dh->dimA <= 32) { KST = 12; KSD = 8; }
     else return GPQ_OK;
   } else {
     if (dimB <= 24) KST = 6; else if (dimB <= 48) KST = 12; else return GPQ_OK;
@@ -1043,10 +1071,9 @@ int tail_stream(gpq_ctx *c, gpq_relin_tables *rt, Two<uint64_t> out, const uint6
   gpq_recon_mfma *tt, *td = nullptr;
   int rc;
   if ((rc = get_tail_direct_padded(c, dimP, dimB, rt, KST, &tt))) return rc;
-  if (dh && (rc = get_recon_mfma(c, dh->bA, WLD, &td, KSD))) return rc;
+  if (dh && (rc = get_addend_rows(c, dh->bA, KSD, &td))) return rc;
   if (!tt->d_bfrag || tt->KS != (unsigned)KST || (dh && (!td->d_bfrag || td->KS != (unsigned)KSD))) return GPQ_OK;
-  const unsigned NTD = dh ? (8 * WLD + 14 + 31) / 32 : 0;
-  const size_t lds = (size_t)KST * 5 * 1024 + (size_t)KSD * NTD * 1024 + (size_t)65 * 16 * 8 + (size_t)65 * WLD * 8;
+  const size_t lds = (size_t)(KST + KSD) * 5 * 1024 + (size_t)2 * 65 * 16 * 8;
   if (lds > kStreamLdsMax) return GPQ_OK;
   if ((rc = ensure_redo(c, (size_t)polys << c->logn, s)) || (rc = ensure_wave_any(c, s))) return rc;
   const unsigned groups = (c->n >> 6) * polys, blocks = stream_blocks(groups);
@@ -1056,10 +1083,10 @@ int tail_stream(gpq_ctx *c, gpq_relin_tables *rt, Two<uint64_t> out, const uint6
                    dh ? (const v4i *)td->d_bfrag : nullptr, dh ? td->d_kc : nullptr, dh ? td->d_pm : nullptr,
                    c->d_redo, tie, amb, c->d_wave_any, dimB, dh ? dh->dimA : 0u, c->logn, W, logql, groups, c->debug_force_redo};
   ProfScope prof(c, GPQ_K_TAIL_STREAM, s);
-  if (dh && KST == 8) rc = launch_tail_stream_t<8, 7, 4, true, 4>(a, lds, blocks, s);
-  else if (dh) rc = launch_tail_stream_t<12, 14, 8, true, 4>(a, lds, blocks, s);
-  else if (KST == 6) rc = launch_tail_stream_t<6, 7, 4, false, 3>(a, lds, blocks, s);
-  else rc = launch_tail_stream_t<12, 14, 8, false, 4>(a, lds, blocks, s);
+  if (dh && KST == 8) rc = launch_tail_stream_t<8, 4, true, 6>(a, lds, blocks, s);
+  else if (dh) rc = launch_tail_stream_t<12, 8, true, 5>(a, lds, blocks, s);
+  else if (KST == 6) rc = launch_tail_stream_t<6, 0, false, 3>(a, lds, blocks, s);
+  else rc = launch_tail_stream_t<12, 0, false, 4>(a, lds, blocks, s);
   if (rc) return rc;
   *scope = FlagScope{c->d_wave_any, blocks * kStreamWaves, groups};
   *done = true;
@@ -1293,7 +1320,7 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
       StageRange stage(square ? "gpq_he_mul: rns_decompose x2 (squaring)" : "gpq_he_mul: rns_decompose x4");
       const unsigned nin = square ? 2 : 4;                                                   // :117-120, one launch: h[0..3] are adjacent
       BigSources src{{in[0] + k0 * bigpoly, in[1] + k0 * bigpoly, in[square ? 0 : 2] + k0 * bigpoly, in[square ? 1 : 3] + k0 * bigpoly}, polys};
-      if ((rc = launch_decompose(c, h[0], src, W, 0, dimA, nin * polys, s))) return rc;
+      if ((rc = launch_decompose(c, h[0], src, W, 0, dimA, nin * polys, s, c->lazy_decompose && c->logn > 12))) return rc;
     }
     const bool pre = can_prescale(c);      // the inverse passes hand the CRT kernels limbs already multiplied by (P/p_d)^-1
     const LimbTab *tabsA = nullptr, *tabsP = nullptr;
@@ -1323,7 +1350,7 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
         if (rc) return rc;
       }
       StageRange stage("gpq_he_mul: he_relin rns_decompose d2");
-      if ((rc = launch_decompose(c, d2hat, d2, W, 0, dimB, polys, s))) return rc;                                  // :59
+      if ((rc = launch_decompose(c, d2hat, d2, W, 0, dimB, polys, s, c->lazy_decompose && c->logn > 12))) return rc;          // :59
     }
     // he_relin, :40-85
     {
@@ -1362,7 +1389,7 @@ extern "C" int gpq_he_swk(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
     const unsigned polys = batch - k0 < m ? batch - k0 : m;
     const size_t pb = (size_t)polys * dimB * n;
     uint64_t *d1hat = sB, *c0hat = sB + pb, *c1hat = sB + 2 * pb;
-    if ((rc = launch_decompose(c, d1hat, d1 + k0 * bigpoly, W, 0, dimB, polys, s))) return rc;                     // :60
+    if ((rc = launch_decompose(c, d1hat, d1 + k0 * bigpoly, W, 0, dimB, polys, s, c->lazy_decompose && c->logn > 12))) return rc;   // :60
     const LimbTab *tabsP = nullptr;
     int tail_mode = 0;
     if ((rc = tail_prescale_mode(c, dimP, dimB, &tabsP, &tail_mode))) return rc;
@@ -1462,6 +1489,14 @@ extern "C" int gpq_set_prescale(gpq_ctx *c, int on) {      // 0: off, 1: the CRT
 extern "C" int gpq_set_stream_bridge(gpq_ctx *c, int on) {
   if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_stream_bridge: null context");
   c->stream_bridge = on != 0;
+  return GPQ_OK;
+}
+
+// gpq_he_mul: its own rns_decompose launches (src/he-mult.c:117-120, :59) may leave residues in (0, 3p) for the forward transforms that read them
+// (default on; canonical with 0).  Same results: the transforms reduce lazily anyway.
+extern "C" int gpq_set_lazy_decompose(gpq_ctx *c, int on) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_lazy_decompose: null context");
+  c->lazy_decompose = on != 0;
   return GPQ_OK;
 }
 

@@ -75,6 +75,7 @@ struct DecomposeMfmaArgs {
   const uint64_t *pk;        // [4 NT][3]: p_j, Kq_j = 2^50 + ((K_j - 2^50) mod p_j), c_j   (zeros for padding primes)
   unsigned W, dim, logn, NT;               // NT: row tiles of 4 primes
   unsigned groups_per_poly, total_groups;  // groups of 64 coefficients
+  unsigned lazy;                           // residues out in (0, 3p) -- what the forward transform behind gpq_he_mul's decompositions accepts -- not canonical
 };
 
 template <int KS>
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void bridge_decompose_mfma(DecomposeMfmaArg
           // is followed by its own vmcnt(0) and the 16 loads of a group would run one after the other
           const unsigned w = 4 * s + 2 * h + e, wc = w < a.W ? w : a.W - 1;
           const uint64_t m = w + 1 < a.W ? 0x8080808080808080ull : 0x0080808080808080ull;
-          const uint64_t v = src[((size_t)wc << a.logn) + 32 * t];
+          const uint64_t v = __builtin_nontemporal_load(&src[((size_t)wc << a.logn) + 32 * t]);
           x[e] = (v ^ m) & (w < a.W ? ~0ull : 0ull);
         }
         X[t][s] = v4i{(int)(uint32_t)x[0], (int)(uint32_t)(x[0] >> 32), (int)(uint32_t)x[1], (int)(uint32_t)(x[1] >> 32)};
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void bridge_decompose_mfma(DecomposeMfmaArg
         const uint64_t Hl = (uint64_t)H & 0x7ffffffu;
         uint64_t v = (Hl << 32) + (uint64_t)L + kq;
         v = (uint64_t)((int64_t)(-c) * Hh + (int64_t)v);               // in (0, 3p)
-        if (j < a.dim) dst[(size_t)j << a.logn] = canon_fold(v, p, (uint32_t)c);
+        if (j < a.dim) __builtin_nontemporal_store(a.lazy ? v : canon_fold(v, p, (uint32_t)c), &dst[(size_t)j << a.logn]);
       }
     }
   }

@@ -20,6 +20,16 @@
 #pragma once
 #include "bridge_mfma.hpp"
 
+#ifndef GPQ_STREAM_LOAD_AUX
+#define GPQ_STREAM_LOAD_AUX 2  /* cache policy of the streamed loads: 0 default, 2 = nt (every residue / word is read once): measured -4 % on the tail kernel */
+#endif
+#ifndef GPQ_STREAM_STORE_AUX
+#define GPQ_STREAM_STORE_AUX 2 /* ... and of the streamed stores (results the next kernel reads from HBM anyway: the slabs are far larger than the caches): another -8 % */
+#endif
+#ifndef GPQ_STREAM_PROBE
+#define GPQ_STREAM_PROBE 0     /* 1: no MFMA; 2: also no column folding (timing probes of where the streaming kernels' time goes; wrong results) */
+#endif
+
 namespace gpq {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -47,41 +57,57 @@ __device__ __forceinline__ BufRsrc window_rsrc(const void *p) { return slab_rsrc
 // Limbs past the polynomial's last read whatever follows it in the slab (the next polynomial, or zeros past the end): their rows of
 // the constant matrix are zero.
 __device__ __forceinline__ void fetch_step(StepRegs &x, BufRsrc rs, unsigned soff, unsigned sh, unsigned lane_off) {
-  x.lo = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, soff, 0);
-  x.hi = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, soff + (1u << sh), 0);
-}
-
-// one k step of a CRT product: NT row tiles x two coefficient tiles (`first`: the accumulators start at zero)
-template <int NT>
-__device__ __forceinline__ void crt_step(v16i (&acc)[2][NT], const StepRegs &x, const v4i *bl /* LDS: fragments of this step, + lane */, bool first) {
-  const v4i A0 = frag_even(x, 0x80808080u), A1 = frag_odd(x, 0x80808080u);
-#pragma unroll
-  for (int q = 0; q < NT; ++q) {
-    const v4i b = bl[q * 64];
-    if (first) {
-      v16i z;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) z[e] = 0;
-      acc[0][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A0, z, 0, 0, 0);
-      acc[1][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A1, z, 0, 0, 0);
-    } else {
-      acc[0][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A0, acc[0][q], 0, 0, 0);
-      acc[1][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A1, acc[1][q], 0, 0, 0);
-    }
-  }
+  x.lo = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, soff, GPQ_STREAM_LOAD_AUX);
+  x.hi = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, soff + (1u << sh), GPQ_STREAM_LOAD_AUX);
 }
 
 // The k steps of a product, statically unrolled over a ring of R slots: step s lives in slot (S0 + s) % R and the slot is refilled --
 // fetch(slot, S0 + s + R): the stream position R further on, in this product, the next one or the next group -- as soon as the step has
-// been turned into fragments.  A scheduling barrier per step keeps the compiler from lifting a whole group's fragment reads and offset
-// arithmetic to the top (spills); a runtime loop over rounds would bring back register copies of the ring behind a vmcnt wait.
+// been turned into fragments.  The constant fragments of step s + 1 are read from LDS while step s multiplies (two fragment sets: a
+// ds_read followed at once by its s_waitcnt and two MFMAs leaves the matrix pipe idle for the LDS latency four times per step).  A
+// scheduling barrier per step keeps the compiler from lifting a whole group's fragment reads and offset arithmetic to the top (spills);
+// a runtime loop over rounds would bring back register copies of the ring behind a vmcnt wait.
 template <int NT, int R, int KS, int S0, class Fetch>
-__device__ __forceinline__ void crt_steps(v16i (&acc)[2][NT], StepRegs (&ring)[R], const v4i *bl, Fetch fetch) {
+__device__ __forceinline__ void crt_steps(v16i (&acc)[2][NT], StepRegs (&ring)[R], const v4i *bl /* LDS: the product's fragments, + lane */, Fetch fetch) {
+  v4i bf[2][NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q) bf[0][q] = bl[q * 64];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const StepRegs x = ring[(S0 + s) % R];
     fetch(ring[(S0 + s) % R], S0 + s + R);
-    crt_step<NT>(acc, x, bl + (size_t)s * NT * 64, s == 0);
+    if (s + 1 < KS) {
+#pragma unroll
+      for (int q = 0; q < NT; ++q) bf[(s + 1) & 1][q] = bl[((size_t)(s + 1) * NT + q) * 64];
+    }
+    const v4i A0 = frag_even(x, 0x80808080u), A1 = frag_odd(x, 0x80808080u);
+#if GPQ_STREAM_PROBE >= 1    /* timing probe (wrong results): no matrix-core work, the fragments are folded into one accumulator register */
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      if (s == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[0][q][e] = 0; acc[1][q][e] = 0; }
+      }
+      acc[0][q][0] ^= A0[0] ^ A0[1] ^ A0[2] ^ A0[3] ^ bf[s & 1][q][0];
+      acc[1][q][0] ^= A1[0] ^ A1[1] ^ A1[2] ^ A1[3];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    continue;
+#endif
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const v4i b = bf[s & 1][q];
+      if (s == 0) {
+        v16i z;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) z[e] = 0;
+        acc[0][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A0, z, 0, 0, 0);
+        acc[1][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A1, z, 0, 0, 0);
+      } else {
+        acc[0][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A0, acc[0][q], 0, 0, 0);
+        acc[1][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, A1, acc[1][q], 0, 0, 0);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -171,6 +197,73 @@ __device__ __forceinline__ void pair_from_load(v4u v, uint64_t &a, uint64_t &b) 
   b = ((uint64_t)hi[1] << 32) | lo[1];
 }
 
+// One row tile (4 primes) of the rns_decompose product over the fragments X of a group (bridge_decompose_mfma's arithmetic), split
+// in two so that callers can issue tile q + 1's MFMAs before the integer epilogue of tile q (the matrix pipe then works under the VALU).
+template <int KSD>
+__device__ __forceinline__ void decompose_tile_product(const v4i *dl /* LDS + lane */, unsigned q, const v4i (&X)[2][KSD], v16i &acc0, v16i &acc1) {
+#pragma unroll
+  for (int s = 0; s < KSD; ++s) {
+    const v4i cf = dl[((size_t)q * KSD + s) * 64];
+    if (s == 0) {
+      v16i z;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) z[e] = 0;
+      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[0][s], z, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[1][s], z, 0, 0, 0);
+    } else {
+      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[0][s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[1][s], acc1, 0, 0, 0);
+    }
+  }
+}
+// ... and its epilogue: x mod p_j for the primes j = 4q .. 4q+3, stored as limbs j, j+1 pairs (lane half h stores limb j + h for
+// coefficients 2r, 2r+1).  pk = [4 NT][3]: p_j, Kq_j, c_j (uniform reads).  out_off = (h << sh) + 16 r.
+// lazy: leave the residue in (0, 3p) -- what the forward transform that reads it accepts (ntt_kernels.hpp: its first stage takes x, y < 4p in
+// every butterfly class) -- instead of canonicalising it (7 of the ~39 VALU instructions per residue).
+__device__ __forceinline__ void decompose_tile_finish(const uint64_t *__restrict__ pk, unsigned q, const v16i &acc0, const v16i &acc1, BufRsrc rs_out,
+                                                      unsigned out_off, unsigned sh, unsigned h, unsigned dim, bool lazy) {
+  uint64_t res[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    int64_t L, H;
+    swap_halves(horner4(acc0[4 * w], acc0[4 * w + 1], acc0[4 * w + 2], acc0[4 * w + 3]),
+                horner4(acc1[4 * w], acc1[4 * w + 1], acc1[4 * w + 2], acc1[4 * w + 3]), L, H);
+    const unsigned j = 4 * q + w;
+    const uint64_t p = pk[3 * j], kq = pk[3 * j + 1];
+    const int c = (int)(uint32_t)pk[3 * j + 2];
+    const int Hh = (int)(H >> 27);
+    const uint64_t Hl = (uint64_t)H & 0x7ffffffu;
+    uint64_t v = (Hl << 32) + (uint64_t)L + kq;
+    v = (uint64_t)((int64_t)(-c) * Hh + (int64_t)v);               // in (0, 3p)
+    res[w] = lazy ? v : canon_fold(v, p, (uint32_t)c);
+  }
+#pragma unroll
+  for (int w = 0; w < 4; w += 2) {
+    const unsigned j = 4 * q + w;
+    const v4u o = pair_for_store(res[w], res[w + 1]);
+    if (j + h < dim) __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, out_off, j << sh, GPQ_STREAM_STORE_AUX);
+  }
+}
+// all NT row tiles of a group, software-pipelined by one
+template <int KSD>
+__device__ __forceinline__ void decompose_tiles(const v4i *dl, const uint64_t *__restrict__ pk, unsigned NT, const v4i (&X)[2][KSD], BufRsrc rs_out,
+                                                unsigned out_off, unsigned sh, unsigned h, unsigned dim, bool lazy) {
+  v16i pa0, pa1, pb0, pb1;
+  decompose_tile_product<KSD>(dl, 0, X, pa0, pa1);
+  for (unsigned q = 0; q < NT; q += 2) {
+    if (q + 1 < NT) decompose_tile_product<KSD>(dl, q + 1, X, pb0, pb1);
+    __builtin_amdgcn_sched_barrier(0);
+    decompose_tile_finish(pk, q, pa0, pa1, rs_out, out_off, sh, h, dim, lazy);
+    __builtin_amdgcn_sched_barrier(0);
+    if (q + 1 < NT) {
+      if (q + 2 < NT) decompose_tile_product<KSD>(dl, q + 2, X, pa0, pa1);
+      __builtin_amdgcn_sched_barrier(0);
+      decompose_tile_finish(pk, q + 1, pb0, pb1, rs_out, out_off, sh, h, dim, lazy);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // CRT(d2hat) -> rns_decompose  (src/he-mult.c:140 feeding :59): poly_rns2mpi's fast path on the limbs of the tensor stage, then the W
 // words of every coefficient -- still in the registers of the lane that finished it -- become the B fragments of bridge_decompose_mfma's
@@ -189,6 +282,7 @@ struct CrtDecomposeArgs {
   unsigned *wave_any;        // [waves of the launch]
   unsigned dimA, dimB, NTD, logn, logq, W, total_groups;
   unsigned force;            // tests: also flag every coefficient whose index is a multiple of it (the exact kernels must then give the same words)
+  unsigned lazy;             // residues out in (0, 3p) for the forward transform that follows (decompose_tile_finish)
 };
 
 template <int WL, int KS, int KSD, int R>
@@ -265,54 +359,20 @@ __global__ __launch_bounds__(512) void bridge_crt_decompose(CrtDecomposeArgs a) 
     }
     const BufRsrc rs_out = window_rsrc(a.out + ((size_t)poly * a.dimB << a.logn) + coef0);       // limb 0 of the polynomial at the group's first coefficient
     const unsigned out_off = (h << sh) + lane16;           // + limb j (uniform): lane half h stores limb j + h for coefficients 2r, 2r+1
-    for (unsigned q = 0; q < a.NTD; ++q) {
-      v16i acc0, acc1;
-#pragma unroll
-      for (int s = 0; s < KSD; ++s) {
-        const v4i cf = dl[((size_t)q * KSD + s) * 64];
-        if (s == 0) {
-          v16i z;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) z[e] = 0;
-          acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[0][s], z, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[1][s], z, 0, 0, 0);
-        } else {
-          acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[0][s], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[1][s], acc1, 0, 0, 0);
-        }
-      }
-      uint64_t res[4];
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {                      // prime j = 4q + w (bridge_decompose_mfma's epilogue)
-        int64_t L, H;
-        swap_halves(horner4(acc0[4 * w], acc0[4 * w + 1], acc0[4 * w + 2], acc0[4 * w + 3]),
-                    horner4(acc1[4 * w], acc1[4 * w + 1], acc1[4 * w + 2], acc1[4 * w + 3]), L, H);
-        const unsigned j = 4 * q + w;
-        const uint64_t p = a.pk[3 * j], kq = a.pk[3 * j + 1];
-        const int c = (int)(uint32_t)a.pk[3 * j + 2];
-        const int Hh = (int)(H >> 27);
-        const uint64_t Hl = (uint64_t)H & 0x7ffffffu;
-        uint64_t v = (Hl << 32) + (uint64_t)L + kq;
-        v = (uint64_t)((int64_t)(-c) * Hh + (int64_t)v);               // in (0, 3p)
-        res[w] = canon_fold(v, p, (uint32_t)c);
-      }
-#pragma unroll
-      for (int w = 0; w < 4; w += 2) {                   // limbs j, j+1
-        const unsigned j = 4 * q + w;
-        const v4u o = pair_for_store(res[w], res[w + 1]);
-        if (j + h < a.dimB) __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, out_off, j << sh, 0);
-      }
-    }
+    decompose_tiles<KSD>(dl, a.pk, a.NTD, X, rs_out, out_off, sh, h, a.dimB, a.lazy != 0);
   }
   if (lane == 0) a.wave_any[pw] = any;
 }
 
 // ---------------------------------------------------------------------------
 // The relinearisation tail (src/he-mult.c:67-77, src/he-automorphism.c:68-76) as ONE product (bridge_mfma.hpp, frac_bits = 104) with its
-// addend made on the spot: DCRT = the addend is poly_rns2mpi(d0hat | d1hat) (src/he-mult.c:139,141), whose CRT product runs in the same
-// wave after the tail's -- d0, d1 never reach memory as words; !DCRT = he_swk's addend, a big slab (or none), read 16 bytes per lane.
-//   T phase: 16-word columns of 2^104 x / P  ->  floor(x / P), the rounding bit, the window flags
-//   D phase: WLD-word columns of d mod 2^(64 WLD), its multiple of P_A from the F columns
+// addend inside: the 16-word columns are the fixed-point number 2^104 x / P, and
+//   DCRT   the addend is poly_rns2mpi(d0hat | d1hat) (src/he-mult.c:139,141): its limbs are MORE ROWS OF THE SAME PRODUCT, with the
+//          constants (P_A / p_d) 2^104 mod 2^1024 -- the columns then hold 2^104 (x / P + d): the fraction bits (x mod P) / P that mpi_rdiv
+//          rounds on are untouched (d's part is a multiple of 2^104), the bits above are floor(x / P) + d.  One accumulator set, one
+//          column folding, no quotient parked in registers while a second product runs; d0, d1 never reach memory as words.  The
+//          multiple of P_A that centring d takes off comes from 14 more fixed-point columns (144 .. 157, next to the tail's 128 .. 141);
+//   !DCRT  he_swk's addend, a big slab (or none), read 16 bytes per lane.
 //   out = smod(floor(x/P) + round + d, 2^logq)
 // ---------------------------------------------------------------------------
 struct TailStreamArgs {
@@ -322,50 +382,59 @@ struct TailStreamArgs {
   Two<const uint64_t> addend;// !DCRT: [polys][W][n] or null places
   Two<uint64_t> out;         // [polys][W][n]
   const v4i *tfrag;          // [KST][5][64]
-  const uint64_t *tkc;       // [18]
+  const uint64_t *tkc;       // [18]: Kf in the last two
   const uint64_t *tpm;       // [65][16]
-  const v4i *dfrag;          // [KSD][NTD][64]
-  const uint64_t *dkc;       // [WLD + 2]
-  const uint64_t *dpm;       // [65][WLD]
+  const v4i *dfrag;          // DCRT: [KSD][5][64]   (get_addend_rows)
+  const uint64_t *dkc;       // [18]
+  const uint64_t *dpm;       // [65][16]
   unsigned char *redo, *tie, *amb_clear;   // [polys][n]
   unsigned *wave_any;
   unsigned dimB, dimA, logn, W, logq, total_groups;
   unsigned force;            // tests: also flag every coefficient whose index is a multiple of it
 };
 
-template <int KST, int WLD, int KSD, bool DCRT, int R>
+constexpr int TAIL_DF_WORD = 18;     // the addend's fixed-point columns are words 18, 19 of the folded columns (the tail's own: 16, 17)
+
+template <int KST, int KSD, bool DCRT, int R>
 __global__ __launch_bounds__(512) void bridge_tail_stream(TailStreamArgs a) {
-  constexpr int WLT = 16, NTT = 5;
-  constexpr int NTD = (8 * WLD + 14 + 31) / 32;
+  constexpr int WL = 16, NT = 5;
   constexpr int NSTEP = KST + (DCRT ? KSD : 0);
   static_assert(NSTEP % R == 0 && R <= KST, "the ring must divide the steps of a group");
-  static_assert(WLD <= 14, "the quotient has 14 words");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  v4i *Tl = reinterpret_cast<v4i *>(smem);
-  v4i *Dl = Tl + KST * NTT * 64;
-  uint64_t *tpml = reinterpret_cast<uint64_t *>(Dl + (DCRT ? KSD * NTD * 64 : 0));
-  uint64_t *dpml = tpml + 65 * WLT;
-  for (unsigned i = threadIdx.x; i < (unsigned)(KST * NTT * 64); i += 512) Tl[i] = a.tfrag[i];
-  for (unsigned i = threadIdx.x; i < 65u * WLT; i += 512) tpml[i] = a.tpm[i];
+  v4i *Tl = reinterpret_cast<v4i *>(smem);                                   // [NSTEP][5][64]: the tail's rows, then the addend's
+  uint64_t *tpml = reinterpret_cast<uint64_t *>(Tl + NSTEP * NT * 64);
+  uint64_t *dpml = tpml + 65 * WL;
+  for (unsigned i = threadIdx.x; i < (unsigned)(KST * NT * 64); i += 512) Tl[i] = a.tfrag[i];
+  for (unsigned i = threadIdx.x; i < 65u * WL; i += 512) tpml[i] = a.tpm[i];
   if (DCRT) {
-    for (unsigned i = threadIdx.x; i < (unsigned)(KSD * NTD * 64); i += 512) Dl[i] = a.dfrag[i];
-    for (unsigned i = threadIdx.x; i < 65u * WLD; i += 512) dpml[i] = a.dpm[i];
+    for (unsigned i = threadIdx.x; i < (unsigned)(KSD * NT * 64); i += 512) Tl[KST * NT * 64 + i] = a.dfrag[i];
+    for (unsigned i = threadIdx.x; i < 65u * WL; i += 512) dpml[i] = a.dpm[i];
   }
   __syncthreads();
   const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned r = lane & 31, h = lane >> 5, lane16 = r * 16;
-  const unsigned lg = a.logn - 6, sh = a.logn + 3;
+#if GPQ_STREAM_PROBE >= 3     /* timing probe: read the slabs as if every group's limbs were contiguous (512 bytes per limb, group after group) */
+  const unsigned lg = a.logn - 6, sh = 9, sh_out = a.logn + 3;
+#else
+  const unsigned lg = a.logn - 6, sh = a.logn + 3, sh_out = sh;
+#endif
   const unsigned nwaves = gridDim.x * 8, pw = blockIdx.x * 8 + wave;
-  const uint64_t tkf0 = a.tkc[WLT], tkf1 = a.tkc[WLT + 1];
-  const uint64_t dkf0 = DCRT ? a.dkc[WLD] : 0, dkf1 = DCRT ? a.dkc[WLD + 1] : 0;
+  const uint64_t tkf0 = a.tkc[WL], tkf1 = a.tkc[WL + 1];
+  const uint64_t dkf0 = DCRT ? a.dkc[WL] : 0, dkf1 = DCRT ? a.dkc[WL + 1] : 0;
   const unsigned lane_off = ((2 * h) << sh) + lane16;
   const BufRsrc rs_c = slab_rsrc(a.chat, a.chat_bytes), rs_d = slab_rsrc(DCRT ? a.dhat : a.chat, DCRT ? a.dhat_bytes : 0);
   auto chat_of = [&](unsigned g) {                         // byte offsets inside the slabs (< 4 GB: the host checks)
     const unsigned poly = g >> lg, coef0 = (g & ((1u << lg) - 1)) << 6;
+#if GPQ_STREAM_PROBE >= 3
+    return (g * a.dimB) << 9;
+#endif
     return ((poly * a.dimB) << sh) + coef0 * 8;
   };
   auto dhat_of = [&](unsigned g) {
     const unsigned poly = g >> lg, coef0 = (g & ((1u << lg) - 1)) << 6;
+#if GPQ_STREAM_PROBE >= 3
+    return (g * a.dimA) << 9;
+#endif
     return ((poly * a.dimA) << sh) + coef0 * 8;
   };
   StepRegs ring[R];
@@ -379,8 +448,7 @@ __global__ __launch_bounds__(512) void bridge_tail_stream(TailStreamArgs a) {
     const unsigned poly = g >> lg, coef0 = (g & ((1u << lg) - 1)) << 6;
     const unsigned gn = g + nwaves < a.total_groups ? g + nwaves : g;
     const unsigned cc = chat_of(g), cn = chat_of(gn), dc = dhat_of(g);
-    const unsigned lo = opaque_v(lane);
-    const v4i *tl = Tl + lo, *dl = Dl + lo;
+    const v4i *tl = Tl + opaque_v(lane);
     // stream position p of a group: the tail's KST steps, then the addend's KSD; from NSTEP on: the next group's
     auto refill = [&](StepRegs &x, int p) {
       const bool nxt = p >= NSTEP;
@@ -388,57 +456,47 @@ __global__ __launch_bounds__(512) void bridge_tail_stream(TailStreamArgs a) {
       if (!DCRT || q < KST) fetch_step(x, rs_c, (nxt ? cn : cc) + ((4u * q) << sh), sh, lane_off);
       else fetch_step(x, rs_d, dc + ((4u * (q - KST)) << sh), sh, lane_off);
     };
+    v16i acc[2][NT];
+    crt_steps<NT, R, NSTEP, 0>(acc, ring, tl, refill);
+    // The fixed-point columns first (k, the centring, the windows), then the 16 words one at a time: V = 2^104 (x / P [+ d]) in two's
+    // complement, x / P underestimated by less than 2^-40.  Its fraction (low 104 bits) decides mpi_rdiv's rounding: within 2^-38 below 1
+    // (the estimate may have borrowed from the integer part) or below 1/2 -> the exact path; the bits above are floor(x / P) [+ d].
+    bool ambiguous, amb_d = false;
+    const unsigned mult = multiple_of<NT, WL>(acc, tkf0, tkf1, ambiguous);
+    const uint64_t *__restrict__ P = tpml + (size_t)mult * WL;
+    const uint64_t *__restrict__ PD = dpml;
+    if (DCRT) PD = dpml + (size_t)multiple_of<NT, TAIL_DF_WORD>(acc, dkf0, dkf1, amb_d) * WL;
+    ambiguous = ambiguous || amb_d;
     uint64_t Q[14];
-    uint64_t cr;
-    bool ambiguous;
-    {
-      v16i acc[2][NTT];
-      crt_steps<NTT, R, KST, 0>(acc, ring, tl, refill);
-      // F first (k, the centring, the window), then the 16 words one at a time: V = 2^104 x / P in two's complement, underestimated by less
-      // than 2^-40.  The fraction (low 104 bits) decides mpi_rdiv's rounding: within 2^-38 below 1 (the estimate may have borrowed from
-      // the integer part) or below 1/2 -> the exact path; the bits above are floor(x / P).
-      const unsigned mult = multiple_of<NTT, WLT>(acc, tkf0, tkf1, ambiguous);
-      const uint64_t *__restrict__ P = tpml + (size_t)mult * WLT;
-      int64_t carry = 0;
-      uint64_t borrow = 0, prev = 0;
-      cr = 0;
+    int64_t carry = 0;
+    uint64_t borrow = 0, prev = 0, cr = 0;
+#if GPQ_STREAM_PROBE >= 2
 #pragma unroll
-      for (int j = 0; j < WLT; ++j) {
-        int64_t L, H;
-        halves_at<NTT>(acc, j, L, H);
-        const u128 t = (u128)fold_word(L, H, carry) - P[j] - borrow;
-        const uint64_t v = (uint64_t)t;
-        borrow = (uint64_t)(t >> 64) & 1;
-        if (j == 1) {
-          const uint64_t f40 = v & ((1ull << 40) - 1), top38 = f40 >> 2;
-          ambiguous = ambiguous || top38 == ((1ull << 38) - 1) || top38 == ((1ull << 37) - 1);
-          cr = f40 >> 39;
-        }
-        if (j >= 2) Q[j - 2] = (prev >> 40) | (v << 24);                                // floor(x / P) mod 2^896
-        prev = v;
-        if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);                              // a row tile of accumulators at a time
+    for (int j = 0; j < 14; ++j) Q[j] = (uint64_t)(unsigned)acc[j & 1][j % NT][0] + P[j] + (DCRT ? PD[j] : 0);
+#else
+#pragma unroll
+    for (int j = 0; j < WL; ++j) {
+      int64_t L, H;
+      halves_at<NT>(acc, j, L, H);
+      u128 t = (u128)fold_word(L, H, carry) - P[j] - borrow;
+      if (DCRT) t -= PD[j];
+      const uint64_t v = (uint64_t)t;
+      borrow = (uint64_t)(0 - (uint64_t)(t >> 64));                                   // 0, 1 or 2
+      if (j == 1) {
+        const uint64_t f40 = v & ((1ull << 40) - 1), top38 = f40 >> 2;
+        ambiguous = ambiguous || top38 == ((1ull << 38) - 1) || top38 == ((1ull << 37) - 1);
+        cr = f40 >> 39;
       }
+      if (j >= 2) Q[j - 2] = (prev >> 40) | (v << 24);                                // floor(x / P) [+ d] mod 2^896
+      prev = v;
+      if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);                              // a row tile of accumulators at a time
     }
-    __builtin_amdgcn_sched_barrier(0);      // (the addend's product must not start under the tail's columns: two accumulator sets do not fit)
+#endif
     if (DCRT) {
-      v16i acc[2][NTD];
-      crt_steps<NTD, R, KSD, KST>(acc, ring, dl, refill);
-      // d mod 2^(64 WLD) = S - (k + centred) P_A, added word by word: modulo 2^logq that is poly_rns2mpi's centred d (src/he-mult.c:139,141)
-      bool amb_d;
-      const unsigned mult = multiple_of<NTD, WLD>(acc, dkf0, dkf1, amb_d);
-      ambiguous = ambiguous || amb_d;
-      const uint64_t *__restrict__ P = dpml + (size_t)mult * WLD;
-      int64_t carry = 0;
-      uint64_t borrow = 0;
 #pragma unroll
-      for (int j = 0; j < WLD; ++j) {
-        int64_t L, H;
-        halves_at<NTD>(acc, j, L, H);
-        const u128 t = (u128)fold_word(L, H, carry) - P[j] - borrow;
-        borrow = (uint64_t)(t >> 64) & 1;
-        const u128 sum = (u128)Q[j] + cr + (uint64_t)t;
-        Q[j] = (uint64_t)sum; cr = (uint64_t)(sum >> 64);
-        if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < 14; ++j) {
+        const u128 t = (u128)Q[j] + cr;
+        Q[j] = (uint64_t)t; cr = (uint64_t)(t >> 64);
       }
     } else {
       const uint64_t *ad = a.addend.at(poly, (size_t)a.W << a.logn);                 // uniform per group
@@ -447,7 +505,7 @@ __global__ __launch_bounds__(512) void bridge_tail_stream(TailStreamArgs a) {
 #pragma unroll
       for (int j = 0; j < 14; j += 2) {
         v4u v = v4u{0, 0, 0, 0};
-        if (ad && j + h < a.W) v = __builtin_amdgcn_raw_buffer_load_b128(rs_ad, (h << sh) + lane16, (unsigned)j << sh, 0);
+        if (ad && j + h < a.W) v = __builtin_amdgcn_raw_buffer_load_b128(rs_ad, (h << sh_out) + lane16, (unsigned)j << sh_out, 0);
         pair_from_load(v, dd[j], dd[j + 1]);
       }
 #pragma unroll
@@ -460,14 +518,21 @@ __global__ __launch_bounds__(512) void bridge_tail_stream(TailStreamArgs a) {
     const size_t flag_at = ((size_t)poly << a.logn) + coef0;
     if (a.force) ambiguous = ambiguous || (coef0 + 2 * r + h) % a.force == 0;
     __builtin_amdgcn_raw_buffer_store_b8((unsigned char)ambiguous, window_rsrc(a.redo + flag_at), 2 * r + h, 0, 0);
+#if GPQ_STREAM_PROBE != 4 && GPQ_STREAM_PROBE != 5
     if (a.tie) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)0, window_rsrc(a.tie + flag_at), 2 * r + h, 0, 0);
     if (a.amb_clear) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)0, window_rsrc(a.amb_clear + flag_at), 2 * r + h, 0, 0);
+#endif
     any |= __builtin_amdgcn_ballot_w64(ambiguous) != 0;
     const BufRsrc rs_out = window_rsrc(a.out.at(poly, (size_t)a.W << a.logn) + coef0);
 #pragma unroll
     for (int j = 0; j < 14; j += 2) {
       const v4u o = pair_for_store(Q[j], Q[j + 1]);
-      if (j + h < a.W) __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, (h << sh) + lane16, (unsigned)j << sh, 0);        // (W <= 14: the host checks)
+#if GPQ_STREAM_PROBE == 5
+      if (o[0] == 0x12345678u && j + h < a.W)
+#else
+      if (j + h < a.W)
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, (h << sh_out) + lane16, (unsigned)j << sh_out, GPQ_STREAM_STORE_AUX);        // (W <= 14: the host checks)
     }
   }
   if (lane == 0) a.wave_any[pw] = any;

@@ -870,6 +870,60 @@ extern "C" int gpq_profile_enable(gpq_ctx *c, int on) {
   c->prof_on = on != 0;
   return GPQ_OK;
 }
+// ---------------------------------------------------------------------------
+// Yardstick kernels (bench.py): what this device's memory system delivers to a plain stream with the library's own access shape --
+// 16 bytes per lane, persistent workgroups striding over the buffer, U independent accesses in flight per lane.  kind 0: copy (read + write),
+// 1: read only, 2: write only.  The rate of the best configuration, measured in the same process as the kernels it is compared with, is the
+// ceiling the HBM-bound kernels are priced against (`of_copy_rate` <= 1 by construction: a kernel that beats it IS the better copy).
+// ---------------------------------------------------------------------------
+namespace {
+typedef unsigned v4w __attribute__((ext_vector_type(4)));
+template <int U, int KIND>
+__global__ void probe_stream(v4w *__restrict__ dst, const v4w *__restrict__ src, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  v4w sink = v4w{0, 0, 0, 0};
+  for (; i + (U - 1) * stride < n16; i += U * stride) {
+    v4w v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = KIND == 2 ? v4w{(unsigned)i, 1u, 2u, 3u} : __builtin_nontemporal_load(&src[i + u * stride]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (KIND == 1) sink ^= v[u];
+      else __builtin_nontemporal_store(v[u], &dst[i + u * stride]);
+    }
+  }
+  for (; i < n16; i += stride) {
+    if (KIND == 1) sink ^= src[i];
+    else dst[i] = KIND == 2 ? v4w{(unsigned)i, 1u, 2u, 3u} : src[i];
+  }
+  if (KIND == 1 && (sink[0] ^ sink[1] ^ sink[2] ^ sink[3]) == 0x9e3779b9u) dst[0] = sink;     // (keeps the loads alive; practically never taken)
+}
+template <int KIND>
+int launch_probe(void *dst, const void *src, size_t bytes, unsigned blocks, unsigned threads, unsigned unroll, hipStream_t s) {
+  const size_t n16 = bytes / 16;
+  switch (unroll) {
+    case 1: hipLaunchKernelGGL((probe_stream<1, KIND>), dim3(blocks), dim3(threads), 0, s, (v4w *)dst, (const v4w *)src, n16); break;
+    case 2: hipLaunchKernelGGL((probe_stream<2, KIND>), dim3(blocks), dim3(threads), 0, s, (v4w *)dst, (const v4w *)src, n16); break;
+    case 4: hipLaunchKernelGGL((probe_stream<4, KIND>), dim3(blocks), dim3(threads), 0, s, (v4w *)dst, (const v4w *)src, n16); break;
+    case 8: hipLaunchKernelGGL((probe_stream<8, KIND>), dim3(blocks), dim3(threads), 0, s, (v4w *)dst, (const v4w *)src, n16); break;
+    default: return gpq_fail(GPQ_ERR_INVALID, "gpq_probe_stream: unroll must be 1, 2, 4 or 8");
+  }
+  return GPQ_OK;
+}
+}  // namespace
+
+extern "C" int gpq_probe_stream(void *dst, const void *src, size_t bytes, int kind, unsigned blocks, unsigned threads, unsigned unroll, void *stream) {
+  if (!dst || !src || bytes < 16 || (bytes & 15) || blocks < 1 || threads < 64 || threads > 1024 || (threads & 63) || kind < 0 || kind > 2)
+    return gpq_fail(GPQ_ERR_INVALID, "gpq_probe_stream: bad arguments");
+  int rc = kind == 0 ? launch_probe<0>(dst, src, bytes, blocks, threads, unroll, (hipStream_t)stream)
+         : kind == 1 ? launch_probe<1>(dst, src, bytes, blocks, threads, unroll, (hipStream_t)stream)
+                     : launch_probe<2>(dst, src, bytes, blocks, threads, unroll, (hipStream_t)stream);
+  if (rc) return rc;
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? GPQ_OK : gpq_fail(GPQ_ERR_HIP, "gpq_probe_stream: launch failed: %s", hipGetErrorString(e));
+}
+
 extern "C" int gpq_profile_kernels(void) { return GPQ_K_COUNT; }
 extern "C" const char *gpq_profile_kernel_name(int k) { return (k >= 0 && k < GPQ_K_COUNT) ? kKernelNames[k] : ""; }
 

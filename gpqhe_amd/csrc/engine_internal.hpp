@@ -96,6 +96,7 @@ struct gpq_ctx {
   size_t redo_cap = 0;
   std::vector<void *> retired;        // outgrown d_redo buffers: a HIP graph captured earlier may still write them, so they live as long as the context
   unsigned *d_wave_any = nullptr;     // one word per wave of the last bridge_stream.hpp launch: did it flag a coefficient (FlagScope)
+  bool lazy_decompose = true;         // gpq_he_mul's own rns_decompose output in (0, 3p): the forward transforms take it (gpq_set_lazy_decompose)
   unsigned debug_force_redo = 0;      // tests (gpq_debug_force_redo)
   bool stream_bridge = true;          // gpq_he_mul / gpq_he_swk: bridge_stream.hpp's fused streaming kernels (gpq_set_stream_bridge(ctx, 0): round 3's separate kernels)
   bool exact_crt = false;             // force the exact CRT kernel (tests)

@@ -133,6 +133,10 @@ class PolyContext:
         """he_mul / he_swk: the fused streaming bridge kernels (default) or round 3's separate kernels; same words"""
         _native.check(self.lib.gpq_set_stream_bridge(self.h, 1 if on else 0), "gpq_set_stream_bridge")
 
+    def set_lazy_decompose(self, on):
+        """he_mul: its internal rns_decompose output may stay in (0, 3p) for the forward transforms (default) or be canonical; same results"""
+        _native.check(self.lib.gpq_set_lazy_decompose(self.h, 1 if on else 0), "gpq_set_lazy_decompose")
+
     def debug_force_redo(self, every):
         """tests: the streaming bridge kernels also flag every coefficient whose index is a multiple of `every` (0: off)"""
         _native.check(self.lib.gpq_debug_force_redo(self.h, int(every)), "gpq_debug_force_redo")

@@ -91,6 +91,10 @@ int gpq_stream_sync(void *stream);
  * (gpq_set_device); a context belongs to the device given to gpq_ctx_create and is used with streams and buffers of that
  * device.  Independent ciphertexts shard over devices without any exchange (tests/c/shard_host.c). */
 int gpq_device_count(void);
+/* Yardstick for the HBM-bound kernels (bench.py `copy_rate`): a plain stream over `bytes` (multiple of 16) with the library's own access shape --
+ * 16 bytes per lane, `blocks` persistent workgroups of `threads` threads, `unroll` (1, 2, 4, 8) independent accesses in flight per lane.
+ * kind 0: dst <- src, 1: read src only, 2: write dst only.  Device pointers; asynchronous on `stream`. */
+int gpq_probe_stream(void *dst, const void *src, size_t bytes, int kind, unsigned blocks, unsigned threads, unsigned unroll, void *stream);
 int gpq_set_device(int device);
 int gpq_stream_create(void **stream);        /* non-blocking stream on the current device */
 int gpq_stream_destroy(void *stream);
@@ -205,6 +209,9 @@ int gpq_set_exact_crt(gpq_ctx *ctx, int on);
  * (src/he-mult.c:140, :59) in one kernel, and the relinearisation tail (:67-77) as one product that makes its addend d0 / d1 (:139, :141) from the
  * limbs on the spot -- d0, d1, d2 never exist as words; 0 = round 3's separate CRT, decompose and tail kernels.  Same words (the tests run both). */
 int gpq_set_stream_bridge(gpq_ctx *ctx, int on);
+/* gpq_he_mul: 1 (default) = its internal rns_decompose launches leave residues in (0, 3p), which the forward transforms behind them accept;
+ * 0 = canonical residues.  Same results. */
+int gpq_set_lazy_decompose(gpq_ctx *ctx, int on);
 /* Tests: the streaming kernels also flag every coefficient whose index is a multiple of `every` for the exact kernels behind them (0 = off). */
 int gpq_debug_force_redo(gpq_ctx *ctx, unsigned every);
 /* With gpq_set_prescale(ctx, 2): the tail of he_relin / he_swk as two kernels with Q's residues in memory between them (0, default) or in one pass per coefficient (1:

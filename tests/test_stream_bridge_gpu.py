@@ -55,9 +55,11 @@ def test_streaming_bridge_equals_the_separate_kernels(engine_ctx, logn, logqL, l
     rlk = [torch.cat([torch.randint(0, g.p[d], (n,), dtype=torch.int64, device="cuda", generator=gen) for d in range(dimB)]) for _ in range(2)]
     try:
         g.set_stream_bridge(False)
+        g.set_lazy_decompose(False)                   # round 3's path: separate kernels, canonical residues between them
         want = _run(g, torch, cts, rlk, W, logql, dimA, dimB, dimP)
         want_sq = _run(g, torch, cts, rlk, W, logql, dimA, dimB, dimP, square=True)
         g.set_stream_bridge(True)
+        g.set_lazy_decompose(True)
         got = _run(g, torch, cts, rlk, W, logql, dimA, dimB, dimP)
         got_sq = _run(g, torch, cts, rlk, W, logql, dimA, dimB, dimP, square=True)
         forced = []
@@ -67,6 +69,7 @@ def test_streaming_bridge_equals_the_separate_kernels(engine_ctx, logn, logqL, l
     finally:
         g.debug_force_redo(0)
         g.set_stream_bridge(True)
+        g.set_lazy_decompose(True)
     names = ("he_mul c0", "he_mul c1", "he_swk c0", "he_swk c1")
     for name, a, b in zip(names, want, got):
         assert torch.equal(a, b), name
@@ -93,14 +96,17 @@ def test_streaming_bridge_across_launch_groups(engine_ctx):
     try:
         g.set_chunk(3)
         g.set_stream_bridge(False)
+        g.set_lazy_decompose(False)
         want = _run(g, torch, cts, rlk, W, logq, dimA, dimB, dimP)
         g.set_stream_bridge(True)
+        g.set_lazy_decompose(True)
         got = _run(g, torch, cts, rlk, W, logq, dimA, dimB, dimP)
         g.debug_force_redo(9)
         forced = _run(g, torch, cts, rlk, W, logq, dimA, dimB, dimP)
     finally:
         g.debug_force_redo(0)
         g.set_stream_bridge(True)
+        g.set_lazy_decompose(True)
         g.set_chunk(32)
     for a, b, c in zip(want, got, forced):
         assert torch.equal(a, b) and torch.equal(a, c)

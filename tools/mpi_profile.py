@@ -12,4 +12,7 @@ if os.environ.get("MPI_PRESCALE"):
     ctx.set_prescale(int(os.environ["MPI_PRESCALE"]))
 if os.environ.get("MPI_STREAM"):
     ctx.set_stream_bridge(os.environ["MPI_STREAM"] == "1")
+    ctx.set_lazy_decompose(os.environ["MPI_STREAM"] == "1")
+if os.environ.get("MPI_LAZY"):
+    ctx.set_lazy_decompose(os.environ["MPI_LAZY"] == "1")
 print(he_mul_mpi_rate(torch, gpqhe_amd, ctx, int(os.environ.get("MPI_BATCH", "64")), iters=int(os.environ.get("MPI_ITERS", "6"))))
