@@ -19,8 +19,10 @@ touches a GPU) starts the N rank processes itself and exits with their status.
   --batch B         ciphertexts per GPU (weak scaling, the default: 64 per GPU)
   --total-batch T   T ciphertexts block-partitioned over the ranks (strong scaling;
                     BASELINE configs[3] = --total-batch 512 at N = 2/4/8)
-With N > 1 the line also carries `with_scatter_gather`: the same shards with the input
-slabs sent from rank 0 and the results returned to it inside the timed region.
+With N > 1 the line also carries `with_host_scatter` (every rank uploads its own shard from
+page-locked host memory and downloads its results: SURVEY.md 8e's alternative) and
+`with_scatter_gather` (the input slabs sent from rank 0 over xGMI and the results returned to it),
+both with the transfers inside the timed region.
 
 Prints ONE JSON line (rank 0).
 """
@@ -167,22 +169,68 @@ def power_state(torch, step, seconds=2.5):
         return None
 
 
-def copy_rate(torch, mib=2048, iters=10):
-    """Bytes read + written per second by a plain device-to-device copy: what a streaming kernel can reach on THIS device (0.6 of the
-    nominal 8 TB/s on the pool's MI355X) -- the yardstick beside `roofline.peak` for the kernels that are HBM-bound."""
-    a = torch.empty(mib * 1024 * 1024 // 8, dtype=torch.int64, device="cuda")
+def copy_rate(torch, gpqhe_amd, mib=2048, iters=8):
+    """What this device's memory system delivers to a PLAIN stream with the library's own access shape (16 bytes per lane, persistent
+    workgroups: gpq_probe_stream), measured in this process: the best read+write copy over a few launch shapes, and the best read-only and
+    write-only streams.  `GBps` (the copy) is the yardstick for `of_copy_rate`: a kernel that reads and writes cannot beat the best plain
+    copy, so every `of_copy_rate` must come out <= 1 -- tests/test_bench_contract.py asserts it (round 3 used torch's Tensor.copy_, which
+    two kernels beat: a soft yardstick)."""
+    from gpqhe_amd import _native
+    lib = _native.load()
+    nbytes = mib * 1024 * 1024
+    a = torch.empty(nbytes // 8, dtype=torch.int64, device="cuda")
     a.random_()
     b = torch.empty_like(a)
-    for _ in range(2):
-        b.copy_(a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        b.copy_(a)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    return {"GBps": round(2 * a.numel() * 8 / ms / 1e6, 1), "how": "torch Tensor.copy_ of %d MiB, device to device, read + written bytes" % mib}
+    st = torch.cuda.current_stream().cuda_stream
+    shapes = {0: [(256, 256, 4), (512, 256, 4), (256, 512, 4), (256, 512, 2), (1024, 256, 2), (2048, 256, 1), (512, 1024, 1)],
+              1: [(256, 256, 8), (256, 512, 4), (512, 256, 4), (2048, 1024, 1), (2048, 256, 1)],
+              2: [(256, 256, 1), (512, 256, 1), (256, 512, 1), (1024, 256, 1)]}
+    best = {}
+    for kind, cfgs in shapes.items():
+        for blocks, threads, unroll in cfgs:
+            for _ in range(2):
+                _native.check(lib.gpq_probe_stream(b.data_ptr(), a.data_ptr(), nbytes, kind, blocks, threads, unroll, st), "gpq_probe_stream")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                _native.check(lib.gpq_probe_stream(b.data_ptr(), a.data_ptr(), nbytes, kind, blocks, threads, unroll, st), "gpq_probe_stream")
+            e1.record()
+            torch.cuda.synchronize()
+            rate = (2 if kind == 0 else 1) * nbytes / (e0.elapsed_time(e1) / iters) / 1e6
+            if rate > best.get(kind, (0, None))[0]:
+                best[kind] = (rate, (blocks, threads, unroll))
+    del a, b
+    return {"GBps": round(best[0][0], 1), "read_only_GBps": round(best[1][0], 1), "write_only_GBps": round(best[2][0], 1),
+            "best_shapes_blocks_threads_unroll": {"copy": best[0][1], "read": best[1][1], "write": best[2][1]},
+            "how": "gpq_probe_stream (the library's own kernels: 16 B per lane, persistent workgroups, nt accesses) over %d MiB, best of %d launch shapes per kind; "
+                   "GBps = read + written bytes of the copy" % (mib, sum(len(v) for v in shapes.values()))}
+
+
+def valu_floor(value_per_gpu, sclk_mhz):
+    """The plain issue floor of the he_mul core at THIS run's clock: SQ_INSTS_VALU per he_mul (newest committed PMC pass) x 4 cycles per
+    wave-instruction on a SIMD-32 / (1024 SIMDs x the shader clock rocm-smi showed during this run).  frac = floor time / measured time:
+    how much of the step the integer VALUs are busy issuing at that clock; the rest is memory latency in the strided passes and launch tails."""
+    import glob
+    import re
+    def order(path):
+        m = re.search(r"r(\d+)[/\\]v(\d+)_", path)
+        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json")), key=order)
+    if not pmcs or not sclk_mhz:
+        return None
+    try:
+        data = json.load(open(pmcs[-1]))
+        per_group = sum(v["SQ_INSTS_VALU"] * (2 if "strided_pass" in name else 1) for name, v in data.items() if not name.startswith("_"))
+        insts = per_group / data.get("_chunk", 16)
+    except (OSError, ValueError, KeyError) as exc:
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+    floor_s = insts * 4 / (1024 * sclk_mhz * 1e6)
+    return {"valu_wave_insts_per_he_mul": int(insts), "cycles_per_wave_inst": 4, "simds": 1024, "sclk_MHz": sclk_mhz,
+            "floor_us_per_he_mul": round(floor_s * 1e6, 2), "floor_he_mul_per_s": round(1 / floor_s, 1),
+            "frac": round(floor_s * value_per_gpu, 4),
+            "insts_source": {"file": os.path.relpath(pmcs[-1], ROOT), "profiled_head": data.get("_head")},
+            "note": "frac = (instructions x 4 cycles / (1024 SIMDs x this run's clock)) x he_mul/s: the share of the step the integer VALUs spend issuing; "
+                    "this, not HBM, is what binds the RNS core (DESIGN.md 5)"}
 
 
 def ntt_rate(torch, gpqhe_amd, logn, dim, batch, iters=20):
@@ -213,10 +261,10 @@ def ntt_rate(torch, gpqhe_amd, logn, dim, batch, iters=20):
             "roundtrip_identity": ok}
 
 
-def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6):
-    """Whole he_mul of src/he-mult.c:88-156 on device big slabs (q = 2^850: decompose, tensor, CRT, relinearise
+def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850):
+    """Whole he_mul of src/he-mult.c:88-156 on device big slabs (q = 2^logq: decompose, tensor, CRT, relinearise
     with exact division by P, centre) -- SURVEY.md 8f rank 1-2, reported beside the RNS-core headline."""
-    logq, W = 850, 14
+    W = logq // 64 + 1
     dimP, dimA, dimB, _ = ctx.he_dims(logq, logq)
     n = ctx.n
     gen = torch.Generator(device="cuda")
@@ -224,7 +272,8 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6):
 
     def centred():
         big = torch.randint(-(1 << 62), 1 << 62, (batch, W, n), dtype=torch.int64, device="cuda", generator=gen)
-        big[:, W - 1] = torch.randint(-(1 << 16), 1 << 16, (batch, n), dtype=torch.int64, device="cuda", generator=gen)
+        top = logq - 2 - 64 * (W - 1)
+        big[:, W - 1] = torch.randint(-(1 << top), 1 << top, (batch, n), dtype=torch.int64, device="cuda", generator=gen)
         return big.reshape(-1).contiguous()
 
     cts = [centred() for _ in range(4)]
@@ -253,8 +302,12 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6):
     #   CRT (poly_rns2mpi) 3 x (dimA in, W out) for d0, d1, d2 + 2 x (cnt in, W addend in, W out)    :139-141, the tail's CRT of Q (:67-77)
     #   relin front       2 x (dimB in, cnt out)                                                    exact division by P, :70
     #   one-product tail  2 x (dimB in, W addend in, W out): replaces the relin front and the tail's CRT
+    #   streaming bridge (gpqhe_amd/csrc/bridge_stream.hpp): CRT(d2hat) -> rns_decompose in one kernel (dimA in, dimB out);
+    #                     the one-product tail with its addend's limbs as rows of the same product, 2 x (dimB + dimA in, W out)
     cnt = dimB - dimP
-    if "bridge_relin_tail_direct" in prof:
+    if "bridge_tail_stream" in prof:
+        words = {"bridge_decompose": 4 * (W + dimA), "bridge_crt_decompose": dimA + dimB, "bridge_tail_stream": 2 * (dimB + dimA + W)}
+    elif "bridge_relin_tail_direct" in prof:
         words = {"bridge_decompose": 4 * (W + dimA) + (W + dimB), "bridge_reconstruct": 3 * (dimA + W), "bridge_relin_tail_direct": 2 * (dimB + 2 * W)}
     else:
         words = {"bridge_decompose": 4 * (W + dimA) + (W + dimB), "bridge_reconstruct": 3 * (dimA + W) + 2 * (cnt + 2 * W), "bridge_relin_front": 2 * (dimB + cnt)}
@@ -276,10 +329,10 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6):
         ach = bridge[kname]["algo_GBps"]
         roof = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                 "bytes_per_batch": int(words[kname] * 8 * n * batch), "ms_per_batch": bridge[kname]["ms_per_batch"],
-                "note": "the bridge kernel with the largest share of this leg; all launches of the kind together (its launches differ in size); "
-                        "PMC of these kernels: profiles/r03/v12_mpi_pmc.txt"}
+                "note": "the bridge kernel with the largest share of this leg; all launches of the kind together; "
+                        "PMC of these kernels: profiles/r04/v2_mpi_pmc.txt"}
     bridge_ms = sum(v["ms_per_batch"] for k, v in kernels.items() if k.startswith("bridge_"))
-    return {"shape": "n=2^16, q=2^850 (W=14 words), dimA/dimB/dimP=%d/%d/%d, batch %d" % (dimA, dimB, dimP, batch),
+    return {"shape": "n=2^%d, q=2^%d (W=%d words), dimA/dimB/dimP=%d/%d/%d, batch %d" % (ctx.logn, logq, W, dimA, dimB, dimP, batch),
             "ms_per_batch": round(ms, 3), "he_mul_per_s": round(batch / (ms * 1e-3), 1),
             "he_mul_plus_he_rescale_per_s": round(batch / (ms_rs * 1e-3), 1),
             "bridge_ms_per_batch": round(bridge_ms, 3), "core_ms_per_batch": round(sum(v["ms_per_batch"] for k, v in kernels.items() if not k.startswith("bridge_")), 3),
@@ -309,7 +362,7 @@ def keyswitch_n17_rate(torch, gpqhe_amd, batch=64, iters=3):
             "algo_GBps": round(algo / (ms * 1e-3) / 1e9, 1)}
 
 
-def reference_signature_latency(timeout_s=150):
+def reference_signature_latency(timeout_s=150, logn=16, logq=850):
     """Batch-1 wall times through GPQHE's own signatures with real libgcrypt integers (the reference's only calling pattern): builds
     tests/c/mpi_host.c against the in-tree library and parses its `hemultime 16 850` report.  A child process (this one holds the GPU
     already; nothing is exec'ed over it).  None when gcc / libgcrypt's runtime are not there."""
@@ -328,13 +381,13 @@ def reference_signature_latency(timeout_s=150):
         try:
             if subprocess.run(cc, capture_output=True, text=True, timeout=120).returncode != 0:
                 return None
-            r = subprocess.run([exe, "hemultime", "16", "850"], capture_output=True, text=True, timeout=timeout_s)
+            r = subprocess.run([exe, "hemultime", str(logn), str(logq)], capture_output=True, text=True, timeout=timeout_s)
         except (OSError, subprocess.TimeoutExpired):
             return None
         if r.returncode != 0:
             return {"error": (r.stderr or r.stdout)[-300:]}
     t = r.stdout
-    out = {"shape": "n=2^16, q=2^850, Delta=2^50 (17 levels), one ciphertext per call, libgcrypt integers in and out", "unit": "ms per call, p50 of 50",
+    out = {"shape": "n=2^%d, q=2^%d, Delta=2^50 (%d levels), one ciphertext per call, libgcrypt integers in and out" % (logn, logq, logq // 50), "unit": "ms per call, p50 of 50",
            "note": "host-bound (16 conversion threads over scattered libgcrypt integers, PCIe): these move by +-30 % with the CPU load of the box; profiles/r03/v13_hemultime_resident.txt",
            "parity_lines": [ln.strip() for ln in t.splitlines() if ln.startswith(("key cache:", "resident polynomials:", "direct mpi access:"))]}
 
@@ -437,6 +490,7 @@ def parse_args(argv=None):
     ap.add_argument("--limb-block", type=int, default=0, help="limbs per launch group (0 = library default: all)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="ciphertexts the CPU baseline replays (0 = skip)")
     ap.add_argument("--no-ntt", action="store_true", help="skip the secondary legs run after the timed region (NTT GB/s, MPI-level he_mul, n=2^17 key switch)")
+    ap.add_argument("--quick", action="store_true", help="of the secondary legs keep only the clock / power sample, the VALU floor and the copy yardstick (tests)")
     ap.add_argument("--streams", type=int, default=1, help="2: tensor stage and key-switch stage on separate HIP streams")
     ap.add_argument("--no-scatter-gather", action="store_true", help="N>1: skip the extra step that has the input slabs scattered from "
                     "rank 0 and the outputs gathered back inside the timed region (SURVEY.md 8d config 4)")
@@ -646,10 +700,18 @@ def main(argv=None):
                 vi = valu_issue(value / world, pw["sclk_MHz"])
                 if vi is not None:
                     out["valu_issue"] = vi
-            cr = copy_rate(torch)
+                vf = valu_floor(value / world, pw["sclk_MHz"])
+                if vf is not None:
+                    out["valu_floor"] = vf
+                    if "frac" in vf:                      # what the evidence says binds the headline kernel; the HBM figures stay (north_star's declared roofline)
+                        out["roofline"]["bound"] = "valu_issue"
+                        out["roofline"]["declared_bound"] = "hbm"
+                        out["roofline"]["valu_floor_frac"] = vf["frac"]
+            cr = copy_rate(torch, gpqhe_amd)
             out["copy_rate"] = cr
-            for rec in out["kernels"].values():               # every kernel's algorithmic rate against that of a plain copy
+            for rec in out["kernels"].values():               # every kernel's algorithmic rate against that of the best plain copy
                 rec["of_copy_rate"] = round(rec["algo_GBps"] / cr["GBps"], 3)
+        if world == 1 and not args.no_ntt and not args.quick:
             # NTT GB/s at the headline ring (n=2^16, 30 limbs) and at BASELINE configs[1] (n=2^15, 10 limbs)
             out["ntt"] = [ntt_rate(torch, gpqhe_amd, 16, DIM_A, B), ntt_rate(torch, gpqhe_amd, 15, 10, 64)]
             del a0, a1, b0, b1, x, d0, d1, d2, c0, c1, wsA, wsB
@@ -662,6 +724,18 @@ def main(argv=None):
             rs = reference_signature_latency()
             if rs is not None:
                 out["reference_signature"] = rs
+            # The reference's own default parameters (tests/gpqhe.c:1296-1299: logn 14, q = 2^438, Delta = 2^50 -- the only shape GPQHE itself
+            # ever runs; BASELINE.md: 1.12 s per he_mul on one CPU core): whole he_mul on device slabs at batch 64, and its own signature, batch 1
+            ctx.close()
+            c14 = gpqhe_amd.PolyContext(14, 24)
+            rd = he_mul_mpi_rate(torch, gpqhe_amd, c14, 64, iters=5, logq=438)
+            c14.close()
+            rd = {k: rd[k] for k in ("shape", "ms_per_batch", "he_mul_per_s", "he_mul_plus_he_rescale_per_s", "bridge_ms_per_batch", "core_ms_per_batch")}
+            rd["reference_cpu_he_mul_per_s"] = round(1 / 1.12, 3)        # SURVEY.md 6 (survey probe, one core)
+            sig = reference_signature_latency(logn=14, logq=438)
+            if sig is not None:
+                rd["reference_signature"] = {k: v for k, v in sig.items() if k not in ("note", "parity_lines")}
+            out["reference_default"] = rd
     if dist is not None and not args.no_scatter_gather:
         # BASELINE configs[3] with the transfers inside the timed region: rank 0 owns the whole batch, every rank works on its
         # shard, results return to rank 0.  A root-GPU scatter is bound by one xGMI link per peer.  This leg is
@@ -693,6 +767,8 @@ def main(argv=None):
             if rank == args.sg_stall_rank:
                 progress["stage"] = "stalled on purpose (--sg-stall-rank)"
                 threading.Event().wait()
+            # SURVEY.md 8e's alternative first: every rank sources its own shard from page-locked host memory (PCIe, all GPUs in parallel)
+            hs = host_scatter_step(torch, ctx, (a0, a1, b0, b1), x, (e0, e1), (wsA, wsB), min(total_batch // world, 16), world, barrier, progress)
             sg = scatter_gather_step(torch, dist, ctx, (a0, a1, b0, b1), x, (e0, e1), (wsA, wsB), min(total_batch // world, 16), world, rank, barrier, progress)
         except Exception as exc:           # noqa: BLE001
             # the peers may be inside a transfer with this rank: no barrier any more (it could never complete); their own watchdogs
@@ -702,12 +778,54 @@ def main(argv=None):
         finished.set()
         watchdog.cancel()
         if rank == 0:
+            out["with_host_scatter"] = hs
             out["with_scatter_gather"] = sg
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_scatter_step(torch, ctx, ins, x, evk, wss, Bs, world, barrier, progress=None):
+    """One step over Bs ciphertexts per rank with every rank sourcing ITS OWN shard from page-locked host memory and returning its five
+    output slabs there, transfers inside the timed region: SURVEY.md 8e's alternative to the root-GPU scatter (which one 153 GB/s xGMI
+    link per peer bounds) -- all GPUs load over their own PCIe links in parallel, no GPU-to-GPU traffic at all.  Needs no process group
+    beyond the barrier and the MAX of the timing."""
+    from gpqhe_amd.dist import max_over_ranks
+    a0, a1, b0, b1 = ins
+    per_a, per_b = DIM_A * ctx.n, DIM_B * ctx.n
+    progress = progress if progress is not None else {}
+    progress["stage"] = "host scatter: staging the shard in page-locked memory"
+    host_in = [v[: Bs * per_a].cpu().pin_memory() for v in (a0, a1, b0, b1)] + [x[: Bs * per_b].cpu().pin_memory()]
+    host_out = [torch.empty(Bs * per_a, dtype=torch.int64).pin_memory() for _ in range(3)] + [torch.empty(Bs * per_b, dtype=torch.int64).pin_memory() for _ in range(2)]
+    dev_in = [torch.empty(h.numel(), dtype=torch.int64, device="cuda") for h in host_in]
+    o = [torch.empty(Bs * per_a, dtype=torch.int64, device="cuda") for _ in range(3)] + [torch.empty(Bs * per_b, dtype=torch.int64, device="cuda") for _ in range(2)]
+    progress["stage"] = "host scatter: barrier before the uploads"
+    barrier()
+    t1 = time.perf_counter()
+    progress["stage"] = "host scatter: uploads, compute, downloads"
+    for d, h in zip(dev_in, host_in):
+        d.copy_(h, non_blocking=True)
+    ctx.he_mul_tensor(o[0], o[1], o[2], dev_in[0], dev_in[1], dev_in[2], dev_in[3], DIM_A, wss[0])
+    ctx.he_keyswitch(o[3], o[4], dev_in[4], evk[0], evk[1], DIM_B, wss[1])
+    for h, d in zip(host_out, o):
+        h.copy_(d, non_blocking=True)
+    progress["stage"] = "host scatter: barrier after the downloads"
+    barrier()
+    dt = time.perf_counter() - t1
+    dt = max_over_ranks(dt) if world > 1 else dt
+    moved = (4 * per_a + per_b + 3 * per_a + 2 * per_b) * 8 * Bs
+    # the results that came back over PCIe are the ones a resident run computes
+    ref = [torch.empty_like(t) for t in o]
+    ctx.he_mul_tensor(ref[0], ref[1], ref[2], a0[: Bs * per_a], a1[: Bs * per_a], b0[: Bs * per_a], b1[: Bs * per_a], DIM_A, wss[0])
+    ctx.he_keyswitch(ref[3], ref[4], x[: Bs * per_b], evk[0], evk[1], DIM_B, wss[1])
+    torch.cuda.synchronize()
+    same = bool(all(torch.equal(h, r.cpu()) for h, r in zip(host_out, ref)))
+    progress["stage"] = "host scatter: done"
+    return {"batch_per_gpu": Bs, "he_mul_per_s": round(Bs * world / dt, 1), "ms": round(dt * 1e3, 2), "bytes_per_gpu_over_pcie": moved,
+            "GBps_per_gpu": round(moved / dt / 1e9, 1), "equals_resident_run": same,
+            "how": "every rank uploads its own shard from page-locked host memory and downloads its five output slabs, inside the timed region (SURVEY.md 8e)"}
 
 
 def scatter_gather_step(torch, dist, ctx, ins, x, evk, wss, Bs, world, rank, barrier, progress=None):

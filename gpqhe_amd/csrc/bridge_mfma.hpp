@@ -20,6 +20,9 @@
 #include "tables.hpp"
 #include "bridge_kernels.hpp"
 
+#ifndef GPQ_DECOMP_PIPE
+#define GPQ_DECOMP_PIPE 0      /* bridge_decompose_mfma: row tiles software-pipelined by one -- measured 9 % SLOWER at three waves per SIMD (profiles/r04/v3_decompose_pipe_ab.txt) */
+#endif
 #ifndef GPQ_FRONT_XG
 #define GPQ_FRONT_XG 8   /* k steps from which the relinearisation front stops fetching the next group early */
 #endif
@@ -117,18 +120,27 @@ __global__ __launch_bounds__(256, 2) void bridge_decompose_mfma(DecomposeMfmaArg
     const unsigned poly = g / a.groups_per_poly, coef0 = (g % a.groups_per_poly) << 6;
     uint64_t *__restrict__ dst = a.slab + ((size_t)poly * a.dim << a.logn) + coef0 + lane;   // this lane finishes coefficient coef0 + lane
     if (KS >= 8 && g != g0) load_X(g);                 // 32-word inputs: no registers left for the early fetch
-    for (unsigned q = 0; q < a.NT; ++q) {
-      v16i acc0, acc1;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { acc0[e] = 0; acc1[e] = 0; }
+    // (GPQ_DECOMP_PIPE = 1: the MFMAs of tile q + 1 issued before the integer epilogue of tile q.  With three waves per SIMD the other waves
+    // already cover a wave's wait for its own products; the second accumulator pair and the barriers cost more than they return.)
+    auto product = [&](unsigned q, v16i &acc0, v16i &acc1) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const v4i cf = Bl[(q * KS + s) * 64 + lane];
-        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[0][s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[1][s], acc1, 0, 0, 0);
+        if (s == 0) {
+          v16i z;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) z[e] = 0;
+          acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[0][s], z, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[1][s], z, 0, 0, 0);
+        } else {
+          acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[0][s], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf, X[1][s], acc1, 0, 0, 0);
+        }
       }
-      // the fragments are dead after the last row tile: fetch the next group's under this one's epilogue
+      // the fragments are dead once the last row tile has been issued: fetch the next group's under the remaining epilogues
       if (KS < 8 && q + 1 == a.NT && g + gstep < a.total_groups) load_X(g + gstep);
+    };
+    auto finish = [&](unsigned q, const v16i &acc0, const v16i &acc1) {
 #pragma unroll
       for (int w = 0; w < 4; ++w) {                    // prime j = 4q + w: digits 0-3 in the lower lanes, 4-7 in the upper
         int64_t L, H;
@@ -143,7 +155,29 @@ __global__ __launch_bounds__(256, 2) void bridge_decompose_mfma(DecomposeMfmaArg
         v = (uint64_t)((int64_t)(-c) * Hh + (int64_t)v);               // in (0, 3p)
         if (j < a.dim) __builtin_nontemporal_store(a.lazy ? v : canon_fold(v, p, (uint32_t)c), &dst[(size_t)j << a.logn]);
       }
+    };
+#if GPQ_DECOMP_PIPE
+    v16i pa0, pa1, pb0, pb1;
+    product(0, pa0, pa1);
+    for (unsigned q = 0; q < a.NT; q += 2) {
+      if (q + 1 < a.NT) product(q + 1, pb0, pb1);
+      __builtin_amdgcn_sched_barrier(0);
+      finish(q, pa0, pa1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 1 < a.NT) {
+        if (q + 2 < a.NT) product(q + 2, pa0, pa1);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(q + 1, pb0, pb1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+#else
+    for (unsigned q = 0; q < a.NT; ++q) {
+      v16i acc0, acc1;
+      product(q, acc0, acc1);
+      finish(q, acc0, acc1);
+    }
+#endif
   }
 }
 

@@ -89,3 +89,45 @@ def test_valu_issue_is_computed_from_committed_evidence_not_from_a_literal():
     assert v["insts_source"]["profiled_head"] and v["bound_source"]["probe_head"]
     import inspect
     assert "3.95" not in inspect.getsource(b.valu_issue)
+
+
+def test_valu_floor_is_the_four_cycle_issue_floor_at_the_given_clock():
+    """bench.py's `valu_floor`: SQ_INSTS_VALU per he_mul from the newest committed PMC pass x 4 cycles per
+    wave-instruction / (1024 SIMDs x the clock of the same run); frac = floor time x he_mul/s, at most 1."""
+    import json
+    b = _bench()
+    v = b.valu_floor(7472.0, 1913)
+    assert "error" not in v, v
+    pmc = json.load(open(os.path.join(ROOT, v["insts_source"]["file"])))
+    per_group = sum(val["SQ_INSTS_VALU"] * (2 if "strided_pass" in k else 1) for k, val in pmc.items() if not k.startswith("_"))
+    insts = per_group / pmc["_chunk"]
+    assert v["valu_wave_insts_per_he_mul"] == int(insts) and v["cycles_per_wave_inst"] == 4 and v["simds"] == 1024
+    floor_s = insts * 4 / (1024 * 1913e6)
+    assert abs(v["frac"] - floor_s * 7472.0) < 1e-3 and 0.8 < v["frac"] <= 1.0          # round 3's operating point: 0.96
+    assert b.valu_floor(7472.0, None) is None
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_the_quick_bench_line_prices_kernels_against_ceilings():
+    """`python bench.py --quick`: the yardstick of `of_copy_rate` is the best of the library's own plain copies measured in the same
+    process, so no kernel may exceed it; the VALU issue floor at the run's clock cannot be exceeded either; the contract keys are there."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-sample", "1", "--quick"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["cpu_baseline"]["bit_exact_vs_gpu"] is True
+    rates = {k: v["of_copy_rate"] for k, v in line["kernels"].items()}
+    assert rates and all(0 < x <= 1.0 for x in rates.values()), (rates, line["copy_rate"])
+    assert line["copy_rate"]["read_only_GBps"] >= line["copy_rate"]["GBps"] * 0.9
+    if "valu_floor" in line:                           # needs rocm-smi for the clock
+        assert 0.5 < line["valu_floor"]["frac"] <= 1.0, line["valu_floor"]
+        assert line["roofline"]["bound"] == "valu_issue" and line["roofline"]["declared_bound"] == "hbm"
+    assert line["roofline"]["peak"] == 8000.0 and 0 < line["roofline"]["frac"] < 1

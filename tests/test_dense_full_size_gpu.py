@@ -71,3 +71,31 @@ def test_he_swk_dense_at_configs4_shape(engine_ctx, oracle_ctx):
     bad0 = [i for i in range(n) if got0[i] != exp0[i]]
     bad1 = [i for i in range(n) if got1[i] != exp1[i]]
     assert not bad0 and not bad1, (len(bad0), len(bad1), bad0[:4], bad1[:4])
+
+
+@pytest.mark.timeout(600)
+def test_he_mul_dense_at_the_reference_default_shape(engine_ctx, oracle_ctx):
+    """tests/gpqhe.c:1296-1299 -- logn 14, q = 2^438, Delta = 2^50: the only shape the reference itself ever runs, and bench.py's
+    `reference_default` leg (16 / 24 limbs, 7 words: the streaming kernels' small instantiations).  A batch of two, ciphertext 0 dense
+    random and ciphertext 1 = the extremes, every coefficient against the restated reference."""
+    import torch
+    logn, logq = 14, 438
+    n, q = 1 << logn, 1 << logq
+    dimP, dimA, dimB, dimevk = engine_ctx(logn, 20).he_dims(logq, logq)
+    assert (dimA, dimB, dimevk) == (16, 24, 24)                                # SURVEY.md 8c context dims
+    g, o = engine_ctx(logn, dimevk), oracle_ctx(logn, dimevk)
+    rng = random.Random(14 * 438)
+    ct = [_centred(rng, n, q) for _ in range(4)]
+    for p in ct:
+        p[:4] = [-(q >> 1), (q >> 1) - 1, 0, -1]
+    rlk0, rlk1 = o.gen(3000, dimevk), o.gen(3001, dimevk)
+    W = logq // 64 + 1
+    dev = [to_device(ints_to_big(v, W)) for v in ct]
+    o0, o1 = torch.empty_like(dev[0]), torch.empty_like(dev[0])
+    g.he_mul(o0, o1, *dev, to_device(rlk0[: dimB * n]), to_device(rlk1[: dimB * n]), W, logq, dimA, dimB, dimP)
+    torch.cuda.synchronize()
+    got0, got1 = big_to_ints(to_host(o0), W, n)[0], big_to_ints(to_host(o1), W, n)[0]
+    exp0, exp1 = ref.he_mul(o, (ct[0], ct[1]), (ct[2], ct[3]), rlk0[: dimB * n], rlk1[: dimB * n], dimP, dimA, dimB, logq)
+    bad0 = [i for i in range(n) if got0[i] != exp0[i]]
+    bad1 = [i for i in range(n) if got1[i] != exp1[i]]
+    assert not bad0 and not bad1, (len(bad0), len(bad1), bad0[:4], bad1[:4])

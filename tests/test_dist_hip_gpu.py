@@ -124,6 +124,11 @@ def test_bench_starts_its_own_ranks():
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
     sg = out["with_scatter_gather"]
     assert "error" not in sg and sg["shards_identical"] is True and sg["he_mul_per_s"] > 0
+    # SURVEY.md 8e's alternative, rehearsed by the same two ranks: every rank uploads its own shard from page-locked host memory and
+    # downloads its results inside the timed region; what comes back over PCIe is what a resident run computes
+    hs = out["with_host_scatter"]
+    assert hs["equals_resident_run"] is True and hs["he_mul_per_s"] > 0 and hs["batch_per_gpu"] == 2
+    assert hs["bytes_per_gpu_over_pcie"] == (7 * 30 + 3 * 45) * 65536 * 8 * hs["batch_per_gpu"]
 
 
 @pytest.mark.timeout(600)
