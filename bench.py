@@ -490,6 +490,7 @@ def parse_args(argv=None):
     ap.add_argument("--limb-block", type=int, default=0, help="limbs per launch group (0 = library default: all)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="ciphertexts the CPU baseline replays (0 = skip)")
     ap.add_argument("--no-ntt", action="store_true", help="skip the secondary legs run after the timed region (NTT GB/s, MPI-level he_mul, n=2^17 key switch)")
+    ap.add_argument("--variant", default=None, help="dev: path of another build of libgpqhe_hip.so (make -C gpqhe_amd/csrc variant ...) for interleaved A/B timing")
     ap.add_argument("--quick", action="store_true", help="of the secondary legs keep only the clock / power sample, the VALU floor and the copy yardstick (tests)")
     ap.add_argument("--streams", type=int, default=1, help="2: tensor stage and key-switch stage on separate HIP streams")
     ap.add_argument("--no-scatter-gather", action="store_true", help="N>1: skip the extra step that has the input slabs scattered from "
@@ -551,6 +552,9 @@ def main(argv=None):
     import torch
     import gpqhe_amd
     from gpqhe_amd.dist import shard_range
+    if args.variant:
+        from gpqhe_amd import _native
+        _native.use_variant(args.variant)
 
     dist = None
     ndev = torch.cuda.device_count()

@@ -7,8 +7,20 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GPQHE_HIP_LIB selects another build of the same library (A/B timing of kernel variants)
-LIB_PATH = os.environ.get("GPQHE_HIP_LIB") or os.path.join(_HERE, "libgpqhe_hip.so")
+LIB_PATH = os.path.join(_HERE, "libgpqhe_hip.so")
+
+
+def use_variant(path):
+    """Load another build of the same library (`make -C gpqhe_amd/csrc variant NAME=..`) instead of the product: for the A/B timing
+    tools and `pytest --variant PATH` only, and only before the first load.  No environment variable can swap the library (round 3's
+    GPQHE_HIP_LIB is gone: the tests must run the product unless they are told otherwise on their command line)."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_variant(%r): the library is already loaded" % path)
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    LIB_PATH = os.path.abspath(path)
+
 
 u64 = C.c_uint64
 vp = C.c_void_p

@@ -9,8 +9,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--variant", default=None, help="path of another build of libgpqhe_hip.so to run the GPU tests through "
+                     "(e.g. the UBSan-instrumented host side, tools/gpu_ubsan.sh); without it the tests load the product, whatever the environment says")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if config.getoption("--variant"):
+        from gpqhe_amd import _native
+        _native.use_variant(config.getoption("--variant"))
 
 
 @pytest.fixture(scope="session")

@@ -76,8 +76,8 @@ def test_he_swk_dense_at_configs4_shape(engine_ctx, oracle_ctx):
 @pytest.mark.timeout(600)
 def test_he_mul_dense_at_the_reference_default_shape(engine_ctx, oracle_ctx):
     """tests/gpqhe.c:1296-1299 -- logn 14, q = 2^438, Delta = 2^50: the only shape the reference itself ever runs, and bench.py's
-    `reference_default` leg (16 / 24 limbs, 7 words: the streaming kernels' small instantiations).  A batch of two, ciphertext 0 dense
-    random and ciphertext 1 = the extremes, every coefficient against the restated reference."""
+    `reference_default` leg (16 / 24 limbs, 7 words: the streaming kernels' small instantiations).  Dense random ciphertexts with the
+    extremes of the centred range riding along, every coefficient against the restated reference."""
     import torch
     logn, logq = 14, 438
     n, q = 1 << logn, 1 << logq

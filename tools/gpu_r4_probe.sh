@@ -6,7 +6,7 @@ specs=("$@")
 for round in 1 2 3; do
   for spec in "${specs[@]}"; do
     parts=($spec)
-    env GPQHE_HIP_LIB=$PWD/gpqhe_amd/${parts[0]} "${parts[@]:1}" timeout -k 10 300 python3 tools/mpi_profile.py 2>/dev/null | python3 -c "
+    env MPI_LIB=$PWD/gpqhe_amd/${parts[0]} "${parts[@]:1}" timeout -k 10 300 python3 tools/mpi_profile.py 2>/dev/null | python3 -c "
 import sys,re
 for l in sys.stdin:
     m=re.search(r\"'he_mul_per_s': ([0-9.]+)\",l); b=re.search(r\"'bridge_ms_per_batch': ([0-9.]+)\",l)

@@ -8,8 +8,8 @@ RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.ubsan_standalone-x8
 (cd gpqhe_amd/csrc && hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Xarch_host -fsanitize=undefined \
    -shared engine.hip bridge.hip dropin.hip mpi_shim.hip -ldl -pthread -o ../libgpqhe_hip_UBSAN.so) || exit 1
 echo "instrumented library built" | tee gpurun_out/ubsan.txt
-LD_PRELOAD=$RT UBSAN_OPTIONS=print_stacktrace=1 GPQHE_HIP_LIB=$PWD/gpqhe_amd/libgpqhe_hip_UBSAN.so \
-  timeout -k 10 1000 python -m pytest tests -m gpu -q -k "not c_host and not mpi_surface and not dropin and not reference_signature" >> gpurun_out/ubsan.txt 2>&1
+LD_PRELOAD=$RT UBSAN_OPTIONS=print_stacktrace=1 \
+  timeout -k 10 1000 python -m pytest tests -m gpu -q --variant $PWD/gpqhe_amd/libgpqhe_hip_UBSAN.so -k "not c_host and not mpi_surface and not dropin and not reference_signature" >> gpurun_out/ubsan.txt 2>&1
 tail -3 gpurun_out/ubsan.txt
 D=$(mktemp -d) && cp gpqhe_amd/libgpqhe_hip_UBSAN.so $D/libgpqhe_hip.so && cp gpqhe_amd/libgpqhe_hip_ctx.so $D/
 gcc -O1 -std=gnu11 -I include tests/c/mpi_host.c -L $D -lgpqhe_hip -lgpqhe_hip_ctx -l:libgcrypt.so.20 -Wl,-rpath,$D -Wl,-rpath,/opt/rocm/lib -Wl,--unresolved-symbols=ignore-in-shared-libs -o $D/mpi_host || exit 1

@@ -2,6 +2,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, gpqhe_amd
+from gpqhe_amd import _native
+if os.environ.get("MPI_LIB"):                      # A/B of library builds (tools/gpu_r4_probe.sh): explicit, before the first load
+    _native.use_variant(os.environ["MPI_LIB"])
 from bench import he_mul_mpi_rate
 ctx = gpqhe_amd.PolyContext(16, 45)
 if os.environ.get("GPQ_BRIDGE_VALU") == "1":      # tool-side switch (tools/gpu_prof_mpi.sh): the library itself reads no environment

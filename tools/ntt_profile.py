@@ -2,6 +2,9 @@
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, gpqhe_amd
+from gpqhe_amd import _native
+if os.environ.get("NTT_LIB"):
+    _native.use_variant(os.environ["NTT_LIB"])
 from bench import rand_slab
 for logn, dim, batch in ((16, 30, 64), (15, 10, 64), (17, 44, 8)):
     ctx = gpqhe_amd.PolyContext(logn, dim)
