@@ -685,6 +685,7 @@ static int hemultime(unsigned logn, unsigned logq)
     he_ct_t tmp, an, bn, inv;
     poly_mpi_t *ps2[8] = {&tmp.c0, &tmp.c1, &an.c0, &an.c1, &bn.c0, &bn.c1, &inv.c0, &inv.c1};
     for (int i = 0; i < 8; i++) poly_alloc(ps2[i]);
+    const int inv_iters = hectx.L > 8 ? 8 : (int)hectx.L - 1;  /* every iteration and the he_moddown in front spend a level (q = 2^438: 8 levels) */
     for (int mem = 1; mem >= 0; mem--) {
       gpq_mpi_shim_set_poly_slots(mem ? 32 : 0);
       double total = 0;
@@ -696,7 +697,7 @@ static int hemultime(unsigned logn, unsigned logq)
         he_addpt(&an, &tmp, &two);
         he_moddown(&an);
         he_addpt(&bn, &tmp, &one);
-        for (int it = 0; it < 8; it++) {
+        for (int it = 0; it < inv_iters; it++) {
           he_mul(&bn, &bn, &bn, &rlk);
           he_rs(&bn);
           he_addpt(&tmp, &bn, &one);
@@ -706,7 +707,7 @@ static int hemultime(unsigned logn, unsigned logq)
         he_copy_ct(&inv, &an);
         total = now_ms() - t0;
       }
-      printf("  he_inv's call sequence, 8 iterations (45 calls, level %u -> %u), %s: %.1f ms\n", hectx.L, inv.l, mem ? "operands resident" : "every call uploads", total);
+      printf("  he_inv's call sequence, %d iterations (%d calls, level %u -> %u), %s: %.1f ms\n", inv_iters, 5 + 5 * inv_iters, hectx.L, inv.l, mem ? "operands resident" : "every call uploads", total);
     }
     gpq_mpi_shim_set_poly_slots(32);
   }
