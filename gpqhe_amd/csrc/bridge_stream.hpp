@@ -199,8 +199,16 @@ __device__ __forceinline__ void pair_from_load(v4u v, uint64_t &a, uint64_t &b) 
 
 // One row tile (4 primes) of the rns_decompose product over the fragments X of a group (bridge_decompose_mfma's arithmetic), split
 // in two so that callers can issue tile q + 1's MFMAs before the integer epilogue of tile q (the matrix pipe then works under the VALU).
+// The per-prime scalars of the tile (p_j, Kq_j, c_j: uniform, scalar loads) are fetched with the product, a tile ahead of their use.
+struct PkTile { uint64_t p[4], kq[4]; unsigned c[4]; };
 template <int KSD>
-__device__ __forceinline__ void decompose_tile_product(const v4i *dl /* LDS + lane */, unsigned q, const v4i (&X)[2][KSD], v16i &acc0, v16i &acc1) {
+__device__ __forceinline__ void decompose_tile_product(const v4i *dl /* LDS + lane */, const uint64_t *__restrict__ pk, unsigned q, const v4i (&X)[2][KSD],
+                                                       v16i &acc0, v16i &acc1, PkTile &t) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const unsigned j = 4 * q + w;
+    t.p[w] = pk[3 * j]; t.kq[w] = pk[3 * j + 1]; t.c[w] = (unsigned)pk[3 * j + 2];
+  }
 #pragma unroll
   for (int s = 0; s < KSD; ++s) {
     const v4i cf = dl[((size_t)q * KSD + s) * 64];
@@ -217,10 +225,10 @@ __device__ __forceinline__ void decompose_tile_product(const v4i *dl /* LDS + la
   }
 }
 // ... and its epilogue: x mod p_j for the primes j = 4q .. 4q+3, stored as limbs j, j+1 pairs (lane half h stores limb j + h for
-// coefficients 2r, 2r+1).  pk = [4 NT][3]: p_j, Kq_j, c_j (uniform reads).  out_off = (h << sh) + 16 r.
+// coefficients 2r, 2r+1).  out_off = (h << sh) + 16 r.
 // lazy: leave the residue in (0, 3p) -- what the forward transform that reads it accepts (ntt_kernels.hpp: its first stage takes x, y < 4p in
 // every butterfly class) -- instead of canonicalising it (7 of the ~39 VALU instructions per residue).
-__device__ __forceinline__ void decompose_tile_finish(const uint64_t *__restrict__ pk, unsigned q, const v16i &acc0, const v16i &acc1, BufRsrc rs_out,
+__device__ __forceinline__ void decompose_tile_finish(const PkTile &t, unsigned q, const v16i &acc0, const v16i &acc1, BufRsrc rs_out,
                                                       unsigned out_off, unsigned sh, unsigned h, unsigned dim, bool lazy) {
   uint64_t res[4];
 #pragma unroll
@@ -228,14 +236,12 @@ __device__ __forceinline__ void decompose_tile_finish(const uint64_t *__restrict
     int64_t L, H;
     swap_halves(horner4(acc0[4 * w], acc0[4 * w + 1], acc0[4 * w + 2], acc0[4 * w + 3]),
                 horner4(acc1[4 * w], acc1[4 * w + 1], acc1[4 * w + 2], acc1[4 * w + 3]), L, H);
-    const unsigned j = 4 * q + w;
-    const uint64_t p = pk[3 * j], kq = pk[3 * j + 1];
-    const int c = (int)(uint32_t)pk[3 * j + 2];
+    const int c = (int)t.c[w];
     const int Hh = (int)(H >> 27);
     const uint64_t Hl = (uint64_t)H & 0x7ffffffu;
-    uint64_t v = (Hl << 32) + (uint64_t)L + kq;
+    uint64_t v = (Hl << 32) + (uint64_t)L + t.kq[w];
     v = (uint64_t)((int64_t)(-c) * Hh + (int64_t)v);               // in (0, 3p)
-    res[w] = lazy ? v : canon_fold(v, p, (uint32_t)c);
+    res[w] = lazy ? v : canon_fold(v, t.p[w], (uint32_t)c);
   }
 #pragma unroll
   for (int w = 0; w < 4; w += 2) {
@@ -249,16 +255,17 @@ template <int KSD>
 __device__ __forceinline__ void decompose_tiles(const v4i *dl, const uint64_t *__restrict__ pk, unsigned NT, const v4i (&X)[2][KSD], BufRsrc rs_out,
                                                 unsigned out_off, unsigned sh, unsigned h, unsigned dim, bool lazy) {
   v16i pa0, pa1, pb0, pb1;
-  decompose_tile_product<KSD>(dl, 0, X, pa0, pa1);
+  PkTile ta, tb;
+  decompose_tile_product<KSD>(dl, pk, 0, X, pa0, pa1, ta);
   for (unsigned q = 0; q < NT; q += 2) {
-    if (q + 1 < NT) decompose_tile_product<KSD>(dl, q + 1, X, pb0, pb1);
+    if (q + 1 < NT) decompose_tile_product<KSD>(dl, pk, q + 1, X, pb0, pb1, tb);
     __builtin_amdgcn_sched_barrier(0);
-    decompose_tile_finish(pk, q, pa0, pa1, rs_out, out_off, sh, h, dim, lazy);
+    decompose_tile_finish(ta, q, pa0, pa1, rs_out, out_off, sh, h, dim, lazy);
     __builtin_amdgcn_sched_barrier(0);
     if (q + 1 < NT) {
-      if (q + 2 < NT) decompose_tile_product<KSD>(dl, q + 2, X, pa0, pa1);
+      if (q + 2 < NT) decompose_tile_product<KSD>(dl, pk, q + 2, X, pa0, pa1, ta);
       __builtin_amdgcn_sched_barrier(0);
-      decompose_tile_finish(pk, q + 1, pb0, pb1, rs_out, out_off, sh, h, dim, lazy);
+      decompose_tile_finish(tb, q + 1, pb0, pb1, rs_out, out_off, sh, h, dim, lazy);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
