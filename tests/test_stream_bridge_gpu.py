@@ -18,7 +18,7 @@ def _centred(torch, gen, batch, W, n, logq):
     """dense random values in [-2^(logq-2), 2^(logq-2)) as W two's-complement words (the words above the value's top word: its sign)"""
     big = torch.randint(-(1 << 62), 1 << 62, (batch, W, n), dtype=torch.int64, device="cuda", generator=gen)
     wt = (logq - 2) // 64
-    top = logq - 2 - 64 * wt
+    top = min(logq - 2 - 64 * wt, 62)            # (torch.randint's bounds are int64)
     big[:, wt] = torch.randint(-(1 << top), 1 << top, (batch, n), dtype=torch.int64, device="cuda", generator=gen)
     for j in range(wt + 1, W):
         big[:, j] = big[:, wt] >> 63

@@ -1,0 +1,67 @@
+"""Randomised soak of the streaming bridge (gpqhe_amd/csrc/bridge_stream.hpp) against round 3's separate kernels: random rings (2^13 .. 2^15),
+moduli, levels, batch sizes, launch groups and forced-redo strides; he_mul, a squaring and he_swk must give identical words.
+usage: python tools/soak_bridge.py [configs] [seed]"""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, gpqhe_amd
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 4)
+ctxs = {}
+
+
+def ctx_for(logn, nprimes):
+    key = (logn, nprimes)
+    if key not in ctxs:
+        ctxs[key] = gpqhe_amd.PolyContext(logn, nprimes)
+    return ctxs[key]
+
+
+def centred(gen, batch, W, n, logq):
+    big = torch.randint(-(1 << 62), 1 << 62, (batch, W, n), dtype=torch.int64, device="cuda", generator=gen)
+    wt = (logq - 2) // 64
+    top = min(logq - 2 - 64 * wt, 62)            # (torch.randint's bounds are int64)
+    big[:, wt] = torch.randint(-(1 << top), 1 << top, (batch, n), dtype=torch.int64, device="cuda", generator=gen)
+    for j in range(wt + 1, W):
+        big[:, j] = big[:, wt] >> 63
+    return big.reshape(-1).contiguous()
+
+
+def run(g, cts, rlk, W, logql, dims):
+    dimP, dimA, dimB = dims
+    o = [torch.empty_like(cts[0]) for _ in range(6)]
+    g.he_mul(o[0], o[1], *cts, rlk[0], rlk[1], W, logql, dimA, dimB, dimP)
+    g.he_mul(o[2], o[3], cts[0], cts[1], cts[0], cts[1], rlk[0], rlk[1], W, logql, dimA, dimB, dimP)
+    g.he_swk(o[4], o[5], cts[2], cts[3], rlk[0], rlk[1], W, logql, dimB, dimP)
+    torch.cuda.synchronize()
+    return o
+
+
+t0 = time.time()
+streamed = 0
+for it in range(N):
+    logn = rng.choice((13, 13, 14, 14, 15))
+    logqL = rng.randrange(100, 881)
+    if logn == 15: logqL = min(logqL, 600)
+    logql = logqL if rng.random() < 0.5 else rng.randrange(60, logqL + 1)
+    batch, chunk, force = rng.randrange(1, 5), rng.choice((1, 2, 3, 32)), rng.choice((0, 0, 1, 7, 64, 257))
+    probe = ctx_for(logn, 20)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logqL, logql)
+    g = ctx_for(logn, max(dimevk, 20))
+    n, W = g.n, logqL // 64 + 1
+    gen = torch.Generator(device="cuda"); gen.manual_seed(rng.randrange(1 << 30))
+    cts = [centred(gen, batch, W, n, logql) for _ in range(4)]
+    rlk = [torch.cat([torch.randint(0, g.p[d], (n,), dtype=torch.int64, device="cuda", generator=gen) for d in range(dimB)]) for _ in range(2)]
+    g.set_chunk(chunk)
+    g.set_stream_bridge(False); g.set_lazy_decompose(False); g.debug_force_redo(0)
+    want = run(g, cts, rlk, W, logql, (dimP, dimA, dimB))
+    g.set_stream_bridge(True); g.set_lazy_decompose(True); g.debug_force_redo(force)
+    got = run(g, cts, rlk, W, logql, (dimP, dimA, dimB))
+    g.debug_force_redo(0); g.set_chunk(32)
+    bad = [i for i, (a, b) in enumerate(zip(want, got)) if not torch.equal(a, b)]
+    if bad:
+        print("MISMATCH at config %d: logn %d logqL %d logql %d dims %s batch %d chunk %d force %d outputs %s" % (it, logn, logqL, logql, (dimP, dimA, dimB), batch, chunk, force, bad), flush=True)
+        sys.exit(1)
+    if it % 10 == 0:
+        print("config %d ok: logn %d q_L 2^%d q_l 2^%d dims P/A/B %d/%d/%d W %d batch %d chunk %d force %d (%.0f s)" % (it, logn, logqL, logql, dimP, dimA, dimB, W, batch, chunk, force, time.time() - t0), flush=True)
+print("soak_bridge ok: %d configurations, every word of he_mul / squaring / he_swk equal between the streaming bridge and the separate kernels (%.0f s)" % (N, time.time() - t0))
