@@ -225,6 +225,11 @@ static int upload_tables(gpq_ctx *c) {
   HIP_TRY(hipMemcpy(c->d_winv, wistd.data(), np * n * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_tabs, tabs.data(), np * sizeof(LimbTab), hipMemcpyHostToDevice));
   c->h_tabs = tabs;
+  // gpq_ntt's zero flags for launches of up to 4096 (polynomial, limb) units exist from the start, so that a FIRST gpq_ntt inside a
+  // stream capture works; larger launches grow them at their first call, outside capture (zero_flags)
+  HIP_TRY(hipMalloc((void **)&c->d_zflag, 4096 * sizeof(unsigned)));
+  HIP_TRY(hipMemset(c->d_zflag, 0, 4096 * sizeof(unsigned)));
+  c->zflag_cap = 4096;
   return GPQ_OK;
 }
 

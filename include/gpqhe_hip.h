@@ -108,12 +108,17 @@ int gpq_free_host(void *hptr);
  * 0..dim-1 of the context.  `stream` is a hipStream_t (NULL = default).
  * Kernels launch on the calling thread's CURRENT device, which must be the context's (gpq_set_device(gpq_ctx_device(ctx)));
  * a call from a thread on another device returns GPQ_ERR_INVALID instead of launching there.  A context and the calls on it
- * are not thread-safe: one host thread per context at a time.
+ * are not thread-safe: one host thread per context at a time -- and ONE STREAM per context at a time: a context carries scratch
+ * that its launches share in stream order (gpq_ntt's zero flags, the per-coefficient redo flags and per-wave words of the bridge,
+ * the table override of gpq_he_mul's inverse passes).  Work that should overlap on several streams uses one context per stream
+ * (contexts of the same ring share nothing mutable; tools/ntt_stream_probe.py, tests/c/shard_host.c do exactly that).
  */
 
 /* ntt / invntt over every limb of every polynomial, in place.
  * Replaces the per-limb calls `ntt(a, rns)` / `invntt(a, rns)`, src/ntt.c:37,54.
- * Inputs are canonical residues in [0, p_d) (what rns_decompose and poly_rns_mul produce).  Outputs are the reference's
+ * Inputs are canonical residues in [0, p_d) (what rns_decompose and poly_rns_mul produce); gpq_invntt also takes the word p_d for a
+ * residue 0 -- the domain of the reference's invntt, and what gpq_ntt hands out -- so gpq_ntt's output goes straight into gpq_invntt
+ * (tests/test_ntt_zero_repr_gpu.py: round trips and limbs that are p_d throughout, every kernel class).  Outputs are the reference's
  * words: gpq_invntt's are canonical; gpq_ntt's are canonical except that a residue 0 is stored as p_d wherever
  * src/ntt.c:47 stores it so (a sum leg x + t == p is kept as p, and survives while its partner's product is 0):
  * limbs whose output contains a zero are redone with the reference's own arithmetic (ref_zero_redo, ntt_kernels.hpp). */

@@ -129,3 +129,35 @@ def test_he_genswk_keys_hold_p_where_the_reference_stores_it(engine_ctx, oracle_
     g.he_genswk(evk0, evk1, *dev, W, dimP, logq, dimevk)
     assert np.array_equal(to_host(evk0), want0)
     assert not to_host(evk1).any()
+
+
+@pytest.mark.parametrize("logn,dim", [(7, 3), (12, 2), (13, 3), (14, 2), (15, 2), (16, 3), (17, 2)])
+def test_gpq_invntt_takes_the_words_gpq_ntt_hands_out(engine_ctx, oracle_ctx, logn, dim):
+    """the library's own forward output (which may hold p for a residue 0, src/ntt.c:47) straight into gpq_invntt, as the
+    reference's invntt accepts it (its domain is [0, p]) -- no canonicalisation in between -- and p-heavy extremes: a limb that is all p,
+    every second word p, p at random places.  Expected: the oracle's inverse of the same residues."""
+    o, g = oracle_ctx(logn, dim), engine_ctx(logn, dim)
+    n, per = o.n, dim * o.n
+    names, slab = slab_of_cases(o, dim, 900 + logn)
+    fwd = to_device(slab)
+    g.poly_ntt(fwd, dim)
+    words = to_host(fwd).copy()
+    assert any(int((words.reshape(-1, n)[i] == np.uint64(o.p[i % dim])).sum()) for i in range(len(names) * dim))
+    g.poly_invntt(fwd, dim)                                           # the round trip through the reference's words is the identity
+    assert np.array_equal(to_host(fwd), slab)
+    rng = np.random.default_rng(logn)
+    extremes = []
+    for kind in range(3):
+        poly = o.gen(70 + kind, dim).reshape(dim, n).copy()
+        for d in range(dim):
+            if kind == 0: poly[d, :] = np.uint64(o.p[d])
+            elif kind == 1: poly[d, ::2] = np.uint64(o.p[d])
+            else: poly[d, rng.random(n) < 0.1] = np.uint64(o.p[d])
+        extremes.append(poly.reshape(-1))
+    ext = np.concatenate(extremes)
+    canon = np.concatenate([ext.reshape(-1, n)[i] % np.uint64(o.p[i % dim]) for i in range(3 * dim)])
+    want = np.concatenate([o.invntt(canon[i * n:(i + 1) * n].copy(), i % dim) for i in range(3 * dim)])
+    dev_p = to_device(ext)
+    g.poly_invntt(dev_p, dim)
+    assert np.array_equal(to_host(dev_p), want)                     # p and 0 are the same residue to the inverse transform
+    assert per == dim * n
