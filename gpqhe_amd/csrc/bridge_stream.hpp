@@ -44,6 +44,18 @@ __device__ __forceinline__ v4i frag_odd(const StepRegs &x, unsigned m) { return 
 // constant fragments from LDS at fixed addresses, and the compiler would keep them in registers across the group loop (80 VGPRs).
 __device__ __forceinline__ unsigned opaque_v(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 
+// Constant tables into LDS at kernel start, 512 threads, four loads in flight per thread (one at a time, the ~100 KB of a workgroup cost a
+// dozen dependent round trips: 15-20 us of a 600 us launch).
+template <typename T>
+__device__ __forceinline__ void stage_lds(T *dst, const T *__restrict__ src, unsigned count) {
+  unsigned i = threadIdx.x;
+  for (; i + 3 * 512 < count; i += 4 * 512) {
+    const T v0 = src[i], v1 = src[i + 512], v2 = src[i + 1024], v3 = src[i + 1536];
+    dst[i] = v0; dst[i + 512] = v1; dst[i + 1024] = v2; dst[i + 1536] = v3;
+  }
+  for (; i < count; i += 512) dst[i] = src[i];
+}
+
 // A slab as a buffer resource (stride 0, range-checked: an access past the end reads zeros / is dropped).  Built from kernel arguments only.
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 __device__ __forceinline__ BufRsrc slab_rsrc(const void *p, size_t bytes) {
@@ -200,14 +212,18 @@ __device__ __forceinline__ void pair_from_load(v4u v, uint64_t &a, uint64_t &b) 
 // One row tile (4 primes) of the rns_decompose product over the fragments X of a group (bridge_decompose_mfma's arithmetic), split
 // in two so that callers can issue tile q + 1's MFMAs before the integer epilogue of tile q (the matrix pipe then works under the VALU).
 // The per-prime scalars of the tile (p_j, Kq_j, c_j: uniform, scalar loads) are fetched with the product, a tile ahead of their use.
+// They are read through the CONSTANT address space: next to the kernel's buffer stores the compiler cannot prove a global table
+// unclobbered, reads it with vector loads -- and waits for them with vmcnt(0), i.e. for every store and prefetch in flight.
 struct PkTile { uint64_t p[4], kq[4]; unsigned c[4]; };
+typedef const __attribute__((address_space(4))) uint64_t *ConstTable;
 template <int KSD>
 __device__ __forceinline__ void decompose_tile_product(const v4i *dl /* LDS + lane */, const uint64_t *__restrict__ pk, unsigned q, const v4i (&X)[2][KSD],
                                                        v16i &acc0, v16i &acc1, PkTile &t) {
+  ConstTable pkc = (ConstTable)pk;
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
     const unsigned j = 4 * q + w;
-    t.p[w] = pk[3 * j]; t.kq[w] = pk[3 * j + 1]; t.c[w] = (unsigned)pk[3 * j + 2];
+    t.p[w] = pkc[3 * j]; t.kq[w] = pkc[3 * j + 1]; t.c[w] = (unsigned)pkc[3 * j + 2];
   }
 #pragma unroll
   for (int s = 0; s < KSD; ++s) {
@@ -302,9 +318,9 @@ __global__ __launch_bounds__(512) void bridge_crt_decompose(CrtDecomposeArgs a) 
   v4i *Dl = Cl + KS * NT * 64;
   const unsigned nD = a.NTD * KSD * 64;
   uint64_t *pml = reinterpret_cast<uint64_t *>(Dl + nD);
-  for (unsigned i = threadIdx.x; i < (unsigned)(KS * NT * 64); i += 512) Cl[i] = a.cfrag[i];
-  for (unsigned i = threadIdx.x; i < nD; i += 512) Dl[i] = a.dfrag[i];
-  for (unsigned i = threadIdx.x; i < 65u * WL; i += 512) pml[i] = a.pm[i];
+  stage_lds(Cl, a.cfrag, (unsigned)(KS * NT * 64));
+  stage_lds(Dl, a.dfrag, nD);
+  stage_lds(pml, a.pm, 65u * WL);
   __syncthreads();
   const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned r = lane & 31, h = lane >> 5, lane16 = r * 16;
@@ -411,11 +427,11 @@ __global__ __launch_bounds__(512) void bridge_tail_stream(TailStreamArgs a) {
   v4i *Tl = reinterpret_cast<v4i *>(smem);                                   // [NSTEP][5][64]: the tail's rows, then the addend's
   uint64_t *tpml = reinterpret_cast<uint64_t *>(Tl + NSTEP * NT * 64);
   uint64_t *dpml = tpml + 65 * WL;
-  for (unsigned i = threadIdx.x; i < (unsigned)(KST * NT * 64); i += 512) Tl[i] = a.tfrag[i];
-  for (unsigned i = threadIdx.x; i < 65u * WL; i += 512) tpml[i] = a.tpm[i];
+  stage_lds(Tl, a.tfrag, (unsigned)(KST * NT * 64));
+  stage_lds(tpml, a.tpm, 65u * WL);
   if (DCRT) {
-    for (unsigned i = threadIdx.x; i < (unsigned)(KSD * NT * 64); i += 512) Tl[KST * NT * 64 + i] = a.dfrag[i];
-    for (unsigned i = threadIdx.x; i < 65u * WL; i += 512) dpml[i] = a.dpm[i];
+    stage_lds(Tl + KST * NT * 64, a.dfrag, (unsigned)(KSD * NT * 64));
+    stage_lds(dpml, a.dpm, 65u * WL);
   }
   __syncthreads();
   const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
