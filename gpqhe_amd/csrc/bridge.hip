@@ -378,13 +378,19 @@ int ensure_redo(gpq_ctx *c, size_t flags, hipStream_t s) {
   return GPQ_OK;
 }
 
+// arguments of the exact kernel bridge_reconstruct<b->WP> for one call (launch_reconstruct, and the fused fallback kernels behind bridge_stream.hpp)
+ReconstructArgs exact_args(const gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned slab_dim,
+                           unsigned slab_first, unsigned logq, bool centre, unsigned char *tie, unsigned logn, const ReconExtra &x) {
+  return ReconstructArgs{c->d_tabs, slab, Two<uint64_t>{big, x.big_b, x.split}, b->d_phat, b->d_phat_inv, b->d_pmult, b->d_phalf, tie, x.only, b->d_inv128,
+                         b->dim, logn, Wout, logq, b->first, slab_dim, slab_first, centre ? 1u : 0u, x.prescaled ? 1u : 0u, x.scope};
+}
+
 int launch_reconstruct(gpq_ctx *c, const gpq_bridge_basis *b, uint64_t *big, unsigned Wout, const uint64_t *slab, unsigned slab_dim,
                        unsigned slab_first, unsigned batch, unsigned logq, bool centre, unsigned char *tie, hipStream_t s, int logn_override = -1,
                        const ReconExtra &x = ReconExtra()) {
   const unsigned logn = logn_override < 0 ? c->logn : (unsigned)logn_override, n = 1u << logn;
   const Two<uint64_t> bigs{big, x.big_b, x.split};
-  ReconstructArgs a{c->d_tabs, slab, bigs, b->d_phat, b->d_phat_inv, b->d_pmult, b->d_phalf, tie, x.only, b->d_inv128,
-                    b->dim, logn, Wout, logq, b->first, slab_dim, slab_first, centre ? 1u : 0u, x.prescaled ? 1u : 0u, x.scope};
+  ReconstructArgs a = exact_args(c, b, big, Wout, slab, slab_dim, slab_first, logq, centre, tie, logn, x);
   if (x.fused) *x.fused = false;
   // fast path: centred result modulo a power of two that needs fewer words than P has
   const unsigned need = (logq + 63) / 64;
@@ -625,8 +631,18 @@ int crt_decompose_stream(gpq_ctx *c, gpq_bridge_basis *bA, uint64_t *out, const 
   const FlagScope scope{c->d_wave_any, blocks * kStreamWaves, groups};
   ReconExtra ex;
   ex.prescaled = true; ex.exact_only = true; ex.only = c->d_redo; ex.scope = scope;
-  if ((rc = launch_reconstruct(c, bA, scratch, W, slab, dimA, 0, polys, logq, true, nullptr, s, -1, ex))) return rc;
-  if ((rc = launch_decompose_masked(c, out, scratch, W, 0, dimB, polys, c->d_redo, scope, s))) return rc;
+  const bool f32 = bA->WP == 32 && W > 7 && W <= 14, f16 = bA->WP == 16 && W <= 7;
+  if (f32 || f16) {                                        // one launch: a thread decomposes the words it has just reconstructed
+    ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s);
+    const ReconstructArgs ra = exact_args(c, bA, scratch, W, slab, dimA, 0, logq, true, nullptr, c->logn, ex);
+    const DecomposeArgs da{c->d_tabs, one_source(scratch), out, W, dimB, c->logn, 0, c->d_redo, scope};
+    const dim3 grid = masked_grid(scope, 128, c->n, polys);
+    if (f32) hipLaunchKernelGGL((bridge_fallback_crt_decompose<32, 14>), grid, dim3(128), 0, s, ra, da);
+    else hipLaunchKernelGGL((bridge_fallback_crt_decompose<16, 7>), grid, dim3(128), 0, s, ra, da);
+  } else {
+    if ((rc = launch_reconstruct(c, bA, scratch, W, slab, dimA, 0, polys, logq, true, nullptr, s, -1, ex))) return rc;
+    if ((rc = launch_decompose_masked(c, out, scratch, W, 0, dimB, polys, c->d_redo, scope, s))) return rc;
+  }
   *done = true;
   return GPQ_OK;
 }
@@ -1122,17 +1138,28 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
     // 64 coefficients the product cannot decide get their weights taken off in place and go through the exact sequence below.
     uint64_t *chat_rw = const_cast<uint64_t *>(chat);
     unsigned char *flags = (unsigned char *)rhat, *amb = flags + ((size_t)polys << c->logn);
-    const unsigned char *redo_only = nullptr;
     const bool direct_ok = !in_place && rt->direct.d_bfrag && W <= 14 && logql <= 896 && c->bridge_mfma;
     FlagScope scope = kNoScope;
     bool streamed = false;
     if (direct_ok && (rc = tail_stream(c, rt, out, chat, dbig, dh, W, dimP, dimB, logql, polys, tie, amb, s, &scope, &streamed))) return rc;
+    // Behind the streaming kernel the exact kernels only see flagged coefficients, and the chains whose hand-overs stay inside a thread are
+    // ONE launch each (bridge_kernels.hpp: bridge_fallback_tail_pre / _post): pre = the addend's exact CRT + the weights off the flagged
+    // groups; the front re-run; post = r, its round bit, Q's exact CRT, the finish.  Three launches where there were seven.
+    const bool fuse_pre = streamed && dh && (dh->bA->WP == 32 || dh->bA->WP == 16);
+    const bool fuse_post = streamed && ((bp->WP == 16 && bq->WP == 32) || (bp->WP == 8 && bq->WP == 16));
+    LimbScaleArgs un{c->d_tabs, chat_rw, rt->d_unscale, direct_ok ? c->d_redo : nullptr, dimB, c->logn, scope};
     if (dh) {
       // the addend as words: for the flagged coefficients only behind the streaming kernel (exact CRT), for all of them otherwise
       ReconExtra dx;
       dx.prescaled = true;
       if (streamed) { dx.exact_only = true; dx.only = c->d_redo; dx.scope = scope; }
-      if ((rc = launch_reconstruct(c, dh->bA, dh->scratch, W, dh->hat, dh->dimA, 0, polys, logql, true, nullptr, s, -1, dx))) return rc;
+      if (fuse_pre) {
+        ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s);
+        const ReconstructArgs dd = exact_args(c, dh->bA, dh->scratch, W, dh->hat, dh->dimA, 0, logql, true, nullptr, c->logn, dx);
+        const dim3 grid = masked_grid(scope, 128, c->n, polys);
+        if (dh->bA->WP == 32) hipLaunchKernelGGL((bridge_fallback_tail_pre<32>), grid, dim3(128), 0, s, dd, un);
+        else hipLaunchKernelGGL((bridge_fallback_tail_pre<16>), grid, dim3(128), 0, s, dd, un);
+      } else if ((rc = launch_reconstruct(c, dh->bA, dh->scratch, W, dh->hat, dh->dimA, 0, polys, logql, true, nullptr, s, -1, dx))) return rc;
       dbig = Two<const uint64_t>{dh->scratch, dh->scratch + (size_t)out.split * W * n, out.split};
     }
     if (direct_ok && !streamed) {
@@ -1145,10 +1172,8 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
         if ((rc = launch_low_mfma16(m, rt->direct.lds_bytes, s))) return rc;
       }
     }
-    if (direct_ok) redo_only = c->d_redo;
     // weights off: for the flagged groups, or -- no product possible (in place, no tables) -- for every coefficient
-    LimbScaleArgs un{c->d_tabs, chat_rw, rt->d_unscale, redo_only, dimB, c->logn, scope};
-    { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_limb_scale, masked_grid(scope, 256, c->n, polys), cblock, 0, s, un); }
+    if (!fuse_pre) { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_limb_scale, masked_grid(scope, 256, c->n, polys), cblock, 0, s, un); }
     if (!direct_ok) return relin_tail(c, out, chat, dbig, W, dimP, dimB, logql, polys, ws, s, 0);
     // the exact sequence on the flagged groups: front (re-run, writing its flags), r for its ambiguous ones, round bits, Q, finish
     const unsigned gpp = c->n >> 6;
@@ -1157,13 +1182,22 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
     if ((rc = launch_relin_front(c, rt->KS, f, rt->lds_bytes, s))) return rc;
     ReconExtra only_amb;
     only_amb.only = amb; only_amb.scope = scope;
-    if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, only_amb))) return rc;
     RoundFixArgs rf{r, bp->d_phalf, amb, flags, tp.Wr, c->logn, scope};
-    { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_roundfix, masked_grid(scope, 256, c->n, polys), cblock, 0, s, rf); }
     ReconExtra q;
     q.prescaled = true; q.exact_only = true; q.only = c->d_redo; q.big_b = out.b; q.split = out.split; q.scope = scope;
-    if ((rc = launch_reconstruct(c, bq, out.a, W, qhat, tp.cnt, 0, polys, logql, true, tie, s, -1, q))) return rc;
     AddRoundArgs ar{out, Two<const uint64_t>{out.a, out.b, out.split}, nullptr, dbig, bp->d_phalf, piq, tie, W, tp.Wr, c->logn, logql, c->d_redo, flags, scope};
+    if (fuse_post) {
+      ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s);
+      const ReconstructArgs rr = exact_args(c, bp, r, tp.Wr, chat, dimB, 0, 0, false, nullptr, c->logn, only_amb);
+      const ReconstructArgs qq = exact_args(c, bq, out.a, W, qhat, tp.cnt, 0, logql, true, tie, c->logn, q);
+      const dim3 grid = masked_grid(scope, 128, c->n, polys);
+      if (bp->WP == 16) hipLaunchKernelGGL((bridge_fallback_tail_post<16, 32>), grid, dim3(128), 0, s, rr, rf, qq, ar);
+      else hipLaunchKernelGGL((bridge_fallback_tail_post<8, 16>), grid, dim3(128), 0, s, rr, rf, qq, ar);
+      return launched("relin_tail");
+    }
+    if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, only_amb))) return rc;
+    { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_roundfix, masked_grid(scope, 256, c->n, polys), cblock, 0, s, rf); }
+    if ((rc = launch_reconstruct(c, bq, out.a, W, qhat, tp.cnt, 0, polys, logql, true, tie, s, -1, q))) return rc;
     { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_addround, masked_grid(scope, 256, c->n, polys), cblock, 0, s, ar); }
     return launched("relin_tail");
   }

@@ -93,10 +93,9 @@ struct DecomposeArgs {
 };
 
 template <int MAXW>
-__global__ __launch_bounds__(256) void bridge_decompose(DecomposeArgs a) {
+__device__ __forceinline__ void decompose_body(const DecomposeArgs &a, unsigned poly, unsigned i) {
   constexpr int ND = (64 * MAXW + 58) / 59;             // 59-bit digits, the top one signed
   constexpr int TOPBITS = 64 * MAXW - 59 * (ND - 1);
-  scoped_or_grid(a.scope, a.logn, 256, [&](unsigned poly, unsigned i) {
   if (a.only && !a.only[((size_t)poly << a.logn) + i]) return;
   const uint64_t *__restrict__ src = a.big.at(poly, (size_t)a.W << a.logn) + i;
   uint64_t w[MAXW + 1];
@@ -127,7 +126,10 @@ __global__ __launch_bounds__(256) void bridge_decompose(DecomposeArgs a) {
     for (int t = ND - 2; t >= 0; --t) r = horner59(r, dg[t], k);
     dst[(size_t)d << a.logn] = canon4(r, k);
   }
-  });
+}
+template <int MAXW>
+__global__ __launch_bounds__(256) void bridge_decompose(DecomposeArgs a) {
+  scoped_or_grid(a.scope, a.logn, 256, [&](unsigned poly, unsigned i) { decompose_body<MAXW>(a, poly, i); });
 }
 
 // ---------------------------------------------------------------------------
@@ -158,8 +160,7 @@ struct ReconstructArgs {
 };
 
 template <int WP>
-__global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
-  scoped_or_grid(a.scope, a.logn, 128, [&](unsigned poly, unsigned i) {
+__device__ __forceinline__ void reconstruct_body(const ReconstructArgs &a, unsigned poly, unsigned i) {
   if (a.only && !a.only[((size_t)poly << a.logn) + i]) return;
   const uint64_t *__restrict__ src = a.slab + (((size_t)poly * a.slab_dim + a.slab_first) << a.logn) + i;
   uint64_t S[WP + 1];
@@ -243,7 +244,10 @@ __global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
   }
   const uint64_t fill = a.logq ? qsign : sext;
   for (unsigned j = WP + 1; j < a.Wout; ++j) dst[(size_t)j << a.logn] = fill;
-  });
+}
+template <int WP>
+__global__ __launch_bounds__(128) void bridge_reconstruct(ReconstructArgs a) {
+  scoped_or_grid(a.scope, a.logn, 128, [&](unsigned poly, unsigned i) { reconstruct_body<WP>(a, poly, i); });
 }
 
 // ---------------------------------------------------------------------------
@@ -366,8 +370,7 @@ struct AddRoundArgs {
   FlagScope scope;             // with `only`: the launch that wrote it
 };
 
-__global__ __launch_bounds__(256) void bridge_addround(AddRoundArgs a) {
-  scoped_or_grid(a.scope, a.logn, 256, [&](unsigned poly, unsigned i) {
+__device__ __forceinline__ void addround_body(const AddRoundArgs &a, unsigned poly, unsigned i) {
   if (a.only && !a.only[((size_t)poly << a.logn) + i]) return;
   int cmp = 0;
   if (a.rflags) {
@@ -404,7 +407,9 @@ __global__ __launch_bounds__(256) void bridge_addround(AddRoundArgs a) {
     }
     outp[o] = v;
   }
-  });
+}
+__global__ __launch_bounds__(256) void bridge_addround(AddRoundArgs a) {
+  scoped_or_grid(a.scope, a.logn, 256, [&](unsigned poly, unsigned i) { addround_body(a, poly, i); });
 }
 
 // Round bits of the coefficients bridge_relin_front_mfma could not decide (RF_AMB): r, made exactly by
@@ -417,8 +422,7 @@ struct RoundFixArgs {
   unsigned Wr, logn;
   FlagScope scope;             // the launch whose flagged groups `amb` lies in
 };
-__global__ __launch_bounds__(256) void bridge_roundfix(RoundFixArgs a) {
-  scoped_or_grid(a.scope, a.logn, 256, [&](unsigned poly, unsigned i) {
+__device__ __forceinline__ void roundfix_body(const RoundFixArgs &a, unsigned poly, unsigned i) {
   const size_t at = ((size_t)poly << a.logn) + i;
   if (!a.amb[at]) return;
   const uint64_t *__restrict__ r = a.r + ((size_t)poly * a.Wr << a.logn) + i;
@@ -428,6 +432,29 @@ __global__ __launch_bounds__(256) void bridge_roundfix(RoundFixArgs a) {
     cmp = rv > hv ? 1 : (rv < hv ? -1 : 0);
   }
   a.flags[at] = cmp > 0 ? 1 : (cmp < 0 ? 2 : 0);
+}
+__global__ __launch_bounds__(256) void bridge_roundfix(RoundFixArgs a) {
+  scoped_or_grid(a.scope, a.logn, 256, [&](unsigned poly, unsigned i) { roundfix_body(a, poly, i); });
+}
+
+// The exact kernels behind a streaming kernel (bridge_stream.hpp), fused where their hand-overs stay inside one thread: every one of them works
+// on a coefficient (or, bridge_limb_scale, on a wave's group of 64) by itself, so a chain of them is one launch in which a thread writes what it
+// reads next.  In the common case -- nothing flagged -- a launch is a few hundred workgroups that read one word each and return; nine of them
+// per launch group were 0.11 ms per 64 ciphertexts, a fifth of what the fast kernels leave to gain.  Scope launches only.
+template <int WP, int MAXW>
+__global__ __launch_bounds__(128) void bridge_fallback_crt_decompose(ReconstructArgs ra, DecomposeArgs da) {
+  scoped_or_grid(ra.scope, ra.logn, 128, [&](unsigned poly, unsigned i) {
+    reconstruct_body<WP>(ra, poly, i);                    // d2 of the flagged coefficients into the scratch words ...
+    decompose_body<MAXW>(da, poly, i);                    // ... and from there over the key switch's limbs (same thread, same addresses)
+  });
+}
+template <int WPP, int WPQ>
+__global__ __launch_bounds__(128) void bridge_fallback_tail_post(ReconstructArgs rr, RoundFixArgs rf, ReconstructArgs qq, AddRoundArgs ar) {
+  scoped_or_grid(rr.scope, rr.logn, 128, [&](unsigned poly, unsigned i) {
+    reconstruct_body<WPP>(rr, poly, i);                   // r = x mod P exactly, where the front could not decide the rounding (amb)
+    roundfix_body(rf, poly, i);                           // its round bit
+    reconstruct_body<WPQ>(qq, poly, i);                   // Q exactly for the flagged coefficients (redo)
+    addround_body(ar, poly, i);                           // + round + d, mod 2^logq
   });
 }
 
@@ -482,14 +509,22 @@ __global__ __launch_bounds__(256) void bridge_big_addsub(BigAddSubArgs k) {
 // hold a non-zero entry of `only`: puts the CRT weights of the one-product tail on a raw slab (gpq_relin_tail_overwriting), or takes them
 // off again for the groups its exact fallback re-runs with the kernels that read raw residues.
 struct LimbScaleArgs { const LimbTab *tabs; uint64_t *chat; const uint64_t *scale; const unsigned char *only; unsigned dim, logn; FlagScope scope; };
-__global__ __launch_bounds__(256) void bridge_limb_scale(LimbScaleArgs a) {
-  scoped_or_grid(a.scope, a.logn, 256, [&](unsigned poly, unsigned i) {     // a wave = one group of 64 either way
+__device__ __forceinline__ void limb_scale_body(const LimbScaleArgs &a, unsigned poly, unsigned i) {     // a wave = one group of 64
   if (a.only && !__builtin_amdgcn_ballot_w64(a.only[((size_t)poly << a.logn) + i] != 0)) return;
   uint64_t *__restrict__ p = a.chat + ((size_t)poly * a.dim << a.logn) + i;
   for (unsigned d = 0; d < a.dim; ++d) {
     const PrimeK k = a.tabs[d].k;
     p[(size_t)d << a.logn] = mulmod_canon(p[(size_t)d << a.logn], a.scale[d], k);
   }
+}
+__global__ __launch_bounds__(256) void bridge_limb_scale(LimbScaleArgs a) {
+  scoped_or_grid(a.scope, a.logn, 256, [&](unsigned poly, unsigned i) { limb_scale_body(a, poly, i); });
+}
+template <int WP>
+__global__ __launch_bounds__(128) void bridge_fallback_tail_pre(ReconstructArgs dd, LimbScaleArgs un) {
+  scoped_or_grid(dd.scope, dd.logn, 128, [&](unsigned poly, unsigned i) {
+    reconstruct_body<WP>(dd, poly, i);                    // the addend d of the flagged coefficients as words (exact CRT of its limbs)
+    limb_scale_body(un, poly, i);                         // the CRT weights off the key switch's limbs of the flagged groups, for the exact tail
   });
 }
 
