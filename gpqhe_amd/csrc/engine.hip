@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 using namespace gpq;
 
@@ -393,9 +394,20 @@ int check_shape(const gpq_ctx *c, unsigned dim, unsigned batch, const char *who)
   return GPQ_OK;
 }
 
-PassArgs make_args(const gpq_ctx *c, unsigned dim, unsigned nslab) {
+// Cache policy of a launch group's slab traffic (PassArgs::nt).  A group whose slabs fit the 256 MiB Infinity Cache wants the default
+// policy: what one kernel writes the next one reads from the cache (NTT pairs at configs[1], batch 64 = 168 MB: 11-15 % slower with nt; at
+// 252 MB still 13 % slower).  A group that cannot fit gains 2.4-6 % from nt loads and stores, which pass without evicting the twiddle
+// tables and each other's lines (336 MB: +4.6 %; the he_mul core at the headline shape: +2.4 %) -- profiles/r04/v10_nt_policy_ab.txt.
+// `slabs` = the slabs of polys x limbs x n words the group moves between its kernels.
+static unsigned nt_for(const gpq_ctx *c, size_t polys, unsigned limbs, unsigned slabs) {
+  if (c->nt_mode >= 0) return (unsigned)c->nt_mode;
+  return polys * limbs * ((size_t)8 << c->logn) * slabs > ((size_t)288 << 20);
+}
+
+PassArgs make_args(const gpq_ctx *c, unsigned dim, unsigned nslab, unsigned nt = 0) {
   PassArgs a;
   memset(&a, 0, sizeof a);
+  a.nt = nt;
   a.tabs = c->d_tabs;
   a.w = c->d_w;
   a.winv = c->d_winv;
@@ -432,10 +444,20 @@ int for_limb_ranges(const gpq_ctx *c, PassArgs a, unsigned dim, const uint64_t *
   return GPQ_OK;
 }
 
+// PassArgs::nt picks the instantiation (a cache policy is an instruction modifier: the flag is a template parameter of the kernels, not a branch
+// in them -- as a run-time select the compiler folds the two loads into one and drops the modifier): f(std::true_type / std::false_type)
+template <typename F>
+static inline void with_nt(unsigned nt, F f) {
+  if (nt) f(std::true_type{});
+  else f(std::false_type{});
+}
+
 template <int M1, int EL, bool INV, bool CANON, typename TW, int CW = 8>
 int launch_strided_t(const PassArgs &a, unsigned gy, unsigned gz, hipStream_t s) {
   using G = StridedGeom<M1, EL>;
-  hipLaunchKernelGGL((strided_pass<M1, EL, INV, CANON, TW, CW>), dim3((1u << CW) >> G::CB, gy, gz), dim3(G::T), 0, s, a);
+  with_nt(a.nt, [&](auto nt) {
+    hipLaunchKernelGGL((strided_pass<M1, EL, INV, CANON, TW, CW, decltype(nt)::value>), dim3((1u << CW) >> G::CB, gy, gz), dim3(G::T), 0, s, a);
+  });
   return GPQ_OK;
 }
 
@@ -466,11 +488,11 @@ int launch_contig(const gpq_ctx *c, const PassArgs &args, unsigned dim, unsigned
     ProfScope prof(c, INV ? GPQ_K_CONTIG_INV : GPQ_K_CONTIG_FWD, s);
     if (c->low9) {
       const dim3 grid9(c->n >> 11, (polys + CONTIG8_POLYS - 1) / CONTIG8_POLYS, limbs);
-      hipLaunchKernelGGL((contig_pass8<INV, TW, 9>), grid9, dim3(CONTIG_WAVES * 64), 0, s, a, polys);
+      with_nt(a.nt, [&](auto nt) { hipLaunchKernelGGL((contig_pass8<INV, TW, 9, decltype(nt)::value>), grid9, dim3(CONTIG_WAVES * 64), 0, s, a, polys); });
       return (int)GPQ_OK;
     }
     const dim3 grid(c->n >> 12, (polys + CONTIG_POLYS - 1) / CONTIG_POLYS, limbs);
-    hipLaunchKernelGGL((contig_pass<INV, TW>), grid, dim3(CONTIG_WAVES * 64), 0, s, a, polys);
+    with_nt(a.nt, [&](auto nt) { hipLaunchKernelGGL((contig_pass<INV, TW, decltype(nt)::value>), grid, dim3(CONTIG_WAVES * 64), 0, s, a, polys); });
     return (int)GPQ_OK;
   });
 }
@@ -553,7 +575,7 @@ extern "C" int gpq_ntt(gpq_ctx *c, uint64_t *slab, unsigned dim, unsigned batch,
   if (!slab) return gpq_fail(GPQ_ERR_INVALID, "gpq_ntt: null slab");
   for (unsigned k0 = 0; k0 < batch; k0 += kMaxPolysPerLaunch) {
     const unsigned polys = batch - k0 < kMaxPolysPerLaunch ? batch - k0 : kMaxPolysPerLaunch;
-    PassArgs a = make_args(c, dim, 1);
+    PassArgs a = make_args(c, dim, 1, nt_for(c, polys, dim, 1));
     a.src[0] = a.dst[0] = slab + (size_t)k0 * ((size_t)dim << c->logn);
     if ((rc = zero_flags(c, (size_t)polys * dim, (hipStream_t)stream, &a.zflag)) != GPQ_OK) return rc;
     a.zstride = dim;
@@ -585,7 +607,7 @@ extern "C" int gpq_invntt(gpq_ctx *c, uint64_t *slab, unsigned dim, unsigned bat
   if (!slab) return gpq_fail(GPQ_ERR_INVALID, "gpq_invntt: null slab");
   for (unsigned k0 = 0; k0 < batch; k0 += kMaxPolysPerLaunch) {
     const unsigned polys = batch - k0 < kMaxPolysPerLaunch ? batch - k0 : kMaxPolysPerLaunch;
-    PassArgs a = make_args(c, dim, 1);
+    PassArgs a = make_args(c, dim, 1, nt_for(c, polys, dim, 1));
     a.src[0] = a.dst[0] = slab + (size_t)k0 * ((size_t)dim << c->logn);
     if ((rc = inverse_slabs(c, a, dim, polys, (hipStream_t)stream)) != GPQ_OK) return rc;
   }
@@ -632,19 +654,23 @@ extern "C" int gpq_poly_mul_rns(gpq_ctx *c, uint64_t *r, uint64_t *a, uint64_t *
   const size_t poly = (size_t)dim << c->logn;
   for (unsigned k0 = 0; k0 < batch; k0 += kMaxPolysPerLaunch / 2) {
     const unsigned polys = batch - k0 < kMaxPolysPerLaunch / 2 ? batch - k0 : kMaxPolysPerLaunch / 2;
-    PassArgs f = make_args(c, dim, 2);
+    const unsigned nt = nt_for(c, polys, dim, 3);
+    PassArgs f = make_args(c, dim, 2, nt);
     f.src[0] = f.dst[0] = a + k0 * poly; f.src[1] = f.dst[1] = b + k0 * poly;
     if ((rc = launch_strided<false>(c, f, dim, polys, s))) return rc;
-    PassArgs m = make_args(c, dim, 1);
+    PassArgs m = make_args(c, dim, 1, nt);
     m.src[0] = f.dst[0]; m.src[1] = f.dst[1]; m.dst[0] = r + k0 * poly;
     if ((rc = for_limb_ranges<true>(c, m, dim, nullptr, nullptr, [&](auto tag, const PassArgs &p, unsigned limbs) {
           using TW = decltype(tag);
           ProfScope prof(c, GPQ_K_CONTIG_FWD, s);
-          if (c->low9) hipLaunchKernelGGL((polymul_mid8<TW, 9>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, p);
-          else hipLaunchKernelGGL((polymul_mid8<TW, 8>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, p);
+          with_nt(p.nt, [&](auto nt) {
+            constexpr bool NT = decltype(nt)::value;
+            if (c->low9) hipLaunchKernelGGL((polymul_mid8<TW, 9, NT>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, p);
+            else hipLaunchKernelGGL((polymul_mid8<TW, 8, NT>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, p);
+          });
           return (int)GPQ_OK;
         }))) return rc;
-    PassArgs b2 = make_args(c, dim, 1);
+    PassArgs b2 = make_args(c, dim, 1, nt);
     b2.src[0] = b2.dst[0] = m.dst[0];
     if ((rc = launch_strided<true>(c, b2, dim, polys, s))) return rc;
   }
@@ -668,20 +694,24 @@ extern "C" int gpq_mulpt_rns(gpq_ctx *c, uint64_t *r0, uint64_t *r1, uint64_t *m
   const size_t poly = (size_t)dim << c->logn;
   for (unsigned k0 = 0; k0 < batch; k0 += kMaxPolysPerLaunch / 4) {
     const unsigned polys = batch - k0 < kMaxPolysPerLaunch / 4 ? batch - k0 : kMaxPolysPerLaunch / 4;
-    PassArgs f = make_args(c, dim, 3);
+    const unsigned nt = nt_for(c, polys, dim, 5);
+    PassArgs f = make_args(c, dim, 3, nt);
     f.src[0] = f.dst[0] = m + k0 * poly; f.src[1] = f.dst[1] = x0 + k0 * poly; f.src[2] = f.dst[2] = x1 + k0 * poly;
     if ((rc = launch_strided<false>(c, f, dim, polys, s))) return rc;
-    PassArgs p = make_args(c, dim, 1);
+    PassArgs p = make_args(c, dim, 1, nt);
     for (int i = 0; i < 3; ++i) p.src[i] = f.dst[i];
     p.dst[0] = r0 + k0 * poly; p.dst[1] = r1 + k0 * poly;
     if ((rc = for_limb_ranges<true>(c, p, dim, nullptr, nullptr, [&](auto tag, const PassArgs &q, unsigned limbs) {
           using TW = decltype(tag);
           ProfScope prof(c, GPQ_K_CONTIG_FWD, s);
-          if (c->low9) hipLaunchKernelGGL((mulpt_mid8<TW, 9>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, q);
-          else hipLaunchKernelGGL((mulpt_mid8<TW, 8>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, q);
+          with_nt(q.nt, [&](auto nt) {
+            constexpr bool NT = decltype(nt)::value;
+            if (c->low9) hipLaunchKernelGGL((mulpt_mid8<TW, 9, NT>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, q);
+            else hipLaunchKernelGGL((mulpt_mid8<TW, 8, NT>), dim3(c->n >> 11, polys, limbs), dim3(CONTIG_WAVES * 64), 0, s, q);
+          });
           return (int)GPQ_OK;
         }))) return rc;
-    PassArgs b2 = make_args(c, dim, 2);
+    PassArgs b2 = make_args(c, dim, 2, nt);
     b2.src[0] = b2.dst[0] = p.dst[0]; b2.src[1] = b2.dst[1] = p.dst[1];
     if ((rc = launch_strided<true>(c, b2, dim, polys, s))) return rc;
   }
@@ -751,26 +781,30 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
       const size_t loff = (size_t)l0 << c->logn;
       // 1. strided forward pass, inputs -> workspace
       StageRange stage("gpq_he_mul_tensor: strided fwd x4 / tensor_mid8 / strided inv x3");
-      PassArgs f = make_args(c, dim, nin);
+      const unsigned nt = nt_for(c, polys, limbs, nin + 3);
+      PassArgs f = make_args(c, dim, nin, nt);
       f.limb0 = l0;
       for (unsigned i = 0; i < nin; ++i) { f.src[i] = in[i] + k0 * poly + loff; f.dst[i] = ws + (size_t)i * chunk * poly + loff; }
       if ((rc = launch_strided<false>(c, f, limbs, polys, s))) return rc;
       // 2. low forward stages, products, low inverse stages -> outputs
-      PassArgs m = make_args(c, dim, 1);
+      PassArgs m = make_args(c, dim, 1, nt);
       m.limb0 = l0;
       for (unsigned i = 0; i < nin; ++i) m.src[i] = f.dst[i];
       m.dst[0] = d0 + k0 * poly + loff; m.dst[1] = d1 + k0 * poly + loff; m.dst[2] = d2 + k0 * poly + loff;
       if ((rc = for_limb_ranges<true>(c, m, limbs, nullptr, nullptr, [&](auto tag, const PassArgs &a, unsigned nl) {
             using TW = decltype(tag);
             ProfScope prof(c, GPQ_K_TENSOR_MID, s);
-            if (square && c->low9) hipLaunchKernelGGL((tensor_sq_mid8<TW, 9>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
-            else if (square) hipLaunchKernelGGL((tensor_sq_mid8<TW, 8>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
-            else if (c->low9) hipLaunchKernelGGL((tensor_mid8<TW, 9>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
-            else hipLaunchKernelGGL((tensor_mid8<TW, 8>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
+            with_nt(a.nt, [&](auto nt) {
+              constexpr bool NT = decltype(nt)::value;
+              if (square && c->low9) hipLaunchKernelGGL((tensor_sq_mid8<TW, 9, NT>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
+              else if (square) hipLaunchKernelGGL((tensor_sq_mid8<TW, 8, NT>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
+              else if (c->low9) hipLaunchKernelGGL((tensor_mid8<TW, 9, NT>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
+              else hipLaunchKernelGGL((tensor_mid8<TW, 8, NT>), dim3(c->n >> 11, polys, nl), dim3(CONTIG_WAVES * 64), 0, s, a);
+            });
             return (int)GPQ_OK;
           }))) return rc;
       // 3. strided inverse pass in place on the three outputs
-      PassArgs b = make_args(c, dim, 3);
+      PassArgs b = make_args(c, dim, 3, nt);
       b.limb0 = l0;
       if (c->inv_tabs_override) b.tabs = c->inv_tabs_override;
       for (int i = 0; i < 3; ++i) { b.src[i] = m.dst[i]; b.dst[i] = m.dst[i]; }
@@ -809,12 +843,13 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
       const unsigned limbs = dim - l0 < lblock ? dim - l0 : lblock;
       const size_t loff = (size_t)l0 << c->logn;
       StageRange stage("gpq_keyswitch: strided fwd / keyswitch_mid8x2 / strided inv x2");
-      PassArgs f = make_args(c, dim, 1);
+      const unsigned nt = nt_for(c, polys, limbs, 3);
+      PassArgs f = make_args(c, dim, 1, nt);
       f.limb0 = l0;
       f.src[0] = x + k0 * poly + loff; f.dst[0] = ws + loff;
       if ((rc = launch_strided<false>(c, f, limbs, polys, s))) return rc;
       KeyswitchArgs m;
-      m.p = make_args(c, dim, 1);
+      m.p = make_args(c, dim, 1, nt);
       m.p.limb0 = l0;
       m.p.src[0] = f.dst[0]; m.p.dst[0] = c0 + k0 * poly + loff; m.p.dst[1] = c1 + k0 * poly + loff;
       m.evk0 = evk0 + loff; m.evk1 = evk1 + loff;
@@ -823,17 +858,20 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
             KeyswitchArgs ka{a, m.evk0, m.evk1};
             ProfScope prof(c, GPQ_K_KEYSWITCH_MID, s);
             const dim3 block(CONTIG_WAVES * 64);
-            if (polys / 2) {
-              if (c->low9) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 9, true>), dim3(c->n >> 11, polys / 2, nl), block, 0, s, ka, 0u);
-              else hipLaunchKernelGGL((keyswitch_mid8x2<TW, 8, true>), dim3(c->n >> 11, polys / 2, nl), block, 0, s, ka, 0u);
-            }
-            if (polys & 1) {           // the odd last polynomial alone (half the arithmetic of a pair that would be stored once)
-              if (c->low9) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 9, false>), dim3(c->n >> 11, 1, nl), block, 0, s, ka, polys - 1);
-              else hipLaunchKernelGGL((keyswitch_mid8x2<TW, 8, false>), dim3(c->n >> 11, 1, nl), block, 0, s, ka, polys - 1);
-            }
+            with_nt(a.nt, [&](auto nt) {
+              constexpr bool NT = decltype(nt)::value;
+              if (polys / 2) {
+                if (c->low9) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 9, true, NT>), dim3(c->n >> 11, polys / 2, nl), block, 0, s, ka, 0u);
+                else hipLaunchKernelGGL((keyswitch_mid8x2<TW, 8, true, NT>), dim3(c->n >> 11, polys / 2, nl), block, 0, s, ka, 0u);
+              }
+              if (polys & 1) {           // the odd last polynomial alone (half the arithmetic of a pair that would be stored once)
+                if (c->low9) hipLaunchKernelGGL((keyswitch_mid8x2<TW, 9, false, NT>), dim3(c->n >> 11, 1, nl), block, 0, s, ka, polys - 1);
+                else hipLaunchKernelGGL((keyswitch_mid8x2<TW, 8, false, NT>), dim3(c->n >> 11, 1, nl), block, 0, s, ka, polys - 1);
+              }
+            });
             return (int)GPQ_OK;
           }))) return rc;
-      PassArgs b = make_args(c, dim, 2);
+      PassArgs b = make_args(c, dim, 2, nt);
       b.limb0 = l0;
       if (c->inv_tabs_override) b.tabs = c->inv_tabs_override;
       for (int i = 0; i < 2; ++i) { b.src[i] = m.p.dst[i]; b.dst[i] = m.p.dst[i]; }
@@ -847,6 +885,13 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
 // limbs up to `split` the split-twiddle ones, the rest the 7-mad ones.  The context picks the cheapest class each limb
 // admits; this call can only move limbs towards the more general (slower) classes -- what the tests use to run every class on
 // every limb and compare bit for bit.  Values above what the chain admits are clamped.
+extern "C" int gpq_set_nt_policy(gpq_ctx *c, int mode) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_nt_policy: null context");
+  if (mode < -1 || mode > 1) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_nt_policy: mode %d (want -1 by working set, 0 never, 1 always)", mode);
+  c->nt_mode = mode;
+  return GPQ_OK;
+}
+
 extern "C" int gpq_set_limb_classes(gpq_ctx *c, unsigned wide, unsigned split) {
   if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_limb_classes: null context");
   c->nsplit = split < c->nsplit_tables ? split : c->nsplit_tables;

@@ -98,6 +98,7 @@ struct gpq_ctx {
   unsigned *d_wave_any = nullptr;     // one word per wave of the last bridge_stream.hpp launch: did it flag a coefficient (FlagScope)
   bool lazy_decompose = true;         // gpq_he_mul's own rns_decompose output in (0, 3p): the forward transforms take it (gpq_set_lazy_decompose)
   unsigned debug_force_redo = 0;      // tests (gpq_debug_force_redo)
+  int nt_mode = -1;                   // slab traffic of the transform kernels with the nt cache policy: -1 by working set (nt_for), 0 never, 1 always
   bool stream_bridge = true;          // gpq_he_mul / gpq_he_swk: bridge_stream.hpp's fused streaming kernels (gpq_set_stream_bridge(ctx, 0): round 3's separate kernels)
   bool exact_crt = false;             // force the exact CRT kernel (tests)
   bool prescale = true;               // gpq_he_mul / gpq_he_swk: inverse passes write limbs pre-multiplied by (P/p_d)^-1 for the CRT kernels (gpq_set_prescale)

@@ -34,6 +34,18 @@
 
 namespace gpq {
 
+// One slab word with the launch's cache policy (PassArgs::nt picks the kernel's NT instantiation on the host).  A template parameter, not an
+// argument: as a run-time select the compiler folds the two loads into one plain load before inlining and the modifier is gone.
+template <bool NT> __device__ __forceinline__ uint64_t slab_ld(const uint64_t *p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT> __device__ __forceinline__ void slab_st(uint64_t *p, uint64_t v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+
 // ---------------------------------------------------------------------------
 // Register groups.  x[] holds E = 2^EL coefficients; register bit b stands for
 // global index bit (rs + b); ibase is the global index of x[0].  A stage on
@@ -229,7 +241,7 @@ struct StridedGeom {
 };
 
 // CW = log2 of the row length the low kernels own: 8, or 9 for n = 2^17 (256-row tiles over 512-coefficient rows).
-template <int M1, int EL, bool INV, bool CANON_OUT, typename TW, int CW = 8>
+template <int M1, int EL, bool INV, bool CANON_OUT, typename TW, int CW = 8, bool NT = false>
 __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArgs a) {
   using G = StridedGeom<M1, EL>;
   constexpr int E = G::E;
@@ -268,7 +280,7 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
   if (!INV) {
     TW twA[tw_count(EL, EL - 1, 0)];
 #pragma unroll
-    for (int e = 0; e < E; ++e) x[e] = src[iA + e * strideA];
+    for (int e = 0; e < E; ++e) x[e] = slab_ld<NT>(&src[iA + e * strideA]);
     load_tw<EL, EL - 1, 0, true>(twA, iA, G::S2 + CW, logn, wt);
     if (G::S2 > 0) load_tw<EL, G::BB, 0, false>(twB, iB, CW, logn, wt);
     ct_group<EL, EL - 1, 0, G::S2 + CW>(x, twA, k);
@@ -280,17 +292,17 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
       for (int e = 0; e < E; ++e) x[e] = lds[G::pad((q << (EL + CB)) + (e << CB) + (tid & (G::C - 1)))];
       ct_group<EL, G::BB, 0, CW>(x, twB, k);
 #pragma unroll
-      for (int e = 0; e < E; ++e) dst[iB + e * strideB] = CANON_OUT ? TwTraits<TW>::canon_fwd(x[e], k) : x[e];
+      for (int e = 0; e < E; ++e) slab_st<NT>(&dst[iB + e * strideB], CANON_OUT ? TwTraits<TW>::canon_fwd(x[e], k) : x[e]);
     } else {
 #pragma unroll
-      for (int e = 0; e < E; ++e) dst[iA + e * strideA] = CANON_OUT ? TwTraits<TW>::canon_fwd(x[e], k) : x[e];
+      for (int e = 0; e < E; ++e) slab_st<NT>(&dst[iA + e * strideA], CANON_OUT ? TwTraits<TW>::canon_fwd(x[e], k) : x[e]);
     }
   } else {
     // top EL row bits; the very last one (len = n/2) carries the n^-1 scaling and is done by gs_last
     TW twA[tw_count(EL, (EL > 1 ? EL - 2 : 0), 0)];
     if (G::S2 > 0) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) x[e] = src[iB + e * strideB];
+      for (int e = 0; e < E; ++e) x[e] = slab_ld<NT>(&src[iB + e * strideB]);
       load_tw<EL, G::BB, 0, false>(twB, iB, CW, logn, wt);
       if (EL > 1) load_tw<EL, (EL > 1 ? EL - 2 : 0), 0, true>(twA, iA, G::S2 + CW, logn, wt);
       gs_group<EL, G::BB, 0>(x, twB, k);
@@ -301,14 +313,14 @@ __global__ __launch_bounds__((StridedGeom<M1, EL>::T)) void strided_pass(PassArg
       for (int e = 0; e < E; ++e) x[e] = lds[G::pad(tid + e * G::T)];
     } else {
 #pragma unroll
-      for (int e = 0; e < E; ++e) x[e] = src[iA + e * strideA];
+      for (int e = 0; e < E; ++e) x[e] = slab_ld<NT>(&src[iA + e * strideA]);
       if (EL > 1) load_tw<EL, (EL > 1 ? EL - 2 : 0), 0, true>(twA, iA, G::S2 + CW, logn, wt);
     }
     if (EL > 1) gs_group<EL, (EL > 1 ? EL - 2 : 0), 0>(x, twA, k);
 #pragma unroll
     for (int e = 0; e < E / 2; ++e) gs_last(x[e], x[e + E / 2], last, k);
 #pragma unroll
-    for (int e = 0; e < E; ++e) dst[iA + e * strideA] = x[e];
+    for (int e = 0; e < E; ++e) slab_st<NT>(&dst[iA + e * strideA], x[e]);
   }
 }
 
@@ -374,13 +386,13 @@ struct ContigTw {
   }
 };
 
-__device__ __forceinline__ void load_h(uint64_t (&x)[16], const uint64_t *__restrict__ p, const ContigLane &ln) {
+template <bool NT> __device__ __forceinline__ void load_h(uint64_t (&x)[16], const uint64_t *__restrict__ p, const ContigLane &ln) {
 #pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = p[ln.hbase + 16 * e];
+  for (int e = 0; e < 16; ++e) x[e] = slab_ld<NT>(&p[ln.hbase + 16 * e]);
 }
-__device__ __forceinline__ void store_h(uint64_t *__restrict__ p, const uint64_t (&x)[16], const ContigLane &ln) {
+template <bool NT> __device__ __forceinline__ void store_h(uint64_t *__restrict__ p, const uint64_t (&x)[16], const ContigLane &ln) {
 #pragma unroll
-  for (int e = 0; e < 16; ++e) p[ln.hbase + 16 * e] = x[e];
+  for (int e = 0; e < 16; ++e) slab_st<NT>(&p[ln.hbase + 16 * e], x[e]);
 }
 __device__ __forceinline__ void load_l(uint64_t (&x)[16], const uint64_t *__restrict__ p, const ContigLane &ln) {
   const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(p + ln.lbase);
@@ -418,11 +430,11 @@ constexpr int CONTIG_POLYS = GPQ_CONTIG_POLYS;
 #define GPQ_CONTIG_MINWAVES 3
 #endif
 // (the plain-twiddle form keeps its 30 twiddles and a prefetched polynomial in registers: 2 waves per SIMD)
-template <bool INV, typename TW>
+template <bool INV, typename TW, bool NT = false>
 __global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTIG_MINWAVES)) void contig_pass(PassArgs a, unsigned polys) {
   using TT = TwTraits<TW>;
   __shared__ uint64_t lds[CONTIG_WAVES * CONTIG_LDS_PER_WAVE];
-  const ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
+  ContigLane ln(lds + (threadIdx.x >> 6) * CONTIG_LDS_PER_WAVE);
   const unsigned wave0 = (blockIdx.x * CONTIG_WAVES + (threadIdx.x >> 6)) << 10;
   const unsigned limb = a.limb0 + blockIdx.z;
   const LimbTab &tab = a.tabs[limb];
@@ -440,11 +452,11 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTI
     ContigTw<TW> twh, twl;
     // Global accesses use the H layout only (16 lanes = 128 contiguous bytes); the L layout
     // (each lane on its own 128-byte line) is reached through one more LDS exchange instead.
-    load_h(x, src, ln);
+    load_h<NT>(x, src, ln);
     twh.load_h(ln, wave0, a.logn, wt);
     twl.load_l(ln, wave0, a.logn, wt);
     for (unsigned i = 0; i < cnt; ++i) {
-      if (i + 1 < cnt) load_h(nx, src + (size_t)(i + 1) * a.poly_stride, ln);
+      if (i + 1 < cnt) load_h<NT>(nx, src + (size_t)(i + 1) * a.poly_stride, ln);
       if (!INV) {
         ct_group<4, 3, 0, 4>(x, twh.t, k);
         ln.h_to_l(x);
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTI
         ln.l_to_h(x);
         gs_group<4, 3, 0>(x, twh.t, k);
       }
-      store_h(dst + (size_t)i * a.poly_stride, x, ln);
+      store_h<NT>(dst + (size_t)i * a.poly_stride, x, ln);
 #pragma unroll
       for (int e = 0; e < 16; ++e) x[e] = nx[e];
     }
@@ -471,7 +483,7 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTI
     ContigTw<TW> tw;
 #pragma unroll
     for (int j = 0; j < CONTIG_POLYS; ++j)
-      if (j < (int)cnt) load_h(x[j], src + (size_t)j * a.poly_stride, ln);
+      if (j < (int)cnt) load_h<NT>(x[j], src + (size_t)j * a.poly_stride, ln);
     if (!INV) {
       tw.load_h(ln, wave0, a.logn, wt);
 #pragma unroll
@@ -487,7 +499,7 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTI
 #pragma unroll
           for (int e = 0; e < 16; ++e) { x[j][e] = TT::canon_fwd(x[j][e], k); zero_watch(zm, x[j][e]); }
           zero_note(a, zm, p0 + j, blockIdx.z);
-          store_h(dst + (size_t)j * a.poly_stride, x[j], ln);
+          store_h<NT>(dst + (size_t)j * a.poly_stride, x[j], ln);
         }
     } else {
       tw.load_l(ln, wave0, a.logn, wt);
@@ -503,7 +515,7 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, (sizeof(TW) == 8 ? 2 : GPQ_CONTI
       for (int j = 0; j < CONTIG_POLYS; ++j)
         if (j < (int)cnt) {
           gs_group<4, 3, 0>(x[j], tw.t, k);
-          store_h(dst + (size_t)j * a.poly_stride, x[j], ln);
+          store_h<NT>(dst + (size_t)j * a.poly_stride, x[j], ln);
         }
     }
   }
@@ -610,14 +622,6 @@ struct Lane8 {
     for (int e = 0; e < 8; ++e) x[e] = lds[pad2(lk + e)];
     wave_lds_sync();
   }
-  __device__ __forceinline__ void load_h(uint64_t (&x)[8], const uint64_t *__restrict__ p) const {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = p[hk + (e << JB)];
-  }
-  __device__ __forceinline__ void store_h(uint64_t *__restrict__ p, const uint64_t (&x)[8]) const {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) p[hk + (e << JB)] = x[e];
-  }
   __device__ __forceinline__ void load_l(uint64_t (&x)[8], const uint64_t *__restrict__ p) const {
     const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(p + lk);
 #pragma unroll
@@ -631,6 +635,22 @@ struct Lane8 {
   template <typename TW> __device__ static __forceinline__ void gs_l(uint64_t (&x)[8], const TW (&u)[tw_count(3, LHI, 0)], const PrimeK &k) { gs_group<3, LHI, 0>(x, u, k); }
   // ... the same group when it opens a standalone inverse transform (canonical inputs)
   template <typename TW> __device__ static __forceinline__ void gs_l_canon(uint64_t (&x)[8], const TW (&u)[tw_count(3, LHI, 0)], const PrimeK &k) { gs_group<3, LHI, 0, true>(x, u, k); }
+};
+
+// ... with the slab accesses (H layout) under the launch's cache policy
+template <int LOW, bool NT>
+struct Lane8N : Lane8<LOW> {
+  using Lane8<LOW>::hk;
+  using Lane8<LOW>::JB;
+  __device__ __forceinline__ Lane8N(uint64_t *wave_lds) : Lane8<LOW>(wave_lds) {}
+  __device__ __forceinline__ void load_h(uint64_t (&x)[8], const uint64_t *__restrict__ p) const {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = slab_ld<NT>(&p[hk + (e << JB)]);
+  }
+  __device__ __forceinline__ void store_h(uint64_t *__restrict__ p, const uint64_t (&x)[8]) const {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) slab_st<NT>(&p[hk + (e << JB)], x[e]);
+  }
 };
 
 // twiddles of one group of one direction: 7 for H and M, 6 or 7 for L
@@ -664,12 +684,12 @@ struct Block8 {             // per-workgroup addressing: 4 waves x 512 coefficie
 #ifndef GPQ_MID8_MINWAVES
 #define GPQ_MID8_MINWAVES 3
 #endif
-template <typename TW, int LOW>
+template <typename TW, int LOW, bool NT = false>
 __global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_MID8_MINWAVES) void tensor_mid8(PassArgs a) {
   using TT = TwTraits<TW>;
-  using L8 = Lane8<LOW>;
+  using L8 = Lane8N<LOW, NT>;
   __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
-  const L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
+  L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
   const Block8 cb(a);
   const PrimeK k = a.tabs[cb.limb].k;
   const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
@@ -724,12 +744,12 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_MID8_MINWAVES) void tensor_m
 // src/he-mult.c:88-156 with both operands the same ciphertext): two forward low-halves instead of four,
 //   d0 = c0 c0, d2 = c1 c1, d1 = c0 c1 + c1 c0 = 2 c0 c1   (the same residues as the general kernel gives for b = a),
 // three inverse low-halves.  src[0..1] = c0, c1 after the strided forward pass; dst[0..2] = d0, d1, d2.
-template <typename TW, int LOW>
+template <typename TW, int LOW, bool NT = false>
 __global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_MID8_MINWAVES) void tensor_sq_mid8(PassArgs a) {
   using TT = TwTraits<TW>;
-  using L8 = Lane8<LOW>;
+  using L8 = Lane8N<LOW, NT>;
   __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
-  const L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
+  L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
   const Block8 cb(a);
   const PrimeK k = a.tabs[cb.limb].k;
   const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
@@ -776,12 +796,12 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_MID8_MINWAVES) void tensor_s
 // Middle of poly_mul's limb loop (src/poly.c:96-103): low forward stages of a and b, a (*) b, low inverse stages.
 // src[0], src[1] = a, b after the strided forward pass; dst[0] = r before the strided inverse pass (r may be a or b: a
 // workgroup reads its 2048 coefficients of both before it writes them).
-template <typename TW, int LOW>
+template <typename TW, int LOW, bool NT = false>
 __global__ __launch_bounds__(CONTIG_WAVES * 64, 4) void polymul_mid8(PassArgs a) {
   using TT = TwTraits<TW>;
-  using L8 = Lane8<LOW>;
+  using L8 = Lane8N<LOW, NT>;
   __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
-  const L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
+  L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
   const Block8 cb(a);
   const PrimeK k = a.tabs[cb.limb].k;
   const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
@@ -811,12 +831,12 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 4) void polymul_mid8(PassArgs a)
 
 // Middle of he_mulpt's limb loop (src/he-mult.c:179-185): low forward stages of m, c0, c1, then m (*) c0 and m (*) c1,
 // low inverse stages of both.  src[0..2] = m, c0, c1 after the strided forward pass; dst[0..1] may be c0, c1.
-template <typename TW, int LOW>
+template <typename TW, int LOW, bool NT = false>
 __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void mulpt_mid8(PassArgs a) {
   using TT = TwTraits<TW>;
-  using L8 = Lane8<LOW>;
+  using L8 = Lane8N<LOW, NT>;
   __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
-  const L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
+  L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
   const Block8 cb(a);
   const PrimeK k = a.tabs[cb.limb].k;
   const TW *__restrict__ wf = TT::table(a, false) + cb.toff, *__restrict__ wi = TT::table(a, true) + cb.toff;
@@ -860,13 +880,13 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void mulpt_mid8(PassArgs a) {
 // twiddle group are fetched once for both -- per polynomial the 16-per-lane kernel reads 960 B of twiddle pairs and 256 B
 // of key per lane against 384 B of its own data -- and the four products of a pair run like the tensor stage (2 forward
 // low-halves, 4 inverse ones).  blockIdx.y = pair of polynomials starting at `first`; an odd last polynomial runs alone in the TWO = false instantiation.
-template <typename TW, int LOW, bool TWO = true>
+template <typename TW, int LOW, bool TWO = true, bool NT = false>
 __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid8x2(KeyswitchArgs ka, unsigned first) {
   using TT = TwTraits<TW>;
-  using L8 = Lane8<LOW>;
+  using L8 = Lane8N<LOW, NT>;
   __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
   const PassArgs &a = ka.p;
-  const L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
+  L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
   const unsigned wave0 = (blockIdx.x * CONTIG_WAVES + (threadIdx.x >> 6)) << 9;
   const unsigned limb = a.limb0 + blockIdx.z;
   const PrimeK k = a.tabs[limb].k;
@@ -936,12 +956,12 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, 3) void keyswitch_mid8x2(Keyswit
 
 // contig_pass in the 8-per-lane geometry (n = 2^17): CONTIG8_POLYS polynomials of the same limb and tile share each twiddle group.
 constexpr int CONTIG8_POLYS = 2;
-template <bool INV, typename TW, int LOW>
+template <bool INV, typename TW, int LOW, bool NT = false>
 __global__ __launch_bounds__(CONTIG_WAVES * 64, 4) void contig_pass8(PassArgs a, unsigned polys) {
   using TT = TwTraits<TW>;
-  using L8 = Lane8<LOW>;
+  using L8 = Lane8N<LOW, NT>;
   __shared__ uint64_t lds[CONTIG_WAVES * LANE8_LDS_PER_WAVE];
-  const L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
+  L8 ln(lds + (threadIdx.x >> 6) * LANE8_LDS_PER_WAVE);
   const unsigned wave0 = (blockIdx.x * CONTIG_WAVES + (threadIdx.x >> 6)) << 9;
   const unsigned limb = a.limb0 + blockIdx.z;
   const PrimeK k = a.tabs[limb].k;

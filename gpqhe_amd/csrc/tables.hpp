@@ -34,6 +34,9 @@ struct PassArgs {
   // reproduces the reference's representation of zero (src/ntt.c:47 stores p, not 0, for a sum x + t == p).
   unsigned *zflag;
   unsigned zstride;
+  // Cache policy of the slab accesses of this launch: 1 = nt (streaming).  Read by the HOST launchers only, which pick the NT instantiation
+  // of the kernel (engine.hip: with_nt, nt_for -- by the launch group's working set against the Infinity Cache).
+  unsigned nt;
 };
 
 }  // namespace gpq

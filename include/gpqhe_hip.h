@@ -217,6 +217,10 @@ int gpq_set_stream_bridge(gpq_ctx *ctx, int on);
 /* gpq_he_mul: 1 (default) = its internal rns_decompose launches leave residues in (0, 3p), which the forward transforms behind them accept;
  * 0 = canonical residues.  Same results. */
 int gpq_set_lazy_decompose(gpq_ctx *ctx, int on);
+/* Cache policy of the slab loads / stores of the transform kernels (gpq_ntt, gpq_invntt, gpq_poly_mul_rns, gpq_mulpt_rns, gpq_he_mul_tensor,
+ * gpq_keyswitch and everything built on them): -1 (default) = non-temporal when a launch group's slabs exceed the Infinity Cache (288 MiB is the
+ * threshold), the default policy when they fit; 0 = never; 1 = always.  Never changes a word. */
+int gpq_set_nt_policy(gpq_ctx *ctx, int mode);
 /* Tests: the streaming kernels also flag every coefficient whose index is a multiple of `every` for the exact kernels behind them (0 = off). */
 int gpq_debug_force_redo(gpq_ctx *ctx, unsigned every);
 /* With gpq_set_prescale(ctx, 2): the tail of he_relin / he_swk as two kernels with Q's residues in memory between them (0, default) or in one pass per coefficient (1:
