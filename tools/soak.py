@@ -40,6 +40,8 @@ def main():
         g = gpqhe_amd.PolyContext(logn, dim)
         g.set_chunk(chunk)
         g.set_limb_block(lblock)
+        nt = rng.choice([-1, 0, 1, 1])                           # cache policy of the slab traffic: the NT instantiations of every kernel / class
+        g.set_nt_policy(nt)
         if classes:
             g.set_limb_classes(*classes)
         per = dim * o.n
@@ -89,10 +91,10 @@ def main():
             exp.append(o.poly_mul_rns(ins[0][sl].copy(), ins[2][sl].copy(), dim))
             for name, a, b in zip(("ntt", "invntt", "d0", "d1", "d2", "c0", "c1", "polymul"), got, exp):
                 if not np.array_equal(a[sl], b):
-                    print("MISMATCH", name, "ciphertext", k, dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, seeds=seeds), flush=True)
+                    print("MISMATCH", name, "ciphertext", k, dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, nt_policy=nt, seeds=seeds), flush=True)
                     sys.exit(1)
         runs += 1
-        print("ok", dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, zero_cases=zero_mode), flush=True)
+        print("ok", dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, nt_policy=nt, zero_cases=zero_mode), flush=True)
         g.close()
     print("soak: %d configurations, no mismatch, %.0f s" % (runs, time.time() - t0))
 
