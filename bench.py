@@ -297,6 +297,13 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850):
         ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
     t.stop()
     ms = t.elapsed_ms() / iters
+    ctx.set_overlap(False)                           # the same on the caller's stream alone (gpq_set_overlap(ctx, 0)): what the two lanes buy
+    t.start()
+    for _ in range(iters):
+        ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
+    t.stop()
+    ms_one = t.elapsed_ms() / iters
+    ctx.set_overlap(True)
     ctx.profile(True)                                # a second pass with HIP events around every launch of this leg (on the launch stream) for the
     for _ in range(iters):                           # breakdown: the events themselves cost a few per cent at small shapes, so the rate above is timed without them
         ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
@@ -348,6 +355,9 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850):
     return {"shape": "n=2^%d, q=2^%d (W=%d words), dimA/dimB/dimP=%d/%d/%d, batch %d" % (ctx.logn, logq, W, dimA, dimB, dimP, batch),
             "ms_per_batch": round(ms, 3), "he_mul_per_s": round(batch / (ms * 1e-3), 1),
             "he_mul_plus_he_rescale_per_s": round(batch / (ms_rs * 1e-3), 1),
+            "lanes": {"default": 2, "one_lane_ms_per_batch": round(ms_one, 3), "one_lane_he_mul_per_s": round(batch / (ms_one * 1e-3), 1),
+                      "note": "gpq_he_mul runs every other launch group (32 ciphertexts) on a second internal stream through a peer context "
+                              "(gpq_set_overlap, default on); the kernel breakdown below is a profiled ONE-lane pass, so its kernel times add up to the one-lane figure"},
             "bridge_ms_per_batch": round(bridge_ms, 3), "core_ms_per_batch": round(sum(v["ms_per_batch"] for k, v in kernels.items() if not k.startswith("bridge_")), 3),
             "bridge_algo_bytes_per_he_mul": int(sum(words.values()) * 8 * n), "kernels": kernels, "roofline": roof}
 

@@ -1341,8 +1341,16 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
   void *wsTail = w;
   gpq_bridge_basis *bA;
   if ((rc = get_basis(c, 0, dimA, &bA))) return rc;
+  PeerLane lane;
+  if (batch > m && (rc = gpq_peer_lane(c, s, [&](gpq_ctx *q) { return gpq_he_mul_workspace_bytes(q, W, dimA, dimB, dimP, m); }, &lane))) return rc;
   for (unsigned k0 = 0; k0 < batch; k0 += m) {
     const unsigned polys = batch - k0 < m ? batch - k0 : m;
+    if (lane.c && ((k0 / m) & 1)) {                              // every other launch group: the same call on the peer, for this group's slice
+      const size_t o = k0 * bigpoly;
+      if ((rc = gpq_he_mul(lane.c, out_c0 + o, out_c1 + o, ct1c0 + o, ct1c1 + o, ct2c0 + o, ct2c1 + o, rlk0, rlk1, W, logql, dimA, dimB, dimP,
+                           polys, lane.ws, lane.s))) return rc;
+      continue;
+    }
     const size_t pa = (size_t)polys * dimA * n, pb = (size_t)polys * dimB * n;
     uint64_t *h[4] = {sA, sA + pa, sA + 2 * pa, sA + 3 * pa};
     uint64_t *d0h = sA + 4 * pa, *d1h = sA + 5 * pa, *d2h = sA + 6 * pa;
@@ -1398,6 +1406,7 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
                          limbs_addend ? Two<const uint64_t>{nullptr, nullptr, polys} : Two<const uint64_t>{d0, d1, polys},
                          W, dimP, dimB, logql, 2 * polys, wsTail, s, tail_mode, limbs_addend ? &dh : nullptr))) return rc;   // :67-77
   }
+  if ((rc = gpq_peer_join(c, s, lane))) return rc;
   return launched("gpq_he_mul");
 }
 
@@ -1419,8 +1428,15 @@ extern "C" int gpq_he_swk(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
   uint64_t *sB = (uint64_t *)w; w += align64((size_t)m * 3 * dimB * n * 8);
   void *wsK = w; w += align64(gpq_keyswitch_workspace_bytes(c, dimB, m));
   void *wsTail = w;
+  PeerLane lane;
+  if (batch > m && (rc = gpq_peer_lane(c, s, [&](gpq_ctx *q) { return gpq_he_swk_workspace_bytes(q, W, dimB, dimP, m); }, &lane))) return rc;
   for (unsigned k0 = 0; k0 < batch; k0 += m) {
     const unsigned polys = batch - k0 < m ? batch - k0 : m;
+    if (lane.c && ((k0 / m) & 1)) {                              // (as in gpq_he_mul)
+      const size_t o = k0 * bigpoly;
+      if ((rc = gpq_he_swk(lane.c, out_c0 + o, out_c1 + o, d0 + o, d1 + o, swk0, swk1, W, logql, dimB, dimP, polys, lane.ws, lane.s))) return rc;
+      continue;
+    }
     const size_t pb = (size_t)polys * dimB * n;
     uint64_t *d1hat = sB, *c0hat = sB + pb, *c1hat = sB + 2 * pb;
     if ((rc = launch_decompose(c, d1hat, d1 + k0 * bigpoly, W, 0, dimB, polys, s, c->lazy_decompose && c->logn > 12))) return rc;   // :60
@@ -1435,6 +1451,7 @@ extern "C" int gpq_he_swk(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
     if ((rc = relin_tail(c, Two<uint64_t>{out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, polys}, c0hat, Two<const uint64_t>{d0 + k0 * bigpoly, nullptr, polys},
                          W, dimP, dimB, logql, 2 * polys, wsTail, s, tail_mode))) return rc;
   }
+  if ((rc = gpq_peer_join(c, s, lane))) return rc;
   return launched("gpq_he_swk");
 }
 extern "C" size_t gpq_he_swk_workspace_bytes(gpq_ctx *c, unsigned W, unsigned dimB, unsigned dimP, unsigned batch) {
@@ -1523,6 +1540,13 @@ extern "C" int gpq_set_prescale(gpq_ctx *c, int on) {      // 0: off, 1: the CRT
 extern "C" int gpq_set_stream_bridge(gpq_ctx *c, int on) {
   if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_stream_bridge: null context");
   c->stream_bridge = on != 0;
+  return GPQ_OK;
+}
+
+// gpq_he_mul / gpq_he_swk over more than one launch group: alternate groups on two streams (default) or all on the caller's.  Same words.
+extern "C" int gpq_set_overlap(gpq_ctx *c, int on) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_overlap: null context");
+  c->overlap = on != 0;
   return GPQ_OK;
 }
 

@@ -300,8 +300,29 @@ extern "C" int gpq_ctx_create_from_tables(gpq_ctx **out, unsigned logn, unsigned
   return GPQ_OK;
 }
 
+int gpq_ctx_clone(const gpq_ctx *c, gpq_ctx **out) {
+  gpq_ctx *q = new (std::nothrow) gpq_ctx();
+  if (!q) return gpq_fail(GPQ_ERR_NOMEM, "out of host memory");
+  q->device = c->device; q->logn = c->logn; q->n = c->n; q->nprimes = c->nprimes;
+  q->p = c->p; q->pinv_mont = c->pinv_mont; q->pinv_barr = c->pinv_barr; q->ninv_mont = c->ninv_mont; q->psi = c->psi;
+  q->zetas = c->zetas; q->zetas_inv = c->zetas_inv;
+  q->overlap = false;
+  int rc = upload_tables(q);
+  if (rc != GPQ_OK) { gpq_ctx_destroy(q); return rc; }
+  *out = q;
+  return GPQ_OK;
+}
+
 extern "C" void gpq_ctx_destroy(gpq_ctx *c) {
   if (!c) return;
+  if (c->peer) {
+    if (c->peer_stream) (void)hipStreamSynchronize(c->peer_stream);
+    gpq_ctx_destroy(c->peer);
+  }
+  if (c->peer_stream) (void)hipStreamDestroy(c->peer_stream);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->peer_ws) (void)hipFree(c->peer_ws);
   if (c->d_w) (void)hipFree(c->d_w);
   if (c->d_winv) (void)hipFree(c->d_winv);
   if (c->d_ws) (void)hipFree(c->d_ws);
@@ -772,8 +793,15 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
   const unsigned nin = square ? 2 : 4;
   const unsigned chunk = tensor_chunk(c, batch);
   const unsigned lblock = limb_block(c, dim);
+  PeerLane lane;                                             // two launch groups in flight (engine_internal.hpp: gpq_peer_lane)
+  if (batch > chunk && (rc = gpq_peer_lane(c, s, [&](gpq_ctx *q) { return gpq_tensor_workspace_bytes(q, dim, chunk); }, &lane))) return rc;
   for (unsigned k0 = 0; k0 < batch; k0 += chunk) {
     const unsigned polys = (batch - k0 < chunk) ? batch - k0 : chunk;
+    if (lane.c && ((k0 / chunk) & 1)) {
+      const size_t o = k0 * poly;
+      if ((rc = gpq_he_mul_tensor(lane.c, d0 + o, d1 + o, d2 + o, a0 + o, a1 + o, b0 + o, b1 + o, dim, polys, lane.ws, lane.s))) return rc;
+      continue;
+    }
     // A launch group = `polys` polynomials x `limbs` limbs of every slab: its three kernels run back to back so that
     // what one writes the next one reads while it is still in the Infinity Cache (gpq_set_limb_block).
     for (unsigned l0 = 0; l0 < dim; l0 += lblock) {
@@ -811,6 +839,7 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
       if ((rc = launch_strided<true>(c, b, limbs, polys, s))) return rc;
     }
   }
+  if ((rc = gpq_peer_join(c, s, lane))) return rc;
   return after_launch("gpq_he_mul_tensor");
 }
 
@@ -837,8 +866,15 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
 
   const unsigned chunk = tensor_chunk(c, batch);
   const unsigned lblock = limb_block(c, dim);
+  PeerLane lane;
+  if (batch > chunk && (rc = gpq_peer_lane(c, s, [&](gpq_ctx *q) { return gpq_keyswitch_workspace_bytes(q, dim, chunk); }, &lane))) return rc;
   for (unsigned k0 = 0; k0 < batch; k0 += chunk) {
     const unsigned polys = (batch - k0 < chunk) ? batch - k0 : chunk;
+    if (lane.c && ((k0 / chunk) & 1)) {
+      const size_t o = k0 * poly;
+      if ((rc = gpq_keyswitch(lane.c, c0 + o, c1 + o, x + o, evk0, evk1, dim, polys, lane.ws, lane.s))) return rc;
+      continue;
+    }
     for (unsigned l0 = 0; l0 < dim; l0 += lblock) {       // launch groups as in gpq_he_mul_tensor
       const unsigned limbs = dim - l0 < lblock ? dim - l0 : lblock;
       const size_t loff = (size_t)l0 << c->logn;
@@ -878,6 +914,7 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
       if ((rc = launch_strided<true>(c, b, limbs, polys, s))) return rc;
     }
   }
+  if ((rc = gpq_peer_join(c, s, lane))) return rc;
   return after_launch("gpq_keyswitch");
 }
 

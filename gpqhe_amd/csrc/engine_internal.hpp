@@ -107,6 +107,15 @@ struct gpq_ctx {
   bool fuse_tail = false;             // gpq_set_fused_tail(ctx, 1): the relinearisation tail in one pass per coefficient (bridge_relin_tail_mfma) -- measured 2 % SLOWER
                                       // than the two-kernel form on the whole he_mul (profiles/r03/v3_fused_tail_ab.txt: both are bound by integer VALU work, not by the
                                       // 60 words per coefficient the fusion saves), kept for the parity tests and as the record of the attempt
+  // gpq_he_mul / gpq_he_swk over more than one launch group: every other group runs on a second stream through a PEER context (its own tables,
+  // scratch and flag words: nothing mutable is shared), so that the HBM-bound bridge kernels of one group run beside the issue-bound transforms
+  // of the other and launch tails fill (gpq_set_overlap; bridge.hip: peer_lane).  The caller's stream orders the whole call as before.
+  bool overlap = true;
+  gpq_ctx *peer = nullptr;
+  hipStream_t peer_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  void *peer_ws = nullptr;
+  size_t peer_ws_bytes = 0;
   unsigned *d_zflag = nullptr;        // per-(polynomial, limb) "output contains a residue 0" flags of gpq_ntt (tables.hpp); zero between calls
   size_t zflag_cap = 0;
   // profiling
@@ -154,4 +163,64 @@ struct ProfScope {
 };
 
 int gpq_fail(int code, const char *fmt, ...);
+// A second context over the same primes and twiddles (host tables copied, device tables built anew), with default settings and no peer of its own.
+int gpq_ctx_clone(const gpq_ctx *c, gpq_ctx **out);
 void gpq_bridge_release(gpq_ctx *c);
+
+// ---------------------------------------------------------------------------
+// Two launch groups in flight (gpq_set_overlap).  A call over more than one launch group hands every other group to the context's PEER -- a
+// second context over the same primes (own tables, scratch, flag words: no mutable state is shared) on a second stream -- by calling the same
+// entry point on it for that group's slice of the batch.  Launch tails of one lane fill with the other's work, and the bridge kernels of one
+// group (HBM-bound) meet transforms of the other (issue-bound): +3.5 ... +4 % whole he_mul at the headline shape, +12 % at the reference's
+// default shape (profiles/r04/v13_two_lanes_ab.txt).  The caller's stream still orders the call as a whole: the peer's stream waits for an
+// event recorded on it at entry, and it waits for the peer's last launch before the call returns.  Not taken while profiling (the breakdown
+// is that of one stream), for a single group, or when a stream capture would have to allocate.
+// ---------------------------------------------------------------------------
+struct PeerLane {
+  gpq_ctx *c = nullptr;
+  hipStream_t s = nullptr;
+  void *ws = nullptr;
+};
+inline void gpq_mirror_settings(gpq_ctx *q, const gpq_ctx *c) {   // whatever decides which kernels a call runs: the peer follows the context it serves
+  q->chunk = c->chunk; q->limb_block = c->limb_block; q->nsplit = c->nsplit; q->nwide = c->nwide;
+  q->bridge_mfma = c->bridge_mfma; q->lazy_decompose = c->lazy_decompose; q->debug_force_redo = c->debug_force_redo; q->nt_mode = c->nt_mode;
+  q->stream_bridge = c->stream_bridge; q->exact_crt = c->exact_crt; q->prescale = c->prescale; q->prescale_upper = c->prescale_upper;
+  q->tail_direct = c->tail_direct; q->fuse_tail = c->fuse_tail;
+}
+// lane->c stays null when the call runs on the caller's stream alone.  `bytes(peer)` = the workspace one launch group needs on the peer.
+template <typename Bytes>
+int gpq_peer_lane(gpq_ctx *c, hipStream_t s, Bytes bytes, PeerLane *lane) {
+  if (!c->overlap || c->prof_on || c->inv_tabs_override) return GPQ_OK;
+  auto hip = [](hipError_t e, const char *what) { return e == hipSuccess ? (int)GPQ_OK : gpq_fail(GPQ_ERR_HIP, "%s: %s", what, hipGetErrorString(e)); };
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return GPQ_OK; }
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  int rc;
+  if (!c->peer) {
+    if (capturing) return GPQ_OK;                                 // (the first call at a shape runs outside capture, as for every scratch buffer)
+    if ((rc = gpq_ctx_clone(c, &c->peer))) return rc;
+    if ((rc = hip(hipStreamCreateWithFlags(&c->peer_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags")) ||
+        (rc = hip(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreateWithFlags")) ||
+        (rc = hip(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreateWithFlags"))) return rc;
+  }
+  gpq_mirror_settings(c->peer, c);
+  const size_t need = bytes(c->peer);
+  if (!need) return GPQ_OK;
+  if (need > c->peer_ws_bytes) {
+    if (capturing) return GPQ_OK;
+    if (c->peer_ws) c->retired.push_back(c->peer_ws);             // a graph captured earlier may still use it
+    c->peer_ws = nullptr; c->peer_ws_bytes = 0;
+    if ((rc = hip(hipMalloc(&c->peer_ws, need), "hipMalloc (peer workspace)"))) return rc;
+    c->peer_ws_bytes = need;
+  }
+  if ((rc = hip(hipEventRecord(c->ev_fork, s), "hipEventRecord")) || (rc = hip(hipStreamWaitEvent(c->peer_stream, c->ev_fork, 0), "hipStreamWaitEvent"))) return rc;
+  lane->c = c->peer; lane->s = c->peer_stream; lane->ws = c->peer_ws;
+  return GPQ_OK;
+}
+inline int gpq_peer_join(gpq_ctx *c, hipStream_t s, const PeerLane &lane) {
+  if (!lane.c) return GPQ_OK;
+  hipError_t e = hipEventRecord(c->ev_join, lane.s);
+  if (e == hipSuccess) e = hipStreamWaitEvent(s, c->ev_join, 0);
+  return e == hipSuccess ? (int)GPQ_OK : gpq_fail(GPQ_ERR_HIP, "joining the peer stream: %s", hipGetErrorString(e));
+}
+

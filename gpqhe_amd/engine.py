@@ -137,6 +137,10 @@ class PolyContext:
         """he_mul: its internal rns_decompose output may stay in (0, 3p) for the forward transforms (default) or be canonical; same results"""
         _native.check(self.lib.gpq_set_lazy_decompose(self.h, 1 if on else 0), "gpq_set_lazy_decompose")
 
+    def set_overlap(self, on):
+        """he_mul / he_swk over several launch groups: alternate groups on a second internal stream (default) or all on the caller's; same words"""
+        _native.check(self.lib.gpq_set_overlap(self.h, 1 if on else 0), "gpq_set_overlap")
+
     def set_nt_policy(self, mode):
         """slab traffic of the transform kernels non-temporal: -1 by working set (default), 0 never, 1 always; never changes a word"""
         _native.check(self.lib.gpq_set_nt_policy(self.h, int(mode)), "gpq_set_nt_policy")
