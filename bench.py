@@ -269,7 +269,7 @@ def ntt_rate(torch, gpqhe_amd, logn, dim, batch, iters=20):
             "ms_per_pair_repetitions": [round(v, 4) for v in reps], "roundtrip_identity": ok}
 
 
-def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850):
+def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=True):
     """Whole he_mul of src/he-mult.c:88-156 on device big slabs (q = 2^logq: decompose, tensor, CRT, relinearise
     with exact division by P, centre) -- SURVEY.md 8f rank 1-2, reported beside the RNS-core headline."""
     W = logq // 64 + 1
@@ -287,6 +287,7 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850):
     cts = [centred() for _ in range(4)]
     rlk0, rlk1 = rand_slab(torch, ctx, dimB, 1, gen), rand_slab(torch, ctx, dimB, 1, gen)
     o0, o1 = torch.empty_like(cts[0]), torch.empty_like(cts[0])
+    ctx.set_overlap(two_lanes)                  # (False: tools/mpi_profile.py under rocprofv3 -- kernel durations of one lane, nothing running beside them)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.15:      # steady clock (see ntt_rate)
         ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
@@ -303,7 +304,7 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850):
         ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
     t.stop()
     ms_one = t.elapsed_ms() / iters
-    ctx.set_overlap(True)
+    ctx.set_overlap(two_lanes)
     ctx.profile(True)                                # a second pass with HIP events around every launch of this leg (on the launch stream) for the
     for _ in range(iters):                           # breakdown: the events themselves cost a few per cent at small shapes, so the rate above is timed without them
         ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
@@ -355,7 +356,7 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850):
     return {"shape": "n=2^%d, q=2^%d (W=%d words), dimA/dimB/dimP=%d/%d/%d, batch %d" % (ctx.logn, logq, W, dimA, dimB, dimP, batch),
             "ms_per_batch": round(ms, 3), "he_mul_per_s": round(batch / (ms * 1e-3), 1),
             "he_mul_plus_he_rescale_per_s": round(batch / (ms_rs * 1e-3), 1),
-            "lanes": {"default": 2, "one_lane_ms_per_batch": round(ms_one, 3), "one_lane_he_mul_per_s": round(batch / (ms_one * 1e-3), 1),
+            "lanes": {"default": 2, "this_run": 2 if two_lanes else 1, "one_lane_ms_per_batch": round(ms_one, 3), "one_lane_he_mul_per_s": round(batch / (ms_one * 1e-3), 1),
                       "note": "gpq_he_mul runs every other launch group (32 ciphertexts) on a second internal stream through a peer context "
                               "(gpq_set_overlap, default on); the kernel breakdown below is a profiled ONE-lane pass, so its kernel times add up to the one-lane figure"},
             "bridge_ms_per_batch": round(bridge_ms, 3), "core_ms_per_batch": round(sum(v["ms_per_batch"] for k, v in kernels.items() if not k.startswith("bridge_")), 3),

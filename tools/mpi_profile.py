@@ -18,4 +18,6 @@ if os.environ.get("MPI_STREAM"):
     ctx.set_lazy_decompose(os.environ["MPI_STREAM"] == "1")
 if os.environ.get("MPI_LAZY"):
     ctx.set_lazy_decompose(os.environ["MPI_LAZY"] == "1")
-print(he_mul_mpi_rate(torch, gpqhe_amd, ctx, int(os.environ.get("MPI_BATCH", "64")), iters=int(os.environ.get("MPI_ITERS", "6"))))
+# MPI_OVERLAP=0: one lane (what a kernel trace / PMC pass should see: nothing running beside the kernel it times)
+print(he_mul_mpi_rate(torch, gpqhe_amd, ctx, int(os.environ.get("MPI_BATCH", "64")), iters=int(os.environ.get("MPI_ITERS", "6")),
+                      two_lanes=os.environ.get("MPI_OVERLAP", "1") != "0"))
