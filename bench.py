@@ -759,7 +759,8 @@ def main(argv=None):
             c14 = gpqhe_amd.PolyContext(14, 24)
             rd = he_mul_mpi_rate(torch, gpqhe_amd, c14, 64, iters=25, logq=438)
             c14.close()
-            rd = {k: rd[k] for k in ("shape", "ms_per_batch", "he_mul_per_s", "he_mul_plus_he_rescale_per_s", "bridge_ms_per_batch", "core_ms_per_batch")}
+            rd = {k: rd[k] for k in ("shape", "ms_per_batch", "he_mul_per_s", "he_mul_plus_he_rescale_per_s", "lanes", "bridge_ms_per_batch", "core_ms_per_batch")}
+            rd["lanes"] = {k: v for k, v in rd["lanes"].items() if k != "note"}
             rd["reference_cpu_he_mul_per_s"] = round(1 / 1.12, 3)        # SURVEY.md 6 (survey probe, one core)
             sig = reference_signature_latency(logn=14, logq=438)
             if sig is not None:

@@ -5,7 +5,7 @@
 set -o pipefail
 mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout -k 10 900 python3 bench.py > gpurun_out/r4_bench.json 2> gpurun_out/r4_bench.err || { tail -5 gpurun_out/r4_bench.err; exit 1; }
-rm -rf gpurun_out/prof_r4 && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r4 -- python3 bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-ntt > gpurun_out/r4_bench_under_rocprof.json 2> gpurun_out/r4_prof.err || { tail gpurun_out/r4_prof.err; exit 1; }
+rm -rf gpurun_out/prof_r4 && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r4 -- python3 bench.py --steps 100 --warmup 2 --cpu-sample 0 --no-ntt > gpurun_out/r4_bench_under_rocprof.json 2> gpurun_out/r4_prof.err || { tail gpurun_out/r4_prof.err; exit 1; }
 cp $(find gpurun_out/prof_r4 -name "*kernel_stats.csv" | head -1) gpurun_out/r4_kernel_stats.csv
 bash tools/gpu_pmc.sh > gpurun_out/r4_pmc.log 2>&1 || { tail gpurun_out/r4_pmc.log; exit 1; }
 cp gpurun_out/pmc_summary.json gpurun_out/r4_pmc_summary.json
