@@ -198,10 +198,10 @@ int gpq_peer_lane(gpq_ctx *c, hipStream_t s, Bytes bytes, PeerLane *lane) {
   int rc;
   if (!c->peer) {
     if (capturing) return GPQ_OK;                                 // (the first call at a shape runs outside capture, as for every scratch buffer)
-    if ((rc = gpq_ctx_clone(c, &c->peer))) return rc;
-    if ((rc = hip(hipStreamCreateWithFlags(&c->peer_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags")) ||
-        (rc = hip(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreateWithFlags")) ||
-        (rc = hip(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreateWithFlags"))) return rc;
+    if (!c->peer_stream && (rc = hip(hipStreamCreateWithFlags(&c->peer_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags"))) return rc;
+    if (!c->ev_fork && (rc = hip(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreateWithFlags"))) return rc;
+    if (!c->ev_join && (rc = hip(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreateWithFlags"))) return rc;
+    if ((rc = gpq_ctx_clone(c, &c->peer))) return rc;              // last: a context with a peer has its stream and events
   }
   gpq_mirror_settings(c->peer, c);
   const size_t need = bytes(c->peer);
