@@ -1,5 +1,6 @@
 """Randomised soak of the streaming bridge (gpqhe_amd/csrc/bridge_stream.hpp) against round 3's separate kernels: random rings (2^13 .. 2^15),
-moduli, levels, batch sizes, launch groups and forced-redo strides; he_mul, a squaring and he_swk must give identical words.
+moduli, levels, batch sizes, launch groups, forced-redo strides, one or two lanes (gpq_set_overlap); he_mul, a squaring and he_swk must give
+identical words (the reference side of the comparison: separate kernels, canonical residues, one lane).
 usage: python tools/soak_bridge.py [configs] [seed]"""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -44,7 +45,8 @@ for it in range(N):
     logqL = rng.randrange(100, 881)
     if logn == 15: logqL = min(logqL, 600)
     logql = logqL if rng.random() < 0.5 else rng.randrange(60, logqL + 1)
-    batch, chunk, force = rng.randrange(1, 5), rng.choice((1, 2, 3, 32)), rng.choice((0, 0, 1, 7, 64, 257))
+    batch, chunk, force = rng.randrange(1, 8), rng.choice((1, 2, 3, 32)), rng.choice((0, 0, 1, 7, 64, 257))
+    lanes = rng.choice((0, 1, 1))
     probe = ctx_for(logn, 20)
     dimP, dimA, dimB, dimevk = probe.he_dims(logqL, logql)
     g = ctx_for(logn, max(dimevk, 20))
@@ -53,15 +55,15 @@ for it in range(N):
     cts = [centred(gen, batch, W, n, logql) for _ in range(4)]
     rlk = [torch.cat([torch.randint(0, g.p[d], (n,), dtype=torch.int64, device="cuda", generator=gen) for d in range(dimB)]) for _ in range(2)]
     g.set_chunk(chunk)
-    g.set_stream_bridge(False); g.set_lazy_decompose(False); g.debug_force_redo(0)
+    g.set_stream_bridge(False); g.set_lazy_decompose(False); g.debug_force_redo(0); g.set_overlap(False)
     want = run(g, cts, rlk, W, logql, (dimP, dimA, dimB))
-    g.set_stream_bridge(True); g.set_lazy_decompose(True); g.debug_force_redo(force)
+    g.set_stream_bridge(True); g.set_lazy_decompose(True); g.debug_force_redo(force); g.set_overlap(lanes)
     got = run(g, cts, rlk, W, logql, (dimP, dimA, dimB))
-    g.debug_force_redo(0); g.set_chunk(32)
+    g.debug_force_redo(0); g.set_chunk(32); g.set_overlap(True)
     bad = [i for i, (a, b) in enumerate(zip(want, got)) if not torch.equal(a, b)]
     if bad:
-        print("MISMATCH at config %d: logn %d logqL %d logql %d dims %s batch %d chunk %d force %d outputs %s" % (it, logn, logqL, logql, (dimP, dimA, dimB), batch, chunk, force, bad), flush=True)
+        print("MISMATCH at config %d: logn %d logqL %d logql %d dims %s batch %d chunk %d force %d lanes %d outputs %s" % (it, logn, logqL, logql, (dimP, dimA, dimB), batch, chunk, force, lanes + 1, bad), flush=True)
         sys.exit(1)
     if it % 10 == 0:
-        print("config %d ok: logn %d q_L 2^%d q_l 2^%d dims P/A/B %d/%d/%d W %d batch %d chunk %d force %d (%.0f s)" % (it, logn, logqL, logql, dimP, dimA, dimB, W, batch, chunk, force, time.time() - t0), flush=True)
+        print("config %d ok: logn %d q_L 2^%d q_l 2^%d dims P/A/B %d/%d/%d W %d batch %d chunk %d force %d lanes %d (%.0f s)" % (it, logn, logqL, logql, dimP, dimA, dimB, W, batch, chunk, force, lanes + 1, time.time() - t0), flush=True)
 print("soak_bridge ok: %d configurations, every word of he_mul / squaring / he_swk equal between the streaming bridge and the separate kernels (%.0f s)" % (N, time.time() - t0))
