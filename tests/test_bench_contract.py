@@ -125,9 +125,11 @@ def test_the_quick_bench_line_prices_kernels_against_ceilings():
         assert key in line, key
     assert line["cpu_baseline"]["bit_exact_vs_gpu"] is True
     rates = {k: v["of_copy_rate"] for k, v in line["kernels"].items()}
-    assert rates and all(0 < x <= 1.0 for x in rates.values()), (rates, line["copy_rate"])
+    # (1.03: two measurements of the yardstick itself differ by up to 3 %; the forward strided pass runs at 0.93-0.97 of it, the others below 0.9)
+    assert rates and all(0 < x <= 1.03 for x in rates.values()), (rates, line["copy_rate"])
+    assert sum(rates.values()) / len(rates) <= 0.95, (rates, line["copy_rate"])
     assert line["copy_rate"]["read_only_GBps"] >= line["copy_rate"]["GBps"] * 0.9
     if "valu_floor" in line:                           # needs rocm-smi for the clock
-        assert 0.5 < line["valu_floor"]["frac"] <= 1.0, line["valu_floor"]
+        assert 0.5 < line["valu_floor"]["frac"] <= 1.05, line["valu_floor"]    # (1.05: the clock is rocm-smi's, sampled beside the run, not inside it)
         assert line["roofline"]["bound"] == "valu_issue" and line["roofline"]["declared_bound"] == "hbm"
     assert line["roofline"]["peak"] == 8000.0 and 0 < line["roofline"]["frac"] < 1
