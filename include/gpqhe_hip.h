@@ -214,7 +214,7 @@ int gpq_set_exact_crt(gpq_ctx *ctx, int on);
  * (src/he-mult.c:140, :59) in one kernel, and the relinearisation tail (:67-77) as one product that makes its addend d0 / d1 (:139, :141) from the
  * limbs on the spot -- d0, d1, d2 never exist as words; 0 = round 3's separate CRT, decompose and tail kernels.  Same words (the tests run both). */
 int gpq_set_stream_bridge(gpq_ctx *ctx, int on);
-/* gpq_he_mul / gpq_he_swk over more than one launch group (batch > gpq_set_chunk's group): 1 (default) = every other group runs on a second,
+/* gpq_he_mul / gpq_he_swk / gpq_he_mul_tensor / gpq_keyswitch over more than one launch group (batch > gpq_set_chunk's group): 1 (default) = every other group runs on a second,
  * internal stream through an internal peer context (own tables and scratch, created on the first such call: about the caller's workspace again
  * in device memory), so that the bridge kernels of one group overlap the transforms of the other; the caller's stream still orders the call
  * as a whole (work queued before it is waited for, work queued after it waits for both lanes).  0 = everything on the caller's stream.
