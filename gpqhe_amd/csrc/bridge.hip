@@ -1139,6 +1139,9 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
     uint64_t *chat_rw = const_cast<uint64_t *>(chat);
     unsigned char *flags = (unsigned char *)rhat, *amb = flags + ((size_t)polys << c->logn);
     const bool direct_ok = !in_place && rt->direct.d_bfrag && W <= 14 && logql <= 896 && c->bridge_mfma;
+    // the flag bytes must have their final size BEFORE any argument block below copies c->d_redo: a later growth (the addend's CRT, the
+    // product) would leave `un` with the outgrown buffer -- stale flags, and reads past its end (found by tools/soak_bridge.py, seed 23)
+    if (direct_ok && (rc = ensure_redo(c, (size_t)polys << c->logn, s))) return rc;
     FlagScope scope = kNoScope;
     bool streamed = false;
     if (direct_ok && (rc = tail_stream(c, rt, out, chat, dbig, dh, W, dimP, dimB, logql, polys, tie, amb, s, &scope, &streamed))) return rc;

@@ -110,3 +110,37 @@ def test_streaming_bridge_across_launch_groups(engine_ctx):
         g.set_chunk(32)
     for a, b, c in zip(want, got, forced):
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_flag_bytes_grow_inside_a_tail_that_cannot_stream():
+    """dimA = 3 (q_l = 2^62 under q_L = 2^627): the streaming kernels decline (fewer than 4 limbs), the addend still arrives as limbs, and the
+    relinearisation tail makes it with the exact-CRT path -- which may be the call that GROWS the context's flag bytes.  Every argument block
+    of that tail must see the grown buffer (found by tools/soak_bridge.py: a block built before the growth kept the outgrown one -- stale
+    flags and reads past its end).  A fresh context, a small call, then a larger one with many coefficients forced through the exact paths."""
+    import gpqhe_amd
+    torch = _torch()
+    logn, logqL, logql = 14, 627, 62
+    probe = gpqhe_amd.PolyContext(logn, 20)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logqL, logql)
+    probe.close()
+    assert dimA == 3
+    n, W = 1 << logn, logqL // 64 + 1
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(62)
+    small = [_centred(torch, gen, 1, W, n, logql) for _ in range(4)]
+    large = [_centred(torch, gen, 5, W, n, logql) for _ in range(4)]
+    ref = gpqhe_amd.PolyContext(logn, max(dimevk, 20))
+    rlk = [torch.cat([torch.randint(0, ref.p[d], (n,), dtype=torch.int64, device="cuda", generator=gen) for d in range(dimB)]) for _ in range(2)]
+    ref.set_stream_bridge(False); ref.set_lazy_decompose(False); ref.set_overlap(False)
+    want = _run(ref, torch, large, rlk, W, logql, dimA, dimB, dimP)
+    ref.close()
+    for lanes in (False, True):
+        g = gpqhe_amd.PolyContext(logn, max(dimevk, 20))
+        g.set_overlap(lanes)
+        g.set_chunk(2)
+        g.debug_force_redo(3)
+        _run(g, torch, small, rlk, W, logql, dimA, dimB, dimP)          # flag bytes sized for one ciphertext
+        got = _run(g, torch, large, rlk, W, logql, dimA, dimB, dimP)    # ... grown inside this call
+        g.close()
+        for name, a, b in zip(("he_mul c0", "he_mul c1", "he_swk c0", "he_swk c1"), want, got):
+            assert torch.equal(a, b), "%s (%s)" % (name, "two lanes" if lanes else "one lane")

@@ -28,12 +28,23 @@ def centred(gen, batch, W, n, logq):
     return big.reshape(-1).contiguous()
 
 
+VERBOSE = os.environ.get("SOAK_VERBOSE") == "1"      # every call announced and waited for: the last line names what a device fault belongs to
+
+
+def step(what, fn):
+    if VERBOSE:
+        print("  ...", what, flush=True)
+    fn()
+    if VERBOSE:
+        torch.cuda.synchronize()
+
+
 def run(g, cts, rlk, W, logql, dims):
     dimP, dimA, dimB = dims
     o = [torch.empty_like(cts[0]) for _ in range(6)]
-    g.he_mul(o[0], o[1], *cts, rlk[0], rlk[1], W, logql, dimA, dimB, dimP)
-    g.he_mul(o[2], o[3], cts[0], cts[1], cts[0], cts[1], rlk[0], rlk[1], W, logql, dimA, dimB, dimP)
-    g.he_swk(o[4], o[5], cts[2], cts[3], rlk[0], rlk[1], W, logql, dimB, dimP)
+    step("he_mul", lambda: g.he_mul(o[0], o[1], *cts, rlk[0], rlk[1], W, logql, dimA, dimB, dimP))
+    step("squaring", lambda: g.he_mul(o[2], o[3], cts[0], cts[1], cts[0], cts[1], rlk[0], rlk[1], W, logql, dimA, dimB, dimP))
+    step("he_swk", lambda: g.he_swk(o[4], o[5], cts[2], cts[3], rlk[0], rlk[1], W, logql, dimB, dimP))
     torch.cuda.synchronize()
     return o
 
@@ -54,10 +65,14 @@ for it in range(N):
     gen = torch.Generator(device="cuda"); gen.manual_seed(rng.randrange(1 << 30))
     cts = [centred(gen, batch, W, n, logql) for _ in range(4)]
     rlk = [torch.cat([torch.randint(0, g.p[d], (n,), dtype=torch.int64, device="cuda", generator=gen) for d in range(dimB)]) for _ in range(2)]
+    if VERBOSE:
+        print("config %d: logn %d q_L 2^%d q_l 2^%d dims P/A/B %d/%d/%d W %d batch %d chunk %d force %d lanes %d" % (it, logn, logqL, logql, dimP, dimA, dimB, W, batch, chunk, force, lanes + 1), flush=True)
     g.set_chunk(chunk)
     g.set_stream_bridge(False); g.set_lazy_decompose(False); g.debug_force_redo(0); g.set_overlap(False)
+    if VERBOSE: print(" separate kernels, one lane", flush=True)
     want = run(g, cts, rlk, W, logql, (dimP, dimA, dimB))
     g.set_stream_bridge(True); g.set_lazy_decompose(True); g.debug_force_redo(force); g.set_overlap(lanes)
+    if VERBOSE: print(" streaming bridge", flush=True)
     got = run(g, cts, rlk, W, logql, (dimP, dimA, dimB))
     g.debug_force_redo(0); g.set_chunk(32); g.set_overlap(True)
     bad = [i for i, (a, b) in enumerate(zip(want, got)) if not torch.equal(a, b)]
