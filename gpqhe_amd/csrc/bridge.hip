@@ -576,7 +576,9 @@ int ensure_wave_any(gpq_ctx *c, hipStream_t s) {
     return gpq_fail(GPQ_ERR_INVALID, "the first call allocates scratch: run it once outside stream capture");
   DeviceScope on_device(c->device);
   HIP_TRY(hipMalloc((void **)&c->d_wave_any, kStreamBlocks * kStreamWaves * sizeof(unsigned)));
-  HIP_TRY(hipMemset(c->d_wave_any, 0, kStreamBlocks * kStreamWaves * sizeof(unsigned)));
+  // on the LAUNCH stream: a plain hipMemset goes to the null stream, which a non-blocking stream (torch's side streams, the peer lane's) does not
+  // wait for -- the producer kernel's flag words could be zeroed after it wrote them (tests/test_stream_bridge_gpu.py: a fresh peer lane)
+  HIP_TRY(hipMemsetAsync(c->d_wave_any, 0, kStreamBlocks * kStreamWaves * sizeof(unsigned), s));
   return GPQ_OK;
 }
 inline unsigned stream_blocks(unsigned total_groups) {

@@ -230,6 +230,7 @@ static int upload_tables(gpq_ctx *c) {
   // stream capture works; larger launches grow them at their first call, outside capture (zero_flags)
   HIP_TRY(hipMalloc((void **)&c->d_zflag, 4096 * sizeof(unsigned)));
   HIP_TRY(hipMemset(c->d_zflag, 0, 4096 * sizeof(unsigned)));
+  HIP_TRY(hipStreamSynchronize(nullptr));      // (a device memset is not host-synchronous: done before any stream of the caller's can see the words)
   c->zflag_cap = 4096;
   return GPQ_OK;
 }
