@@ -73,14 +73,21 @@ def main():
                         ins[0][base:base + o.n] = o.invntt(t % np.uint64(o.p[d]), d)
         ev = [o.gen(seeds[5], dim), o.gen(seeds[6], dim)]
         dev = [to_device(v) for v in ins]
-        f = dev[0].clone(); g.poly_ntt(f, dim)
-        i = dev[1].clone(); g.poly_invntt(i, dim)
-        d = [torch.empty_like(dev[0]) for _ in range(3)]
-        g.he_mul_tensor(d[0], d[1], d[2], dev[0], dev[1], dev[2], dev[3], dim)
-        c = [torch.empty_like(dev[0]) for _ in range(2)]
-        g.he_keyswitch(c[0], c[1], dev[4], to_device(ev[0]), to_device(ev[1]), dim)
-        pa, pb, pr = dev[0].clone(), dev[2].clone(), torch.empty_like(dev[0])
-        g.poly_mul_rns(pr, pa, pb, dim)
+        evd = [to_device(ev[0]), to_device(ev[1])]
+        lanes = rng.choice([0, 1, 1])                            # two launch groups in flight (gpq_set_overlap) where a call has more than one
+        g.set_overlap(lanes)
+        side = torch.cuda.Stream() if rng.random() < 0.4 else None   # a non-blocking side stream: nothing may lean on the null stream's ordering
+        torch.cuda.synchronize()
+        import contextlib
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            f = dev[0].clone(); g.poly_ntt(f, dim)
+            i = dev[1].clone(); g.poly_invntt(i, dim)
+            d = [torch.empty_like(dev[0]) for _ in range(3)]
+            g.he_mul_tensor(d[0], d[1], d[2], dev[0], dev[1], dev[2], dev[3], dim)
+            c = [torch.empty_like(dev[0]) for _ in range(2)]
+            g.he_keyswitch(c[0], c[1], dev[4], evd[0], evd[1], dim)
+            pa, pb, pr = dev[0].clone(), dev[2].clone(), torch.empty_like(dev[0])
+            g.poly_mul_rns(pr, pa, pb, dim)
         torch.cuda.synchronize()
         got = [to_host(t) for t in (f, i, d[0], d[1], d[2], c[0], c[1], pr)]
         for k in range(batch):
@@ -91,10 +98,10 @@ def main():
             exp.append(o.poly_mul_rns(ins[0][sl].copy(), ins[2][sl].copy(), dim))
             for name, a, b in zip(("ntt", "invntt", "d0", "d1", "d2", "c0", "c1", "polymul"), got, exp):
                 if not np.array_equal(a[sl], b):
-                    print("MISMATCH", name, "ciphertext", k, dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, nt_policy=nt, seeds=seeds), flush=True)
+                    print("MISMATCH", name, "ciphertext", k, dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, nt_policy=nt, lanes=lanes + 1, side_stream=side is not None, seeds=seeds), flush=True)
                     sys.exit(1)
         runs += 1
-        print("ok", dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, nt_policy=nt, zero_cases=zero_mode), flush=True)
+        print("ok", dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, nt_policy=nt, lanes=lanes + 1, side_stream=side is not None, zero_cases=zero_mode), flush=True)
         g.close()
     print("soak: %d configurations, no mismatch, %.0f s" % (runs, time.time() - t0))
 

@@ -71,14 +71,27 @@ for it in range(N):
     g.set_stream_bridge(False); g.set_lazy_decompose(False); g.debug_force_redo(0); g.set_overlap(False)
     if VERBOSE: print(" separate kernels, one lane", flush=True)
     want = run(g, cts, rlk, W, logql, (dimP, dimA, dimB))
-    g.set_stream_bridge(True); g.set_lazy_decompose(True); g.debug_force_redo(force); g.set_overlap(lanes)
-    if VERBOSE: print(" streaming bridge", flush=True)
-    got = run(g, cts, rlk, W, logql, (dimP, dimA, dimB))
+    # the side under test: the context with its history, or (a third of the time) a FRESH context -- every scratch buffer, table and the peer lane
+    # made inside these calls -- after a smaller call of the same kind (buffers grow inside the larger one), on a non-blocking side stream
+    fresh = rng.random() < 0.33
+    h = gpqhe_amd.PolyContext(logn, max(dimevk, 20)) if fresh else g
+    h.set_chunk(chunk); h.set_stream_bridge(True); h.set_lazy_decompose(True); h.debug_force_redo(force); h.set_overlap(lanes)
+    if VERBOSE: print(" streaming bridge%s" % (" (fresh context, side stream, small call first)" if fresh else ""), flush=True)
+    if fresh:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            if batch > 1:
+                run(h, [t[: t.numel() // batch].contiguous() for t in cts], rlk, W, logql, (dimP, dimA, dimB))
+            got = run(h, cts, rlk, W, logql, (dimP, dimA, dimB))
+        h.close()
+    else:
+        got = run(h, cts, rlk, W, logql, (dimP, dimA, dimB))
     g.debug_force_redo(0); g.set_chunk(32); g.set_overlap(True)
     bad = [i for i, (a, b) in enumerate(zip(want, got)) if not torch.equal(a, b)]
     if bad:
-        print("MISMATCH at config %d: logn %d logqL %d logql %d dims %s batch %d chunk %d force %d lanes %d outputs %s" % (it, logn, logqL, logql, (dimP, dimA, dimB), batch, chunk, force, lanes + 1, bad), flush=True)
+        print("MISMATCH at config %d: logn %d logqL %d logql %d dims %s batch %d chunk %d force %d lanes %d fresh %d outputs %s" % (it, logn, logqL, logql, (dimP, dimA, dimB), batch, chunk, force, lanes + 1, fresh, bad), flush=True)
         sys.exit(1)
     if it % 10 == 0:
-        print("config %d ok: logn %d q_L 2^%d q_l 2^%d dims P/A/B %d/%d/%d W %d batch %d chunk %d force %d lanes %d (%.0f s)" % (it, logn, logqL, logql, dimP, dimA, dimB, W, batch, chunk, force, lanes + 1, time.time() - t0), flush=True)
+        print("config %d ok: logn %d q_L 2^%d q_l 2^%d dims P/A/B %d/%d/%d W %d batch %d chunk %d force %d lanes %d%s (%.0f s)" % (it, logn, logqL, logql, dimP, dimA, dimB, W, batch, chunk, force, lanes + 1, " fresh" if fresh else "", time.time() - t0), flush=True)
 print("soak_bridge ok: %d configurations, every word of he_mul / squaring / he_swk equal between the streaming bridge and the separate kernels (%.0f s)" % (N, time.time() - t0))
