@@ -76,6 +76,16 @@ for it in range(N):
     fresh = rng.random() < 0.33
     h = gpqhe_amd.PolyContext(logn, max(dimevk, 20)) if fresh else g
     h.set_chunk(chunk); h.set_stream_bridge(True); h.set_lazy_decompose(True); h.debug_force_redo(force); h.set_overlap(lanes)
+    # a quarter of the time one of the older kernel families instead of the default (every setting must give the same words, also from a fresh
+    # context, after growth, on a side stream): prescale 0 / 1 / 2 (+ the fused tail), the integer-VALU bridge, the exact CRT everywhere
+    other = rng.choice((None, None, None, "prescale0", "prescale1", "prescale2", "prescale2+fused", "valu", "exact", "nostream"))
+    if other == "prescale0": h.set_prescale(0)
+    elif other == "prescale1": h.set_prescale(1)
+    elif other == "prescale2": h.set_prescale(2)
+    elif other == "prescale2+fused": h.set_prescale(2); h.set_fused_tail(True)
+    elif other == "valu": h.set_bridge_mfma(False)
+    elif other == "exact": h.set_exact_crt(True)
+    elif other == "nostream": h.set_stream_bridge(False)
     if VERBOSE: print(" streaming bridge%s" % (" (fresh context, side stream, small call first)" if fresh else ""), flush=True)
     if fresh:
         side = torch.cuda.Stream()
@@ -88,10 +98,11 @@ for it in range(N):
     else:
         got = run(h, cts, rlk, W, logql, (dimP, dimA, dimB))
     g.debug_force_redo(0); g.set_chunk(32); g.set_overlap(True)
+    g.set_prescale(3); g.set_fused_tail(False); g.set_bridge_mfma(True); g.set_exact_crt(False); g.set_stream_bridge(True)
     bad = [i for i, (a, b) in enumerate(zip(want, got)) if not torch.equal(a, b)]
     if bad:
-        print("MISMATCH at config %d: logn %d logqL %d logql %d dims %s batch %d chunk %d force %d lanes %d fresh %d outputs %s" % (it, logn, logqL, logql, (dimP, dimA, dimB), batch, chunk, force, lanes + 1, fresh, bad), flush=True)
+        print("MISMATCH at config %d: logn %d logqL %d logql %d dims %s batch %d chunk %d force %d lanes %d fresh %d settings %s outputs %s" % (it, logn, logqL, logql, (dimP, dimA, dimB), batch, chunk, force, lanes + 1, fresh, other, bad), flush=True)
         sys.exit(1)
     if it % 10 == 0:
-        print("config %d ok: logn %d q_L 2^%d q_l 2^%d dims P/A/B %d/%d/%d W %d batch %d chunk %d force %d lanes %d%s (%.0f s)" % (it, logn, logqL, logql, dimP, dimA, dimB, W, batch, chunk, force, lanes + 1, " fresh" if fresh else "", time.time() - t0), flush=True)
+        print("config %d ok: logn %d q_L 2^%d q_l 2^%d dims P/A/B %d/%d/%d W %d batch %d chunk %d force %d lanes %d%s (%.0f s)" % (it, logn, logqL, logql, dimP, dimA, dimB, W, batch, chunk, force, lanes + 1, (" fresh" if fresh else "") + (" " + other if other else ""), time.time() - t0), flush=True)
 print("soak_bridge ok: %d configurations, every word of he_mul / squaring / he_swk equal between the streaming bridge and the separate kernels (%.0f s)" % (N, time.time() - t0))
