@@ -1,4 +1,4 @@
-"""Randomised soak of the streaming bridge (gpqhe_amd/csrc/bridge_stream.hpp) against round 3's separate kernels: random rings (2^13 .. 2^15),
+"""Randomised soak of the streaming bridge (gpqhe_amd/csrc/bridge_stream.hpp) against round 3's separate kernels: random rings (2^13 .. 2^15; now and then 2^8 .. 2^12 and 2^16),
 moduli, levels, batch sizes, launch groups, forced-redo strides, one or two lanes (gpq_set_overlap); he_mul, a squaring and he_swk must give
 identical words (the reference side of the comparison: separate kernels, canonical residues, one lane).
 usage: python tools/soak_bridge.py [configs] [seed]"""
@@ -52,11 +52,12 @@ def run(g, cts, rlk, W, logql, dims):
 t0 = time.time()
 streamed = 0
 for it in range(N):
-    logn = rng.choice((13, 13, 14, 14, 15))
+    logn = rng.choice((13, 13, 14, 14, 15) if rng.random() < 0.85 else (8, 10, 12, 16))     # now and then the small rings (no two-pass transform) and the headline ring
     logqL = rng.randrange(100, 881)
     if logn == 15: logqL = min(logqL, 600)
     logql = logqL if rng.random() < 0.5 else rng.randrange(60, logqL + 1)
     batch, chunk, force = rng.randrange(1, 8), rng.choice((1, 2, 3, 32)), rng.choice((0, 0, 1, 7, 64, 257))
+    if logn == 16: batch = min(batch, 3)
     lanes = rng.choice((0, 1, 1))
     probe = ctx_for(logn, 20)
     dimP, dimA, dimB, dimevk = probe.he_dims(logqL, logql)
