@@ -353,7 +353,7 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=T
         roof = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                 "bytes_per_batch": int(words[kname] * 8 * n * batch), "ms_per_batch": bridge[kname]["ms_per_batch"],
                 "note": "the bridge kernel with the largest share of this leg; all launches of the kind together; "
-                        "PMC of these kernels: profiles/r04/v14_mpi_pmc.txt"}
+                        "PMC of these kernels: profiles/r04/v17_mpi_pmc.txt"}
     bridge_ms = sum(v["ms_per_batch"] for k, v in kernels.items() if k.startswith("bridge_"))
     return {"shape": "n=2^%d, q=2^%d (W=%d words), dimA/dimB/dimP=%d/%d/%d, batch %d" % (ctx.logn, logq, W, dimA, dimB, dimP, batch),
             "ms_per_batch": round(ms, 3), "he_mul_per_s": round(batch / (ms * 1e-3), 1),
