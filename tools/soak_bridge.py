@@ -1,5 +1,5 @@
 """Randomised soak of the streaming bridge (gpqhe_amd/csrc/bridge_stream.hpp) against round 3's separate kernels: random rings (2^13 .. 2^15; now and then 2^8 .. 2^12 and 2^16),
-moduli, levels, batch sizes, launch groups, forced-redo strides, one or two lanes (gpq_set_overlap); he_mul, a squaring and he_swk must give
+moduli, levels, batch sizes, launch groups, forced-redo strides, one or two lanes (gpq_set_overlap); he_mul, a squaring, he_swk, poly_mul, he_mulpt and he_rs must give
 identical words (the reference side of the comparison: separate kernels, canonical residues, one lane).
 usage: python tools/soak_bridge.py [configs] [seed]"""
 import os, random, sys, time
@@ -39,12 +39,20 @@ def step(what, fn):
         torch.cuda.synchronize()
 
 
-def run(g, cts, rlk, W, logql, dims):
+def run(g, cts, rlk, W, logql, dims, pt=None):
     dimP, dimA, dimB = dims
+    if pt is None:
+        pt = (cts[3] >> 20 if W == 1 else cts[3]).clone()       # some plaintext of the same shape
     o = [torch.empty_like(cts[0]) for _ in range(6)]
     step("he_mul", lambda: g.he_mul(o[0], o[1], *cts, rlk[0], rlk[1], W, logql, dimA, dimB, dimP))
     step("squaring", lambda: g.he_mul(o[2], o[3], cts[0], cts[1], cts[0], cts[1], rlk[0], rlk[1], W, logql, dimA, dimB, dimP))
     step("he_swk", lambda: g.he_swk(o[4], o[5], cts[2], cts[3], rlk[0], rlk[1], W, logql, dimB, dimP))
+    # the other callers of the bridge (src/poly.c:84-107, src/he-mult.c:159-196, src/he-rescale.c:33-54): poly_mul, he_mulpt, he_rs
+    o += [torch.empty_like(cts[0]) for _ in range(3)] + [cts[2].clone(), cts[3].clone()]
+    step("poly_mul", lambda: g.poly_mul(o[6], cts[0], cts[1], W, dimA, logql))
+    step("he_mulpt", lambda: g.he_mulpt(o[7], o[8], cts[0], cts[1], pt, W, logql, dimA))
+    ld = min(50, logql - 8)
+    step("he_rs", lambda: g.he_rs(o[9], o[10], W, ld, logql - ld))
     torch.cuda.synchronize()
     return o
 
@@ -70,8 +78,11 @@ for it in range(N):
         print("config %d: logn %d q_L 2^%d q_l 2^%d dims P/A/B %d/%d/%d W %d batch %d chunk %d force %d lanes %d" % (it, logn, logqL, logql, dimP, dimA, dimB, W, batch, chunk, force, lanes + 1), flush=True)
     g.set_chunk(chunk)
     g.set_stream_bridge(False); g.set_lazy_decompose(False); g.debug_force_redo(0); g.set_overlap(False)
+    ref_exact = rng.random() < 0.5                               # half of the time the reference side is the most conservative path: exact CRT, integer-VALU decompose
+    g.set_exact_crt(ref_exact); g.set_bridge_mfma(not ref_exact)
     if VERBOSE: print(" separate kernels, one lane", flush=True)
     want = run(g, cts, rlk, W, logql, (dimP, dimA, dimB))
+    g.set_exact_crt(False); g.set_bridge_mfma(True)
     # the side under test: the context with its history, or (a third of the time) a FRESH context -- every scratch buffer, table and the peer lane
     # made inside these calls -- after a smaller call of the same kind (buffers grow inside the larger one), on a non-blocking side stream
     fresh = rng.random() < 0.33
@@ -106,4 +117,4 @@ for it in range(N):
         sys.exit(1)
     if it % 10 == 0:
         print("config %d ok: logn %d q_L 2^%d q_l 2^%d dims P/A/B %d/%d/%d W %d batch %d chunk %d force %d lanes %d%s (%.0f s)" % (it, logn, logqL, logql, dimP, dimA, dimB, W, batch, chunk, force, lanes + 1, (" fresh" if fresh else "") + (" " + other if other else ""), time.time() - t0), flush=True)
-print("soak_bridge ok: %d configurations, every word of he_mul / squaring / he_swk equal between the streaming bridge and the separate kernels (%.0f s)" % (N, time.time() - t0))
+print("soak_bridge ok: %d configurations, every word of he_mul / squaring / he_swk / poly_mul / he_mulpt / he_rs equal between the streaming bridge and the separate kernels (%.0f s)" % (N, time.time() - t0))
