@@ -15,7 +15,7 @@ def _run(args, timeout):
     r = subprocess.run([sys.executable] + args, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     tail = (r.stdout + r.stderr)[-1500:]
     assert r.returncode == 0, tail
-    assert "MISMATCH" not in r.stdout and "fault" not in (r.stdout + r.stderr).lower(), tail
+    assert "MISMATCH" not in r.stdout and "memory access fault" not in (r.stdout + r.stderr).lower(), tail
     return r.stdout
 
 
