@@ -271,7 +271,7 @@ def ntt_rate(torch, gpqhe_amd, logn, dim, batch, iters=20):
             "ms_per_pair_repetitions": [round(v, 4) for v in reps], "roundtrip_identity": ok}
 
 
-def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=True):
+def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=True, checked=None):
     """Whole he_mul of src/he-mult.c:88-156 on device big slabs (q = 2^logq: decompose, tensor, CRT, relinearise
     with exact division by P, centre) -- SURVEY.md 8f rank 1-2, reported beside the RNS-core headline."""
     W = logq // 64 + 1
@@ -320,6 +320,23 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=T
         ctx.he_rs(o0, o1, W, 50, logq - 50)
     t.stop()
     ms_rs = t.elapsed_ms() / iters
+    check = None
+    if checked:
+        # Outside every timed region: one more product + rescale at this launch shape, and the first and last ciphertext of EACH launch group
+        # packed up for the restated reference (oracle/expect.py: src/he-mult.c:88-156, src/he-rescale.c:33-54) -- main() runs the workers at the
+        # end of the run and writes `bit_exact_vs_restated_reference` into this leg
+        ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
+        r0, r1 = o0.clone(), o1.clone()
+        ctx.he_rs(r0, r1, W, 50, logq - 50)
+        torch.cuda.synchronize()
+        group, per = 32, W * n
+        picks = sorted({k for g0 in range(0, batch, group) for k in (g0, min(g0 + group, batch) - 1)})
+        host = gpqhe_amd.to_host
+        k0h, k1h = host(rlk0), host(rlk1)
+        check = {"leg": checked, "picks": picks, "names": ("c0", "c1", "rs0", "rs1"),
+                 "tasks": [dict(kind="he_mul", logn=ctx.logn, dimP=dimP, dimA=dimA, dimB=dimB, W=W, logq=logq, rs=50, rlk0=k0h, rlk1=k1h,
+                                ct=[host(v[k * per:(k + 1) * per]) for v in cts]) for k in picks],
+                 "got": [{nm: host(v[k * per:(k + 1) * per]) for nm, v in zip(("c0", "c1", "rs0", "rs1"), (o0, o1, r0, r1))} for k in picks]}
     # Algorithmic bytes of the bridge per he_mul, each slab read or written once (words of 8 bytes per coefficient):
     #   rns_decompose     4 x (W in, dimA out) + (W in, dimB out)                                   src/he-mult.c:117-120, :59
     #   CRT (poly_rns2mpi) 3 x (dimA in, W out) for d0, d1, d2 + 2 x (cnt in, W addend in, W out)    :139-141, the tail's CRT of Q (:67-77)
@@ -362,7 +379,119 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=T
                       "note": "gpq_he_mul runs every other launch group (32 ciphertexts) on a second internal stream through a peer context "
                               "(gpq_set_overlap, default on); the kernel breakdown below is a profiled ONE-lane pass, so its kernel times add up to the one-lane figure"},
             "bridge_ms_per_batch": round(bridge_ms, 3), "core_ms_per_batch": round(sum(v["ms_per_batch"] for k, v in kernels.items() if not k.startswith("bridge_")), 3),
-            "bridge_algo_bytes_per_he_mul": int(sum(words.values()) * 8 * n), "kernels": kernels, "roofline": roof}
+            "bridge_algo_bytes_per_he_mul": int(sum(words.values()) * 8 * n), "kernels": kernels, "roofline": roof, "_check": check}
+
+
+def he_swk_mpi_rate(torch, gpqhe_amd, batch=64, iters=3, logn=17, logq=835, checked="he_swk_mpi_level"):
+    """BASELINE configs[4] as the function the reference runs: whole he_swk (src/he-automorphism.c:40-85 -- rns_decompose of d1, the key-switch
+    inner product over dimB limbs, CRT, exact division by P, + d0, centring) at n = 2^17, q = 2^835 on device big slabs, batch 64."""
+    W = logq // 64 + 1
+    dimP = (logq + 1 + logn) // 59 + 1                                   # hectx.dim, src/precomp.c:401
+    probe = gpqhe_amd.PolyContext(logn, dimP)
+    P = 1
+    for p in probe.p[:dimP]:
+        P *= p
+    probe.close()
+    dimB = (logq + 1 + (P << logq).bit_length() + logn) // 59 + 1        # src/he-automorphism.c:52
+    ctx = gpqhe_amd.PolyContext(logn, dimB)
+    n = ctx.n
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1717)
+
+    def centred():
+        big = torch.randint(-(1 << 62), 1 << 62, (batch, W, n), dtype=torch.int64, device="cuda", generator=gen)
+        top = logq - 2 - 64 * (W - 1)
+        big[:, W - 1] = torch.randint(-(1 << top), 1 << top, (batch, n), dtype=torch.int64, device="cuda", generator=gen)
+        return big.reshape(-1).contiguous()
+
+    d0, d1 = centred(), centred()
+    swk0, swk1 = rand_slab(torch, ctx, dimB, 1, gen), rand_slab(torch, ctx, dimB, 1, gen)
+    o0, o1 = torch.empty_like(d0), torch.empty_like(d0)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.15:      # steady clock (see ntt_rate)
+        ctx.he_swk(o0, o1, d0, d1, swk0, swk1, W, logq, dimB, dimP)
+        torch.cuda.synchronize()
+    t = gpqhe_amd.StreamTimer()
+    res = {}
+    for lanes in (1, 0):
+        ctx.set_overlap(bool(lanes))
+        ctx.he_swk(o0, o1, d0, d1, swk0, swk1, W, logq, dimB, dimP)
+        t.start()
+        for _ in range(iters):
+            ctx.he_swk(o0, o1, d0, d1, swk0, swk1, W, logq, dimB, dimP)
+        t.stop()
+        res[lanes] = t.elapsed_ms() / iters
+    ctx.profile(True)                            # one-lane pass with HIP events around every launch for the breakdown (gpq_profile takes no lane)
+    for _ in range(iters):
+        ctx.he_swk(o0, o1, d0, d1, swk0, swk1, W, logq, dimB, dimP)
+    torch.cuda.synchronize()
+    ctx.profile(False)
+    prof = ctx.profile_collect()
+    ctx.set_overlap(True)
+    # algorithmic words per coefficient, each slab read or written once: rns_decompose of d1 (W in, dimB out); the key switch (SURVEY.md 8d Stage B:
+    # 3 reads + 2 writes per limb, here split over its three kernels); the tail: c0hat, c1hat (2 dimB) + d0 (W) in, c0, c1 (2 W) out
+    words = {"bridge_decompose": W + dimB, "strided_fwd": 2 * dimB, "keyswitch_mid": 5 * dimB, "strided_inv": 4 * dimB,
+             "bridge_tail_stream": 2 * dimB + 3 * W, "bridge_relin_tail_direct": 2 * dimB + 3 * W}
+    total_ms = sum(v[0] for v in prof.values())
+    kernels = {}
+    for name, (kms, kcnt) in prof.items():
+        per_call = kms / iters
+        rec = {"ms_per_batch": round(per_call, 4), "launches_per_batch": round(kcnt / iters, 2), "share": round(kms / total_ms, 3)}
+        if name in words:
+            rec["algo_words_per_coefficient"] = words[name]
+            rec["algo_GBps"] = round(words[name] * 8 * n * batch / (per_call * 1e-3) / 1e9, 1)
+            rec["hbm_frac"] = round(rec["algo_GBps"] / HBM_PEAK_GBS, 4)
+        kernels[name] = rec
+    check = None
+    if checked:
+        ctx.he_swk(o0, o1, d0, d1, swk0, swk1, W, logq, dimB, dimP)
+        torch.cuda.synchronize()
+        group, per = 32, W * n
+        picks = [0, batch - 1] if batch > group else [0]            # first polynomial pair of the first launch group, last of the last
+        host = gpqhe_amd.to_host
+        k0h, k1h = host(swk0), host(swk1)
+        check = {"leg": checked, "picks": picks, "names": ("c0", "c1"),
+                 "tasks": [dict(kind="he_swk", logn=logn, dimP=dimP, dimB=dimB, W=W, logq=logq, swk0=k0h, swk1=k1h,
+                                d0=host(d0[k * per:(k + 1) * per]), d1=host(d1[k * per:(k + 1) * per])) for k in picks],
+                 "got": [{nm: host(v[k * per:(k + 1) * per]) for nm, v in zip(("c0", "c1"), (o0, o1))} for k in picks]}
+    ctx.close()
+    ms = res[1]
+    whole = (W + 2 * dimB) + 5 * dimB + (2 * dimB + 3 * W)          # decompose out + key switch + tail, the slabs between them counted once each way
+    return {"shape": "n=2^%d, q=2^%d (W=%d words), dimB/dimP=%d/%d, batch %d: BASELINE configs[4] on one GPU" % (logn, logq, W, dimB, dimP, batch),
+            "ms_per_batch": round(ms, 3), "he_swk_per_s": round(batch / (ms * 1e-3), 1),
+            "lanes": {"this_run": 2, "one_lane_ms_per_batch": round(res[0], 3), "one_lane_he_swk_per_s": round(batch / (res[0] * 1e-3), 1)},
+            "bridge_ms_per_batch": round(sum(v["ms_per_batch"] for k, v in kernels.items() if k.startswith("bridge_")), 3),
+            "core_ms_per_batch": round(sum(v["ms_per_batch"] for k, v in kernels.items() if not k.startswith("bridge_")), 3),
+            "algo_bytes_per_he_swk": int(whole * 8 * n), "algo_GBps": round(whole * 8 * n * batch / (ms * 1e-3) / 1e9, 1),
+            "hbm_frac": round(whole * 8 * n * batch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernels": kernels, "_check": check}
+
+
+def run_checks(out, checks):
+    """The restated reference (oracle/expect.py: bigint_ref.he_mul / he_swk, the C oracle's limb loops + Python integers for everything libgcrypt
+    does) on the ciphertexts the whole-function legs picked at their own launch shapes, all in parallel worker processes after every timed leg
+    has finished; writes `bit_exact_vs_restated_reference` into each leg.  The oracle is the checker here, never the thing measured."""
+    from oracle import expect
+    checks = [c for c in checks if c]
+    if not checks:
+        return
+    t0 = time.perf_counter()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    want = expect.expect_many([t for c in checks for t in c["tasks"]], workers=max(1, min(8, cores)))
+    dt = time.perf_counter() - t0
+    i = 0
+    for c in checks:
+        bad = []
+        for k, got in zip(c["picks"], c["got"]):
+            for nm in c["names"]:
+                if not np.array_equal(got[nm], want[i][nm]):
+                    bad.append("%s of ciphertext %d" % (nm, k))
+            i += 1
+        out[c["leg"]]["bit_exact_vs_restated_reference"] = {
+            "ok": not bad, "ciphertexts": c["picks"], "outputs": list(c["names"]), "mismatches": bad,
+            "how": "first and last ciphertext of each launch group of 32 at this leg's own launch shape (lanes on), every coefficient, against "
+                   "oracle/bigint_ref (src/he-mult.c:88-156 / src/he-automorphism.c:40-85, src/he-rescale.c:33-54 restated); outside the timed regions; "
+                   "%.0f s of CPU for all checked legs together" % dt}
 
 
 def keyswitch_n17_rate(torch, gpqhe_amd, batch=64, iters=3):
@@ -519,6 +648,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-ntt", action="store_true", help="skip the secondary legs run after the timed region (NTT GB/s, MPI-level he_mul, n=2^17 key switch)")
     ap.add_argument("--variant", default=None, help="dev: path of another build of libgpqhe_hip.so (make -C gpqhe_amd/csrc variant ...) for interleaved A/B timing")
     ap.add_argument("--quick", action="store_true", help="of the secondary legs keep only the clock / power sample, the VALU floor and the copy yardstick (tests)")
+    ap.add_argument("--no-check", action="store_true", help="skip the restated-reference check of the whole-function legs (about 40 s of CPU after the timed legs)")
     ap.add_argument("--streams", type=int, default=1, help="2: tensor stage and key-switch stage on separate HIP streams")
     ap.add_argument("--no-scatter-gather", action="store_true", help="N>1: skip the extra step that has the input slabs scattered from "
                     "rank 0 and the outputs gathered back inside the timed region (SURVEY.md 8d config 4)")
@@ -749,8 +879,12 @@ def main(argv=None):
             torch.cuda.empty_cache()
             out["ntt"].append(ntt_rate(torch, gpqhe_amd, 16, DIM_A, 4 * B))   # launch size matters: 4 GiB slab
             out["ntt"].append(ntt_rate(torch, gpqhe_amd, 15, 10, 2048))       # configs[1]'s ring at a launch that fills the chip (5 GiB)
-            out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, B, iters=5)   # BASELINE configs[2]: he_mul + he_rescale, batch 64
+            checks = []
+            out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, B, iters=5, checked="he_mul_mpi_level")   # BASELINE configs[2]: he_mul + he_rescale, batch 64
+            checks.append(out["he_mul_mpi_level"].pop("_check"))
             out["keyswitch_n17"] = keyswitch_n17_rate(torch, gpqhe_amd)
+            out["he_swk_mpi_level"] = he_swk_mpi_rate(torch, gpqhe_amd)             # BASELINE configs[4] as the reference's function, one GPU
+            checks.append(out["he_swk_mpi_level"].pop("_check"))
             out["squaring_core"] = squaring_rate(torch, gpqhe_amd, ctx, B)
             rs = reference_signature_latency()
             if rs is not None:
@@ -759,8 +893,9 @@ def main(argv=None):
             # ever runs; BASELINE.md: 1.12 s per he_mul on one CPU core): whole he_mul on device slabs at batch 64, and its own signature, batch 1
             ctx.close()
             c14 = gpqhe_amd.PolyContext(14, 24)
-            rd = he_mul_mpi_rate(torch, gpqhe_amd, c14, 64, iters=25, logq=438)
+            rd = he_mul_mpi_rate(torch, gpqhe_amd, c14, 64, iters=25, logq=438, checked="reference_default")
             c14.close()
+            checks.append(rd.pop("_check"))
             rd = {k: rd[k] for k in ("shape", "ms_per_batch", "he_mul_per_s", "he_mul_plus_he_rescale_per_s", "lanes", "bridge_ms_per_batch", "core_ms_per_batch")}
             rd["lanes"] = {k: v for k, v in rd["lanes"].items() if k != "note"}
             rd["reference_cpu_he_mul_per_s"] = round(1 / 1.12, 3)        # SURVEY.md 6 (survey probe, one core)
@@ -768,6 +903,8 @@ def main(argv=None):
             if sig is not None:
                 rd["reference_signature"] = {k: v for k, v in sig.items() if k not in ("note", "parity_lines")}
             out["reference_default"] = rd
+            if not args.no_check:
+                run_checks(out, checks)
     if dist is not None and not args.no_scatter_gather:
         # BASELINE configs[3] with the transfers inside the timed region: rank 0 owns the whole batch, every rank works on its
         # shard, results return to rank 0.  A root-GPU scatter is bound by one xGMI link per peer.  This leg is

@@ -75,6 +75,8 @@ SIGNATURES = {
     "gpq_set_exact_crt": (C.c_int, [vp, C.c_int]),
     "gpq_set_stream_bridge": (C.c_int, [vp, C.c_int]),
     "gpq_debug_force_redo": (C.c_int, [vp, C.c_uint]),
+    "gpq_debug_zero_watch": (C.c_int, [vp, C.c_int]),
+    "gpq_debug_zero_flags": (C.c_long, [vp, vp, vp, C.c_size_t]),
     "gpq_set_lazy_decompose": (C.c_int, [vp, C.c_int]),
     "gpq_set_nt_policy": (C.c_int, [vp, C.c_int]),
     "gpq_set_overlap": (C.c_int, [vp, C.c_int]),

@@ -330,6 +330,7 @@ extern "C" void gpq_ctx_destroy(gpq_ctx *c) {
   if (c->d_winvs) (void)hipFree(c->d_winvs);
   if (c->d_tabs) (void)hipFree(c->d_tabs);
   if (c->d_zflag) (void)hipFree(c->d_zflag);
+  if (c->d_zwatch) (void)hipFree(c->d_zwatch);
   gpq_bridge_release(c);
   for (gpq_prof_rec &r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
@@ -567,7 +568,7 @@ int launch_reference(const gpq_ctx *c, const PassArgs &a, unsigned dim, unsigned
 }
 
 // in-place forward transform of the slab given in a.src[0] = a.dst[0], in the reference's representation (a.zflag set)
-int forward_slabs(const gpq_ctx *c, PassArgs a, unsigned dim, unsigned polys, hipStream_t s) {
+int forward_slabs(gpq_ctx *c, PassArgs a, unsigned dim, unsigned polys, hipStream_t s) {
   int rc;
   if (!two_pass(c)) rc = launch_small<false>(c, a, dim, polys, s);
   else {
@@ -576,7 +577,16 @@ int forward_slabs(const gpq_ctx *c, PassArgs a, unsigned dim, unsigned polys, hi
     rc = launch_contig<false>(c, a, dim, polys, s);
   }
   if (rc != GPQ_OK) return rc;
-  return launch_reference(c, a, dim, polys, 0, s);
+  // gpq_debug_zero_watch: what the forward kernels flagged, and what ref_zero_redo left, as copies on the launch stream
+  const size_t words = (size_t)polys * dim;
+  const bool watch = c->d_zwatch && a.zflag && words <= c->zwatch_cap;
+  if (watch) HIP_TRY(hipMemcpyAsync(c->d_zwatch, a.zflag, words * sizeof(unsigned), hipMemcpyDeviceToDevice, s));
+  if ((rc = launch_reference(c, a, dim, polys, 0, s)) != GPQ_OK) return rc;
+  if (watch) {
+    HIP_TRY(hipMemcpyAsync(c->d_zwatch + c->zwatch_cap, a.zflag, words * sizeof(unsigned), hipMemcpyDeviceToDevice, s));
+    c->zwatch_count = words;
+  }
+  return GPQ_OK;
 }
 
 int inverse_slabs(const gpq_ctx *c, PassArgs a, unsigned dim, unsigned polys, hipStream_t s) {
@@ -604,6 +614,36 @@ extern "C" int gpq_ntt(gpq_ctx *c, uint64_t *slab, unsigned dim, unsigned batch,
     if ((rc = forward_slabs(c, a, dim, polys, (hipStream_t)stream)) != GPQ_OK) return rc;
   }
   return after_launch("gpq_ntt");
+}
+
+// Debug door of the zero watch (tests; HISTORY.md round 5): with the watch on, every gpq_ntt launch group leaves two copies of its flag words
+// -- as the forward kernels wrote them and as ref_zero_redo left them -- so that "flag never set", "flag cleared early" and "redo wrong" can be
+// told apart.  gpq_debug_zero_flags waits for the device and hands out the copies of the LAST launch group (polys * dim words each).
+extern "C" int gpq_debug_zero_watch(gpq_ctx *c, int on) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_debug_zero_watch: null context");
+  DeviceScope on_device(c->device);
+  if (!on) {
+    if (c->d_zwatch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->d_zwatch)); }
+    c->d_zwatch = nullptr; c->zwatch_cap = c->zwatch_count = 0;
+    return GPQ_OK;
+  }
+  if (!c->d_zwatch) {
+    const size_t want = (size_t)kMaxPolysPerLaunch * c->nprimes, cap = want < ((size_t)1 << 20) ? want : ((size_t)1 << 20);   // larger launch groups are not watched
+    HIP_TRY(hipMalloc((void **)&c->d_zwatch, 2 * cap * sizeof(unsigned)));
+    HIP_TRY(hipMemset(c->d_zwatch, 0xff, 2 * cap * sizeof(unsigned)));
+    HIP_TRY(hipDeviceSynchronize());
+    c->zwatch_cap = cap; c->zwatch_count = 0;
+  }
+  return GPQ_OK;
+}
+extern "C" long gpq_debug_zero_flags(gpq_ctx *c, unsigned *before, unsigned *after, size_t capacity) {
+  if (!c || !c->d_zwatch) return -1;
+  DeviceScope on_device(c->device);
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  const size_t words = c->zwatch_count < capacity ? c->zwatch_count : capacity;
+  if (before && hipMemcpy(before, c->d_zwatch, words * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (after && hipMemcpy(after, c->d_zwatch + c->zwatch_cap, words * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (long)c->zwatch_count;
 }
 
 // src/ntt.c:37-73 executed as written (inverse = 0: ntt, else invntt) on every limb of the slab, for ANY input words --

@@ -118,6 +118,10 @@ struct gpq_ctx {
   size_t peer_ws_bytes = 0;
   unsigned *d_zflag = nullptr;        // per-(polynomial, limb) "output contains a residue 0" flags of gpq_ntt (tables.hpp); zero between calls
   size_t zflag_cap = 0;
+  // gpq_debug_zero_watch: copies of the flag words of gpq_ntt's LAST launch group as the forward kernels left them (before ref_zero_redo) and
+  // as ref_zero_redo left them (after), taken on the launch stream; [0, zwatch_cap) before, [zwatch_cap, 2 zwatch_cap) after
+  unsigned *d_zwatch = nullptr;
+  size_t zwatch_cap = 0, zwatch_count = 0;
   // profiling
   bool prof_on = false;
   std::vector<gpq_prof_rec> prof;     // launches recorded since the last reset

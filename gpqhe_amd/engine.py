@@ -149,6 +149,18 @@ class PolyContext:
         """tests: the streaming bridge kernels also flag every coefficient whose index is a multiple of `every` (0: off)"""
         _native.check(self.lib.gpq_debug_force_redo(self.h, int(every)), "gpq_debug_force_redo")
 
+    def debug_zero_watch(self, on=True):
+        """tests: keep copies of gpq_ntt's zero-flag words before and after the redo kernel (src/ntt.c:45-48)"""
+        _native.check(self.lib.gpq_debug_zero_watch(self.h, 1 if on else 0), "gpq_debug_zero_watch")
+
+    def debug_zero_flags(self, count):
+        """(before, after) flag words of the last gpq_ntt launch group, word [polynomial * dim + limb]"""
+        before, after = np.zeros(count, dtype=np.uint32), np.zeros(count, dtype=np.uint32)
+        got = self.lib.gpq_debug_zero_flags(self.h, before.ctypes.data_as(C.c_void_p), after.ctypes.data_as(C.c_void_p), count)
+        if got != count:
+            raise RuntimeError("gpq_debug_zero_flags: %d words watched, %d asked for" % (got, count))
+        return before, after
+
     def set_exact_crt(self, on):
         _native.check(self.lib.gpq_set_exact_crt(self.h, 1 if on else 0), "gpq_set_exact_crt")
 

@@ -229,6 +229,13 @@ int gpq_set_lazy_decompose(gpq_ctx *ctx, int on);
 int gpq_set_nt_policy(gpq_ctx *ctx, int mode);
 /* Tests: the streaming kernels also flag every coefficient whose index is a multiple of `every` for the exact kernels behind them (0 = off). */
 int gpq_debug_force_redo(gpq_ctx *ctx, unsigned every);
+/* Tests: the zero watch of gpq_ntt (the reference stores p, not 0, at some positions of a forward transform, src/ntt.c:45-48; the forward
+ * kernels flag every (polynomial, limb) whose output holds a residue 0 and a kernel that executes src/ntt.c as written redoes those limbs).
+ * With the watch on, each launch group of gpq_ntt leaves a copy of its flag words as the forward kernels wrote them and a copy as the redo
+ * kernel left them; gpq_debug_zero_flags waits for the device and hands out both for the LAST launch group (word [polynomial * dim + limb];
+ * `before` 1 = flagged, `after` all 0), returning the number of words of that group (at most `capacity` are written), -1 without a watch. */
+int gpq_debug_zero_watch(gpq_ctx *ctx, int on);
+long gpq_debug_zero_flags(gpq_ctx *ctx, unsigned *before, unsigned *after, size_t capacity);
 /* With gpq_set_prescale(ctx, 2): the tail of he_relin / he_swk as two kernels with Q's residues in memory between them (0, default) or in one pass per coefficient (1:
  * measured 2 % slower on the whole he_mul -- both forms are bound by integer VALU work); same results. */
 int gpq_set_fused_tail(gpq_ctx *ctx, int on);

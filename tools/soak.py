@@ -20,6 +20,26 @@ from gpqhe_amd import to_device, to_host  # noqa: E402
 from oracle.oracle import OracleCtx  # noqa: E402
 
 
+def diagnose(name, k, got, exp, sl, tensor, rerun, p):
+    """Everything a later reader needs from a mismatch (round 4's record held one line): which words, what they hold, whether a second download
+    of the same tensor still differs (transfer or device memory) and whether the same call on the same inputs differs again (deterministic or
+    transient)."""
+    a, b = got[sl], exp
+    bad = np.flatnonzero(a != b)
+    print("  differing words: %d of %d; first %s" % (bad.size, a.size, bad[:8].tolist()), flush=True)
+    for j in bad[:8]:
+        print("    [%d] got %d expected %d%s" % (j, int(a[j]), int(b[j]), "  (got 0)" if a[j] == 0 else "  (got a prime)" if int(a[j]) in p else ""), flush=True)
+    if bad.size:
+        runs = np.split(bad, np.flatnonzero(np.diff(bad) != 1) + 1)
+        print("  contiguous runs: %d, longest %d, span [%d, %d]" % (len(runs), max(len(r) for r in runs), int(bad[0]), int(bad[-1])), flush=True)
+    again = to_host(tensor)[sl]
+    print("  second download of the same tensor: %s" % ("equal to the first" if np.array_equal(again, a) else
+                                                         "DIFFERENT (%d words; now %s the expectation)" % (int((again != a).sum()), "equal to" if np.array_equal(again, b) else "still unlike")), flush=True)
+    fresh = to_host(rerun())[sl]
+    print("  same call again on the same inputs: %s" % ("bit-exact this time (transient)" if np.array_equal(fresh, b) else
+                                                         "differs again (%d words, %s)" % (int((fresh != b).sum()), "the same words" if np.array_equal(fresh, a) else "other words")), flush=True)
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -98,7 +118,20 @@ def main():
             exp.append(o.poly_mul_rns(ins[0][sl].copy(), ins[2][sl].copy(), dim))
             for name, a, b in zip(("ntt", "invntt", "d0", "d1", "d2", "c0", "c1", "polymul"), got, exp):
                 if not np.array_equal(a[sl], b):
+                    def rerun(name=name):
+                        if name == "ntt":
+                            t = dev[0].clone(); g.poly_ntt(t, dim); return t
+                        if name == "invntt":
+                            t = dev[1].clone(); g.poly_invntt(t, dim); return t
+                        if name in ("d0", "d1", "d2"):
+                            t = [torch.empty_like(dev[0]) for _ in range(3)]
+                            g.he_mul_tensor(t[0], t[1], t[2], dev[0], dev[1], dev[2], dev[3], dim); return t[int(name[1])]
+                        if name in ("c0", "c1"):
+                            t = [torch.empty_like(dev[0]) for _ in range(2)]
+                            g.he_keyswitch(t[0], t[1], dev[4], evd[0], evd[1], dim); return t[int(name[1])]
+                        t = torch.empty_like(dev[0]); g.poly_mul_rns(t, dev[0].clone(), dev[2].clone(), dim); return t
                     print("MISMATCH", name, "ciphertext", k, dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, nt_policy=nt, lanes=lanes + 1, side_stream=side is not None, seeds=seeds), flush=True)
+                    diagnose(name, k, a, b, sl, dict(zip(("ntt", "invntt", "d0", "d1", "d2", "c0", "c1", "polymul"), (f, i, d[0], d[1], d[2], c[0], c[1], pr)))[name], rerun, set(o.p))
                     sys.exit(1)
         runs += 1
         print("ok", dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, nt_policy=nt, lanes=lanes + 1, side_stream=side is not None, zero_cases=zero_mode), flush=True)
