@@ -271,7 +271,7 @@ def ntt_rate(torch, gpqhe_amd, logn, dim, batch, iters=20):
             "ms_per_pair_repetitions": [round(v, 4) for v in reps], "roundtrip_identity": ok}
 
 
-def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=True, checked=None):
+def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=True, checked=None, sample_clocks=False):
     """Whole he_mul of src/he-mult.c:88-156 on device big slabs (q = 2^logq: decompose, tensor, CRT, relinearise
     with exact division by P, centre) -- SURVEY.md 8f rank 1-2, reported beside the RNS-core headline."""
     W = logq // 64 + 1
@@ -289,6 +289,10 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=T
     cts = [centred() for _ in range(4)]
     rlk0, rlk1 = rand_slab(torch, ctx, dimB, 1, gen), rand_slab(torch, ctx, dimB, 1, gen)
     o0, o1 = torch.empty_like(cts[0]), torch.empty_like(cts[0])
+    ctx.set_overlap(-1)                         # what the library picks for this shape by itself (gpq_set_overlap's default)
+    ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
+    torch.cuda.synchronize()
+    default_lanes = ctx.last_lanes()
     ctx.set_overlap(two_lanes)                  # (False: tools/mpi_profile.py under rocprofv3 -- kernel durations of one lane, nothing running beside them)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.15:      # steady clock (see ntt_rate)
@@ -306,6 +310,14 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=T
         ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
     t.stop()
     ms_one = t.elapsed_ms() / iters
+    # the clock under each mode (the lanes share one power cap: where two lanes buy nothing, this says whether the clock gave the gain back)
+    clocks = {}
+    if sample_clocks:
+        for lanes in (1, 0):
+            ctx.set_overlap(bool(lanes))
+            pw = power_state(torch, lambda: ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP), seconds=1.2)
+            if pw is not None:
+                clocks["two_lanes" if lanes else "one_lane"] = {"sclk_MHz": pw["sclk_MHz"], "package_W": pw["package_W"]}
     ctx.set_overlap(two_lanes)
     ctx.profile(True)                                # a second pass with HIP events around every launch of this leg (on the launch stream) for the
     for _ in range(iters):                           # breakdown: the events themselves cost a few per cent at small shapes, so the rate above is timed without them
@@ -375,9 +387,12 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=T
     return {"shape": "n=2^%d, q=2^%d (W=%d words), dimA/dimB/dimP=%d/%d/%d, batch %d" % (ctx.logn, logq, W, dimA, dimB, dimP, batch),
             "ms_per_batch": round(ms, 3), "he_mul_per_s": round(batch / (ms * 1e-3), 1),
             "he_mul_plus_he_rescale_per_s": round(batch / (ms_rs * 1e-3), 1),
-            "lanes": {"default": 2, "this_run": 2 if two_lanes else 1, "one_lane_ms_per_batch": round(ms_one, 3), "one_lane_he_mul_per_s": round(batch / (ms_one * 1e-3), 1),
-                      "note": "gpq_he_mul runs every other launch group (32 ciphertexts) on a second internal stream through a peer context "
-                              "(gpq_set_overlap, default on); the kernel breakdown below is a profiled ONE-lane pass, so its kernel times add up to the one-lane figure"},
+            "lanes": {"default": default_lanes, "this_run": 2 if two_lanes else 1, "one_lane_ms_per_batch": round(ms_one, 3), "one_lane_he_mul_per_s": round(batch / (ms_one * 1e-3), 1),
+                      "gain_this_device": round(ms_one / ms - 1, 4), "clocks": clocks or None,
+                      "note": "`default` = the lanes the library picked by itself at this shape (gpq_last_lanes after a call under gpq_set_overlap(ctx, -1): two while the peer's "
+                              "per-group workspace costs <= 16 GiB).  With two lanes every other launch group (32 ciphertexts) runs on a second internal stream through a peer "
+                              "context.  The gain is launch tails and depends on the device at this shape (driver's round-4 box +0.15 %, builder's boxes +3.5 ... +3.9 %; never a "
+                              "loss); the kernel breakdown below is a profiled ONE-lane pass, so its kernel times add up to the one-lane figure"},
             "bridge_ms_per_batch": round(bridge_ms, 3), "core_ms_per_batch": round(sum(v["ms_per_batch"] for k, v in kernels.items() if not k.startswith("bridge_")), 3),
             "bridge_algo_bytes_per_he_mul": int(sum(words.values()) * 8 * n), "kernels": kernels, "roofline": roof, "_check": check}
 
@@ -411,6 +426,7 @@ def he_swk_mpi_rate(torch, gpqhe_amd, batch=64, iters=3, logn=17, logq=835, chec
     while time.perf_counter() - t0 < 0.15:      # steady clock (see ntt_rate)
         ctx.he_swk(o0, o1, d0, d1, swk0, swk1, W, logq, dimB, dimP)
         torch.cuda.synchronize()
+    default_lanes = ctx.last_lanes()             # (the warm-up calls ran under the library's own choice)
     t = gpqhe_amd.StreamTimer()
     res = {}
     for lanes in (1, 0):
@@ -427,7 +443,7 @@ def he_swk_mpi_rate(torch, gpqhe_amd, batch=64, iters=3, logn=17, logq=835, chec
     torch.cuda.synchronize()
     ctx.profile(False)
     prof = ctx.profile_collect()
-    ctx.set_overlap(True)
+    ctx.set_overlap(-1)
     # algorithmic words per coefficient, each slab read or written once: rns_decompose of d1 (W in, dimB out); the key switch (SURVEY.md 8d Stage B:
     # 3 reads + 2 writes per limb, here split over its three kernels); the tail: c0hat, c1hat (2 dimB) + d0 (W) in, c0, c1 (2 W) out
     words = {"bridge_decompose": W + dimB, "strided_fwd": 2 * dimB, "keyswitch_mid": 5 * dimB, "strided_inv": 4 * dimB,
@@ -459,7 +475,8 @@ def he_swk_mpi_rate(torch, gpqhe_amd, batch=64, iters=3, logn=17, logq=835, chec
     whole = (W + 2 * dimB) + 5 * dimB + (2 * dimB + 3 * W)          # decompose out + key switch + tail, the slabs between them counted once each way
     return {"shape": "n=2^%d, q=2^%d (W=%d words), dimB/dimP=%d/%d, batch %d: BASELINE configs[4] on one GPU" % (logn, logq, W, dimB, dimP, batch),
             "ms_per_batch": round(ms, 3), "he_swk_per_s": round(batch / (ms * 1e-3), 1),
-            "lanes": {"this_run": 2, "one_lane_ms_per_batch": round(res[0], 3), "one_lane_he_swk_per_s": round(batch / (res[0] * 1e-3), 1)},
+            "lanes": {"default": default_lanes, "this_run": 2, "one_lane_ms_per_batch": round(res[0], 3), "one_lane_he_swk_per_s": round(batch / (res[0] * 1e-3), 1),
+                      "gain_this_device": round(res[0] / ms - 1, 4)},
             "bridge_ms_per_batch": round(sum(v["ms_per_batch"] for k, v in kernels.items() if k.startswith("bridge_")), 3),
             "core_ms_per_batch": round(sum(v["ms_per_batch"] for k, v in kernels.items() if not k.startswith("bridge_")), 3),
             "algo_bytes_per_he_swk": int(whole * 8 * n), "algo_GBps": round(whole * 8 * n * batch / (ms * 1e-3) / 1e9, 1),
@@ -648,6 +665,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-ntt", action="store_true", help="skip the secondary legs run after the timed region (NTT GB/s, MPI-level he_mul, n=2^17 key switch)")
     ap.add_argument("--variant", default=None, help="dev: path of another build of libgpqhe_hip.so (make -C gpqhe_amd/csrc variant ...) for interleaved A/B timing")
     ap.add_argument("--quick", action="store_true", help="of the secondary legs keep only the clock / power sample, the VALU floor and the copy yardstick (tests)")
+    ap.add_argument("--lanes", choices=("auto", "1", "2"), default="auto", help="RNS-core steps: gpq_set_overlap of the context (auto = the library's default; 1 for kernel traces "
+                    "and PMC passes, whose durations should be those of kernels with nothing running beside them)")
     ap.add_argument("--no-check", action="store_true", help="skip the restated-reference check of the whole-function legs (about 40 s of CPU after the timed legs)")
     ap.add_argument("--streams", type=int, default=1, help="2: tensor stage and key-switch stage on separate HIP streams")
     ap.add_argument("--no-scatter-gather", action="store_true", help="N>1: skip the extra step that has the input slabs scattered from "
@@ -745,6 +764,7 @@ def main(argv=None):
         B, total_batch, scaling = args.batch, args.batch * world, "weak"
 
     ctx = gpqhe_amd.PolyContext(LOGN, DIM_B)
+    ctx.set_overlap({"auto": -1, "1": 0, "2": 1}[args.lanes])
     if args.chunk:
         ctx.set_chunk(args.chunk)
     if args.limb_block:
@@ -859,8 +879,6 @@ def main(argv=None):
             if pw is not None:
                 out["power"] = pw
                 vi = valu_issue(value / world, pw["sclk_MHz"])
-                if vi is not None:
-                    out["valu_issue"] = vi
                 vf = valu_floor(value / world, pw["sclk_MHz"])
                 if vf is not None:
                     out["valu_floor"] = vf
@@ -868,6 +886,27 @@ def main(argv=None):
                         out["roofline"]["bound"] = "valu_issue"
                         out["roofline"]["declared_bound"] = "hbm"
                         out["roofline"]["valu_floor_frac"] = vf["frac"]
+                        # ONE block with the three denominators the same measurement can be put over: they differ by what they
+                        # charge to "issue" -- and the last line says which term is the largest.  The two probe-derived ones are only given when
+                        # the probe was evaluated on THESE kernel headers (a stale probe is omitted, never shipped with a flag).
+                        den = {"four_cycles_per_wave_instruction_at_this_clock": vf["frac"]}
+                        fresh = vi is not None and "error" not in vi and not vi.get("stale") and vi.get("frac_of_probe_cycles_per_inst")
+                        if fresh:
+                            den["own_mix_probe_cycles_per_instruction_at_this_clock"] = vi["frac_of_probe_cycles_per_inst"]
+                            den["own_mix_probe_at_its_uncapped_clock"] = vi["frac_of_valu_issue_rate"]
+                            clk = vi["bound_source"].get("probe_sclk_MHz")
+                            if clk:
+                                den["clock_this_run_over_probe_clock"] = round(pw["sclk_MHz"] / clk, 3)
+                            den["reading"] = ("the core issues at %.2f of the 4-cycle convention and %.2f of what its own instruction mix reaches per cycle with no memory "
+                                              "traffic; against that probe at the clock it runs at un-capped the core is at %.2f: the package power cap (this run %d MHz at %.0f W) "
+                                              "is the largest single term, not issue slots" % (den["four_cycles_per_wave_instruction_at_this_clock"],
+                                                                                               den["own_mix_probe_cycles_per_instruction_at_this_clock"],
+                                                                                               den["own_mix_probe_at_its_uncapped_clock"], pw["sclk_MHz"], pw["package_W"]))
+                            vi.pop("stale", None)
+                            out["valu_issue"] = vi
+                        else:
+                            den["probe_denominators"] = "omitted: tools/issue_probe has not been evaluated on the kernel headers of this tree (tools/valu_bound.py)"
+                        vf["denominators"] = den
             cr = copy_rate(torch, gpqhe_amd)
             out["copy_rate"] = cr
             for rec in out["kernels"].values():               # every kernel's algorithmic rate against that of the best plain copy
@@ -880,7 +919,7 @@ def main(argv=None):
             out["ntt"].append(ntt_rate(torch, gpqhe_amd, 16, DIM_A, 4 * B))   # launch size matters: 4 GiB slab
             out["ntt"].append(ntt_rate(torch, gpqhe_amd, 15, 10, 2048))       # configs[1]'s ring at a launch that fills the chip (5 GiB)
             checks = []
-            out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, B, iters=5, checked="he_mul_mpi_level")   # BASELINE configs[2]: he_mul + he_rescale, batch 64
+            out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, B, iters=5, checked="he_mul_mpi_level", sample_clocks=True)   # BASELINE configs[2]: he_mul + he_rescale, batch 64
             checks.append(out["he_mul_mpi_level"].pop("_check"))
             out["keyswitch_n17"] = keyswitch_n17_rate(torch, gpqhe_amd)
             out["he_swk_mpi_level"] = he_swk_mpi_rate(torch, gpqhe_amd)             # BASELINE configs[4] as the reference's function, one GPU
@@ -893,7 +932,7 @@ def main(argv=None):
             # ever runs; BASELINE.md: 1.12 s per he_mul on one CPU core): whole he_mul on device slabs at batch 64, and its own signature, batch 1
             ctx.close()
             c14 = gpqhe_amd.PolyContext(14, 24)
-            rd = he_mul_mpi_rate(torch, gpqhe_amd, c14, 64, iters=25, logq=438, checked="reference_default")
+            rd = he_mul_mpi_rate(torch, gpqhe_amd, c14, 64, iters=25, logq=438, checked="reference_default", sample_clocks=True)
             c14.close()
             checks.append(rd.pop("_check"))
             rd = {k: rd[k] for k in ("shape", "ms_per_batch", "he_mul_per_s", "he_mul_plus_he_rescale_per_s", "lanes", "bridge_ms_per_batch", "core_ms_per_batch")}

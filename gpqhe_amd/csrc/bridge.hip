@@ -1347,7 +1347,7 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
   gpq_bridge_basis *bA;
   if ((rc = get_basis(c, 0, dimA, &bA))) return rc;
   PeerLane lane;
-  if (batch > m && (rc = gpq_peer_lane(c, s, [&](gpq_ctx *q) { return gpq_he_mul_workspace_bytes(q, W, dimA, dimB, dimP, m); }, &lane))) return rc;
+  if (batch > m && (rc = gpq_peer_lane(c, s, gpq_lane_key(1, W, dimA, dimB, dimP, m ^ (logql << 8)), [&](gpq_ctx *q) { return gpq_he_mul_workspace_bytes(q, W, dimA, dimB, dimP, m); }, &lane))) return rc;
   for (unsigned k0 = 0; k0 < batch; k0 += m) {
     const unsigned polys = batch - k0 < m ? batch - k0 : m;
     if (lane.c && ((k0 / m) & 1)) {                              // every other launch group: the same call on the peer, for this group's slice
@@ -1411,7 +1411,9 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
                          limbs_addend ? Two<const uint64_t>{nullptr, nullptr, polys} : Two<const uint64_t>{d0, d1, polys},
                          W, dimP, dimB, logql, 2 * polys, wsTail, s, tail_mode, limbs_addend ? &dh : nullptr))) return rc;   // :67-77
   }
+  const unsigned lanes_used = lane.c ? 2u : 1u;
   if ((rc = gpq_peer_join(c, s, lane))) return rc;
+  c->last_lanes = lanes_used;   // (after the nested entry points of the groups, which record their own)
   return launched("gpq_he_mul");
 }
 
@@ -1434,7 +1436,7 @@ extern "C" int gpq_he_swk(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
   void *wsK = w; w += align64(gpq_keyswitch_workspace_bytes(c, dimB, m));
   void *wsTail = w;
   PeerLane lane;
-  if (batch > m && (rc = gpq_peer_lane(c, s, [&](gpq_ctx *q) { return gpq_he_swk_workspace_bytes(q, W, dimB, dimP, m); }, &lane))) return rc;
+  if (batch > m && (rc = gpq_peer_lane(c, s, gpq_lane_key(2, W, 0, dimB, dimP, m ^ (logql << 8)), [&](gpq_ctx *q) { return gpq_he_swk_workspace_bytes(q, W, dimB, dimP, m); }, &lane))) return rc;
   for (unsigned k0 = 0; k0 < batch; k0 += m) {
     const unsigned polys = batch - k0 < m ? batch - k0 : m;
     if (lane.c && ((k0 / m) & 1)) {                              // (as in gpq_he_mul)
@@ -1456,7 +1458,9 @@ extern "C" int gpq_he_swk(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
     if ((rc = relin_tail(c, Two<uint64_t>{out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, polys}, c0hat, Two<const uint64_t>{d0 + k0 * bigpoly, nullptr, polys},
                          W, dimP, dimB, logql, 2 * polys, wsTail, s, tail_mode))) return rc;
   }
+  const unsigned lanes_used = lane.c ? 2u : 1u;
   if ((rc = gpq_peer_join(c, s, lane))) return rc;
+  c->last_lanes = lanes_used;   // (after the nested entry points of the groups, which record their own)
   return launched("gpq_he_swk");
 }
 extern "C" size_t gpq_he_swk_workspace_bytes(gpq_ctx *c, unsigned W, unsigned dimB, unsigned dimP, unsigned batch) {
@@ -1551,9 +1555,11 @@ extern "C" int gpq_set_stream_bridge(gpq_ctx *c, int on) {
 // gpq_he_mul / gpq_he_swk over more than one launch group: alternate groups on two streams (default) or all on the caller's.  Same words.
 extern "C" int gpq_set_overlap(gpq_ctx *c, int on) {
   if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_set_overlap: null context");
-  c->overlap = on != 0;
+  c->overlap = on < 0 ? -1 : (on != 0);
   return GPQ_OK;
 }
+// lanes the last gpq_he_mul / gpq_he_swk / gpq_he_mul_tensor / gpq_keyswitch call on this context ran on (1 or 2)
+extern "C" unsigned gpq_last_lanes(const gpq_ctx *c) { return c ? c->last_lanes : 0; }
 
 // gpq_he_mul: its own rns_decompose launches (src/he-mult.c:117-120, :59) may leave residues in (0, 3p) for the forward transforms that read them
 // (default on; canonical with 0).  Same results: the transforms reduce lazily anyway.

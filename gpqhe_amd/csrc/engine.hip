@@ -190,7 +190,8 @@ static int upload_tables(gpq_ctx *c) {
     LimbTab &t = tabs[d];
     t.k.p = p; t.k.p2 = 2 * p; t.k.p4 = 4 * p; t.k.c = (uint32_t)(p - (1ull << 59)); t.k.c1 = t.k.c + 1;
     t.k.kx0 = t.k.c1; t.k.kx1 = (uint64_t)t.k.c1 - 4 * p; t.k.ky = 4 * p - 2 * (uint64_t)t.k.c1;
-    t.k.kx1s = (uint64_t)t.k.c1 - 2 * p; t.k.kys = 2 * p - 2 * (uint64_t)t.k.c1;
+    t.k.kys = 2 * p - 2 * (uint64_t)t.k.c1;
+    t.k.p3 = 3 * p; t.k.np3 = (uint64_t)0 - 3 * p; t.k.kx1x = (uint64_t)t.k.c1 - 3 * p; t.k.kyx = 3 * p - 2 * (uint64_t)t.k.c1;
     t.k.np = (uint64_t)0 - p; t.k.np2 = (uint64_t)0 - 2 * p; t.k.np4 = (uint64_t)0 - 4 * p;
     t.ninv = from_mont(c->ninv_mont[d]);
     t.winv1_ninv = n >= 2 ? mulm(wistd[d * n + 1], t.ninv, p) : t.ninv;
@@ -307,7 +308,7 @@ int gpq_ctx_clone(const gpq_ctx *c, gpq_ctx **out) {
   q->device = c->device; q->logn = c->logn; q->n = c->n; q->nprimes = c->nprimes;
   q->p = c->p; q->pinv_mont = c->pinv_mont; q->pinv_barr = c->pinv_barr; q->ninv_mont = c->ninv_mont; q->psi = c->psi;
   q->zetas = c->zetas; q->zetas_inv = c->zetas_inv;
-  q->overlap = false;
+  q->overlap = 0;
   int rc = upload_tables(q);
   if (rc != GPQ_OK) { gpq_ctx_destroy(q); return rc; }
   *out = q;
@@ -835,7 +836,7 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
   const unsigned chunk = tensor_chunk(c, batch);
   const unsigned lblock = limb_block(c, dim);
   PeerLane lane;                                             // two launch groups in flight (engine_internal.hpp: gpq_peer_lane)
-  if (batch > chunk && (rc = gpq_peer_lane(c, s, [&](gpq_ctx *q) { return gpq_tensor_workspace_bytes(q, dim, chunk); }, &lane))) return rc;
+  if (batch > chunk && (rc = gpq_peer_lane(c, s, gpq_lane_key(3, dim, chunk, 0, 0, 0), [&](gpq_ctx *q) { return gpq_tensor_workspace_bytes(q, dim, chunk); }, &lane))) return rc;
   for (unsigned k0 = 0; k0 < batch; k0 += chunk) {
     const unsigned polys = (batch - k0 < chunk) ? batch - k0 : chunk;
     if (lane.c && ((k0 / chunk) & 1)) {
@@ -880,7 +881,9 @@ extern "C" int gpq_he_mul_tensor(gpq_ctx *c, uint64_t *d0, uint64_t *d1, uint64_
       if ((rc = launch_strided<true>(c, b, limbs, polys, s))) return rc;
     }
   }
+  const unsigned lanes_used = lane.c ? 2u : 1u;
   if ((rc = gpq_peer_join(c, s, lane))) return rc;
+  c->last_lanes = lanes_used;   // (after the nested entry points of the groups, which record their own)
   return after_launch("gpq_he_mul_tensor");
 }
 
@@ -908,7 +911,7 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
   const unsigned chunk = tensor_chunk(c, batch);
   const unsigned lblock = limb_block(c, dim);
   PeerLane lane;
-  if (batch > chunk && (rc = gpq_peer_lane(c, s, [&](gpq_ctx *q) { return gpq_keyswitch_workspace_bytes(q, dim, chunk); }, &lane))) return rc;
+  if (batch > chunk && (rc = gpq_peer_lane(c, s, gpq_lane_key(4, dim, chunk, 0, 0, 0), [&](gpq_ctx *q) { return gpq_keyswitch_workspace_bytes(q, dim, chunk); }, &lane))) return rc;
   for (unsigned k0 = 0; k0 < batch; k0 += chunk) {
     const unsigned polys = (batch - k0 < chunk) ? batch - k0 : chunk;
     if (lane.c && ((k0 / chunk) & 1)) {
@@ -955,7 +958,9 @@ extern "C" int gpq_keyswitch(gpq_ctx *c, uint64_t *c0, uint64_t *c1, const uint6
       if ((rc = launch_strided<true>(c, b, limbs, polys, s))) return rc;
     }
   }
+  const unsigned lanes_used = lane.c ? 2u : 1u;
   if ((rc = gpq_peer_join(c, s, lane))) return rc;
+  c->last_lanes = lanes_used;   // (after the nested entry points of the groups, which record their own)
   return after_launch("gpq_keyswitch");
 }
 

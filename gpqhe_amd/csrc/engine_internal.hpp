@@ -1,6 +1,7 @@
 // engine_internal.hpp -- the context object behind the opaque gpq_ctx handle.
 #pragma once
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 #include "tables.hpp"
@@ -110,7 +111,10 @@ struct gpq_ctx {
   // gpq_he_mul / gpq_he_swk over more than one launch group: every other group runs on a second stream through a PEER context (its own tables,
   // scratch and flag words: nothing mutable is shared), so that the HBM-bound bridge kernels of one group run beside the issue-bound transforms
   // of the other and launch tails fill (gpq_set_overlap; bridge.hip: peer_lane).  The caller's stream orders the whole call as before.
-  bool overlap = true;
+  int overlap = -1;                   // gpq_set_overlap: -1 (default) = two lanes when the peer's workspace is affordable (kPeerAutoWorkspaceBytes), 0 = never, 1 = always
+  bool peer_failed = false;           // the peer (or its workspace) could not be created once: one lane from then on
+  unsigned last_lanes = 1;            // lanes the last multi-group entry point ran on (gpq_last_lanes)
+  std::set<unsigned long long> peer_warm;   // call shapes the peer has run outside a stream capture (gpq_lane_key)
   gpq_ctx *peer = nullptr;
   hipStream_t peer_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -184,6 +188,15 @@ struct PeerLane {
   gpq_ctx *c = nullptr;
   hipStream_t s = nullptr;
   void *ws = nullptr;
+  // set once the peer stream has been forked off the caller's: the lane is joined on EVERY exit path of the call (an early `return rc` inside the
+  // group loop must not leave queued peer work unordered against the caller's stream, nor a stream capture with an unjoined fork)
+  gpq_ctx *owner = nullptr;
+  hipStream_t caller = nullptr;
+  PeerLane() = default;
+  PeerLane(const PeerLane &) = delete;
+  PeerLane &operator=(const PeerLane &) = delete;
+  inline int join();
+  ~PeerLane() { (void)join(); }
 };
 inline void gpq_mirror_settings(gpq_ctx *q, const gpq_ctx *c) {   // whatever decides which kernels a call runs: the peer follows the context it serves
   q->chunk = c->chunk; q->limb_block = c->limb_block; q->nsplit = c->nsplit; q->nwide = c->nwide;
@@ -191,40 +204,63 @@ inline void gpq_mirror_settings(gpq_ctx *q, const gpq_ctx *c) {   // whatever de
   q->stream_bridge = c->stream_bridge; q->exact_crt = c->exact_crt; q->prescale = c->prescale; q->prescale_upper = c->prescale_upper;
   q->tail_direct = c->tail_direct; q->fuse_tail = c->fuse_tail;
 }
-// lane->c stays null when the call runs on the caller's stream alone.  `bytes(peer)` = the workspace one launch group needs on the peer.
+// What gpq_set_overlap(ctx, -1) -- the default -- allows the peer's per-group workspace to cost.  Two lanes pay through launch tails, so the gain
+// shrinks as the kernels of a group grow: +10-15 % at the reference's default shape (logn 14: 0.1 GB per group) on every device measured,
+// +0.15 ... +3.9 % by device at the headline shape (5.6 GB per group), +1.6 % for he_swk at n = 2^17 (7 GB); never a loss (profiles/r04/v13_two_lanes_ab.txt,
+// BENCH_r04.json, profiles/r05).  The cost is device memory: the peer's own tables (as much again as the context's) and this workspace.
+constexpr size_t kPeerAutoWorkspaceBytes = (size_t)16 << 30;
+// lane->c stays null when the call runs on the caller's stream alone.  `key` names the call shape (entry point, dimensions, group size): a lane is
+// only taken inside a stream capture when the peer has already run that very shape outside one (its first-use table builds allocate and copy).
+// `bytes(peer)` = the workspace one launch group needs on the peer.  A peer that cannot be created (or whose workspace cannot be allocated) is not
+// an error of the call: the HIP error is cleared, the context stops trying, and the call runs on one lane.
 template <typename Bytes>
-int gpq_peer_lane(gpq_ctx *c, hipStream_t s, Bytes bytes, PeerLane *lane) {
-  if (!c->overlap || c->prof_on || c->inv_tabs_override) return GPQ_OK;
-  auto hip = [](hipError_t e, const char *what) { return e == hipSuccess ? (int)GPQ_OK : gpq_fail(GPQ_ERR_HIP, "%s: %s", what, hipGetErrorString(e)); };
+int gpq_peer_lane(gpq_ctx *c, hipStream_t s, unsigned long long key, Bytes bytes, PeerLane *lane) {
+  if (c->overlap == 0 || c->peer_failed || c->prof_on || c->inv_tabs_override) return GPQ_OK;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return GPQ_OK; }
   const bool capturing = cap != hipStreamCaptureStatusNone;
-  int rc;
+  if (capturing && (!c->peer || !c->peer_warm.count(key))) return GPQ_OK;     // (before bytes(peer): sizing a new shape may allocate on the peer)
+  auto give_up = [&](const char *what) {                                       // one lane from now on, for this context
+    (void)hipGetLastError();
+    c->peer_failed = true;
+    fprintf(stderr, "gpqhe_hip: second lane unavailable (%s): this context continues on one lane\n", what);
+    return (int)GPQ_OK;
+  };
   if (!c->peer) {
-    if (capturing) return GPQ_OK;                                 // (the first call at a shape runs outside capture, as for every scratch buffer)
-    if (!c->peer_stream && (rc = hip(hipStreamCreateWithFlags(&c->peer_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags"))) return rc;
-    if (!c->ev_fork && (rc = hip(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreateWithFlags"))) return rc;
-    if (!c->ev_join && (rc = hip(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreateWithFlags"))) return rc;
-    if ((rc = gpq_ctx_clone(c, &c->peer))) return rc;              // last: a context with a peer has its stream and events
+    if (!c->peer_stream && hipStreamCreateWithFlags(&c->peer_stream, hipStreamNonBlocking) != hipSuccess) return give_up("hipStreamCreateWithFlags");
+    if (!c->ev_fork && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return give_up("hipEventCreateWithFlags");
+    if (!c->ev_join && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return give_up("hipEventCreateWithFlags");
+    if (gpq_ctx_clone(c, &c->peer) != GPQ_OK) { c->peer = nullptr; return give_up("peer context"); }   // last: a context with a peer has its stream and events
   }
   gpq_mirror_settings(c->peer, c);
   const size_t need = bytes(c->peer);
   if (!need) return GPQ_OK;
+  if (c->overlap < 0 && need > kPeerAutoWorkspaceBytes) return GPQ_OK;        // auto: not at this price
   if (need > c->peer_ws_bytes) {
     if (capturing) return GPQ_OK;
+    void *fresh = nullptr;
+    if (hipMalloc(&fresh, need) != hipSuccess) return give_up("hipMalloc of the peer workspace");
     if (c->peer_ws) c->retired.push_back(c->peer_ws);             // a graph captured earlier may still use it
-    c->peer_ws = nullptr; c->peer_ws_bytes = 0;
-    if ((rc = hip(hipMalloc(&c->peer_ws, need), "hipMalloc (peer workspace)"))) return rc;
-    c->peer_ws_bytes = need;
+    c->peer_ws = fresh; c->peer_ws_bytes = need;
   }
-  if ((rc = hip(hipEventRecord(c->ev_fork, s), "hipEventRecord")) || (rc = hip(hipStreamWaitEvent(c->peer_stream, c->ev_fork, 0), "hipStreamWaitEvent"))) return rc;
-  lane->c = c->peer; lane->s = c->peer_stream; lane->ws = c->peer_ws;
+  hipError_t e = hipEventRecord(c->ev_fork, s);
+  if (e == hipSuccess) e = hipStreamWaitEvent(c->peer_stream, c->ev_fork, 0);
+  if (e != hipSuccess) return gpq_fail(GPQ_ERR_HIP, "forking the peer stream: %s", hipGetErrorString(e));
+  if (!capturing) c->peer_warm.insert(key);
+  lane->c = c->peer; lane->s = c->peer_stream; lane->ws = c->peer_ws; lane->owner = c; lane->caller = s;
   return GPQ_OK;
 }
-inline int gpq_peer_join(gpq_ctx *c, hipStream_t s, const PeerLane &lane) {
-  if (!lane.c) return GPQ_OK;
-  hipError_t e = hipEventRecord(c->ev_join, lane.s);
-  if (e == hipSuccess) e = hipStreamWaitEvent(s, c->ev_join, 0);
+inline int PeerLane::join() {
+  if (!c || !owner) return GPQ_OK;
+  hipError_t e = hipEventRecord(owner->ev_join, s);
+  if (e == hipSuccess) e = hipStreamWaitEvent(caller, owner->ev_join, 0);
+  c = nullptr; owner = nullptr;
   return e == hipSuccess ? (int)GPQ_OK : gpq_fail(GPQ_ERR_HIP, "joining the peer stream: %s", hipGetErrorString(e));
+}
+inline int gpq_peer_join(gpq_ctx *, hipStream_t, PeerLane &lane) { return lane.join(); }
+inline unsigned long long gpq_lane_key(unsigned entry, unsigned a, unsigned b, unsigned c3, unsigned d, unsigned e) {
+  unsigned long long h = 0xcbf29ce484222325ull;
+  for (unsigned v : {entry, a, b, c3, d, e}) { h ^= v; h *= 0x100000001b3ull; }
+  return h;
 }
 

@@ -22,8 +22,10 @@
 #include <stdint.h>
 
 #define GPQ_FOLD_CMAX 319000000u /* < 2^28.25 */
-// Split-twiddle multiply (below): one fold finishes when 3*2^30*c < 2^59, i.e. c <= floor(2^29/3).
-#define GPQ_SPLIT_CMAX 178956971u /* c < this: every prime of the n <= 2^16 chains, the first ones at n = 2^17 */
+// Split-twiddle multiply (below): one fold finishes, and the butterflies' ranges (forward < 6p, inverse < 3p) close, when
+// 3.5*2^30*c < 2^60, i.e. c < 2^30/3.5 = 2^28.19.  (Round 5: until then the class kept data < 4p / < 2p, which needs 3*2^30*c < 2^59 --
+// c < 2^27.415 -- and left the last 13 of the 44 limbs of n = 2^17 to the 7-mad class: +25 % time per limb, profiles/r05.)
+#define GPQ_SPLIT_CMAX 306000000u /* c < this: every prime of the chains up to n = 2^17 */
 // Forward butterflies that skip every other conditional subtraction (ct_bfly_wide below) need c < 2^27.
 #define GPQ_WIDE_CMAX 134217000u
 
@@ -40,7 +42,9 @@ struct PrimeK {        // per-limb constants handed to kernels (uniform per bloc
   uint64_t p2, p4;     // 2p, 4p
   uint64_t kx0, kx1;   // c+1 and c+1-4p (mod 2^64): the two addends of the CT x-leg select
   uint64_t ky;         // 4p - 2(c+1)
-  uint64_t kx1s, kys;  // split-twiddle butterflies (data < 4p): c+1-2p (mod 2^64) and 2p - 2(c+1)
+  uint64_t kys;        // wide-split forward butterflies: 2p - 2(c+1)
+  uint64_t p3, np3;    // 3p and -3p (mod 2^64): the split class subtracts 3p (forward data < 6p, inverse data < 3p)
+  uint64_t kx1x, kyx;  // split-twiddle forward butterflies: c+1-3p (mod 2^64) and 3p - 2(c+1)
   uint64_t np, np2, np4;  // -p, -2p, -4p (mod 2^64): a conditional subtraction is an ADD of one of these or of zero (csub1/2/4)
   uint32_t c;          // p - 2^59
   uint32_t c1;         // c + 1
@@ -107,6 +111,7 @@ __device__ __forceinline__ uint64_t csub_by(uint64_t x, uint64_t m, uint64_t neg
 __device__ __forceinline__ uint64_t csub1(uint64_t x, const PrimeK &k) { return csub_by(x, k.p, k.np); }
 __device__ __forceinline__ uint64_t csub2(uint64_t x, const PrimeK &k) { return csub_by(x, k.p2, k.np2); }
 __device__ __forceinline__ uint64_t csub4(uint64_t x, const PrimeK &k) { return csub_by(x, k.p4, k.np4); }
+__device__ __forceinline__ uint64_t csub3(uint64_t x, const PrimeK &k) { return csub_by(x, k.p3, k.np3); }
 
 // value < 8p -> [0,p)
 __device__ __forceinline__ uint64_t canon8(uint64_t x, const PrimeK &k) {
@@ -141,14 +146,16 @@ __device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, uint64_t w, co
 // Split-twiddle multiply: when the multiplier is a table constant w, the table also
 // carries w2 = w*2^31 mod p, and with a = ah*2^31 + al
 //   a*w == al*w + ah*w2  (mod p),   al < 2^31, ah <= 2^30 for a < 4p
-// is a 91-bit sum of two 32x60 products (4 mads, the column carries ride in the mad
+// is a 92-bit sum of two 32x60 products (4 mads, the column carries ride in the mad
 // addends) whose part above 2^59 fits 32 bits: ONE fold by c finishes.  5 v_mad_u64_u32
 // instead of 7 and no 128-bit shift.  Both constants are stored negated (p-w, p-w2), so
 //   a*w == -(tl + 2^59*th) == c*th - tl == c*th + (2^59-1-tl) + (c+1) - p
-// and the subtraction is again a complement.  Returns T' with a*w == T' + (c+1) (mod p),
-//   th <= 3*2^30,  T' <= c*th + 2^59 - 1 < 2p - (c+1)      for c < GPQ_SPLIT_CMAX,
-// so T'+(c+1) < 2p: the Harvey ranges [0,4p) forward / [0,2p) inverse close with one
-// conditional subtraction per butterfly.  Measured (tools/bfly_lab): +20 % CT, +27 % GS.
+// and the subtraction is again a complement.  Returns T' with a*w == T' + (c+1) (mod p).
+// For a multiplicand a < 6p:  ah <= 3*2^29,  th <= 3.5*2^30,  T' <= c*th + 2^59 - 1 < 3p - (c+1)   for c < GPQ_SPLIT_CMAX,
+// so t = T' + (c+1) < 3p and the ranges [0, 6p) forward / [0, 3p) inverse close with ONE conditional subtraction (of 3p) per
+// butterfly:  forward  xr = x - [x >= 3p] 3p < 3p,  x' = xr + t < 6p,  y' = xr + 3p - t in (0, 6p);
+//             inverse  v = x + y < 6p,  x' = v - [v >= 3p] 3p < 3p,  d = x + 3p - y in (0, 6p),  y' = t < 3p.
+// (tests/test_lazy_ranges.py is the integer model; measured in tools/bfly_lab at the 4p / 2p ranges: +20 % CT, +27 % GS over the 7-mad form.)
 // ---------------------------------------------------------------------------
 typedef ulonglong2 TwS;   // .x = p - w, .y = p - (w*2^31 mod p)
 
@@ -160,7 +167,7 @@ __device__ __forceinline__ uint64_t mulmod_split(uint64_t a, const W &w, const P
   const uint32_t al = (uint32_t)a & 0x7fffffffu;
   const uint32_t ah = __builtin_amdgcn_alignbit((uint32_t)(a >> 32), (uint32_t)a, 31);
   uint64_t t0 = mad_u64(al, (uint32_t)w.x, 0);
-  t0 = mad_u64(ah, (uint32_t)w.y, t0);                         // < 2^63 + 2^62
+  t0 = mad_u64(ah, (uint32_t)w.y, t0);                         // < 2^63 + 2^63 - ... : al < 2^31, ah < 2^31 (a < 8p), constants < 2^32
   asm GPQ_PIN_VOLATILE("" : "+v"(t0));                                 // keep the carries inside the mads (see mulmod_raw_t)
   uint64_t t1 = mad_u64(al, (uint32_t)(w.x >> 32), (uint32_t)(t0 >> 32));
   asm GPQ_PIN_VOLATILE("" : "+v"(t1));
@@ -171,19 +178,19 @@ __device__ __forceinline__ uint64_t mulmod_split(uint64_t a, const W &w, const P
   return mad_u64(k.c, th, ntl);
 }
 
-// Cooley-Tukey, split twiddle.  in: x,y < 4p ; out: x,y < 4p.
+// Cooley-Tukey, split twiddle.  in: x,y < 6p ; out: x,y < 6p.
 __device__ __forceinline__ void ct_bfly(uint64_t &x, uint64_t &y, const TwS &w, const PrimeK &k) {
   const uint64_t t = mulmod_split(y, w, k);
-  const uint64_t xs = x + (x >= k.p2 ? k.kx1s : k.kx0);
+  const uint64_t xs = x + (x >= k.p3 ? k.kx1x : k.kx0);
   x = xs + t;
-  y = xs + k.kys - t;
+  y = xs + k.kyx - t;
 }
-// Gentleman-Sande, split twiddle.  in: x,y < 2p ; out: x,y < 2p.
+// Gentleman-Sande, split twiddle.  in: x,y < 3p ; out: x,y < 3p.
 template <typename W>
 __device__ __forceinline__ void gs_bfly_split(uint64_t &x, uint64_t &y, const W &w, const PrimeK &k) {
   const uint64_t v = x + y;
-  const uint64_t d = x + k.p2 - y;  // (0, 4p)
-  x = csub2(v, k);
+  const uint64_t d = x + k.p3 - y;  // (0, 6p)
+  x = csub3(v, k);
   y = mulmod_split(d, w, k) + k.c1;
 }
 __device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, const TwS &w, const PrimeK &k) { gs_bfly_split(x, y, w, k); }

@@ -64,7 +64,7 @@ constexpr int tw_off(int EL, int BHI, int b) { return (1 << (EL - b - 1)) - (1 <
 // registers is not always unrolled completely, and a runtime-indexed register
 // array goes to scratch: measured 8x slower on the n=2^17 forward pass).
 // TW is the table entry type: uint64_t (plain twiddle, 7-mad multiply, data < 8p / < 4p) or
-// TwS (split pair, 5-mad multiply, data < 4p / < 2p); the butterflies are overloaded on it.
+// TwS (split pair, 5-mad multiply, data < 6p / < 3p); the butterflies are overloaded on it.
 template <int EL, int BHI, int B, int BLO, bool UNIFORM, int NTW, typename TW>
 __device__ __forceinline__ void load_tw_bits(TW (&tw)[NTW], unsigned ibase, int rs, unsigned logn,
                                              const TW *__restrict__ w) {
@@ -155,11 +155,11 @@ __device__ __forceinline__ void gs_last(uint64_t &x, uint64_t &y, const LastK<ui
   x = canon4(mulmod_lazy(s, t.ninv, k), k);
   y = canon4(mulmod_lazy(d, t.winv1_ninv, k), k);
 }
-__device__ __forceinline__ void gs_last(uint64_t &x, uint64_t &y, const LastK<TwS> &t, const PrimeK &k) {   // in: x,y < 2p
-  const uint64_t s = x + y;                 // < 4p
-  const uint64_t d = x + k.p2 - y;          // (0, 4p)
-  x = csub1(mulmod_split(s, t.ninv, k) + k.c1, k);
-  y = csub1(mulmod_split(d, t.winv1_ninv, k) + k.c1, k);
+__device__ __forceinline__ void gs_last(uint64_t &x, uint64_t &y, const LastK<TwS> &t, const PrimeK &k) {   // in: x,y < 3p
+  const uint64_t s = x + y;                 // < 6p
+  const uint64_t d = x + k.p3 - y;          // (0, 6p)
+  x = canon4(mulmod_split(s, t.ninv, k) + k.c1, k);            // products < 3p
+  y = canon4(mulmod_split(d, t.winv1_ninv, k) + k.c1, k);
 }
 
 // Per twiddle type: the table pointers of a launch and the lazy ranges the butterflies keep.
@@ -177,11 +177,13 @@ template <> struct TwTraits<uint64_t> {
 };
 template <> struct TwTraits<TwS> {
   __device__ static __forceinline__ const TwS *table(const PassArgs &a, bool inv) { return inv ? a.winvs : a.ws; }
-  __device__ static __forceinline__ uint64_t canon_fwd(uint64_t x, const PrimeK &k) { return canon4(x, k); }   // forward data < 4p
-  __device__ static __forceinline__ uint64_t canon_inv(uint64_t x, const PrimeK &k) { return csub1(x, k); }   // inverse data < 2p
+  __device__ static __forceinline__ uint64_t canon_fwd(uint64_t x, const PrimeK &k) { return canon_fold(x, k.p, k.c); }   // forward data < 6p
+  __device__ static __forceinline__ uint64_t canon_inv(uint64_t x, const PrimeK &k) { return canon4(x, k); }   // inverse data < 3p
   __device__ static __forceinline__ uint64_t inv_from4(uint64_t x, const PrimeK &k) { return csub2(x, k); }
   __device__ static __forceinline__ uint64_t inv_from8(uint64_t x, const PrimeK &k) { return csub2(csub4(x, k), k); }
-  __device__ static __forceinline__ uint64_t left(uint64_t x, const PrimeK &k) { return csub2(x, k); }
+  // products (mulmod_lazy: th of the 7-mad fold must fit 32 bits, c * (a b >> 59) < 2^91): left < 2p, right < 6p as it comes: 12 p^2, th < 12 c < 2^32
+  // for c < GPQ_SPLIT_CMAX, and the product leaves below 4p (12 c^2 < 1.95 * 2^59)
+  __device__ static __forceinline__ uint64_t left(uint64_t x, const PrimeK &k) { return csub2(csub4(x, k), k); }
   __device__ static __forceinline__ uint64_t right(uint64_t x, const PrimeK &) { return x; }
 };
 

@@ -120,7 +120,7 @@ inline const HashKey &hash_key() {
   return key;
 }
 // words [lo, hi) of one polynomial: four multiply-xor lanes (the multiply's latency is covered, the loop runs at memory speed)
-uint64_t hash_words(const uint64_t *a, size_t lo, size_t hi) {
+inline uint64_t hash_words(const uint64_t *a, size_t lo, size_t hi) {
   const HashKey &key = hash_key();
   const uint64_t M = key.mul;
   uint64_t h[4] = {key.init[0], key.init[1], key.init[2], key.init[3]};

@@ -138,8 +138,13 @@ class PolyContext:
         _native.check(self.lib.gpq_set_lazy_decompose(self.h, 1 if on else 0), "gpq_set_lazy_decompose")
 
     def set_overlap(self, on):
-        """he_mul / he_swk over several launch groups: alternate groups on a second internal stream (default) or all on the caller's; same words"""
-        _native.check(self.lib.gpq_set_overlap(self.h, 1 if on else 0), "gpq_set_overlap")
+        """he_mul / he_swk / tensor / key switch over several launch groups: -1 = two lanes when affordable (default), 0 / False = one, 1 / True = two; same words"""
+        v = -1 if (on is not True and on is not False and int(on) < 0) else (1 if on else 0)
+        _native.check(self.lib.gpq_set_overlap(self.h, v), "gpq_set_overlap")
+
+    def last_lanes(self):
+        """lanes (1 or 2) the last multi-group call on this context ran on"""
+        return int(self.lib.gpq_last_lanes(self.h))
 
     def set_nt_policy(self, mode):
         """slab traffic of the transform kernels non-temporal: -1 by working set (default), 0 never, 1 always; never changes a word"""

@@ -214,12 +214,18 @@ int gpq_set_exact_crt(gpq_ctx *ctx, int on);
  * (src/he-mult.c:140, :59) in one kernel, and the relinearisation tail (:67-77) as one product that makes its addend d0 / d1 (:139, :141) from the
  * limbs on the spot -- d0, d1, d2 never exist as words; 0 = round 3's separate CRT, decompose and tail kernels.  Same words (the tests run both). */
 int gpq_set_stream_bridge(gpq_ctx *ctx, int on);
-/* gpq_he_mul / gpq_he_swk / gpq_he_mul_tensor / gpq_keyswitch over more than one launch group (batch > gpq_set_chunk's group): 1 (default) = every other group runs on a second,
- * internal stream through an internal peer context (own tables and scratch, created on the first such call: about the caller's workspace again
- * in device memory), so that the bridge kernels of one group overlap the transforms of the other; the caller's stream still orders the call
- * as a whole (work queued before it is waited for, work queued after it waits for both lanes).  0 = everything on the caller's stream.
- * Same words.  Not taken while gpq_profile is on. */
+/* gpq_he_mul / gpq_he_swk / gpq_he_mul_tensor / gpq_keyswitch over more than one launch group (batch > gpq_set_chunk's group): with two LANES every
+ * other group runs on a second, internal stream through an internal peer context, so that the launch tails of one group fill with the other's
+ * kernels; the caller's stream still orders the call as a whole (work queued before it is waited for, work queued after it waits for both lanes).
+ * `on` = -1 (default): two lanes when the peer's per-group workspace costs at most 16 GiB; 0: never; 1: always.  Same words either way.
+ * COST: the peer owns its own device tables (as much again as the context's: 0.15 GB at n = 2^16 / 45 limbs, plus the bridge constants) and a
+ * workspace for one launch group (the size gpq_*_workspace_bytes reports for a batch of one group: 5.6 GB for gpq_he_mul at the headline shape),
+ * allocated at the first multi-group call.  GAIN: +10-15 % at the reference's default shape (logn 14) on every device measured; at the headline
+ * shape it depends on the device (+0.15 % ... +3.9 %: a group's kernels are long, the lanes share one power cap); never a loss.  If the peer or
+ * its workspace cannot be allocated the call runs on one lane (one line on stderr, no error).  Not taken while gpq_profile is on.
+ * gpq_last_lanes: the lanes (1 or 2) the last such call on this context ran on. */
 int gpq_set_overlap(gpq_ctx *ctx, int on);
+unsigned gpq_last_lanes(const gpq_ctx *ctx);
 /* gpq_he_mul: 1 (default) = its internal rns_decompose launches leave residues in (0, 3p), which the forward transforms behind them accept;
  * 0 = canonical residues.  Same results. */
 int gpq_set_lazy_decompose(gpq_ctx *ctx, int on);

@@ -132,4 +132,10 @@ def test_the_quick_bench_line_prices_kernels_against_ceilings():
     if "valu_floor" in line:                           # needs rocm-smi for the clock
         assert 0.5 < line["valu_floor"]["frac"] <= 1.05, line["valu_floor"]    # (1.05: the clock is rocm-smi's, sampled beside the run, not inside it)
         assert line["roofline"]["bound"] == "valu_issue" and line["roofline"]["declared_bound"] == "hbm"
+        # one block of denominators; nothing stale is ever shipped: a probe evaluated on other kernel headers is omitted, not flagged
+        den = line["valu_floor"]["denominators"]
+        assert den["four_cycles_per_wave_instruction_at_this_clock"] == line["valu_floor"]["frac"]
+        assert "stale" not in line.get("valu_issue", {})
+        assert ("valu_issue" in line) == ("own_mix_probe_at_its_uncapped_clock" in den)
+    assert "stale" not in json.dumps(line)
     assert line["roofline"]["peak"] == 8000.0 and 0 < line["roofline"]["frac"] < 1

@@ -164,3 +164,21 @@ def test_a_failing_rccl_group_costs_the_transfer_leg_only():
     assert out["value"] > 0 and out["n_gpus"] == 2 and out["ranks_seen"] == 2
     assert "nccl" in out["config"]["backend"] and "gloo" in out["config"]["backend"]
     assert out["with_scatter_gather"]["error"] and "scatter" in out["with_scatter_gather"]["stage"]
+
+
+@pytest.mark.timeout(400)
+def test_rccl_first_contact_on_one_gpu():
+    """RCCL doing something other than failing: one rank on cuda:0, control plane gloo, data plane
+    `new_group(backend="nccl")` as bench.py builds it, in a CHILD started before this process has touched the GPU for it: an all_reduce, an
+    all_gather, a grouped self send/recv of three 45-limb polynomials (the call shape of the scatter / gather leg), the library's own
+    scatter_slab / gather_slab over that group.  No N > 1 number exists or is claimed (the driver's 8-GPU run is the first)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_first_contact.py"), str(_free_port()), "240"], env=env, capture_output=True, text=True,
+                       timeout=330, cwd=ROOT)
+    steps = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    names = [s["step"] for s in steps]
+    assert r.returncode == 0 and names[-1] == "done", (r.returncode, names, r.stderr[-1500:])
+    assert steps[0] == {"step": "groups", "data_backend": "nccl"}
+    assert all(s.get("ok", True) for s in steps), steps
+    assert names == ["groups", "all_reduce", "all_gather", "self_sendrecv", "scatter_gather", "max_over_ranks", "done"]

@@ -6,7 +6,7 @@ import random
 import pytest
 
 M64 = (1 << 64) - 1
-SPLIT_CMAX = 178956971   # GPQ_SPLIT_CMAX
+SPLIT_CMAX = 306000000   # GPQ_SPLIT_CMAX
 WIDE_CMAX = 134217000    # GPQ_WIDE_CMAX
 
 
@@ -30,17 +30,71 @@ def pairs(p, w):
     return p - w, p - ((w << 31) % p)
 
 
-@pytest.mark.parametrize("c", [4849665, 113508353, SPLIT_CMAX - 1])
-def test_split_multiply_below_2p_for_operands_below_4p(c):
+@pytest.mark.parametrize("c", [4849665, 113508353, 178956970, 218103809, SPLIT_CMAX - 1])
+def test_split_multiply_below_3p_for_operands_below_6p(c):
+    """mulmod_split for the split class (round 5: forward data < 6p, inverse data < 3p, one conditional subtraction of 3p per butterfly):
+    a multiplicand below 6p gives th <= 3.5 * 2^30 and a product term below 3p for every c the class admits (c < 2^30 / 3.5)."""
     p = (1 << 59) + c
     rnd = random.Random(c)
-    for a in [0, 1, 4 * p - 1, 4 * p - 2, (1 << 61) - 1, 1 << 61] + [rnd.randrange(4 * p) for _ in range(3000)]:
+    for a in [0, 1, 6 * p - 1, 6 * p - 2, 4 * p - 1, (1 << 61) - 1, 1 << 61, (1 << 61) + (1 << 60), 3 * (1 << 60) + (1 << 31) - 1] + [rnd.randrange(6 * p) for _ in range(3000)]:
         for w in (1, p - 1, rnd.randrange(1, p)):
             t = mulmod_split(a, *pairs(p, w), c) + c + 1
-            assert t < 2 * p and t % p == a * w % p
+            assert t < 3 * p and t % p == a * w % p
     for wx in (p - 1, 1):
         for wy in (p - 1, 1):
-            assert mulmod_split(4 * p - 1, wx, wy, c) + c + 1 < 2 * p
+            assert mulmod_split(6 * p - 1, wx, wy, c) + c + 1 < 3 * p
+
+
+@pytest.mark.parametrize("c", [4849665, 178956970, 218103809, SPLIT_CMAX - 1])
+def test_split_stage_ranges_close(c):
+    """ct_bfly / gs_bfly_split / gs_last of the split class as modarith.hpp writes them: forward x, y < 6p stay < 6p, inverse x, y < 3p stay
+    < 3p, the last inverse stage (n^-1 folded in) canonicalises products below 3p with two conditional subtractions."""
+    p = (1 << 59) + c
+    c1 = c + 1
+    kx0, kx1x, kyx = c1, (c1 - 3 * p) & M64, 3 * p - 2 * c1
+    rnd = random.Random(c + 7)
+    edge = [0, 1, p - 1, p, 3 * p - 1, 3 * p, 6 * p - 1, 6 * p - 2, (1 << 61) - 1, 1 << 61, 3 * (1 << 60)]
+    for _ in range(4000):
+        w = rnd.choice([1, 2, p - 1, rnd.randrange(1, p)])
+        wx, wy = pairs(p, w)
+        x = rnd.choice(edge + [rnd.randrange(6 * p)]) % (6 * p)
+        y = rnd.choice(edge + [rnd.randrange(6 * p)]) % (6 * p)
+        T = mulmod_split(y, wx, wy, c)
+        assert (T + c1) % p == y * w % p and T + c1 < 3 * p
+        xs = (x + (kx1x if x >= 3 * p else kx0)) & M64
+        x2, y2 = (xs + T) & M64, (xs + kyx - T) & M64
+        assert x2 % p == (x + y * w) % p and y2 % p == (x - y * w) % p
+        assert x2 < 6 * p and y2 < 6 * p
+        # inverse
+        x, y = x % (3 * p), y % (3 * p)
+        v, d = x + y, x + 3 * p - y
+        assert 0 < d < 6 * p
+        x2 = v - 3 * p if v >= 3 * p else v
+        y2 = mulmod_split(d, wx, wy, c) + c1
+        assert x2 < 3 * p and x2 % p == (x + y) % p and y2 < 3 * p and y2 % p == (x - y) * w % p
+        for val, arg in ((x + y, x + y), (x - y, d)):
+            t = mulmod_split(arg, wx, wy, c) + c1
+            assert t < 3 * p
+            t = t - 2 * p if t >= 2 * p else t
+            t = t - p if t >= p else t
+            assert t == val * w % p
+
+
+def test_product_operands_of_the_split_class_fit_the_general_multiply():
+    """mid kernels, split limbs: left operand < 2p, right operand < 6p (forward data as it comes): the 7-mad multiply's th fits 32 bits and
+    the product leaves below 4p for the largest c of the class."""
+    c = SPLIT_CMAX - 1
+    p = (1 << 59) + c
+    a, w = 2 * p - 1, 6 * p - 1
+    a0, a1, w0, w1 = a & 0xFFFFFFFF, a >> 32, w & 0xFFFFFFFF, w >> 32
+    assert a0 * w1 + ((a0 * w0) >> 32) + a1 * w0 <= M64
+    x = a * w
+    xh = x >> 59
+    assert xh <= M64
+    t = c * xh
+    assert (t >> 59) < (1 << 32)
+    tprime = (x & ((1 << 59) - 1)) + c * (t >> 59) + ((1 << 59) - 1 - (t & ((1 << 59) - 1)))
+    assert tprime + c + 1 < 4 * p and (tprime + c + 1) % p == x % p
 
 
 @pytest.mark.parametrize("c", [4849665, 113508353, WIDE_CMAX - 1])

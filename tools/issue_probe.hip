@@ -90,7 +90,8 @@ int main(int argc, char **argv) {
   memset((void *)&tab, 0, sizeof tab);
   tab.k.p = p; tab.k.p2 = 2 * p; tab.k.p4 = 4 * p; tab.k.c = (uint32_t)(p - (1ull << 59)); tab.k.c1 = tab.k.c + 1;
   tab.k.kx0 = tab.k.c1; tab.k.kx1 = (uint64_t)tab.k.c1 - 4 * p; tab.k.ky = 4 * p - 2 * (uint64_t)tab.k.c1;
-  tab.k.kx1s = (uint64_t)tab.k.c1 - 2 * p; tab.k.kys = 2 * p - 2 * (uint64_t)tab.k.c1;
+  tab.k.kys = 2 * p - 2 * (uint64_t)tab.k.c1;
+  tab.k.p3 = 3 * p; tab.k.np3 = (uint64_t)0 - 3 * p; tab.k.kx1x = (uint64_t)tab.k.c1 - 3 * p; tab.k.kyx = 3 * p - 2 * (uint64_t)tab.k.c1;
   tab.k.np = (uint64_t)0 - p; tab.k.np2 = (uint64_t)0 - 2 * p; tab.k.np4 = (uint64_t)0 - 4 * p;
   tab.ninv = 281474976710656ull % p;
   TwW htw[64 * 7];
