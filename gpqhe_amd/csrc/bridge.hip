@@ -1091,7 +1091,7 @@ int tail_stream(gpq_ctx *c, gpq_relin_tables *rt, Two<uint64_t> out, const uint6
   if ((rc = get_tail_direct_padded(c, dimP, dimB, rt, KST, &tt))) return rc;
   if (dh && (rc = get_addend_rows(c, dh->bA, KSD, &td))) return rc;
   if (!tt->d_bfrag || tt->KS != (unsigned)KST || (dh && (!td->d_bfrag || td->KS != (unsigned)KSD))) return GPQ_OK;
-  const size_t lds = (size_t)(KST + KSD) * 5 * 1024 + (size_t)2 * 65 * 16 * 8;
+  const size_t lds = (size_t)(KST + KSD) * 5 * 1024 + (size_t)2 * 65 * kTailRow * 8;
   if (lds > kStreamLdsMax) return GPQ_OK;
   if ((rc = ensure_redo(c, (size_t)polys << c->logn, s)) || (rc = ensure_wave_any(c, s))) return rc;
   const unsigned groups = (c->n >> 6) * polys, blocks = stream_blocks(groups);

@@ -56,6 +56,19 @@ __device__ __forceinline__ void stage_lds(T *dst, const T *__restrict__ src, uns
   for (; i < count; i += 512) dst[i] = src[i];
 }
 
+// The table of multiples [65][WL] into LDS with rows of WL + 1 words.  Every lane reads ITS row (the multiple of P its coefficient takes off): with
+// WL = 16 a row is 128 bytes, rows then differ by 32 banks and the 64 lanes of a ds_read_b64 share two bank pairs -- 11.2 M conflict cycles per launch of
+// bridge_tail_stream, the only kernel of the library with any (profiles/r04/v17_mpi_pmc.txt).  At 136 bytes the rows of 32 consecutive multiples
+// start in 32 different bank pairs.
+#ifndef GPQ_TAIL_ROW
+#define GPQ_TAIL_ROW 17   /* 16 = unpadded (round 4), for A/B builds */
+#endif
+constexpr int kTailRow = GPQ_TAIL_ROW;          // words per row of the tail's tables of multiples in LDS (WL = 16, + 1)
+template <int WL>
+__device__ __forceinline__ void stage_multiples(uint64_t *dst, const uint64_t *__restrict__ src) {
+  for (unsigned i = threadIdx.x; i < 65u * WL; i += 512) dst[(i / WL) * kTailRow + i % WL] = src[i];
+}
+
 // A slab as a buffer resource (stride 0, range-checked: an access past the end reads zeros / is dropped).  Built from kernel arguments only.
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 __device__ __forceinline__ BufRsrc slab_rsrc(const void *p, size_t bytes) {
@@ -426,12 +439,12 @@ __global__ __launch_bounds__(512) void bridge_tail_stream(TailStreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   v4i *Tl = reinterpret_cast<v4i *>(smem);                                   // [NSTEP][5][64]: the tail's rows, then the addend's
   uint64_t *tpml = reinterpret_cast<uint64_t *>(Tl + NSTEP * NT * 64);
-  uint64_t *dpml = tpml + 65 * WL;
+  uint64_t *dpml = tpml + 65 * kTailRow;
   stage_lds(Tl, a.tfrag, (unsigned)(KST * NT * 64));
-  stage_lds(tpml, a.tpm, 65u * WL);
+  stage_multiples<WL>(tpml, a.tpm);
   if (DCRT) {
     stage_lds(Tl + KST * NT * 64, a.dfrag, (unsigned)(KSD * NT * 64));
-    stage_lds(dpml, a.dpm, 65u * WL);
+    stage_multiples<WL>(dpml, a.dpm);
   }
   __syncthreads();
   const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -486,9 +499,9 @@ __global__ __launch_bounds__(512) void bridge_tail_stream(TailStreamArgs a) {
     // (the estimate may have borrowed from the integer part) or below 1/2 -> the exact path; the bits above are floor(x / P) [+ d].
     bool ambiguous, amb_d = false;
     const unsigned mult = multiple_of<NT, WL>(acc, tkf0, tkf1, ambiguous);
-    const uint64_t *__restrict__ P = tpml + (size_t)mult * WL;
+    const uint64_t *__restrict__ P = tpml + (size_t)mult * kTailRow;
     const uint64_t *__restrict__ PD = dpml;
-    if (DCRT) PD = dpml + (size_t)multiple_of<NT, TAIL_DF_WORD>(acc, dkf0, dkf1, amb_d) * WL;
+    if (DCRT) PD = dpml + (size_t)multiple_of<NT, TAIL_DF_WORD>(acc, dkf0, dkf1, amb_d) * kTailRow;
     ambiguous = ambiguous || amb_d;
     uint64_t Q[14];
     int64_t carry = 0;

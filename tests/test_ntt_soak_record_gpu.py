@@ -116,3 +116,36 @@ def test_the_recorded_configuration_words_and_flags(oracle_ctx):
         assert np.array_equal(to_host(r), want_ntt)
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("logn,dim,batch", [(12, 2, 3), (13, 3, 5), (16, 3, 5), (17, 2, 3)])
+def test_zero_flags_are_set_exactly_where_the_output_holds_a_residue_zero(oracle_ctx, logn, dim, batch):
+    """The debug door over several (polynomial, limb) units and kernel geometries: the forward kernels flag exactly the units whose transform
+    holds a residue 0 (where the reference stores 0 or p, src/ntt.c:45-48), the redo kernel clears exactly those, and an odd polynomial count
+    exercises the partner-less workgroup row of contig_pass / contig_pass8."""
+    o = oracle_ctx(logn, dim)
+    n = o.n
+    rng = random.Random(1000 * logn + dim)
+    slab = np.concatenate([o.gen(70 + k, dim) for k in range(batch)])
+    want_flags = np.zeros(batch * dim, dtype=np.uint32)
+    for k in range(batch):
+        for d in range(dim):
+            if rng.random() < 0.5:
+                base = (k * dim + d) * n
+                t = o.ntt(slab[base:base + n], d)
+                t[rng.randrange(n)] = 0
+                slab[base:base + n] = o.invntt(t % np.uint64(o.p[d]), d)
+                want_flags[k * dim + d] = 1
+    assert 0 < want_flags.sum() < batch * dim
+    want = o.ntt_slab(slab, dim)
+    g = gpqhe_amd.PolyContext(logn, dim)
+    try:
+        g.debug_zero_watch(True)
+        dev = to_device(slab)
+        g.poly_ntt(dev, dim)
+        before, after = g.debug_zero_flags(batch * dim)
+        assert before.tolist() == want_flags.tolist()
+        assert not after.any()
+        assert np.array_equal(to_host(dev), want)
+    finally:
+        g.close()
