@@ -2,7 +2,7 @@
 # PMC passes over a short bench run (kernel-trace + counters only; one counter group per pass).
 set -o pipefail
 mkdir -p gpurun_out; export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 1 --warmup 1 --batch 16 --cpu-sample 0 --no-ntt"
+BENCH="python3 bench.py --lanes 1 --steps 1 --warmup 1 --batch 16 --cpu-sample 0 --no-ntt"
 pass() { # name, counters...
   local name=$1; shift
   rm -rf gpurun_out/pmc_$name
@@ -27,7 +27,7 @@ for k,v in out.items():
 res["_chunk"]=16
 import os
 res["_head"]=open("tools/.head").read().strip() if os.path.exists("tools/.head") else None
-res["_command"]="python3 bench.py --steps 1 --warmup 1 --batch 16 --cpu-sample 0 --no-ntt (one rocprofv3 --pmc pass per counter group)"
+res["_command"]="python3 bench.py --lanes 1 --steps 1 --warmup 1 --batch 16 --cpu-sample 0 --no-ntt (one rocprofv3 --pmc pass per counter group)"
 json.dump(res, open('gpurun_out/pmc_summary.json','w'), indent=1)
 for k,v in res.items():
     if k.startswith('_'): continue
