@@ -331,6 +331,13 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=T
         ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
         ctx.he_rs(o0, o1, W, 50, logq - 50)
     t.stop()
+    ms_rs_two = t.elapsed_ms() / iters
+    # ... as ONE call (gpq_he_mul_rs: the rounding division rides in the relinearisation tail; same words, tests/test_he_mul_rs_gpu.py)
+    ctx.he_mul_rs(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP, 50)
+    t.start()
+    for _ in range(iters):
+        ctx.he_mul_rs(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP, 50)
+    t.stop()
     ms_rs = t.elapsed_ms() / iters
     check = None
     if checked:
@@ -338,8 +345,8 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=T
         # packed up for the restated reference (oracle/expect.py: src/he-mult.c:88-156, src/he-rescale.c:33-54) -- main() runs the workers at the
         # end of the run and writes `bit_exact_vs_restated_reference` into this leg
         ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
-        r0, r1 = o0.clone(), o1.clone()
-        ctx.he_rs(r0, r1, W, 50, logq - 50)
+        r0, r1 = torch.empty_like(o0), torch.empty_like(o1)
+        ctx.he_mul_rs(r0, r1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP, 50)      # the fused call is what the rate above timed: check ITS words
         torch.cuda.synchronize()
         group, per = 32, W * n
         picks = sorted({k for g0 in range(0, batch, group) for k in (g0, min(g0 + group, batch) - 1)})
@@ -387,6 +394,7 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=T
     return {"shape": "n=2^%d, q=2^%d (W=%d words), dimA/dimB/dimP=%d/%d/%d, batch %d" % (ctx.logn, logq, W, dimA, dimB, dimP, batch),
             "ms_per_batch": round(ms, 3), "he_mul_per_s": round(batch / (ms * 1e-3), 1),
             "he_mul_plus_he_rescale_per_s": round(batch / (ms_rs * 1e-3), 1),
+            "he_mul_then_he_rescale_two_calls_per_s": round(batch / (ms_rs_two * 1e-3), 1),
             "lanes": {"default": default_lanes, "this_run": 2 if two_lanes else 1, "one_lane_ms_per_batch": round(ms_one, 3), "one_lane_he_mul_per_s": round(batch / (ms_one * 1e-3), 1),
                       "gain_this_device": round(ms_one / ms - 1, 4), "clocks": clocks or None,
                       "note": "`default` = the lanes the library picked by itself at this shape (gpq_last_lanes after a call under gpq_set_overlap(ctx, -1): two while the peer's "
@@ -935,7 +943,7 @@ def main(argv=None):
             rd = he_mul_mpi_rate(torch, gpqhe_amd, c14, 64, iters=25, logq=438, checked="reference_default", sample_clocks=True)
             c14.close()
             checks.append(rd.pop("_check"))
-            rd = {k: rd[k] for k in ("shape", "ms_per_batch", "he_mul_per_s", "he_mul_plus_he_rescale_per_s", "lanes", "bridge_ms_per_batch", "core_ms_per_batch")}
+            rd = {k: rd[k] for k in ("shape", "ms_per_batch", "he_mul_per_s", "he_mul_plus_he_rescale_per_s", "he_mul_then_he_rescale_two_calls_per_s", "lanes", "bridge_ms_per_batch", "core_ms_per_batch")}
             rd["lanes"] = {k: v for k, v in rd["lanes"].items() if k != "note"}
             rd["reference_cpu_he_mul_per_s"] = round(1 / 1.12, 3)        # SURVEY.md 6 (survey probe, one core)
             sig = reference_signature_latency(logn=14, logq=438)

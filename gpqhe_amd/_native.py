@@ -96,6 +96,7 @@ SIGNATURES = {
     "gpq_he_dims": (C.c_int, [vp, C.c_uint, C.c_uint] + [C.POINTER(C.c_uint)] * 4),
     "gpq_he_mul_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
     "gpq_he_mul": (C.c_int, [vp] * 9 + [C.c_uint] * 6 + [vp, vp]),
+    "gpq_he_mul_rs": (C.c_int, [vp] * 9 + [C.c_uint] * 7 + [vp, vp]),
     "gpq_relin_tail_workspace_bytes": (C.c_size_t, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
     "gpq_relin_tail": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
     "gpq_relin_tail_overwriting": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),

@@ -1099,7 +1099,8 @@ int tail_stream(gpq_ctx *c, gpq_relin_tables *rt, Two<uint64_t> out, const uint6
   if (chat_bytes >= 0xfffff000ull || dhat_bytes >= 0xfffff000ull) return GPQ_OK;
   TailStreamArgs a{chat, dh ? dh->hat : nullptr, chat_bytes, dhat_bytes, dbig, out, (const v4i *)tt->d_bfrag, tt->d_kc, tt->d_pm,
                    dh ? (const v4i *)td->d_bfrag : nullptr, dh ? td->d_kc : nullptr, dh ? td->d_pm : nullptr,
-                   c->d_redo, tie, amb, c->d_wave_any, dimB, dh ? dh->dimA : 0u, c->logn, W, logql, groups, c->debug_force_redo};
+                   c->d_redo, tie, amb, c->d_wave_any, dimB, dh ? dh->dimA : 0u, c->logn, W, logql, groups, c->debug_force_redo,
+                   c->tail_rs, c->tail_rs ? logql - c->tail_rs : 0u};
   ProfScope prof(c, GPQ_K_TAIL_STREAM, s);
   if (dh && KST == 8) rc = launch_tail_stream_t<8, 4, true, 6>(a, lds, blocks, s);
   else if (dh) rc = launch_tail_stream_t<12, 8, true, 5>(a, lds, blocks, s);
@@ -1150,6 +1151,15 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
     // Behind the streaming kernel the exact kernels only see flagged coefficients, and the chains whose hand-overs stay inside a thread are
     // ONE launch each (bridge_kernels.hpp: bridge_fallback_tail_pre / _post): pre = the addend's exact CRT + the weights off the flagged
     // groups; the front re-run; post = r, its round bit, Q's exact CRT, the finish.  Three launches where there were seven.
+    // gpq_he_mul_rs: the streaming kernel rescaled what it decided; the coefficients it flagged are written unrescaled by the exact kernels
+    // below and finished here (same flags, same scope)
+    auto finish_rs = [&]() {
+      if (!c->tail_rs || !streamed) return;
+      ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s);
+      RescaleMaskedArgs ra{out, c->d_redo, W, c->logn, c->tail_rs, logql - c->tail_rs, scope};
+      hipLaunchKernelGGL(bridge_rescale_masked, masked_grid(scope, 256, c->n, polys), dim3(256), 0, s, ra);
+      c->tail_rs_done = true;
+    };
     const bool fuse_pre = streamed && dh && (dh->bA->WP == 32 || dh->bA->WP == 16);
     const bool fuse_post = streamed && ((bp->WP == 16 && bq->WP == 32) || (bp->WP == 8 && bq->WP == 16));
     LimbScaleArgs un{c->d_tabs, chat_rw, rt->d_unscale, direct_ok ? c->d_redo : nullptr, dimB, c->logn, scope};
@@ -1198,12 +1208,14 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
       const dim3 grid = masked_grid(scope, 128, c->n, polys);
       if (bp->WP == 16) hipLaunchKernelGGL((bridge_fallback_tail_post<16, 32>), grid, dim3(128), 0, s, rr, rf, qq, ar);
       else hipLaunchKernelGGL((bridge_fallback_tail_post<8, 16>), grid, dim3(128), 0, s, rr, rf, qq, ar);
+      finish_rs();
       return launched("relin_tail");
     }
     if ((rc = launch_reconstruct(c, bp, r, tp.Wr, chat, dimB, 0, polys, 0, false, nullptr, s, -1, only_amb))) return rc;
     { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_roundfix, masked_grid(scope, 256, c->n, polys), cblock, 0, s, rf); }
     if ((rc = launch_reconstruct(c, bq, out.a, W, qhat, tp.cnt, 0, polys, logql, true, tie, s, -1, q))) return rc;
     { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_addround, masked_grid(scope, 256, c->n, polys), cblock, 0, s, ar); }
+    finish_rs();
     return launched("relin_tail");
   }
 
@@ -1325,9 +1337,25 @@ extern "C" size_t gpq_he_mul_workspace_bytes(gpq_ctx *c, unsigned W, unsigned di
 // he_mul, src/he-mult.c:88-156 (decl src/gpqhe.h:147), on big slabs of W words, q_l = 2^logql.
 // ct = ct1 * ct2 relinearised with rlk (NTT-domain slabs of at least dimB limbs).  The l / nu / B
 // bookkeeping of :92-95 stays with the caller.
+// rs = 0: he_mul; rs = log2(Delta): he_mul followed by he_rs (src/he-rescale.c:33-54) with q_(l-1) = 2^(logql - rs), the rescale applied by the tail
+// kernel on the way out where that kernel runs (1 <= rs <= 63), by the rescale kernel on the group's outputs otherwise.
+static int he_mul_impl(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *ct1c0, const uint64_t *ct1c1,
+                       const uint64_t *ct2c0, const uint64_t *ct2c1, const uint64_t *rlk0, const uint64_t *rlk1, unsigned W,
+                       unsigned logql, unsigned dimA, unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream, unsigned rs);
 extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *ct1c0, const uint64_t *ct1c1,
                           const uint64_t *ct2c0, const uint64_t *ct2c1, const uint64_t *rlk0, const uint64_t *rlk1, unsigned W,
                           unsigned logql, unsigned dimA, unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream) {
+  return he_mul_impl(c, out_c0, out_c1, ct1c0, ct1c1, ct2c0, ct2c1, rlk0, rlk1, W, logql, dimA, dimB, dimP, batch, workspace, stream, 0);
+}
+extern "C" int gpq_he_mul_rs(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *ct1c0, const uint64_t *ct1c1,
+                             const uint64_t *ct2c0, const uint64_t *ct2c1, const uint64_t *rlk0, const uint64_t *rlk1, unsigned W,
+                             unsigned logql, unsigned dimA, unsigned dimB, unsigned dimP, unsigned logDelta, unsigned batch, void *workspace, void *stream) {
+  if (!logDelta || logDelta >= logql) return gpq_fail(GPQ_ERR_INVALID, "gpq_he_mul_rs: 0 < logDelta < logql");
+  return he_mul_impl(c, out_c0, out_c1, ct1c0, ct1c1, ct2c0, ct2c1, rlk0, rlk1, W, logql, dimA, dimB, dimP, batch, workspace, stream, logDelta);
+}
+static int he_mul_impl(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *ct1c0, const uint64_t *ct1c1,
+                       const uint64_t *ct2c0, const uint64_t *ct2c1, const uint64_t *rlk0, const uint64_t *rlk1, unsigned W,
+                       unsigned logql, unsigned dimA, unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream, unsigned rs) {
   int rc = check(c, dimA, batch, "gpq_he_mul");
   if (rc || (rc = check(c, dimB, batch, "gpq_he_mul"))) return rc;
   if (!out_c0 || !out_c1 || !ct1c0 || !ct1c1 || !ct2c0 || !ct2c1 || !rlk0 || !rlk1 || !workspace || !logql || W < (logql + 63) / 64)
@@ -1352,8 +1380,8 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
     const unsigned polys = batch - k0 < m ? batch - k0 : m;
     if (lane.c && ((k0 / m) & 1)) {                              // every other launch group: the same call on the peer, for this group's slice
       const size_t o = k0 * bigpoly;
-      if ((rc = gpq_he_mul(lane.c, out_c0 + o, out_c1 + o, ct1c0 + o, ct1c1 + o, ct2c0 + o, ct2c1 + o, rlk0, rlk1, W, logql, dimA, dimB, dimP,
-                           polys, lane.ws, lane.s))) return rc;
+      if ((rc = he_mul_impl(lane.c, out_c0 + o, out_c1 + o, ct1c0 + o, ct1c1 + o, ct2c0 + o, ct2c1 + o, rlk0, rlk1, W, logql, dimA, dimB, dimP,
+                            polys, lane.ws, lane.s, rs))) return rc;
       continue;
     }
     const size_t pa = (size_t)polys * dimA * n, pb = (size_t)polys * dimB * n;
@@ -1407,9 +1435,15 @@ extern "C" int gpq_he_mul(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const 
     StageRange stage("gpq_he_mul: he_relin tail (CRT, exact division by P, + d)");
     // c0 and c1 as one batch of 2 x polys polynomials: c0hat | c1hat and d0 | d1 are adjacent, the outputs are the caller's two slabs
     const TailD dh{d0h, bA, dimA, d0};
-    if ((rc = relin_tail(c, Two<uint64_t>{out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, polys}, c0hat,
-                         limbs_addend ? Two<const uint64_t>{nullptr, nullptr, polys} : Two<const uint64_t>{d0, d1, polys},
-                         W, dimP, dimB, logql, 2 * polys, wsTail, s, tail_mode, limbs_addend ? &dh : nullptr))) return rc;   // :67-77
+    c->tail_rs = rs >= 1 && rs <= 63 ? rs : 0;                  // the tail kernel shifts inside one word; other Deltas take the rescale kernel below
+    c->tail_rs_done = false;
+    rc = relin_tail(c, Two<uint64_t>{out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, polys}, c0hat,
+                    limbs_addend ? Two<const uint64_t>{nullptr, nullptr, polys} : Two<const uint64_t>{d0, d1, polys},
+                    W, dimP, dimB, logql, 2 * polys, wsTail, s, tail_mode, limbs_addend ? &dh : nullptr);                     // :67-77
+    const bool rescaled = c->tail_rs_done;
+    c->tail_rs = 0; c->tail_rs_done = false;
+    if (rc) return rc;
+    if (rs && !rescaled && (rc = gpq_he_rs(c, out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, W, rs, logql - rs, polys, stream))) return rc;   // src/he-rescale.c:33-54
   }
   const unsigned lanes_used = lane.c ? 2u : 1u;
   if ((rc = gpq_peer_join(c, s, lane))) return rc;

@@ -844,27 +844,24 @@ __global__ __launch_bounds__(256) void bridge_addsub(AddSubArgs p) {
 // ---------------------------------------------------------------------------
 struct RescaleArgs { uint64_t *big; unsigned W, logn, s, logql; };
 
-__global__ __launch_bounds__(256) void bridge_rescale(RescaleArgs a) {
-  const unsigned n = 1u << a.logn;
-  const unsigned i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  uint64_t *__restrict__ c = a.big + ((size_t)blockIdx.y * a.W << a.logn) + i;
-  const unsigned ws = a.s >> 6, bs = a.s & 63;
+// one coefficient in place: c = word 0 of the coefficient inside its big slab [W][n]
+__device__ __forceinline__ void rescale_coefficient(uint64_t *__restrict__ c, unsigned W, unsigned logn, unsigned s, unsigned logql) {
+  const unsigned ws = s >> 6, bs = s & 63;
   auto word = [&](unsigned j) -> uint64_t {               // sign-extended read
-    return j < a.W ? c[(size_t)j << a.logn] : (uint64_t)((int64_t)c[(size_t)(a.W - 1) << a.logn] >> 63);
+    return j < W ? c[(size_t)j << logn] : (uint64_t)((int64_t)c[(size_t)(W - 1) << logn] >> 63);
   };
   // remainder r = c mod 2^s  >  2^(s-1)  <=>  bit s-1 set and some lower bit set
   uint64_t carry = 0;
-  if (a.s) {
-    const unsigned hb = a.s - 1, hw = hb >> 6, hbit = hb & 63;
+  if (s) {
+    const unsigned hb = s - 1, hw = hb >> 6, hbit = hb & 63;
     const uint64_t wh = word(hw);
     uint64_t lower = wh & ((1ull << hbit) - 1);
     for (unsigned j = 0; j < hw; ++j) lower |= word(j);
     carry = ((wh >> hbit) & 1) && lower;
   }
-  const unsigned sb = a.logql - 1;
+  const unsigned sb = logql - 1;
   uint64_t qsign = 0;
-  for (unsigned j = 0; j < a.W; ++j) {
+  for (unsigned j = 0; j < W; ++j) {
     const uint64_t lo = word(j + ws), hi = word(j + ws + 1);
     uint64_t v = bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
     const uint64_t v1 = v + carry;
@@ -872,13 +869,30 @@ __global__ __launch_bounds__(256) void bridge_rescale(RescaleArgs a) {
     v = v1;
     const unsigned base = 64 * j;
     if (base + 64 > sb && base <= sb) qsign = 0 - ((v >> (sb - base)) & 1);
-    if (base >= a.logql) v = qsign;
-    else if (base + 64 > a.logql) {
-      const uint64_t mask = (1ull << (a.logql - base)) - 1;
+    if (base >= logql) v = qsign;
+    else if (base + 64 > logql) {
+      const uint64_t mask = (1ull << (logql - base)) - 1;
       v = (v & mask) | (qsign & ~mask);
     }
-    c[(size_t)j << a.logn] = v;
+    c[(size_t)j << logn] = v;
   }
+}
+
+__global__ __launch_bounds__(256) void bridge_rescale(RescaleArgs a) {
+  const unsigned n = 1u << a.logn;
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  rescale_coefficient(a.big + ((size_t)blockIdx.y * a.W << a.logn) + i, a.W, a.logn, a.s, a.logql);
+}
+
+// The same for the coefficients a streaming tail flagged (gpq_he_mul_rs: the tail kernel rescales what it decides itself in registers; the exact
+// kernels behind it write the flagged coefficients unrescaled, and this finishes them).
+struct RescaleMaskedArgs { Two<uint64_t> out; const unsigned char *only; unsigned W, logn, s, logql; FlagScope scope; };
+__global__ __launch_bounds__(256) void bridge_rescale_masked(RescaleMaskedArgs a) {
+  scoped_or_grid(a.scope, a.logn, 256, [&](unsigned poly, unsigned i) {
+    if (!a.only[((size_t)poly << a.logn) + i]) return;
+    rescale_coefficient(a.out.at(poly, (size_t)a.W << a.logn) + i, a.W, a.logn, a.s, a.logql);
+  });
 }
 
 }  // namespace gpq

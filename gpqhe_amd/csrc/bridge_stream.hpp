@@ -427,7 +427,24 @@ struct TailStreamArgs {
   unsigned *wave_any;
   unsigned dimB, dimA, logn, W, logq, total_groups;
   unsigned force;            // tests: also flag every coefficient whose index is a multiple of it
+  unsigned rs_s, rs_logq;    // gpq_he_mul_rs: he_rs (src/he-rescale.c:45-48) on the way out -- rounding division by 2^rs_s (1 .. 63), centred mod 2^rs_logq; 0 = off
 };
+
+// V = floor(V / 2^s) + [V mod 2^s > 2^(s-1)] on a sign-extended value of NV words, 1 <= s <= 63 (mpi_rdiv, src/types.c:115-128: floor for
+// negatives, ties down) -- bridge_kernels.hpp's rescale_coefficient on registers
+template <int NV>
+__device__ __forceinline__ void rescale_words(uint64_t (&V)[NV], unsigned s) {
+  uint64_t carry = ((V[0] >> (s - 1)) & 1) & (uint64_t)((V[0] & ((1ull << (s - 1)) - 1)) != 0);
+  const uint64_t sign = (uint64_t)((int64_t)V[NV - 1] >> 63);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const uint64_t hi = j + 1 < NV ? V[j + 1] : sign;
+    const uint64_t v = (V[j] >> s) | (hi << (64 - s));
+    const uint64_t v1 = v + carry;
+    carry = v1 < v;
+    V[j] = v1;
+  }
+}
 
 constexpr int TAIL_DF_WORD = 18;     // the addend's fixed-point columns are words 18, 19 of the folded columns (the tail's own: 16, 17)
 
@@ -551,6 +568,10 @@ __global__ __launch_bounds__(512) void bridge_tail_stream(TailStreamArgs a) {
       }
     }
     sign_extend<14>(Q, a.logq);
+    if (a.rs_s) {                                                                     // (uniform) he_rs on the way out
+      rescale_words<14>(Q, a.rs_s);
+      sign_extend<14>(Q, a.rs_logq);
+    }
     const size_t flag_at = ((size_t)poly << a.logn) + coef0;
     if (a.force) ambiguous = ambiguous || (coef0 + 2 * r + h) % a.force == 0;
     __builtin_amdgcn_raw_buffer_store_b8((unsigned char)ambiguous, window_rsrc(a.redo + flag_at), 2 * r + h, 0, 0);

@@ -111,6 +111,10 @@ struct gpq_ctx {
   // gpq_he_mul / gpq_he_swk over more than one launch group: every other group runs on a second stream through a PEER context (its own tables,
   // scratch and flag words: nothing mutable is shared), so that the HBM-bound bridge kernels of one group run beside the issue-bound transforms
   // of the other and launch tails fill (gpq_set_overlap; bridge.hip: peer_lane).  The caller's stream orders the whole call as before.
+  // gpq_he_mul_rs: log2(Delta) of the he_rs the tail of the CURRENT call applies on the way out (0 = none), and whether the tail of the current
+  // launch group did (streaming kernel + masked finish); otherwise the caller runs the plain rescale kernel on the group's outputs
+  unsigned tail_rs = 0;
+  bool tail_rs_done = false;
   int overlap = -1;                   // gpq_set_overlap: -1 (default) = two lanes when the peer's workspace is affordable (kPeerAutoWorkspaceBytes), 0 = never, 1 = always
   bool peer_failed = false;           // the peer (or its workspace) could not be created once: one lane from then on
   unsigned last_lanes = 1;            // lanes the last multi-group entry point ran on (gpq_last_lanes)

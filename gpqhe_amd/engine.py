@@ -216,6 +216,16 @@ class PolyContext:
                                           self._ptr(rlk0), self._ptr(rlk1), W, logql, dimA, dimB, dimP, batch, self._ptr(ws), self._stream()), "gpq_he_mul")
         return ws
 
+    def he_mul_rs(self, out_c0, out_c1, ct1c0, ct1c1, ct2c0, ct2c1, rlk0, rlk1, W, logql, dimA, dimB, dimP, logDelta):
+        """he_mul then he_rs (src/he-mult.c:88-156, src/he-rescale.c:33-54) in one call: the rescale rides in the relinearisation tail."""
+        torch = _torch()
+        batch = ct1c0.numel() // (W * self.n)
+        nbytes = self.lib.gpq_he_mul_workspace_bytes(self.h, W, dimA, dimB, dimP, batch)
+        ws = torch.empty(nbytes // 8 + 8, dtype=torch.int64, device=self._dev)
+        _native.check(self.lib.gpq_he_mul_rs(self.h, self._ptr(out_c0), self._ptr(out_c1), self._ptr(ct1c0), self._ptr(ct1c1), self._ptr(ct2c0), self._ptr(ct2c1),
+                                             self._ptr(rlk0), self._ptr(rlk1), W, logql, dimA, dimB, dimP, logDelta, batch, self._ptr(ws), self._stream()), "gpq_he_mul_rs")
+        return ws
+
     def relin_tail(self, out, chat, d, W, logql, dimB, dimP):
         """src/he-mult.c:67-77 alone (d = None: nothing added)."""
         torch = _torch()

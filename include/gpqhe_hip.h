@@ -288,6 +288,13 @@ size_t gpq_he_mul_workspace_bytes(gpq_ctx *ctx, unsigned W, unsigned dimA, unsig
 int gpq_he_mul(gpq_ctx *ctx, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *ct1c0, const uint64_t *ct1c1,
                const uint64_t *ct2c0, const uint64_t *ct2c1, const uint64_t *rlk0, const uint64_t *rlk1, unsigned W,
                unsigned logql, unsigned dimA, unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream);
+/* he_mul followed by he_rs (src/he-mult.c:88-156, then src/he-rescale.c:33-54 with Delta = 2^logDelta and q_(l-1) = 2^(logql - logDelta)): the same words
+ * as gpq_he_mul + gpq_he_rs(out_c0, out_c1, W, logDelta, logql - logDelta), with the rounding division applied by the relinearisation tail on the way
+ * out (1 <= logDelta <= 63 and the streaming tail; every other case runs the two calls), so that the outputs are not read and written once more:
+ * BASELINE configs[2] is "he_mul + he_rescale".  Workspace as gpq_he_mul. */
+int gpq_he_mul_rs(gpq_ctx *ctx, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *ct1c0, const uint64_t *ct1c1,
+                  const uint64_t *ct2c0, const uint64_t *ct2c1, const uint64_t *rlk0, const uint64_t *rlk1, unsigned W,
+                  unsigned logql, unsigned dimA, unsigned dimB, unsigned dimP, unsigned logDelta, unsigned batch, void *workspace, void *stream);
 
 /* The tail of he_relin / he_swk on its own, src/he-mult.c:67-77: chat = key-switch output slab of dimB
  * limbs, d = big slab added afterwards (NULL: none, as for c1 in he_swk):
