@@ -53,6 +53,9 @@ def run(g, cts, rlk, W, logql, dims, pt=None):
     step("he_mulpt", lambda: g.he_mulpt(o[7], o[8], cts[0], cts[1], pt, W, logql, dimA))
     ld = min(50, logql - 8)
     step("he_rs", lambda: g.he_rs(o[9], o[10], W, ld, logql - ld))
+    # he_mul + he_rs as one call (round 5): fused into the streaming tail on the side under test, two calls inside on the reference side
+    o += [torch.empty_like(cts[0]) for _ in range(2)]
+    step("he_mul_rs", lambda: g.he_mul_rs(o[11], o[12], *cts, rlk[0], rlk[1], W, logql, dimA, dimB, dimP, ld))
     torch.cuda.synchronize()
     return o
 
@@ -117,4 +120,4 @@ for it in range(N):
         sys.exit(1)
     if it % 10 == 0:
         print("config %d ok: logn %d q_L 2^%d q_l 2^%d dims P/A/B %d/%d/%d W %d batch %d chunk %d force %d lanes %d%s (%.0f s)" % (it, logn, logqL, logql, dimP, dimA, dimB, W, batch, chunk, force, lanes + 1, (" fresh" if fresh else "") + (" " + other if other else ""), time.time() - t0), flush=True)
-print("soak_bridge ok: %d configurations, every word of he_mul / squaring / he_swk / poly_mul / he_mulpt / he_rs equal between the streaming bridge and the separate kernels (%.0f s)" % (N, time.time() - t0))
+print("soak_bridge ok: %d configurations, every word of he_mul / squaring / he_swk / poly_mul / he_mulpt / he_rs / he_mul_rs equal between the streaming bridge and the separate kernels (%.0f s)" % (N, time.time() - t0))
