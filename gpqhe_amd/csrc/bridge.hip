@@ -1592,6 +1592,13 @@ extern "C" int gpq_set_overlap(gpq_ctx *c, int on) {
   c->overlap = on < 0 ? -1 : (on != 0);
   return GPQ_OK;
 }
+// tests: make the next creation of the peer lane fail the way an allocation would (the call must run on one lane and say so once)
+extern "C" int gpq_debug_fail_peer(gpq_ctx *c, int on) {
+  if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_debug_fail_peer: null context");
+  c->debug_peer_fail = on != 0;
+  if (!on) c->peer_failed = false;
+  return GPQ_OK;
+}
 // lanes the last gpq_he_mul / gpq_he_swk / gpq_he_mul_tensor / gpq_keyswitch call on this context ran on (1 or 2)
 extern "C" unsigned gpq_last_lanes(const gpq_ctx *c) { return c ? c->last_lanes : 0; }
 

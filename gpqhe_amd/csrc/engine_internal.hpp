@@ -117,6 +117,7 @@ struct gpq_ctx {
   bool tail_rs_done = false;
   int overlap = -1;                   // gpq_set_overlap: -1 (default) = two lanes when the peer's workspace is affordable (kPeerAutoWorkspaceBytes), 0 = never, 1 = always
   bool peer_failed = false;           // the peer (or its workspace) could not be created once: one lane from then on
+  bool debug_peer_fail = false;       // tests (gpq_debug_fail_peer): the next attempt to create the peer fails as an allocation would
   unsigned last_lanes = 1;            // lanes the last multi-group entry point ran on (gpq_last_lanes)
   std::set<unsigned long long> peer_warm;   // call shapes the peer has run outside a stream capture (gpq_lane_key)
   gpq_ctx *peer = nullptr;
@@ -231,6 +232,7 @@ int gpq_peer_lane(gpq_ctx *c, hipStream_t s, unsigned long long key, Bytes bytes
     return (int)GPQ_OK;
   };
   if (!c->peer) {
+    if (c->debug_peer_fail) return give_up("gpq_debug_fail_peer");
     if (!c->peer_stream && hipStreamCreateWithFlags(&c->peer_stream, hipStreamNonBlocking) != hipSuccess) return give_up("hipStreamCreateWithFlags");
     if (!c->ev_fork && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return give_up("hipEventCreateWithFlags");
     if (!c->ev_join && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return give_up("hipEventCreateWithFlags");

@@ -142,6 +142,10 @@ class PolyContext:
         v = -1 if (on is not True and on is not False and int(on) < 0) else (1 if on else 0)
         _native.check(self.lib.gpq_set_overlap(self.h, v), "gpq_set_overlap")
 
+    def debug_fail_peer(self, on=True):
+        """tests: the next creation of the peer lane fails like an allocation would"""
+        _native.check(self.lib.gpq_debug_fail_peer(self.h, 1 if on else 0), "gpq_debug_fail_peer")
+
     def last_lanes(self):
         """lanes (1 or 2) the last multi-group call on this context ran on"""
         return int(self.lib.gpq_last_lanes(self.h))

@@ -226,6 +226,9 @@ int gpq_set_stream_bridge(gpq_ctx *ctx, int on);
  * gpq_last_lanes: the lanes (1 or 2) the last such call on this context ran on. */
 int gpq_set_overlap(gpq_ctx *ctx, int on);
 unsigned gpq_last_lanes(const gpq_ctx *ctx);
+/* Tests: 1 = the next attempt to create the peer lane fails as an allocation would (the call runs on one lane, one line on stderr, and the context
+ * stops trying); 0 = back to normal (and the context may try again). */
+int gpq_debug_fail_peer(gpq_ctx *ctx, int on);
 /* gpq_he_mul: 1 (default) = its internal rns_decompose launches leave residues in (0, 3p), which the forward transforms behind them accept;
  * 0 = canonical residues.  Same results. */
 int gpq_set_lazy_decompose(gpq_ctx *ctx, int on);

@@ -189,3 +189,39 @@ def test_rns_core_on_two_lanes(engine_ctx, logn, dim, batch, chunk):
     for i, (w, x, y) in enumerate(zip(want, got, again)):
         assert torch.equal(w, x) and torch.equal(w, y), "result %d" % i
     assert bool((want[1] != 0).any()) and bool((want[7] != 0).any())
+
+
+def test_a_peer_that_cannot_be_created_means_one_lane_not_an_error():
+    """when the peer context (or its workspace) cannot be allocated the call must run on the caller's stream alone -- same words,
+    no error, and the context stops trying (gpq_debug_fail_peer stands in for the failing allocation); cleared, the lanes come back.
+    A context of its own: the session-cached ones may own a peer already."""
+    import torch
+    import gpqhe_amd
+    logn, logq, batch = 13, 300, 5
+    probe = gpqhe_amd.PolyContext(logn, 20)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logq, logq)
+    probe.close()
+    g = gpqhe_amd.PolyContext(logn, dimevk)
+    try:
+        n, W = g.n, (logq + 64) // 64
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(31)
+        cts = [_centred(torch, gen, batch, W, n, logq) for _ in range(4)]
+        rlk = [torch.cat([torch.randint(0, g.p[d], (n,), dtype=torch.int64, device="cuda", generator=gen) for d in range(dimB)]) for _ in range(2)]
+        dims = (dimA, dimB, dimP)
+        g.set_chunk(2)
+        g.set_overlap(False)
+        want = _run(g, torch, cts, rlk, W, logq, dims)
+        g.set_overlap(True)
+        g.debug_fail_peer(True)
+        got = _run(g, torch, cts, rlk, W, logq, dims)
+        assert g.last_lanes() == 1
+        again = _run(g, torch, cts, rlk, W, logq, dims)            # the context does not retry call after call
+        assert g.last_lanes() == 1
+        g.debug_fail_peer(False)
+        back = _run(g, torch, cts, rlk, W, logq, dims)
+        assert g.last_lanes() == 2
+        for a, b, c, d in zip(want, got, again, back):
+            assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+    finally:
+        g.close()
