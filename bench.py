@@ -529,17 +529,24 @@ def keyswitch_n17_rate(torch, gpqhe_amd, batch=64, iters=3):
     e0, e1 = rand_slab(torch, ctx, dim, 1, gen), rand_slab(torch, ctx, dim, 1, gen)
     c0, c1 = torch.empty_like(x), torch.empty_like(x)
     ws = ctx.keyswitch_workspace(dim, batch)
-    ctx.he_keyswitch(c0, c1, x, e0, e1, dim, ws)
-    t = gpqhe_amd.StreamTimer()
-    t.start()
-    for _ in range(iters):
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.15:      # steady clock (see ntt_rate): this leg used to time three calls straight after context construction
         ctx.he_keyswitch(c0, c1, x, e0, e1, dim, ws)
-    t.stop()
-    ms = t.elapsed_ms() / iters
+        torch.cuda.synchronize()
+    t = gpqhe_amd.StreamTimer()
+    reps = []
+    for _ in range(3):
+        t.start()
+        for _ in range(iters):
+            ctx.he_keyswitch(c0, c1, x, e0, e1, dim, ws)
+        t.stop()
+        reps.append(t.elapsed_ms() / iters)
+    ms = sorted(reps)[1]
     algo = 5 * dim * (8 << logn) * batch
     ctx.close()
     return {"shape": "n=2^17, 44 limbs, batch %d" % batch, "ms_per_batch": round(ms, 3), "keyswitch_per_s": round(batch / (ms * 1e-3), 1),
-            "algo_GBps": round(algo / (ms * 1e-3) / 1e9, 1)}
+            "algo_GBps": round(algo / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "ms_per_batch_repetitions": [round(v, 3) for v in reps]}
 
 
 def reference_signature_latency(timeout_s=150, logn=16, logq=850):
@@ -926,6 +933,7 @@ def main(argv=None):
             torch.cuda.empty_cache()
             out["ntt"].append(ntt_rate(torch, gpqhe_amd, 16, DIM_A, 4 * B))   # launch size matters: 4 GiB slab
             out["ntt"].append(ntt_rate(torch, gpqhe_amd, 15, 10, 2048))       # configs[1]'s ring at a launch that fills the chip (5 GiB)
+            out["ntt"].append(ntt_rate(torch, gpqhe_amd, 17, 44, 64, iters=6))      # configs[4]'s ring and limb count (27 wide-split + 17 split limbs)
             checks = []
             out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, B, iters=5, checked="he_mul_mpi_level", sample_clocks=True)   # BASELINE configs[2]: he_mul + he_rescale, batch 64
             checks.append(out["he_mul_mpi_level"].pop("_check"))
