@@ -149,3 +149,20 @@ def test_zero_flags_are_set_exactly_where_the_output_holds_a_residue_zero(oracle
         assert np.array_equal(to_host(dev), want)
     finally:
         g.close()
+
+
+def test_the_recorded_configuration_as_the_first_gpu_work_of_a_fresh_process():
+    """The record was the FIRST configuration of its process: the same check once more in a child process that has done nothing on the GPU before
+    (device out of idle, freshly mapped memory, first context).  One run per suite run -- not a loop."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from oracle.oracle import OracleCtx\n"
+            "import tests.test_ntt_soak_record_gpu as m\n"
+            "cache = {}\n"
+            "m.test_the_recorded_configuration_words_and_flags(lambda logn, dim: cache.setdefault((logn, dim), OracleCtx(logn, dim)))\n"
+            "print('fresh process: words and flags ok')\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "fresh process: words and flags ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
