@@ -27,3 +27,9 @@ def test_bridge_soak_short():
 def test_rns_soak_short():
     out = _run([os.path.join(ROOT, "tools", "soak.py"), "25", "3"], 600)
     assert "no mismatch" in out
+
+
+def test_bridge_oracle_soak_short():
+    """the bridge's callers against the restated reference (oracle/bigint_ref) on random small rings, moduli, levels, groups, lanes, forced exact paths"""
+    out = _run([os.path.join(ROOT, "tools", "soak_bridge_oracle.py"), "40", "7"], 600)
+    assert "soak_bridge_oracle ok: 40 configurations" in out
