@@ -6,7 +6,7 @@ oracle's limb loops -- at rings small enough for Python integers (n = 64 ... 512
 moduli and levels (every limb count / word count the kernels are instantiated for), batches over several launch groups, one or two lanes, forced
 exact paths, he_mul, gpq_he_mul_rs with a random Delta, he_swk, he_rs.
 
-    python tools/soak_bridge_oracle.py [configurations] [seed]
+    python tools/soak_bridge_oracle.py [configurations] [seed] [share of two-pass rings, e.g. 0.5]
 """
 import os
 import random
@@ -25,6 +25,7 @@ from oracle.oracle import OracleCtx  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+BIG_EVERY = 1.0 - float(sys.argv[3]) if len(sys.argv) > 3 else 1.0       # third argument: share of configurations on a two-pass ring (n = 2^13, 2^14), default none
 torch.cuda.set_device(0)
 ctxs, oracles = {}, {}
 
@@ -48,10 +49,13 @@ def centred(logq, n):
 
 t0 = time.time()
 for it in range(N):
-    logn = rng.choice((6, 6, 7, 8, 9))
+    logn = rng.choice((6, 6, 7, 8, 9)) if rng.random() < BIG_EVERY else rng.choice((13, 13, 14))   # now and then a two-pass ring (seconds of Python integers per ciphertext)
     logqL = rng.randrange(70, 1001)
     logql = logqL if rng.random() < 0.5 else rng.randrange(61, logqL + 1)
     batch, chunk, force, lanes = rng.randrange(1, 6), rng.choice((1, 2, 32)), rng.choice((0, 0, 1, 5, 64)), rng.choice((0, 1))
+    if logn >= 13:
+        batch, logqL = min(batch, 2), min(logqL, 900 if logn == 13 else 600)
+        logql = min(logql, logqL)
     probe, _ = pair(logn, 20)
     dimP, dimA, dimB, dimevk = probe.he_dims(logqL, logql)
     g, o = pair(logn, max(dimevk, 20))
