@@ -114,6 +114,60 @@ def test_the_recorded_configuration_words_and_flags(oracle_ctx):
         # the device's own literal src/ntt.c:37-52 on the same input agrees as well (a third opinion beside the two-pass kernels and the oracle)
         r = dev[0].clone(); g.poly_ntt_reference(r, dim)
         assert np.array_equal(to_host(r), want_ntt)
+        # round 6: the observation the record could not make -- every INPUT, as it sits on the device after all eight calls, is word for word its
+        # host source (nothing was damaged on the way in, nothing wrote into an input); tools/soak.py prints the same at any mismatch
+        for j, (t, h) in enumerate(zip(dev, ins)):
+            assert np.array_equal(to_host(t), h), ("input %d changed on the device" % j, np.flatnonzero(to_host(t) != h)[:8])
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("logn,dim,batch", [(16, 1, 3), (13, 3, 5), (15, 2, 3), (17, 2, 3)])
+def test_no_call_of_the_soak_sequence_writes_outside_its_operands(oracle_ctx, logn, dim, batch):
+    """the polynomial that differed is the LAST 512 KiB of `f` and borders the clone gpq_invntt transforms in place -- can any of the
+    later calls address below its base pointer or beyond its end?  Every operand of the soak's call sequence carved out of ONE allocation with a
+    canary band on each side (the record's geometry first: odd polynomial count, one limb, nt 1): after the eight calls every band still holds its
+    canary, every input still holds its host source, and the outputs are the oracle's."""
+    o = oracle_ctx(logn, dim)
+    n = o.n
+    per = dim * n
+    words = batch * per
+    BAND = 4096                                                   # 32 KiB: keeps every operand 128-byte aligned
+    CANARY = -0x0123456789abcdf                                   # int64 view of a word no residue can be
+    names = ["in0", "in1", "in2", "in3", "in4", "f", "i", "d0", "d1", "d2", "c0", "c1", "pa", "pb", "pr"]
+    torch.cuda.set_device(0)
+    arena = torch.full((len(names) * (words + BAND) + BAND,), CANARY, dtype=torch.int64, device="cuda")
+    view = {nm: arena[BAND + j * (words + BAND): BAND + j * (words + BAND) + words] for j, nm in enumerate(names)}
+    ins = [np.concatenate([o.gen(900 + 10 * s + k, dim) for k in range(batch)]) for s in range(5)]
+    ev = [o.gen(77, dim), o.gen(78, dim)]
+    g = gpqhe_amd.PolyContext(logn, dim)
+    try:
+        g.set_chunk(3); g.set_nt_policy(1)
+        for j in range(5):
+            view["in%d" % j].copy_(to_device(ins[j]))
+        evd = [to_device(ev[0]), to_device(ev[1])]
+        view["f"].copy_(view["in0"]); g.poly_ntt(view["f"], dim)
+        view["i"].copy_(view["in1"]); g.poly_invntt(view["i"], dim)
+        g.he_mul_tensor(view["d0"], view["d1"], view["d2"], view["in0"], view["in1"], view["in2"], view["in3"], dim)
+        g.he_keyswitch(view["c0"], view["c1"], view["in4"], evd[0], evd[1], dim)
+        view["pa"].copy_(view["in0"]); view["pb"].copy_(view["in2"])
+        g.poly_mul_rns(view["pr"], view["pa"], view["pb"], dim)
+        torch.cuda.synchronize()
+        host = to_host(arena).view(np.int64)
+        for j in range(len(names) + 1):
+            band = host[j * (words + BAND): j * (words + BAND) + BAND]
+            assert (band == CANARY).all(), ("canary band %d (before %s) was written" % (j, names[j] if j < len(names) else "the end"),
+                                            np.flatnonzero(band != CANARY)[:8])
+        for j in range(5):
+            assert np.array_equal(to_host(view["in%d" % j]), ins[j]), "input %d changed" % j
+        assert np.array_equal(to_host(view["f"]), o.ntt_slab(ins[0], dim))
+        assert np.array_equal(to_host(view["i"]), o.ntt_slab(ins[1], dim, inverse=True))
+        for k in range(batch):
+            sl = slice(k * per, (k + 1) * per)
+            exp = list(o.he_mul_tensor(*[v[sl].copy() for v in ins[:4]], dim)) + list(o.keyswitch(ins[4][sl].copy(), ev[0], ev[1], dim))
+            exp.append(o.poly_mul_rns(ins[0][sl].copy(), ins[2][sl].copy(), dim))
+            for nm, b in zip(("d0", "d1", "d2", "c0", "c1", "pr"), exp):
+                assert np.array_equal(to_host(view[nm])[sl], b), (nm, k)
     finally:
         g.close()
 

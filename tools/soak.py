@@ -20,24 +20,87 @@ from gpqhe_amd import to_device, to_host  # noqa: E402
 from oracle.oracle import OracleCtx  # noqa: E402
 
 
-def diagnose(name, k, got, exp, sl, tensor, rerun, p):
-    """Everything a later reader needs from a mismatch (round 4's record held one line): which words, what they hold, whether a second download
-    of the same tensor still differs (transfer or device memory) and whether the same call on the same inputs differs again (deterministic or
-    transient)."""
+def diagnose(name, k, got, exp, sl, tensor, rerun, p, inputs=(), third=None, oracle_again=None, out=print):
+    """Everything a later reader needs from a mismatch (round 4's record held one line).  Observations, in the order that splits the candidate
+    causes of the one open record (HISTORY.md R5.1 / R6.1):
+
+      which words, what they hold; a SECOND download of the same tensor (transfer back vs device memory); the INPUT tensors of the call downloaded
+      and compared word for word with their host sources (upload / first-touch damage, or something wrote into an input, vs a kernel fault); the
+      device's literal src/ntt.c (`third`, ntt / invntt only) on the device-resident input as a third opinion beside the fast path and the oracle;
+      the oracle run once more on the same host input (is the checker itself deterministic); the same call again on the same inputs (deterministic
+      vs transient).
+
+    `inputs` = [(label, device tensor, host array)], `third` = callable -> device tensor, `oracle_again` = callable -> host array (this slice's
+    expectation recomputed).  Returns the set of verdict words the report ends with (tests/test_soak_diagnose.py feeds it every case)."""
     a, b = got[sl], exp
     bad = np.flatnonzero(a != b)
-    print("  differing words: %d of %d; first %s" % (bad.size, a.size, bad[:8].tolist()), flush=True)
+    out("  differing words: %d of %d; first %s" % (bad.size, a.size, bad[:8].tolist()))
     for j in bad[:8]:
-        print("    [%d] got %d expected %d%s" % (j, int(a[j]), int(b[j]), "  (got 0)" if a[j] == 0 else "  (got a prime)" if int(a[j]) in p else ""), flush=True)
+        out("    [%d] got %d expected %d%s" % (j, int(a[j]), int(b[j]), "  (got 0)" if a[j] == 0 else "  (got a prime)" if int(a[j]) in p else ""))
     if bad.size:
         runs = np.split(bad, np.flatnonzero(np.diff(bad) != 1) + 1)
-        print("  contiguous runs: %d, longest %d, span [%d, %d]" % (len(runs), max(len(r) for r in runs), int(bad[0]), int(bad[-1])), flush=True)
+        out("  contiguous runs: %d, longest %d, span [%d, %d]" % (len(runs), max(len(r) for r in runs), int(bad[0]), int(bad[-1])))
+    verdict = set()
     again = to_host(tensor)[sl]
-    print("  second download of the same tensor: %s" % ("equal to the first" if np.array_equal(again, a) else
-                                                         "DIFFERENT (%d words; now %s the expectation)" % (int((again != a).sum()), "equal to" if np.array_equal(again, b) else "still unlike")), flush=True)
+    if np.array_equal(again, a):
+        out("  second download of the same tensor: equal to the first")
+    else:
+        out("  second download of the same tensor: DIFFERENT (%d words; now %s the expectation)" % (int((again != a).sum()), "equal to" if np.array_equal(again, b) else "still unlike"))
+        verdict.add("download-transient" if np.array_equal(again, b) else "device-memory-changing")
+    # (i) the inputs as they sit on the device NOW against the host arrays they were uploaded from
+    for label, dev_t, host in inputs:
+        on_dev = to_host(dev_t)
+        host = np.ascontiguousarray(host, dtype=np.uint64)
+        if on_dev.shape == host.shape and np.array_equal(on_dev, host):
+            out("  input %s on the device: equal to its host source (%d words)" % (label, host.size))
+        else:
+            diff = np.flatnonzero(on_dev != host) if on_dev.shape == host.shape else np.arange(0)
+            inside = diff[(diff >= sl.start) & (diff < sl.stop)] if diff.size else diff
+            out("  input %s on the device: DIFFERS from its host source (%d words, first %s; %d of them inside this ciphertext's slice)"
+                % (label, diff.size, diff[:8].tolist(), inside.size))
+            verdict.add("input-damaged")
+    # (ii) the device's own literal src/ntt.c on the device-resident input
+    if third is not None:
+        t3 = to_host(third())[sl]
+        if np.array_equal(t3, b):
+            out("  device src/ntt.c as written (gpq_ntt_reference) on the device-resident input: equal to the oracle -> the fast path's output is the odd one")
+            verdict.add("third-opinion-with-oracle")
+        elif np.array_equal(t3, a):
+            out("  device src/ntt.c as written (gpq_ntt_reference) on the device-resident input: equal to the FAST PATH -> the device agrees with itself, "
+                "input or oracle is the odd one")
+            verdict.add("third-opinion-with-fast-path")
+        else:
+            out("  device src/ntt.c as written (gpq_ntt_reference): unlike both (%d words off the oracle, %d off the fast path)" % (int((t3 != b).sum()), int((t3 != a).sum())))
+            verdict.add("third-opinion-alone")
+    # (iii) the checker once more
+    if oracle_again is not None:
+        b2 = oracle_again()
+        if np.array_equal(b2, b):
+            out("  oracle run again on the same host input: equal to its first answer")
+        else:
+            out("  oracle run again on the same host input: DIFFERENT from its first answer (%d words; now %s the device)" % (int((b2 != b).sum()), "equal to" if np.array_equal(b2, a) else "still unlike"))
+            verdict.add("oracle-transient")
     fresh = to_host(rerun())[sl]
-    print("  same call again on the same inputs: %s" % ("bit-exact this time (transient)" if np.array_equal(fresh, b) else
-                                                         "differs again (%d words, %s)" % (int((fresh != b).sum()), "the same words" if np.array_equal(fresh, a) else "other words")), flush=True)
+    if np.array_equal(fresh, b):
+        out("  same call again on the same inputs: bit-exact this time (transient)")
+        verdict.add("call-transient")
+    else:
+        out("  same call again on the same inputs: differs again (%d words, %s)" % (int((fresh != b).sum()), "the same words" if np.array_equal(fresh, a) else "other words"))
+        verdict.add("call-deterministic")
+    # what the combination proves (DESIGN.md section 2 states the three cases)
+    if "input-damaged" in verdict:
+        reading = "the data was wrong BEFORE the kernels ran (upload / first touch) or an input was overwritten later: not a transform fault"
+    elif "oracle-transient" in verdict:
+        reading = "the CHECKER changed its answer: host-side fault (memory, the oracle library), not the device"
+    elif "download-transient" in verdict:
+        reading = "device memory held the right words; the first copy back to the host was wrong"
+    elif "call-transient" in verdict:
+        reading = "inputs intact on the device, output wrong in device memory, the same launches right the second time: a transient fault of the " \
+                  "kernels' stores / ordering (or a later writer), not of their arithmetic"
+    else:
+        reading = "inputs intact, output wrong again: a deterministic kernel bug -- this configuration is a regression test now"
+    out("  reading: " + reading)
+    return verdict
 
 
 def main():
@@ -131,7 +194,25 @@ def main():
                             g.he_keyswitch(t[0], t[1], dev[4], evd[0], evd[1], dim); return t[int(name[1])]
                         t = torch.empty_like(dev[0]); g.poly_mul_rns(t, dev[0].clone(), dev[2].clone(), dim); return t
                     print("MISMATCH", name, "ciphertext", k, dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, nt_policy=nt, lanes=lanes + 1, side_stream=side is not None, seeds=seeds), flush=True)
-                    diagnose(name, k, a, b, sl, dict(zip(("ntt", "invntt", "d0", "d1", "d2", "c0", "c1", "polymul"), (f, i, d[0], d[1], d[2], c[0], c[1], pr)))[name], rerun, set(o.p))
+                    outs = dict(zip(("ntt", "invntt", "d0", "d1", "d2", "c0", "c1", "polymul"), (f, i, d[0], d[1], d[2], c[0], c[1], pr)))
+                    feeds = {"ntt": [0], "invntt": [1], "d0": [0, 1, 2, 3], "d1": [0, 1, 2, 3], "d2": [0, 1, 2, 3], "c0": [4], "c1": [4], "polymul": [0, 2]}[name]
+                    inputs = [("ins[%d]" % j, dev[j], ins[j]) for j in feeds]
+                    if name in ("c0", "c1"):
+                        inputs += [("evk0", evd[0], ev[0]), ("evk1", evd[1], ev[1])]
+                    third = None
+                    if name in ("ntt", "invntt"):
+                        def third(name=name):
+                            t = dev[0 if name == "ntt" else 1].clone(); g.poly_ntt_reference(t, dim, inverse=(name == "invntt")); return t
+                    want = ("ntt", "invntt", "d0", "d1", "d2", "c0", "c1", "polymul").index(name)
+
+                    def oracle_again(want=want, sl=sl):
+                        e = [o.ntt_slab(ins[0][sl].copy(), dim), o.ntt_slab(ins[1][sl].copy(), dim, inverse=True)]
+                        e += list(o.he_mul_tensor(*[v[sl].copy() for v in ins[:4]], dim))
+                        e += list(o.keyswitch(ins[4][sl].copy(), ev[0], ev[1], dim))
+                        e.append(o.poly_mul_rns(ins[0][sl].copy(), ins[2][sl].copy(), dim))
+                        return e[want]
+                    diagnose(name, k, a, b, sl, outs[name], rerun, set(o.p), inputs=inputs, third=third, oracle_again=oracle_again,
+                             out=lambda line: print(line, flush=True))
                     sys.exit(1)
         runs += 1
         print("ok", dict(logn=logn, dim=dim, batch=batch, chunk=chunk, limb_block=lblock, classes=classes, nt_policy=nt, lanes=lanes + 1, side_stream=side is not None, zero_cases=zero_mode), flush=True)
