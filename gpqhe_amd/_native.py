@@ -82,6 +82,7 @@ SIGNATURES = {
     "gpq_set_overlap": (C.c_int, [vp, C.c_int]),
     "gpq_last_lanes": (C.c_uint, [vp]),
     "gpq_debug_fail_peer": (C.c_int, [vp, C.c_int]),
+    "gpq_debug_table_bytes": (C.c_size_t, [vp, C.c_int]),
     "gpq_set_fused_tail": (C.c_int, [vp, C.c_int]),
     "gpq_big_transpose": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint, C.c_int, vp]),
     "gpq_big_addsub": (C.c_int, [vp, vp, vp, vp, C.c_uint, C.c_uint, C.c_int, vp]),

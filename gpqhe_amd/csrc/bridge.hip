@@ -95,8 +95,8 @@ Big floor_pow2_div(unsigned bits, const Big &m) {  // floor(2^bits / m), restori
 // (src/poly.h:35-38); sub-ranges serve the exact division of he_relin.
 int get_basis(gpq_ctx *c, unsigned first, unsigned dim, gpq_bridge_basis **out) {
   const auto key = std::make_pair(first, dim);
-  auto it = c->bases.find(key);
-  if (it != c->bases.end()) { *out = &it->second; return GPQ_OK; }
+  auto it = c->cache->bases.find(key);
+  if (it != c->cache->bases.end()) { *out = &it->second; return GPQ_OK; }
   if (dim < 1 || first + dim > c->nprimes || dim > 63)
     return gpq_fail(GPQ_ERR_INVALID, "bridge: limbs %u..%u outside the chain of %u (at most 63 per basis)", first, first + dim, c->nprimes);
   Big P{1};
@@ -119,10 +119,10 @@ int get_basis(gpq_ctx *c, unsigned first, unsigned dim, gpq_bridge_basis **out) 
   Big m = P;
   for (int k = 5; k >= 0; --k) { put(pmult, (size_t)k * (WP + 1), m, WP + 1); mul_small(m, 2); }  // P,2P,..,32P at rows 5..0
   DeviceScope on_device(c->device);
-  HIP_TRY(hipMalloc((void **)&b.d_phat, phat.size() * 8));
-  HIP_TRY(hipMalloc((void **)&b.d_phat_inv, pinv.size() * 8));
-  HIP_TRY(hipMalloc((void **)&b.d_pmult, pmult.size() * 8));
-  HIP_TRY(hipMalloc((void **)&b.d_phalf, phalf.size() * 8));
+  HIP_TRY(gpq_table_malloc(c, (void **)&b.d_phat, phat.size() * 8));
+  HIP_TRY(gpq_table_malloc(c, (void **)&b.d_phat_inv, pinv.size() * 8));
+  HIP_TRY(gpq_table_malloc(c, (void **)&b.d_pmult, pmult.size() * 8));
+  HIP_TRY(gpq_table_malloc(c, (void **)&b.d_phalf, phalf.size() * 8));
   HIP_TRY(hipMemcpy(b.d_phat, phat.data(), phat.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b.d_phat_inv, pinv.data(), pinv.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b.d_pmult, pmult.data(), pmult.size() * 8, hipMemcpyHostToDevice));
@@ -132,28 +132,28 @@ int get_basis(gpq_ctx *c, unsigned first, unsigned dim, gpq_bridge_basis **out) 
     const u128h q = ~(u128h)0 / c->p[first + d];                     // floor(2^128 / p_d): p_d does not divide 2^128
     inv128[2 * d] = (uint64_t)q; inv128[2 * d + 1] = (uint64_t)(q >> 64);
   }
-  HIP_TRY(hipMalloc((void **)&b.d_inv128, inv128.size() * 8));
+  HIP_TRY(gpq_table_malloc(c, (void **)&b.d_inv128, inv128.size() * 8));
   HIP_TRY(hipMemcpy(b.d_inv128, inv128.data(), inv128.size() * 8, hipMemcpyHostToDevice));
   b.h_phat_inv = pinv;
   b.h_P = P;
   b.h_phat = phat;
-  *out = &(c->bases[key] = b);
+  *out = &(c->cache->bases[key] = b);
   return GPQ_OK;
 }
 
 int get_relin(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables **out) {
   const auto key = std::make_pair(dimP, dimB);
-  auto it = c->relins.find(key);
-  if (it != c->relins.end()) { *out = &it->second; return GPQ_OK; }
+  auto it = c->cache->relins.find(key);
+  if (it != c->cache->relins.end()) { *out = &it->second; return GPQ_OK; }
   gpq_bridge_basis *bp;
   int rc = get_basis(c, 0, dimP, &bp);
   if (rc) return rc;
   std::vector<uint64_t> pinv(dimB - dimP);
   for (unsigned d = dimP; d < dimB; ++d) pinv[d - dimP] = powm(mod_small(bp->h_P, c->p[d]), c->p[d] - 2, c->p[d]);
   gpq_relin_tables t;
-  HIP_TRY(hipMalloc((void **)&t.d_pinv, pinv.size() * 8));
+  HIP_TRY(gpq_table_malloc(c, (void **)&t.d_pinv, pinv.size() * 8));
   HIP_TRY(hipMemcpy(t.d_pinv, pinv.data(), pinv.size() * 8, hipMemcpyHostToDevice));
-  *out = &(c->relins[key] = t);
+  *out = &(c->cache->relins[key] = t);
   return GPQ_OK;
 }
 
@@ -173,7 +173,7 @@ int get_scaled_tabs(gpq_ctx *c, gpq_bridge_basis *b, const LimbTab **out) {
       if (b->first + d < c->nsplit_tables) { e.ninv_s = pair_of(e.ninv, p); e.winv1_ninv_s = pair_of(e.winv1_ninv, p); }
     }
     DeviceScope on_device(c->device);
-    HIP_TRY(hipMalloc((void **)&b->d_tabs_scaled, t.size() * sizeof(LimbTab)));
+    HIP_TRY(gpq_table_malloc(c, (void **)&b->d_tabs_scaled, t.size() * sizeof(LimbTab)));
     HIP_TRY(hipMemcpy(b->d_tabs_scaled, t.data(), t.size() * sizeof(LimbTab), hipMemcpyHostToDevice));
   }
   *out = b->d_tabs_scaled;
@@ -277,10 +277,10 @@ int build_recon_mfma(gpq_ctx *c, const std::vector<uint64_t> &primes, const std:
       mP = nxt;
     }
     DeviceScope on_device(c->device);
-    HIP_TRY(hipMalloc(&t.d_bfrag, bf.size()));
-    HIP_TRY(hipMalloc((void **)&t.d_lk, lk.size() * 8));
-    HIP_TRY(hipMalloc((void **)&t.d_kc, kc.size() * 8));
-    HIP_TRY(hipMalloc((void **)&t.d_pm, pm.size() * 8));
+    HIP_TRY(gpq_table_malloc(c, (void **)&t.d_bfrag, bf.size()));
+    HIP_TRY(gpq_table_malloc(c, (void **)&t.d_lk, lk.size() * 8));
+    HIP_TRY(gpq_table_malloc(c, (void **)&t.d_kc, kc.size() * 8));
+    HIP_TRY(gpq_table_malloc(c, (void **)&t.d_pm, pm.size() * 8));
     HIP_TRY(hipMemcpy(t.d_bfrag, bf.data(), bf.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.d_lk, lk.data(), lk.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.d_kc, kc.data(), kc.size() * 8, hipMemcpyHostToDevice));
@@ -460,8 +460,8 @@ int get_decomp_mfma(gpq_ctx *c, unsigned limb0, unsigned dim, unsigned W, gpq_de
   const unsigned KSnat = W <= 4 ? 1 : W <= 8 ? 2 : W <= 16 ? 4 : 8;
   if (KSforce <= KSnat) KSforce = 0;
   const auto key = std::make_pair(std::make_pair(limb0, dim), W + 1000 * KSforce);
-  auto it = c->decomps.find(key);
-  if (it != c->decomps.end()) { *out = &it->second; return GPQ_OK; }
+  auto it = c->cache->decomps.find(key);
+  if (it != c->cache->decomps.end()) { *out = &it->second; return GPQ_OK; }
   gpq_decomp_mfma t;
   const unsigned KB = 8 * W;
   t.KS = KSforce ? KSforce : KSnat;                      // (KSforce: zero columns up to the k steps a bridge_stream.hpp instantiation runs)
@@ -494,12 +494,12 @@ int get_decomp_mfma(gpq_ctx *c, unsigned limb0, unsigned dim, unsigned W, gpq_de
       }
     }
     DeviceScope on_device(c->device);
-    HIP_TRY(hipMalloc(&t.d_bfrag, bf.size()));
-    HIP_TRY(hipMalloc((void **)&t.d_pk, pk.size() * 8));
+    HIP_TRY(gpq_table_malloc(c, (void **)&t.d_bfrag, bf.size()));
+    HIP_TRY(gpq_table_malloc(c, (void **)&t.d_pk, pk.size() * 8));
     HIP_TRY(hipMemcpy(t.d_bfrag, bf.data(), bf.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.d_pk, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
   }
-  *out = &(c->decomps[key] = t);
+  *out = &(c->cache->decomps[key] = t);
   return GPQ_OK;
 }
 
@@ -667,7 +667,16 @@ int launched(const char *who) {
 }  // namespace
 
 void gpq_bridge_release(gpq_ctx *c) {
-  for (auto &kv : c->bases) {
+  // the context's own mutable words
+  if (c->d_redo) (void)hipFree(c->d_redo);
+  c->d_redo = nullptr; c->redo_cap = 0;
+  if (c->d_wave_any) (void)hipFree(c->d_wave_any);
+  c->d_wave_any = nullptr;
+  for (void *old : c->retired) (void)hipFree(old);
+  c->retired.clear();
+  // the constant cache: the owner's to free (a peer lane borrows its parent's, engine_internal.hpp)
+  if (c->tables_of || !c->cache) { c->cache = nullptr; return; }
+  for (auto &kv : c->cache->bases) {
     (void)hipFree(kv.second.d_phat); (void)hipFree(kv.second.d_phat_inv);
     (void)hipFree(kv.second.d_pmult); (void)hipFree(kv.second.d_phalf); (void)hipFree(kv.second.d_inv128);
     if (kv.second.d_tabs_scaled) (void)hipFree(kv.second.d_tabs_scaled);
@@ -678,14 +687,7 @@ void gpq_bridge_release(gpq_ctx *c) {
       if (m.second.d_pm) (void)hipFree(m.second.d_pm);
     }
   }
-  if (c->d_redo) (void)hipFree(c->d_redo);
-  c->d_redo = nullptr; c->redo_cap = 0;
-  if (c->d_wave_any) (void)hipFree(c->d_wave_any);
-  c->d_wave_any = nullptr;
-  for (void *old : c->retired) (void)hipFree(old);
-  c->retired.clear();
-  c->bases.clear();
-  for (auto &kv : c->relins) {
+  for (auto &kv : c->cache->relins) {
     (void)hipFree(kv.second.d_pinv);
     for (void *q : {kv.second.d_bfrag, (void *)kv.second.d_lk, (void *)kv.second.d_pk, (void *)kv.second.d_tkp, (void *)kv.second.d_kf,
                     kv.second.d_bfrag_w, (void *)kv.second.d_pk_w, (void *)kv.second.d_tkp_w, (void *)kv.second.d_tabs_w,
@@ -696,9 +698,9 @@ void gpq_bridge_release(gpq_ctx *c) {
       for (void *q : {m.second.d_bfrag, (void *)m.second.d_lk, (void *)m.second.d_kc, (void *)m.second.d_pm})
         if (q) (void)hipFree(q);
   }
-  c->relins.clear();
-  for (auto &kv : c->decomps) { if (kv.second.d_bfrag) (void)hipFree(kv.second.d_bfrag); if (kv.second.d_pk) (void)hipFree(kv.second.d_pk); }
-  c->decomps.clear();
+  for (auto &kv : c->cache->decomps) { if (kv.second.d_bfrag) (void)hipFree(kv.second.d_bfrag); if (kv.second.d_pk) (void)hipFree(kv.second.d_pk); }
+  delete c->cache;
+  c->cache = nullptr;
 }
 
 extern "C" int gpq_set_bridge_mfma(gpq_ctx *c, int on) {
@@ -909,21 +911,21 @@ int get_relin_front(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables *
     }
   }
   DeviceScope on_device(c->device);
-  HIP_TRY(hipMalloc(&rt->d_bfrag, bf.size()));
-  HIP_TRY(hipMalloc((void **)&rt->d_lk, lk.size() * 8));
-  HIP_TRY(hipMalloc((void **)&rt->d_pk, pk.size() * 8));
-  HIP_TRY(hipMalloc((void **)&rt->d_tkp, tkp.size() * 8));
-  HIP_TRY(hipMalloc((void **)&rt->d_kf, kf.size() * 8));
+  HIP_TRY(gpq_table_malloc(c, (void **)&rt->d_bfrag, bf.size()));
+  HIP_TRY(gpq_table_malloc(c, (void **)&rt->d_lk, lk.size() * 8));
+  HIP_TRY(gpq_table_malloc(c, (void **)&rt->d_pk, pk.size() * 8));
+  HIP_TRY(gpq_table_malloc(c, (void **)&rt->d_tkp, tkp.size() * 8));
+  HIP_TRY(gpq_table_malloc(c, (void **)&rt->d_kf, kf.size() * 8));
   HIP_TRY(hipMemcpy(rt->d_bfrag, bf.data(), bf.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(rt->d_lk, lk.data(), lk.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(rt->d_pk, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(rt->d_tkp, tkp.data(), tkp.size() * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(rt->d_kf, kf.data(), kf.size() * 8, hipMemcpyHostToDevice));
   if (!tw.empty()) {
-    HIP_TRY(hipMalloc(&rt->d_bfrag_w, bfw.size()));
-    HIP_TRY(hipMalloc((void **)&rt->d_pk_w, pkw.size() * 8));
-    HIP_TRY(hipMalloc((void **)&rt->d_tkp_w, tkpw.size() * 8));
-    HIP_TRY(hipMalloc((void **)&rt->d_tabs_w, tw.size() * sizeof(LimbTab)));
+    HIP_TRY(gpq_table_malloc(c, (void **)&rt->d_bfrag_w, bfw.size()));
+    HIP_TRY(gpq_table_malloc(c, (void **)&rt->d_pk_w, pkw.size() * 8));
+    HIP_TRY(gpq_table_malloc(c, (void **)&rt->d_tkp_w, tkpw.size() * 8));
+    HIP_TRY(gpq_table_malloc(c, (void **)&rt->d_tabs_w, tw.size() * sizeof(LimbTab)));
     HIP_TRY(hipMemcpy(rt->d_bfrag_w, bfw.data(), bfw.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(rt->d_pk_w, pkw.data(), pkw.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(rt->d_tkp_w, tkpw.data(), tkpw.size() * 8, hipMemcpyHostToDevice));
@@ -971,8 +973,8 @@ int get_tail_direct(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_tables *
   if ((rc = get_scaled_tabs(c, bB, &tabs))) return rc;
   rt->d_tabs_direct = tabs;
   DeviceScope on_device(c->device);
-  HIP_TRY(hipMalloc((void **)&rt->d_scale, dimB * 8));
-  HIP_TRY(hipMalloc((void **)&rt->d_unscale, dimB * 8));
+  HIP_TRY(gpq_table_malloc(c, (void **)&rt->d_scale, dimB * 8));
+  HIP_TRY(gpq_table_malloc(c, (void **)&rt->d_unscale, dimB * 8));
   HIP_TRY(hipMemcpy(rt->d_scale, scale.data(), dimB * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(rt->d_unscale, unscale.data(), dimB * 8, hipMemcpyHostToDevice));
   return GPQ_OK;
@@ -1595,8 +1597,8 @@ extern "C" int gpq_set_overlap(gpq_ctx *c, int on) {
 // tests: make the next creation of the peer lane fail the way an allocation would (the call must run on one lane and say so once)
 extern "C" int gpq_debug_fail_peer(gpq_ctx *c, int on) {
   if (!c) return gpq_fail(GPQ_ERR_INVALID, "gpq_debug_fail_peer: null context");
-  c->debug_peer_fail = on != 0;
-  if (!on) c->peer_failed = false;
+  c->debug_peer_fail = on == 3 ? 0 : on;                         // 3: stop failing allocations but keep what was declined so far
+  if (!on) { c->peer_failed = false; c->peer_ws_declined = 0; }
   return GPQ_OK;
 }
 // lanes the last gpq_he_mul / gpq_he_swk / gpq_he_mul_tensor / gpq_keyswitch call on this context ran on (1 or 2)

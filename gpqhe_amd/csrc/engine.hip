@@ -161,15 +161,18 @@ uint64_t inv_mod_2_64(uint64_t q) {  // Newton; equals the 64-step product of sr
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
+static int alloc_zero_flags(gpq_ctx *c);
 static int upload_tables(gpq_ctx *c) {
   const size_t n = c->n, np = c->nprimes;
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (c->device < 0 || c->device >= ndev) return gpq_fail(GPQ_ERR_INVALID, "device %d outside 0..%d", c->device, ndev - 1);
   DeviceScope on_device(c->device);
-  HIP_TRY(hipMalloc((void **)&c->d_w, np * n * sizeof(uint64_t)));
-  HIP_TRY(hipMalloc((void **)&c->d_winv, np * n * sizeof(uint64_t)));
-  HIP_TRY(hipMalloc((void **)&c->d_tabs, np * sizeof(LimbTab)));
+  if (!c->cache) c->cache = new (std::nothrow) gpq_table_cache();
+  if (!c->cache) return gpq_fail(GPQ_ERR_NOMEM, "out of host memory");
+  HIP_TRY(gpq_table_malloc(c, (void **)&c->d_w, np * n * sizeof(uint64_t)));
+  HIP_TRY(gpq_table_malloc(c, (void **)&c->d_winv, np * n * sizeof(uint64_t)));
+  HIP_TRY(gpq_table_malloc(c, (void **)&c->d_tabs, np * sizeof(LimbTab)));
   std::vector<uint64_t> wstd(np * n), wistd(np * n);
   std::vector<LimbTab> tabs(np);
   for (size_t d = 0; d < np; ++d) {
@@ -218,8 +221,8 @@ static int upload_tables(gpq_ctx *c) {
       tabs[d].ninv_s = pair_of(tabs[d].ninv, p);
       tabs[d].winv1_ninv_s = pair_of(tabs[d].winv1_ninv, p);
     }
-    HIP_TRY(hipMalloc((void **)&c->d_ws, ns * n * sizeof(TwS)));
-    HIP_TRY(hipMalloc((void **)&c->d_winvs, ns * n * sizeof(TwS)));
+    HIP_TRY(gpq_table_malloc(c, (void **)&c->d_ws, ns * n * sizeof(TwS)));
+    HIP_TRY(gpq_table_malloc(c, (void **)&c->d_winvs, ns * n * sizeof(TwS)));
     HIP_TRY(hipMemcpy(c->d_ws, ws.data(), ns * n * sizeof(TwS), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_winvs, wis.data(), ns * n * sizeof(TwS), hipMemcpyHostToDevice));
   }
@@ -227,6 +230,12 @@ static int upload_tables(gpq_ctx *c) {
   HIP_TRY(hipMemcpy(c->d_winv, wistd.data(), np * n * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_tabs, tabs.data(), np * sizeof(LimbTab), hipMemcpyHostToDevice));
   c->h_tabs = tabs;
+  return alloc_zero_flags(c);
+}
+
+// gpq_ntt's zero flags: the one device allocation every context -- a peer lane too -- owns from its creation
+static int alloc_zero_flags(gpq_ctx *c) {
+  DeviceScope on_device(c->device);
   // gpq_ntt's zero flags for launches of up to 4096 (polynomial, limb) units exist from the start, so that a FIRST gpq_ntt inside a
   // stream capture works; larger launches grow them at their first call, outside capture (zero_flags)
   HIP_TRY(hipMalloc((void **)&c->d_zflag, 4096 * sizeof(unsigned)));
@@ -307,9 +316,15 @@ int gpq_ctx_clone(const gpq_ctx *c, gpq_ctx **out) {
   if (!q) return gpq_fail(GPQ_ERR_NOMEM, "out of host memory");
   q->device = c->device; q->logn = c->logn; q->n = c->n; q->nprimes = c->nprimes;
   q->p = c->p; q->pinv_mont = c->pinv_mont; q->pinv_barr = c->pinv_barr; q->ninv_mont = c->ninv_mont; q->psi = c->psi;
-  q->zetas = c->zetas; q->zetas_inv = c->zetas_inv;
+  // (no host twiddles: gpq_ctx_zetas is the parent's business; nothing the peer runs reads them)
   q->overlap = 0;
-  int rc = upload_tables(q);
+  // every read-only device table is the parent's (engine_internal.hpp: gpq_table_cache)
+  q->tables_of = c;
+  q->d_w = c->d_w; q->d_winv = c->d_winv; q->d_ws = c->d_ws; q->d_winvs = c->d_winvs; q->d_tabs = c->d_tabs;
+  q->h_tabs = c->h_tabs;
+  q->nsplit = c->nsplit; q->nsplit_tables = c->nsplit_tables; q->nwide = c->nwide; q->nwide_max = c->nwide_max; q->low9 = c->low9;
+  q->cache = c->cache;
+  int rc = alloc_zero_flags(q);
   if (rc != GPQ_OK) { gpq_ctx_destroy(q); return rc; }
   *out = q;
   return GPQ_OK;
@@ -319,23 +334,37 @@ extern "C" void gpq_ctx_destroy(gpq_ctx *c) {
   if (!c) return;
   if (c->peer) {
     if (c->peer_stream) (void)hipStreamSynchronize(c->peer_stream);
-    gpq_ctx_destroy(c->peer);
+    gpq_ctx_destroy(c->peer);                                    // before the tables it borrows go
   }
   if (c->peer_stream) (void)hipStreamDestroy(c->peer_stream);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->peer_ws) (void)hipFree(c->peer_ws);
-  if (c->d_w) (void)hipFree(c->d_w);
-  if (c->d_winv) (void)hipFree(c->d_winv);
-  if (c->d_ws) (void)hipFree(c->d_ws);
-  if (c->d_winvs) (void)hipFree(c->d_winvs);
-  if (c->d_tabs) (void)hipFree(c->d_tabs);
+  if (!c->tables_of) {
+    if (c->d_w) (void)hipFree(c->d_w);
+    if (c->d_winv) (void)hipFree(c->d_winv);
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->d_winvs) (void)hipFree(c->d_winvs);
+    if (c->d_tabs) (void)hipFree(c->d_tabs);
+  }
   if (c->d_zflag) (void)hipFree(c->d_zflag);
   if (c->d_zwatch) (void)hipFree(c->d_zwatch);
   gpq_bridge_release(c);
   for (gpq_prof_rec &r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
   delete c;
+}
+
+// Tests / DESIGN section 6: read-only device memory the context owns (which = 0: transform tables + every bridge constant built so far), what its
+// peer lane owns of the same kind (1: zero by construction, the peer borrows), and whether a peer exists (2).
+extern "C" size_t gpq_debug_table_bytes(const gpq_ctx *c, int which) {
+  if (!c) return 0;
+  if (which == 0) return c->cache && !c->tables_of ? c->cache->device_bytes : 0;
+  if (which == 1) return c->peer && !c->peer->tables_of && c->peer->cache ? c->peer->cache->device_bytes : 0;
+  if (which == 2) return c->peer ? 1 : 0;
+  if (which == 3) return c->peer ? (size_t)(c->peer->d_w == c->d_w && c->peer->d_winv == c->d_winv && c->peer->d_ws == c->d_ws && c->peer->d_winvs == c->d_winvs &&
+                                            c->peer->d_tabs == c->d_tabs && c->peer->cache == c->cache) : 0;
+  return 0;
 }
 
 extern "C" unsigned gpq_ctx_logn(const gpq_ctx *c) { return c->logn; }

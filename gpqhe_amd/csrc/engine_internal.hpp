@@ -69,6 +69,18 @@ struct gpq_relin_tables {
   uint64_t *d_scale = nullptr, *d_unscale = nullptr;
 };
 
+// Everything a context builds once and only reads afterwards on the device: the transform tables of upload_tables (engine.hip) and the bridge
+// constants bridge.hip builds at first use.  ONE object per prime chain: a context's peer lane (gpq_ctx_clone) points at its parent's, so the second
+// lane costs no table memory, no table-building time, and "the peer's tables differ" is not a state the library can be in.  Built and read by the
+// one host thread that drives the context (single caller); uploads are synchronous hipMemcpy, so a launch on either lane's stream that
+// follows a build on the host sees the table.
+struct gpq_table_cache {
+  std::map<std::pair<unsigned, unsigned>, gpq_bridge_basis> bases;   // by (first limb, count), built on first use
+  std::map<std::pair<unsigned, unsigned>, gpq_relin_tables> relins;  // by (dimP, dimB)
+  std::map<std::pair<std::pair<unsigned, unsigned>, unsigned>, gpq_decomp_mfma> decomps;  // by ((first limb, limbs), W)
+  size_t device_bytes = 0;            // read-only device memory behind this cache and the transform tables (gpq_table_malloc)
+};
+
 struct gpq_ctx {
   int device = 0;
   unsigned logn = 0, n = 0, nprimes = 0;
@@ -90,9 +102,8 @@ struct gpq_ctx {
   // with n^-1 (and winv[1] n^-1) multiplied by a CRT weight, so that the limbs leave the transform already scaled for the
   // reconstruction that follows (bridge.hip: ScaledInverse).  Internal to gpq_he_mul / gpq_he_swk.
   const gpq::LimbTab *inv_tabs_override = nullptr;
-  std::map<std::pair<unsigned, unsigned>, gpq_bridge_basis> bases;   // by (first limb, count), built on first use
-  std::map<std::pair<unsigned, unsigned>, gpq_relin_tables> relins;  // by (dimP, dimB)
-  std::map<std::pair<std::pair<unsigned, unsigned>, unsigned>, gpq_decomp_mfma> decomps;  // by ((first limb, limbs), W)
+  gpq_table_cache *cache = nullptr;   // the lazily built bridge constants (owned unless tables_of is set)
+  const gpq_ctx *tables_of = nullptr; // a peer lane: d_w / d_winv / d_ws / d_winvs / d_tabs and `cache` are the PARENT's, borrowed for the parent's lifetime
   bool bridge_mfma = true;            // matrix-core decompose / CRT (gpq_set_bridge_mfma(ctx, 0): the integer-VALU kernels)
   unsigned char *d_redo = nullptr;    // per-coefficient "redo exactly" flags of the fast CRT path
   size_t redo_cap = 0;
@@ -113,12 +124,13 @@ struct gpq_ctx {
   // launch group did (streaming kernel + masked finish); otherwise the caller runs the plain rescale kernel on the group's outputs
   unsigned tail_rs = 0;
   bool tail_rs_done = false;
-  // gpq_he_mul / gpq_he_swk over more than one launch group: every other group runs on a second stream through a PEER context (its own tables,
-  // scratch and flag words: nothing mutable is shared), so that the HBM-bound bridge kernels of one group run beside the issue-bound transforms
+  // gpq_he_mul / gpq_he_swk over more than one launch group: every other group runs on a second stream through a PEER context (the parent's
+  // read-only tables; its own scratch and flag words: nothing mutable is shared), so that the HBM-bound bridge kernels of one group run beside the issue-bound transforms
   // of the other and launch tails fill (gpq_set_overlap; bridge.hip: peer_lane).  The caller's stream orders the whole call as before.
   int overlap = -1;                   // gpq_set_overlap: -1 (default) = two lanes when the peer's workspace is affordable (kPeerAutoWorkspaceBytes), 0 = never, 1 = always
-  bool peer_failed = false;           // the peer (or its workspace) could not be created once: one lane from then on
-  bool debug_peer_fail = false;       // tests (gpq_debug_fail_peer): the next attempt to create the peer fails as an allocation would
+  bool peer_failed = false;           // the peer (its stream, events, flag words) could not be created once: one lane from then on
+  size_t peer_ws_declined = 0;        // a peer workspace of this many bytes could not be allocated: shapes that need as much or more run on one lane, smaller ones still get two
+  int debug_peer_fail = 0;            // tests (gpq_debug_fail_peer): 1 = the next attempt to create the peer fails as an allocation would, 2 = the next workspace allocation does
   unsigned last_lanes = 1;            // lanes the last multi-group entry point ran on (gpq_last_lanes)
   std::set<unsigned long long> peer_warm;   // call shapes the peer has run outside a stream capture (gpq_lane_key)
   gpq_ctx *peer = nullptr;
@@ -177,8 +189,16 @@ struct ProfScope {
 };
 
 int gpq_fail(int code, const char *fmt, ...);
-// A second context over the same primes and twiddles (host tables copied, device tables built anew), with default settings and no peer of its own.
+// A second context over the same primes for the peer lane: every read-only device table (twiddles, split pairs, LimbTab, the bridge's constant
+// cache) is the parent's, borrowed; its own are only the mutable words (zero flags, redo flags, wave words, scratch).  Default settings, no peer of
+// its own; must be destroyed before the parent (gpq_ctx_destroy does).
 int gpq_ctx_clone(const gpq_ctx *c, gpq_ctx **out);
+// hipMalloc of a read-only table, accounted in the context's table cache (gpq_debug_table_bytes)
+inline hipError_t gpq_table_malloc(gpq_ctx *c, void **p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess && c->cache) c->cache->device_bytes += bytes;
+  return e;
+}
 void gpq_bridge_release(gpq_ctx *c);
 
 // ---------------------------------------------------------------------------
@@ -213,19 +233,26 @@ inline void gpq_mirror_settings(gpq_ctx *q, const gpq_ctx *c) {   // whatever de
 // What gpq_set_overlap(ctx, -1) -- the default -- allows the peer's per-group workspace to cost.  Two lanes pay through launch tails, so the gain
 // shrinks as the kernels of a group grow: +10-15 % at the reference's default shape (logn 14: 0.1 GB per group) on every device measured,
 // +0.15 ... +3.9 % by device at the headline shape (5.6 GB per group), +1.6 % for he_swk at n = 2^17 (7 GB); never a loss (profiles/r04/v13_two_lanes_ab.txt,
-// BENCH_r04.json, profiles/r05).  The cost is device memory: the peer's own tables (as much again as the context's) and this workspace.
+// BENCH_r04.json, profiles/r05).  The cost is device memory: this workspace (the tables are shared with the parent since round 6).
 constexpr size_t kPeerAutoWorkspaceBytes = (size_t)16 << 30;
 // lane->c stays null when the call runs on the caller's stream alone.  `key` names the call shape (entry point, dimensions, group size): a lane is
-// only taken inside a stream capture when the peer has already run that very shape outside one (its first-use table builds allocate and copy).
-// `bytes(peer)` = the workspace one launch group needs on the peer.  A peer that cannot be created (or whose workspace cannot be allocated) is not
-// an error of the call: the HIP error is cleared, the context stops trying, and the call runs on one lane.
+// only taken inside a stream capture when the peer has already run that very shape outside one (first-use table builds allocate and copy).
+// `bytes(ctx)` = the workspace one launch group needs (evaluated on the context itself: the peer shares its tables and follows its settings).  A
+// peer that cannot be created is not an error of the call: the HIP error is cleared, the context stops trying, and the call runs on one lane; a
+// WORKSPACE that cannot be allocated declines shapes of that size only.
 template <typename Bytes>
 int gpq_peer_lane(gpq_ctx *c, hipStream_t s, unsigned long long key, Bytes bytes, PeerLane *lane) {
   if (c->overlap == 0 || c->peer_failed || c->prof_on || c->inv_tabs_override) return GPQ_OK;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return GPQ_OK; }
   const bool capturing = cap != hipStreamCaptureStatusNone;
-  if (capturing && (!c->peer || !c->peer_warm.count(key))) return GPQ_OK;     // (before bytes(peer): sizing a new shape may allocate on the peer)
+  if (capturing && (!c->peer || !c->peer_warm.count(key))) return GPQ_OK;     // (before bytes(): sizing a new shape may build tables, which allocates)
+  // The price first, on the context itself (the peer runs the same settings over the same tables): a shape the auto mode declines, or one whose
+  // workspace already failed to allocate, never creates the peer and costs nothing.
+  const size_t need = bytes(c);
+  if (!need) return GPQ_OK;
+  if (c->overlap < 0 && need > kPeerAutoWorkspaceBytes) return GPQ_OK;        // auto: not at this price
+  if (c->peer_ws_declined && need >= c->peer_ws_declined) return GPQ_OK;      // this size did not fit once
   auto give_up = [&](const char *what) {                                       // one lane from now on, for this context
     (void)hipGetLastError();
     c->peer_failed = true;
@@ -233,20 +260,22 @@ int gpq_peer_lane(gpq_ctx *c, hipStream_t s, unsigned long long key, Bytes bytes
     return (int)GPQ_OK;
   };
   if (!c->peer) {
-    if (c->debug_peer_fail) return give_up("gpq_debug_fail_peer");
+    if (c->debug_peer_fail == 1) return give_up("gpq_debug_fail_peer");
     if (!c->peer_stream && hipStreamCreateWithFlags(&c->peer_stream, hipStreamNonBlocking) != hipSuccess) return give_up("hipStreamCreateWithFlags");
     if (!c->ev_fork && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return give_up("hipEventCreateWithFlags");
     if (!c->ev_join && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return give_up("hipEventCreateWithFlags");
     if (gpq_ctx_clone(c, &c->peer) != GPQ_OK) { c->peer = nullptr; return give_up("peer context"); }   // last: a context with a peer has its stream and events
   }
   gpq_mirror_settings(c->peer, c);
-  const size_t need = bytes(c->peer);
-  if (!need) return GPQ_OK;
-  if (c->overlap < 0 && need > kPeerAutoWorkspaceBytes) return GPQ_OK;        // auto: not at this price
   if (need > c->peer_ws_bytes) {
     if (capturing) return GPQ_OK;
     void *fresh = nullptr;
-    if (hipMalloc(&fresh, need) != hipSuccess) return give_up("hipMalloc of the peer workspace");
+    if (c->debug_peer_fail == 2 || hipMalloc(&fresh, need) != hipSuccess) {   // this shape only: smaller ones keep their second lane, nothing else is given up
+      (void)hipGetLastError();
+      c->peer_ws_declined = need;
+      fprintf(stderr, "gpqhe_hip: no room for a second lane's workspace of %zu bytes: shapes of this size run on one lane\n", need);
+      return GPQ_OK;
+    }
     if (c->peer_ws) c->retired.push_back(c->peer_ws);             // a graph captured earlier may still use it
     c->peer_ws = fresh; c->peer_ws_bytes = need;
   }

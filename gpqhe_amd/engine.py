@@ -143,8 +143,12 @@ class PolyContext:
         _native.check(self.lib.gpq_set_overlap(self.h, v), "gpq_set_overlap")
 
     def debug_fail_peer(self, on=True):
-        """tests: the next creation of the peer lane fails like an allocation would"""
-        _native.check(self.lib.gpq_debug_fail_peer(self.h, 1 if on else 0), "gpq_debug_fail_peer")
+        """tests: the next creation of the peer lane (True / 1) or the next allocation of its workspace (2) fails like an allocation would"""
+        _native.check(self.lib.gpq_debug_fail_peer(self.h, int(on)), "gpq_debug_fail_peer")
+
+    def debug_table_bytes(self, which=0):
+        """read-only device bytes owned by the context (0) / by its peer lane (1: zero, the peer borrows); 2: a peer exists; 3: the peer's table pointers are the context's"""
+        return int(self.lib.gpq_debug_table_bytes(self.h, which))
 
     def last_lanes(self):
         """lanes (1 or 2) the last multi-group call on this context ran on"""

@@ -218,17 +218,22 @@ int gpq_set_stream_bridge(gpq_ctx *ctx, int on);
  * other group runs on a second, internal stream through an internal peer context, so that the launch tails of one group fill with the other's
  * kernels; the caller's stream still orders the call as a whole (work queued before it is waited for, work queued after it waits for both lanes).
  * `on` = -1 (default): two lanes when the peer's per-group workspace costs at most 16 GiB; 0: never; 1: always.  Same words either way.
- * COST: the peer owns its own device tables (as much again as the context's: 0.15 GB at n = 2^16 / 45 limbs, plus the bridge constants) and a
- * workspace for one launch group (the size gpq_*_workspace_bytes reports for a batch of one group: 5.6 GB for gpq_he_mul at the headline shape),
- * allocated at the first multi-group call.  GAIN: +10-15 % at the reference's default shape (logn 14) on every device measured; at the headline
- * shape it depends on the device (+0.15 % ... +3.9 %: a group's kernels are long, the lanes share one power cap); never a loss.  If the peer or
- * its workspace cannot be allocated the call runs on one lane (one line on stderr, no error).  Not taken while gpq_profile is on.
+ * COST: a workspace for one launch group (the size gpq_*_workspace_bytes reports for a batch of one group: 5.6 GB for gpq_he_mul at the headline
+ * shape), allocated at the first multi-group call that will use it.  The peer borrows every read-only device table of the context (twiddles, split
+ * pairs, per-limb constants, bridge constants: gpq_debug_table_bytes) and owns only its flag words and scratch.  GAIN: +10-15 % at the reference's default shape (logn 14) on every device measured; at the headline
+ * shape it depends on the device (+0.15 % ... +3.9 %: a group's kernels are long, the lanes share one power cap); never a loss.  If the peer cannot
+ * be created the context continues on one lane; if a workspace cannot be allocated, shapes of that size do (one line on stderr, no error).  Not taken while gpq_profile is on.
  * gpq_last_lanes: the lanes (1 or 2) the last such call on this context ran on. */
 int gpq_set_overlap(gpq_ctx *ctx, int on);
 unsigned gpq_last_lanes(const gpq_ctx *ctx);
 /* Tests: 1 = the next attempt to create the peer lane fails as an allocation would (the call runs on one lane, one line on stderr, and the context
- * stops trying); 0 = back to normal (and the context may try again). */
+ * stops trying); 2 = the next allocation of the peer's WORKSPACE fails (shapes that need that many bytes or more run on one lane from then on,
+ * smaller ones keep two); 3 = stop failing but remember what was declined; 0 = back to normal (and the context may try again). */
 int gpq_debug_fail_peer(gpq_ctx *ctx, int on);
+/* Tests / accounting: read-only device memory (bytes) behind the context -- which = 0: the transform tables and every bridge constant built so far,
+ * owned by the context; 1: what its peer lane owns of the same kind (0 by construction: the peer borrows); 2: 1 when a peer lane exists; 3: 1 when
+ * every table pointer of the peer IS the context's. */
+size_t gpq_debug_table_bytes(const gpq_ctx *ctx, int which);
 /* gpq_he_mul: 1 (default) = its internal rns_decompose launches leave residues in (0, 3p), which the forward transforms behind them accept;
  * 0 = canonical residues.  Same results. */
 int gpq_set_lazy_decompose(gpq_ctx *ctx, int on);

@@ -225,3 +225,58 @@ def test_a_peer_that_cannot_be_created_means_one_lane_not_an_error():
             assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
     finally:
         g.close()
+
+
+def test_the_peer_lane_borrows_every_table_and_a_failed_workspace_declines_that_size_only():
+    """Round 6: the peer lane owns no read-only device table -- twiddles, split pairs, LimbTab and the bridge's
+    constant cache are the parent's, by pointer -- so the second lane costs its workspace only; and a workspace that cannot be allocated declines
+    shapes of that size, not the lane (a smaller shape still runs on two); what exists for a lane that has not run yet is a context object and its flag words."""
+    import torch
+    import gpqhe_amd
+    logn, logq = 13, 300
+    probe = gpqhe_amd.PolyContext(logn, 20)
+    dimP, dimA, dimB, dimevk = probe.he_dims(logq, logq)
+    probe.close()
+    g = gpqhe_amd.PolyContext(logn, dimevk)
+    try:
+        n, W = g.n, (logq + 64) // 64
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(32)
+        rlk = [torch.cat([torch.randint(0, g.p[d], (n,), dtype=torch.int64, device="cuda", generator=gen) for d in range(dimB)]) for _ in range(2)]
+        dims = (dimA, dimB, dimP)
+        big = [_centred(torch, gen, 8, W, n, logq) for _ in range(4)]
+        small = [t[:4 * W * n] for t in big]
+        g.set_overlap(False)
+        g.set_chunk(4)
+        want_big = _run(g, torch, big, rlk, W, logq, dims)         # groups of 4: the larger workspace
+        g.set_chunk(2)
+        want_small = _run(g, torch, small, rlk, W, logq, dims)     # groups of 2: the smaller one
+        assert g.debug_table_bytes(2) == 0                          # one lane so far: no peer exists
+        owned = g.debug_table_bytes(0)
+        assert owned > 2 * dimevk * n * 8                           # at least the two plain twiddle tables
+        # the workspace of the larger shape "does not fit": one lane for it, and no peer was created for nothing before the price was known
+        g.set_overlap(True)
+        g.set_chunk(4)
+        g.debug_fail_peer(2)
+        got_big = _run(g, torch, big, rlk, W, logq, dims)
+        assert g.last_lanes() == 1
+        assert g.debug_table_bytes(2) == 1                          # (the peer itself is cheap and exists; it holds no workspace)
+        g.set_chunk(2)
+        g.debug_fail_peer(3)                                        # 3: allocations work again, what was declined stays declined
+        got_small = _run(g, torch, small, rlk, W, logq, dims)
+        assert g.last_lanes() == 2
+        g.set_chunk(4)
+        again_big = _run(g, torch, big, rlk, W, logq, dims)         # the declined size stays declined
+        assert g.last_lanes() == 1
+        g.debug_fail_peer(False)                                    # cleared: the larger shape gets its lane
+        back_big = _run(g, torch, big, rlk, W, logq, dims)
+        assert g.last_lanes() == 2
+        for a, b, c, d in zip(want_big, got_big, again_big, back_big):
+            assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+        for a, b in zip(want_small, got_small):
+            assert torch.equal(a, b)
+        # the peer exists now and holds no table of its own; the parent's tables did not grow by a second copy
+        assert g.debug_table_bytes(2) == 1 and g.debug_table_bytes(1) == 0 and g.debug_table_bytes(3) == 1
+        assert g.debug_table_bytes(0) < owned + (1 << 20)          # (+ the constants the two-lane shapes built at first use, no second set of twiddles)
+    finally:
+        g.close()
