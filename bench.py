@@ -271,7 +271,7 @@ def ntt_rate(torch, gpqhe_amd, logn, dim, batch, iters=20):
             "ms_per_pair_repetitions": [round(v, 4) for v in reps], "roundtrip_identity": ok}
 
 
-def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=True, checked=None, sample_clocks=False):
+def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=True, checked=None, sample_clocks=False, brief=False, restore_overlap=-1, group=32):
     """Whole he_mul of src/he-mult.c:88-156 on device big slabs (q = 2^logq: decompose, tensor, CRT, relinearise
     with exact division by P, centre) -- SURVEY.md 8f rank 1-2, reported beside the RNS-core headline."""
     W = logq // 64 + 1
@@ -304,6 +304,17 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=T
         ctx.he_mul(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP)
     t.stop()
     ms = t.elapsed_ms() / iters
+    lanes_this_run = ctx.last_lanes()                # what the timed calls really ran on (a declined peer means 1 whatever was asked for)
+    if brief:                                        # bench.py --quick: the two rates, nothing else
+        ctx.he_mul_rs(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP, 50)
+        t.start()
+        for _ in range(iters):
+            ctx.he_mul_rs(o0, o1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP, 50)
+        t.stop()
+        ctx.set_overlap(restore_overlap)
+        return {"shape": "n=2^%d, q=2^%d (W=%d words), dimA/dimB/dimP=%d/%d/%d, batch %d" % (ctx.logn, logq, W, dimA, dimB, dimP, batch),
+                "ms_per_batch": round(ms, 3), "he_mul_per_s": round(batch / (ms * 1e-3), 1),
+                "he_mul_plus_he_rescale_per_s": round(batch / (t.elapsed_ms() / iters * 1e-3), 1), "lanes": {"default": default_lanes, "this_run": lanes_this_run}}
     ctx.set_overlap(False)                           # the same on the caller's stream alone (gpq_set_overlap(ctx, 0)): what the two lanes buy
     t.start()
     for _ in range(iters):
@@ -348,7 +359,7 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=T
         r0, r1 = torch.empty_like(o0), torch.empty_like(o1)
         ctx.he_mul_rs(r0, r1, *cts, rlk0, rlk1, W, logq, dimA, dimB, dimP, 50)      # the fused call is what the rate above timed: check ITS words
         torch.cuda.synchronize()
-        group, per = 32, W * n
+        per = W * n                                  # `group` = the context's launch group (--chunk; the library's default is 32)
         picks = sorted({k for g0 in range(0, batch, group) for k in (g0, min(g0 + group, batch) - 1)})
         host = gpqhe_amd.to_host
         k0h, k1h = host(rlk0), host(rlk1)
@@ -391,11 +402,12 @@ def he_mul_mpi_rate(torch, gpqhe_amd, ctx, batch, iters=6, logq=850, two_lanes=T
                 "note": "the bridge kernel with the largest share of this leg; all launches of the kind together; "
                         "PMC of these kernels: profiles/r04/v17_mpi_pmc.txt"}
     bridge_ms = sum(v["ms_per_batch"] for k, v in kernels.items() if k.startswith("bridge_"))
+    ctx.set_overlap(restore_overlap)                 # the caller's setting (--lanes) back: the legs behind this one run on the shared context
     return {"shape": "n=2^%d, q=2^%d (W=%d words), dimA/dimB/dimP=%d/%d/%d, batch %d" % (ctx.logn, logq, W, dimA, dimB, dimP, batch),
             "ms_per_batch": round(ms, 3), "he_mul_per_s": round(batch / (ms * 1e-3), 1),
             "he_mul_plus_he_rescale_per_s": round(batch / (ms_rs * 1e-3), 1),
             "he_mul_then_he_rescale_two_calls_per_s": round(batch / (ms_rs_two * 1e-3), 1),
-            "lanes": {"default": default_lanes, "this_run": 2 if two_lanes else 1, "one_lane_ms_per_batch": round(ms_one, 3), "one_lane_he_mul_per_s": round(batch / (ms_one * 1e-3), 1),
+            "lanes": {"default": default_lanes, "this_run": lanes_this_run, "one_lane_ms_per_batch": round(ms_one, 3), "one_lane_he_mul_per_s": round(batch / (ms_one * 1e-3), 1),
                       "gain_this_device": round(ms_one / ms - 1, 4), "clocks": clocks or None,
                       "note": "`default` = the lanes the library picked by itself at this shape (gpq_last_lanes after a call under gpq_set_overlap(ctx, -1): two while the peer's "
                               "per-group workspace costs <= 16 GiB).  With two lanes every other launch group (32 ciphertexts) runs on a second internal stream through a peer "
@@ -437,9 +449,11 @@ def he_swk_mpi_rate(torch, gpqhe_amd, batch=64, iters=3, logn=17, logq=835, chec
     default_lanes = ctx.last_lanes()             # (the warm-up calls ran under the library's own choice)
     t = gpqhe_amd.StreamTimer()
     res = {}
+    ran = {}
     for lanes in (1, 0):
         ctx.set_overlap(bool(lanes))
         ctx.he_swk(o0, o1, d0, d1, swk0, swk1, W, logq, dimB, dimP)
+        ran[lanes] = ctx.last_lanes()
         t.start()
         for _ in range(iters):
             ctx.he_swk(o0, o1, d0, d1, swk0, swk1, W, logq, dimB, dimP)
@@ -483,7 +497,7 @@ def he_swk_mpi_rate(torch, gpqhe_amd, batch=64, iters=3, logn=17, logq=835, chec
     whole = (W + 2 * dimB) + 5 * dimB + (2 * dimB + 3 * W)          # decompose out + key switch + tail, the slabs between them counted once each way
     return {"shape": "n=2^%d, q=2^%d (W=%d words), dimB/dimP=%d/%d, batch %d: BASELINE configs[4] on one GPU" % (logn, logq, W, dimB, dimP, batch),
             "ms_per_batch": round(ms, 3), "he_swk_per_s": round(batch / (ms * 1e-3), 1),
-            "lanes": {"default": default_lanes, "this_run": 2, "one_lane_ms_per_batch": round(res[0], 3), "one_lane_he_swk_per_s": round(batch / (res[0] * 1e-3), 1),
+            "lanes": {"default": default_lanes, "this_run": ran[1], "one_lane_ms_per_batch": round(res[0], 3), "one_lane_he_swk_per_s": round(batch / (res[0] * 1e-3), 1),
                       "gain_this_device": round(res[0] / ms - 1, 4)},
             "bridge_ms_per_batch": round(sum(v["ms_per_batch"] for k, v in kernels.items() if k.startswith("bridge_")), 3),
             "core_ms_per_batch": round(sum(v["ms_per_batch"] for k, v in kernels.items() if not k.startswith("bridge_")), 3),
@@ -682,6 +696,7 @@ def parse_args(argv=None):
     ap.add_argument("--quick", action="store_true", help="of the secondary legs keep only the clock / power sample, the VALU floor and the copy yardstick (tests)")
     ap.add_argument("--lanes", choices=("auto", "1", "2"), default="auto", help="RNS-core steps: gpq_set_overlap of the context (auto = the library's default; 1 for kernel traces "
                     "and PMC passes, whose durations should be those of kernels with nothing running beside them)")
+    ap.add_argument("--no-affinity", action="store_true", help="leave the process's CPU mask alone (default: bind to the CPUs of the GPU's NUMA node before the first HIP call)")
     ap.add_argument("--no-check", action="store_true", help="skip the restated-reference check of the whole-function legs (about 40 s of CPU after the timed legs)")
     ap.add_argument("--streams", type=int, default=1, help="2: tensor stage and key-switch stage on separate HIP streams")
     ap.add_argument("--no-scatter-gather", action="store_true", help="N>1: skip the extra step that has the input slabs scattered from "
@@ -739,6 +754,17 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:      # never run another rank count than the one asked for and report it as if it were
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+
+    # Placement first: confine this rank to the CPUs of ITS GPU's NUMA node -- in-process, from sysfs, before torch is
+    # imported and before the first HIP call (the runtime's helper threads inherit the mask; `with_host_scatter` first-touches its page-locked
+    # staging memory on that node).  The single-process N = 1 run does the same for device 0, so `--gpus 1` under a launcher and the plain run are
+    # one code path.  Never an error: `affinity` in the line says what was done.
+    from gpqhe_amd import affinity
+    try:
+        nvis = len(affinity.visible_nodes(affinity.gpu_nodes(), os.environ))
+    except (OSError, ValueError):
+        nvis = 0
+    aff = affinity.bind_to_gpu(local % nvis if (world > 1 and nvis) else 0) if not args.no_affinity else {"bound": False, "why_not": "--no-affinity"}
 
     import torch
     import gpqhe_amd
@@ -819,17 +845,23 @@ def main(argv=None):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0          # this rank's own K steps (what a slow device shows in); the reported time is the one behind the barrier
+    if dist is not None:
+        dist.barrier()
     dt = time.perf_counter() - t0
     ctx.profile(False)
     prof = ctx.profile_collect()
     ranks_seen, devices = 1, ["cuda:%d" % dev_index]
+    mine = {"rank": rank, "device": "cuda:%d" % dev_index, "batch": B, "he_mul_per_s": round(B * args.steps / dt_own, 1),
+            "ms_per_step": round(dt_own / args.steps * 1e3, 3), "affinity": aff}
+    from gpqhe_amd.dist import gather_rank_records, summarize_ranks
+    per_rank = gather_rank_records(mine)
     if dist is not None:
         from gpqhe_amd.dist import max_over_ranks
         dt = max_over_ranks(dt)
         ranks_seen = dist.get_world_size()
-        devices = [None] * ranks_seen
-        dist.all_gather_object(devices, "cuda:%d" % dev_index)
+        devices = [r["device"] for r in per_rank]
 
     if rank == 0:
         total_he_mul = total_batch * args.steps
@@ -881,6 +913,13 @@ def main(argv=None):
                            "achieved_GBps_per_gpu": round(ALGO_BYTES_PER_HE_MUL * value / world / 1e9, 1),
                            "hbm_frac_per_gpu": round(ALGO_BYTES_PER_HE_MUL * value / world / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": kernels,
+            # every rank's OWN rate over the same K steps (before the closing barrier), beside the aggregate that the MAX of the wall time gives:
+            # a slow device (the pool's parts differ by +-4 %) or a badly placed rank shows here, not only as a lower `value`
+            "per_rank": summarize_ranks(per_rank),
+            "affinity": aff,
+            # BASELINE's metric is "he_mul/sec + NTT GB/s": the second half and the whole-function rate as TOP-LEVEL scalars (filled in by the legs
+            # below; None when a leg was not run: N > 1, --no-ntt)
+            "ntt_GBps": None, "ntt_hbm_frac": None, "he_mul_whole_per_s": None, "he_mul_plus_he_rescale_whole_per_s": None,
         }
         if world == 1 and args.cpu_sample > 0:
             s = min(args.cpu_sample, B)
@@ -926,17 +965,31 @@ def main(argv=None):
             out["copy_rate"] = cr
             for rec in out["kernels"].values():               # every kernel's algorithmic rate against that of the best plain copy
                 rec["of_copy_rate"] = round(rec["algo_GBps"] / cr["GBps"], 3)
+        if world == 1 and not args.no_ntt and args.quick:
+            # the quick line still carries both halves of the metric: one NTT leg (the headline ring) and the whole function, timed briefly
+            head = ntt_rate(torch, gpqhe_amd, 16, DIM_A, B, iters=8)
+            out["ntt"] = [head]
+            out["ntt_GBps"], out["ntt_hbm_frac"] = head["GBps"], head["hbm_frac"]
+            del a0, a1, b0, b1, x, d0, d1, d2, c0, c1, wsA, wsB
+            torch.cuda.empty_cache()
+            whole = he_mul_mpi_rate(torch, gpqhe_amd, ctx, B, iters=3, brief=True, two_lanes=args.lanes != "1", restore_overlap={"auto": -1, "1": 0, "2": 1}[args.lanes], group=chunk)
+            out["he_mul_mpi_level"] = whole
+            out["he_mul_whole_per_s"], out["he_mul_plus_he_rescale_whole_per_s"] = whole["he_mul_per_s"], whole["he_mul_plus_he_rescale_per_s"]
         if world == 1 and not args.no_ntt and not args.quick:
             # NTT GB/s at the headline ring (n=2^16, 30 limbs) and at BASELINE configs[1] (n=2^15, 10 limbs)
             out["ntt"] = [ntt_rate(torch, gpqhe_amd, 16, DIM_A, B), ntt_rate(torch, gpqhe_amd, 15, 10, 64)]
+            out["ntt_GBps"], out["ntt_hbm_frac"] = out["ntt"][0]["GBps"], out["ntt"][0]["hbm_frac"]     # n = 2^16 x 30 limbs x batch, forward + inverse
             del a0, a1, b0, b1, x, d0, d1, d2, c0, c1, wsA, wsB
             torch.cuda.empty_cache()
             out["ntt"].append(ntt_rate(torch, gpqhe_amd, 16, DIM_A, 4 * B))   # launch size matters: 4 GiB slab
             out["ntt"].append(ntt_rate(torch, gpqhe_amd, 15, 10, 2048))       # configs[1]'s ring at a launch that fills the chip (5 GiB)
             out["ntt"].append(ntt_rate(torch, gpqhe_amd, 17, 44, 64, iters=6))      # configs[4]'s ring and limb count (27 wide-split + 17 split limbs)
             checks = []
-            out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, B, iters=5, checked="he_mul_mpi_level", sample_clocks=True)   # BASELINE configs[2]: he_mul + he_rescale, batch 64
+            out["he_mul_mpi_level"] = he_mul_mpi_rate(torch, gpqhe_amd, ctx, B, iters=5, checked="he_mul_mpi_level", sample_clocks=True, two_lanes=args.lanes != "1",
+                                                      restore_overlap={"auto": -1, "1": 0, "2": 1}[args.lanes], group=chunk)   # BASELINE configs[2]: he_mul + he_rescale, batch 64
             checks.append(out["he_mul_mpi_level"].pop("_check"))
+            out["he_mul_whole_per_s"] = out["he_mul_mpi_level"]["he_mul_per_s"]                              # src/he-mult.c:88-156 as a whole, device slabs
+            out["he_mul_plus_he_rescale_whole_per_s"] = out["he_mul_mpi_level"]["he_mul_plus_he_rescale_per_s"]   # BASELINE configs[2]'s pair as one call
             out["keyswitch_n17"] = keyswitch_n17_rate(torch, gpqhe_amd)
             out["he_swk_mpi_level"] = he_swk_mpi_rate(torch, gpqhe_amd)             # BASELINE configs[4] as the reference's function, one GPU
             checks.append(out["he_swk_mpi_level"].pop("_check"))

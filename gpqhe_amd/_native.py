@@ -45,6 +45,8 @@ SIGNATURES = {
     "gpq_copy": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "gpq_stream_sync": (C.c_int, [vp]),
     "gpq_device_count": (C.c_int, []),
+    "gpq_bind_thread_to_device": (C.c_int, [C.c_int]),
+    "gpq_device_local_cpus": (C.c_int, [C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]),
     "gpq_probe_stream": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint, vp]),
     "gpq_set_device": (C.c_int, [C.c_int]),
     "gpq_stream_create": (C.c_int, [C.POINTER(vp)]),

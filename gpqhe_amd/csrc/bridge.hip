@@ -1075,7 +1075,8 @@ int get_tail_direct_padded(gpq_ctx *c, unsigned dimP, unsigned dimB, gpq_relin_t
 // The one-product tail as a stream (bridge_stream.hpp), with the addend's CRT in the same kernel when it comes as limbs.  *scope = the
 // launch's per-wave words for the masked kernels behind it; *done = false: not covered (shape, settings).
 int tail_stream(gpq_ctx *c, gpq_relin_tables *rt, Two<uint64_t> out, const uint64_t *chat, Two<const uint64_t> dbig, const TailD *dh, unsigned W,
-                unsigned dimP, unsigned dimB, unsigned logql, unsigned polys, unsigned char *tie, unsigned char *amb, hipStream_t s, FlagScope *scope, bool *done) {
+                unsigned dimP, unsigned dimB, unsigned logql, unsigned polys, unsigned char *tie, unsigned char *amb, hipStream_t s, FlagScope *scope, bool *done,
+                unsigned rs = 0) {
   *done = false;
   const unsigned need = (logql + 63) / 64;
   if (!c->stream_bridge || W > 14 || W < need || logql > 896) return GPQ_OK;
@@ -1102,7 +1103,7 @@ int tail_stream(gpq_ctx *c, gpq_relin_tables *rt, Two<uint64_t> out, const uint6
   TailStreamArgs a{chat, dh ? dh->hat : nullptr, chat_bytes, dhat_bytes, dbig, out, (const v4i *)tt->d_bfrag, tt->d_kc, tt->d_pm,
                    dh ? (const v4i *)td->d_bfrag : nullptr, dh ? td->d_kc : nullptr, dh ? td->d_pm : nullptr,
                    c->d_redo, tie, amb, c->d_wave_any, dimB, dh ? dh->dimA : 0u, c->logn, W, logql, groups, c->debug_force_redo,
-                   c->tail_rs, c->tail_rs ? logql - c->tail_rs : 0u};
+                   rs, rs ? logql - rs : 0u};
   ProfScope prof(c, GPQ_K_TAIL_STREAM, s);
   if (dh && KST == 8) rc = launch_tail_stream_t<8, 4, true, 6>(a, lds, blocks, s);
   else if (dh) rc = launch_tail_stream_t<12, 8, true, 5>(a, lds, blocks, s);
@@ -1119,7 +1120,11 @@ int tail_stream(gpq_ctx *c, gpq_relin_tables *rt, Two<uint64_t> out, const uint6
 // launch group are one batch (their chat slabs are adjacent in the workspace), half the launches and twice their size.
 // chat_prescaled: the limbs below dimP already hold chat_d * (P/p_d)^-1 (ScaledInverse on the key switch's inverse pass).
 int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const uint64_t> dbig, unsigned W, unsigned dimP, unsigned dimB,
-               unsigned logql, unsigned polys, void *ws, hipStream_t s, int chat_prescaled = 0, const TailD *dh = nullptr) {
+               unsigned logql, unsigned polys, void *ws, hipStream_t s, int chat_prescaled = 0, const TailD *dh = nullptr,
+               unsigned rs = 0, bool *rs_done = nullptr) {
+  // rs / rs_done (gpq_he_mul_rs): log2(Delta) of the he_rs the tail applies on the way out where its streaming kernel runs (1 <= rs <= 63), and
+  // whether it did; explicit parameters -- gpq_he_swk and gpq_relin_tail share this function and pass neither
+  if (rs_done) *rs_done = false;
   TailPlan tp;
   int rc = tail_plan(c, W, dimP, dimB, polys, &tp);
   if (rc) return rc;
@@ -1149,18 +1154,18 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
     if (direct_ok && (rc = ensure_redo(c, (size_t)polys << c->logn, s))) return rc;
     FlagScope scope = kNoScope;
     bool streamed = false;
-    if (direct_ok && (rc = tail_stream(c, rt, out, chat, dbig, dh, W, dimP, dimB, logql, polys, tie, amb, s, &scope, &streamed))) return rc;
+    if (direct_ok && (rc = tail_stream(c, rt, out, chat, dbig, dh, W, dimP, dimB, logql, polys, tie, amb, s, &scope, &streamed, rs_done ? rs : 0u))) return rc;
     // Behind the streaming kernel the exact kernels only see flagged coefficients, and the chains whose hand-overs stay inside a thread are
     // ONE launch each (bridge_kernels.hpp: bridge_fallback_tail_pre / _post): pre = the addend's exact CRT + the weights off the flagged
     // groups; the front re-run; post = r, its round bit, Q's exact CRT, the finish.  Three launches where there were seven.
     // gpq_he_mul_rs: the streaming kernel rescaled what it decided; the coefficients it flagged are written unrescaled by the exact kernels
     // below and finished here (same flags, same scope)
     auto finish_rs = [&]() {
-      if (!c->tail_rs || !streamed) return;
+      if (!rs || !rs_done || !streamed) return;
       ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s);
-      RescaleMaskedArgs ra{out, c->d_redo, W, c->logn, c->tail_rs, logql - c->tail_rs, scope};
+      RescaleMaskedArgs ra{out, c->d_redo, W, c->logn, rs, logql - rs, scope};
       hipLaunchKernelGGL(bridge_rescale_masked, masked_grid(scope, 256, c->n, polys), dim3(256), 0, s, ra);
-      c->tail_rs_done = true;
+      *rs_done = true;
     };
     const bool fuse_pre = streamed && dh && (dh->bA->WP == 32 || dh->bA->WP == 16);
     const bool fuse_post = streamed && ((bp->WP == 16 && bq->WP == 32) || (bp->WP == 8 && bq->WP == 16));
@@ -1191,7 +1196,7 @@ int relin_tail(gpq_ctx *c, Two<uint64_t> out, const uint64_t *chat, Two<const ui
     }
     // weights off: for the flagged groups, or -- no product possible (in place, no tables) -- for every coefficient
     if (!fuse_pre) { ProfScope prof(c, GPQ_K_BRIDGE_EXACT, s); hipLaunchKernelGGL(bridge_limb_scale, masked_grid(scope, 256, c->n, polys), cblock, 0, s, un); }
-    if (!direct_ok) return relin_tail(c, out, chat, dbig, W, dimP, dimB, logql, polys, ws, s, 0);
+    if (!direct_ok) return relin_tail(c, out, chat, dbig, W, dimP, dimB, logql, polys, ws, s, 0);   // (no rs: the caller rescales)
     // the exact sequence on the flagged groups: front (re-run, writing its flags), r for its ambiguous ones, round bits, Q, finish
     const unsigned gpp = c->n >> 6;
     RelinFrontArgs f{chat, qhat, (const v4i *)rt->d_bfrag, rt->d_lk, rt->d_pk, rt->d_tkp, rt->d_kf, flags, amb,
@@ -1358,10 +1363,11 @@ extern "C" int gpq_he_mul_rs(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, con
 static int he_mul_impl(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const uint64_t *ct1c0, const uint64_t *ct1c1,
                        const uint64_t *ct2c0, const uint64_t *ct2c1, const uint64_t *rlk0, const uint64_t *rlk1, unsigned W,
                        unsigned logql, unsigned dimA, unsigned dimB, unsigned dimP, unsigned batch, void *workspace, void *stream, unsigned rs) {
-  int rc = check(c, dimA, batch, "gpq_he_mul");
-  if (rc || (rc = check(c, dimB, batch, "gpq_he_mul"))) return rc;
+  const char *who = rs ? "gpq_he_mul_rs" : "gpq_he_mul";          // errors and launch checks name the entry point the caller used
+  int rc = check(c, dimA, batch, who);
+  if (rc || (rc = check(c, dimB, batch, who))) return rc;
   if (!out_c0 || !out_c1 || !ct1c0 || !ct1c1 || !ct2c0 || !ct2c1 || !rlk0 || !rlk1 || !workspace || !logql || W < (logql + 63) / 64)
-    return gpq_fail(GPQ_ERR_INVALID, "gpq_he_mul: bad arguments");
+    return gpq_fail(GPQ_ERR_INVALID, "%s: bad arguments", who);
   hipStream_t s = (hipStream_t)stream;
   const size_t n = c->n, bigpoly = (size_t)W * n;
   const unsigned m = batch < c->chunk ? batch : c->chunk;
@@ -1437,20 +1443,18 @@ static int he_mul_impl(gpq_ctx *c, uint64_t *out_c0, uint64_t *out_c1, const uin
     StageRange stage("gpq_he_mul: he_relin tail (CRT, exact division by P, + d)");
     // c0 and c1 as one batch of 2 x polys polynomials: c0hat | c1hat and d0 | d1 are adjacent, the outputs are the caller's two slabs
     const TailD dh{d0h, bA, dimA, d0};
-    c->tail_rs = rs >= 1 && rs <= 63 ? rs : 0;                  // the tail kernel shifts inside one word; other Deltas take the rescale kernel below
-    c->tail_rs_done = false;
+    bool rescaled = false;
     rc = relin_tail(c, Two<uint64_t>{out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, polys}, c0hat,
                     limbs_addend ? Two<const uint64_t>{nullptr, nullptr, polys} : Two<const uint64_t>{d0, d1, polys},
-                    W, dimP, dimB, logql, 2 * polys, wsTail, s, tail_mode, limbs_addend ? &dh : nullptr);                     // :67-77
-    const bool rescaled = c->tail_rs_done;
-    c->tail_rs = 0; c->tail_rs_done = false;
+                    W, dimP, dimB, logql, 2 * polys, wsTail, s, tail_mode, limbs_addend ? &dh : nullptr,                      // :67-77
+                    rs >= 1 && rs <= 63 ? rs : 0u, &rescaled);   // the tail kernel shifts inside one word; other Deltas take the rescale kernel below
     if (rc) return rc;
     if (rs && !rescaled && (rc = gpq_he_rs(c, out_c0 + k0 * bigpoly, out_c1 + k0 * bigpoly, W, rs, logql - rs, polys, stream))) return rc;   // src/he-rescale.c:33-54
   }
   const unsigned lanes_used = lane.c ? 2u : 1u;
   if ((rc = gpq_peer_join(c, s, lane))) return rc;
   c->last_lanes = lanes_used;   // (after the nested entry points of the groups, which record their own)
-  return launched("gpq_he_mul");
+  return launched(who);
 }
 
 // he_swk, src/he-automorphism.c:40-85: key-switch d1 with swk, c0 += d0, on big slabs, q_l = 2^logql.

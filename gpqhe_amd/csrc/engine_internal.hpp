@@ -120,10 +120,6 @@ struct gpq_ctx {
   bool fuse_tail = false;             // gpq_set_fused_tail(ctx, 1): the relinearisation tail in one pass per coefficient (bridge_relin_tail_mfma) -- measured 2 % SLOWER
                                       // than the two-kernel form on the whole he_mul (profiles/r03/v3_fused_tail_ab.txt: both are bound by integer VALU work, not by the
                                       // 60 words per coefficient the fusion saves), kept for the parity tests and as the record of the attempt
-  // gpq_he_mul_rs: log2(Delta) of the he_rs the tail of the CURRENT call applies on the way out (0 = none), and whether the tail of the current
-  // launch group did (streaming kernel + masked finish); otherwise the caller runs the plain rescale kernel on the group's outputs
-  unsigned tail_rs = 0;
-  bool tail_rs_done = false;
   // gpq_he_mul / gpq_he_swk over more than one launch group: every other group runs on a second stream through a PEER context (the parent's
   // read-only tables; its own scratch and flag words: nothing mutable is shared), so that the HBM-bound bridge kernels of one group run beside the issue-bound transforms
   // of the other and launch tails fill (gpq_set_overlap; bridge.hip: peer_lane).  The caller's stream orders the whole call as before.

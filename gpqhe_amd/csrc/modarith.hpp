@@ -28,6 +28,14 @@
 #define GPQ_SPLIT_CMAX 306000000u /* c < this: every prime of the chains up to n = 2^17 */
 // Forward butterflies that skip every other conditional subtraction (ct_bfly_wide below) need c < 2^27.
 #define GPQ_WIDE_CMAX 134217000u
+// The margins of the split class are narrow (0.25 % and 2.5 %): raising GPQ_SPLIT_CMAX must fail here, not in a product.
+//   7 * 2^29 * c < 2^60   one fold finishes: a multiplicand < 6p has th <= 3.5 * 2^30 and t = c*th + 2^59 + (c+1) stays below 3p
+//   12 * c < 2^32         variable * variable products of the middle kernels, left < 2p, right < 6p (TwTraits<TwS>): the 7-mad fold's th fits 32 bits
+//   12 * c^2 < 2^60       ... and such a product leaves below 4p (tests/test_lazy_ranges.py: the integer model of all three)
+static_assert(7ull * (1ull << 29) * GPQ_SPLIT_CMAX < (1ull << 60), "GPQ_SPLIT_CMAX: the single fold of mulmod_split no longer finishes below 3p");
+static_assert(12ull * GPQ_SPLIT_CMAX < (1ull << 32), "GPQ_SPLIT_CMAX: th of mulmod_lazy(left < 2p, right < 6p) no longer fits 32 bits");
+static_assert(12ull * GPQ_SPLIT_CMAX * GPQ_SPLIT_CMAX < (1ull << 60), "GPQ_SPLIT_CMAX: a product of the split class no longer leaves below 4p");
+static_assert(GPQ_WIDE_CMAX <= (1u << 27) && GPQ_WIDE_CMAX <= GPQ_SPLIT_CMAX && GPQ_SPLIT_CMAX <= GPQ_FOLD_CMAX, "butterfly classes must nest: wide <= split <= 7-mad");
 
 #ifndef GPQ_PIN_VOLATILE
 #define GPQ_PIN_VOLATILE volatile

@@ -719,7 +719,8 @@ __global__ __launch_bounds__(CONTIG_WAVES * 64, GPQ_MID8_MINWAVES) void tensor_m
   tw.load_l(ln, cb.wave0, a.logn, wi);               // inverse twiddles arrive under the products
   uint64_t d1[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {                      // products: left operand < 2p, right operand < 4p  =>  a*b < 8p^2, as mulmod_lazy needs (TwTraits::left / right)8
+  for (int e = 0; e < 8; ++e) {                      // products: TwTraits::left / right put the operands where mulmod_lazy's second fold fits 32 bits and the product leaves
+                                                     // below 4p -- 7-mad class: left < 2p, right < 4p (8 p^2); split: left < 2p, right < 6p (12 p^2, 12 c^2 < 2^60); wide: left < 4p, right < 6p
     const uint64_t u0 = TT::left(a0[e], k), u1 = TT::left(a1[e], k);
     const uint64_t v0 = TT::right(b0[e], k), v1 = TT::right(b1[e], k);
     a0[e] = TT::inv_from4(mulmod_lazy(u0, v0, k), k);                                   // d0

@@ -115,6 +115,23 @@ def max_over_ranks(seconds, device=None):
     return float(t.item())
 
 
+def gather_rank_records(mine):
+    """Every rank's record (a small dict: rank, device, its OWN rate over the timed steps, where it was placed) on every rank, in rank order;
+    control plane.  One rank: [mine]."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [mine]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, mine)
+    return out
+
+
+def summarize_ranks(records):
+    """What bench.py prints beside the MAX-time aggregate: the slowest and the fastest rank's own he_mul/s, their sum (what the job would do if no
+    rank waited for another), and the records themselves -- a slow device or a badly placed rank is visible, not just a lower `value`."""
+    rates = [r["he_mul_per_s"] for r in records]
+    return {"he_mul_per_s_min": min(rates), "he_mul_per_s_max": max(rates), "sum_of_own_rates": round(sum(rates), 1), "ranks": records}
+
+
 def _default_device():
     """Where a shard lands when the caller names no device: the GPU when the slabs travel over RCCL."""
     return torch.device("cuda", torch.cuda.current_device()) if data_backend() == "nccl" else torch.device("cpu")

@@ -102,6 +102,16 @@ int gpq_stream_destroy(void *stream);
  * are staged and a download waits for the work queued before it. */
 int gpq_malloc_host(void **hptr, size_t bytes);
 int gpq_free_host(void *hptr);
+/* Host placement on a multi-socket node (no counterpart in the reference, which is single-threaded: SURVEY.md 8e).  A C host that drives several
+ * GPUs runs one worker thread per device and calls gpq_bind_thread_to_device(device) as the thread's FIRST action -- before gpq_set_device -- so
+ * that the thread, and the page-locked buffers it allocates next, sit on the socket the GPU hangs off.  Pure sysfs, no HIP call: HIP device i is
+ * the i-th GPU node of /sys/class/kfd/kfd/topology/nodes whose render node this process can open, after ROCR_VISIBLE_DEVICES and HIP_VISIBLE_DEVICES
+ * (integer lists); its CPUs are /sys/class/drm/renderD<minor>/device/local_cpulist.  Returns the number of CPUs the thread is now confined to, or 0
+ * when nothing was changed (unknown topology, one memory domain, already confined, not allowed): never an error.
+ * gpq_device_local_cpus only looks: the count and, in `cpulist`, the kernel's list text ("0-47,96-143"); `sysfs_root` NULL = "/" (tests hand it a
+ * fake tree).  The rank processes of bench.py do the same in Python (gpqhe_amd/affinity.py) before their first HIP call. */
+int gpq_bind_thread_to_device(int device);
+int gpq_device_local_cpus(int device, const char *sysfs_root, char *cpulist, size_t cap);
 
 /* ---- slab operations ------------------------------------------------------
  * All slabs are device pointers to uint64_t[batch][dim][n] using primes

@@ -139,3 +139,19 @@ def test_the_quick_bench_line_prices_kernels_against_ceilings():
         assert ("valu_issue" in line) == ("own_mix_probe_at_its_uncapped_clock" in den)
     assert "stale" not in json.dumps(line)
     assert line["roofline"]["peak"] == 8000.0 and 0 < line["roofline"]["frac"] < 1
+    # round 6: both halves of BASELINE's metric ("he_mul/sec + NTT GB/s") and the whole function as top-level scalars the driver's parser keeps
+    for key in ("ntt_GBps", "ntt_hbm_frac", "he_mul_whole_per_s", "he_mul_plus_he_rescale_whole_per_s", "per_rank", "affinity"):
+        assert key in line, key
+    assert 500 < line["ntt_GBps"] < 8000 and abs(line["ntt_hbm_frac"] - line["ntt_GBps"] / 8000) < 1e-3
+    assert 1000 < line["he_mul_plus_he_rescale_whole_per_s"] <= line["he_mul_whole_per_s"] * 1.05 < line["value"] * 1.05
+    pr = line["per_rank"]
+    assert len(pr["ranks"]) == 1 and pr["he_mul_per_s_min"] == pr["he_mul_per_s_max"] == pr["ranks"][0]["he_mul_per_s"]
+    assert abs(pr["ranks"][0]["he_mul_per_s"] / line["value"] - 1) < 0.02       # one rank: its own rate IS the aggregate (the closing barrier is a no-op)
+    assert isinstance(line["affinity"]["bound"], bool)
+
+
+def test_top_level_metric_keys_are_in_every_line_shape():
+    """the scalars exist (as None) even when their legs do not run: a parser never has to guess (source-level check, no GPU)"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"ntt_GBps": None, "ntt_hbm_frac": None, "he_mul_whole_per_s": None, "he_mul_plus_he_rescale_whole_per_s": None' in src
+    assert src.index("affinity.bind_to_gpu(") < src.index("    import torch\n    import gpqhe_amd\n")   # placement before torch / HIP in a rank

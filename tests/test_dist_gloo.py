@@ -83,3 +83,48 @@ def test_two_rank_scatter_compute_gather(two_planes):
         assert p.exitcode == 0
     assert ok, "gathered multi-rank result differs from the single-process result"
     assert slowest == 2.0  # MAX over ranks of (1.0, 2.0)
+
+
+def _placed_worker(rank, world, port, q, root):
+    """what a bench.py rank does around its timed region, without a GPU: place itself (fake two-socket sysfs tree; the mask change is recorded, not
+    applied), take its own time, gather every rank's record over the control plane, MAX the wall time"""
+    from gpqhe_amd import affinity
+    from gpqhe_amd.dist import gather_rank_records, summarize_ranks
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    asked = []
+    aff = affinity.bind_to_gpu(rank * 5, root, environ={}, setaffinity=asked.append, getaffinity=lambda: set(range(192)))   # devices 0 and 5: one per socket
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        own = 0.5 * (1 + rank)                                            # rank 1 is the slow device
+        mine = {"rank": rank, "device": "cuda:%d" % (rank * 5), "batch": 64, "he_mul_per_s": round(64 / own, 1), "ms_per_step": own * 1e3, "affinity": aff,
+                "asked_cpus": sorted(asked[0])[:1] + sorted(asked[0])[-1:] if asked else None}
+        records = gather_rank_records(mine)
+        wall = max_over_ranks(own)
+        if rank == 0:
+            q.put((summarize_ranks(records), wall))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_ranks_place_themselves_and_report_their_own_rates(tmp_path):
+    """per-rank placement (each rank on the socket of ITS GPU) and per-rank rates beside the MAX-time aggregate, over gloo"""
+    from tests.test_affinity import _tree
+    root = _tree(tmp_path)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_placed_worker, args=(r, world, port, q, root)) for r in range(world)]
+    for p in procs:
+        p.start()
+    summary, wall = q.get(timeout=150)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert wall == 1.0                                                    # the aggregate is priced on the slowest rank ...
+    assert summary["he_mul_per_s_min"] == 64.0 and summary["he_mul_per_s_max"] == 128.0 and summary["sum_of_own_rates"] == 192.0   # ... and the line shows who that was
+    r0, r1 = summary["ranks"]
+    assert (r0["rank"], r1["rank"]) == (0, 1) and (r0["device"], r1["device"]) == ("cuda:0", "cuda:5")
+    assert r0["affinity"]["bound"] and r0["affinity"]["numa_node"] == 0 and r0["asked_cpus"] == [0, 143]
+    assert r1["affinity"]["bound"] and r1["affinity"]["numa_node"] == 1 and r1["asked_cpus"] == [48, 191]

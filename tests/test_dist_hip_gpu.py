@@ -109,22 +109,29 @@ def test_two_ranks_run_the_hip_core_on_their_shards(logn, dim_a, dim_b, batch):
 
 @pytest.mark.timeout(900)
 def test_bench_starts_its_own_ranks():
-    """`python bench.py --gpus 2` with WORLD_SIZE unset: the parent spawns two ranks (gloo: both on the one GPU here),
-    the line says n_gpus = ranks_seen = 2 and carries the scatter/gather leg; --total-batch shards 5 as 3 + 2."""
+    """`python bench.py --gpus 4` with WORLD_SIZE unset: the parent spawns four ranks (gloo: all on the one GPU here -- the rehearsal of the driver's
+    first multi-GPU run), the line says n_gpus = ranks_seen = 4 and carries both transfer legs; --total-batch shards 9 as 3 + 2 + 2 + 2; every rank
+    reports its placement and its OWN rate beside the MAX-time aggregate (round 6)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--total-batch", "5",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--total-batch", "9",
            "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--no-ntt"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=840, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["devices"] == ["cuda:0", "cuda:0"]
-    assert out["scaling"] == "strong" and out["config"]["total_batch"] == 5 and out["config"]["batch_per_gpu"] == 3
+    assert out["n_gpus"] == 4 and out["ranks_seen"] == 4 and out["devices"] == ["cuda:0"] * 4
+    assert out["scaling"] == "strong" and out["config"]["total_batch"] == 9 and out["config"]["batch_per_gpu"] == 3
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
+    pr = out["per_rank"]
+    assert [x["rank"] for x in pr["ranks"]] == [0, 1, 2, 3] and [x["batch"] for x in pr["ranks"]] == [3, 2, 2, 2]
+    assert 0 < pr["he_mul_per_s_min"] <= pr["he_mul_per_s_max"] and all(isinstance(x["affinity"]["bound"], bool) for x in pr["ranks"])
+    assert out["value"] <= pr["sum_of_own_rates"] * 1.001                 # the aggregate waits for the slowest rank: never more than the own rates add up to
+    for key in ("ntt_GBps", "ntt_hbm_frac", "he_mul_whole_per_s", "he_mul_plus_he_rescale_whole_per_s"):
+        assert key in out and out[key] is None                            # single-GPU legs: present, not run at N > 1
     sg = out["with_scatter_gather"]
     assert "error" not in sg and sg["shards_identical"] is True and sg["he_mul_per_s"] > 0
-    # SURVEY.md 8e's alternative, rehearsed by the same two ranks: every rank uploads its own shard from page-locked host memory and
+    # SURVEY.md 8e's alternative, rehearsed by the same ranks: every rank uploads its own shard from page-locked host memory and
     # downloads its results inside the timed region; what comes back over PCIe is what a resident run computes
     hs = out["with_host_scatter"]
     assert hs["equals_resident_run"] is True and hs["he_mul_per_s"] > 0 and hs["batch_per_gpu"] == 2

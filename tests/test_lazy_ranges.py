@@ -97,6 +97,45 @@ def test_product_operands_of_the_split_class_fit_the_general_multiply():
     assert tprime + c + 1 < 4 * p and (tprime + c + 1) % p == x % p
 
 
+def _general_multiply(a, w, c):
+    """mulmod_raw_t / mulmod_lazy (the 7-mad form) with every register bound asserted; returns the lazily reduced product"""
+    p = (1 << 59) + c
+    a0, a1, w0, w1 = a & 0xFFFFFFFF, a >> 32, w & 0xFFFFFFFF, w >> 32
+    mid = a0 * w1 + ((a0 * w0) >> 32)
+    assert mid <= M64
+    mid += a1 * w0
+    assert mid <= M64                                              # the middle column of the 64 x 64 product
+    hi = a1 * w1 + (mid >> 32)
+    assert hi <= M64
+    x = a * w
+    xh = x >> 59
+    assert xh <= M64
+    t = c * xh
+    th = t >> 59
+    assert th < (1 << 32)                                          # the second fold is ONE 32 x 32 multiply
+    r = (x & ((1 << 59) - 1)) + c * th + ((1 << 59) - 1 - (t & ((1 << 59) - 1))) + c + 1
+    assert r <= M64 and r % p == x % p
+    return r
+
+
+def test_products_of_the_split_class_over_random_operands():
+    """the widened class leaves 2.5 % between 12 c^2 and 2^60; one edge pair guarded it.  Random left < 2p, right < 6p for the
+    largest c (and the real chain's), plus the corners: th fits 32 bits, the product leaves below 4p, d1 = sum of two below 8p."""
+    rng = random.Random(2859)
+    for c in (SPLIT_CMAX - 1, 218103809, 4849665):
+        p = (1 << 59) + c
+        corners = [(2 * p - 1, 6 * p - 1), (2 * p - 1, 0), (0, 6 * p - 1), (p, 3 * p), (2 * p - 1, 4 * p), (1, 6 * p - 1)]
+        worst = 0
+        for a, w in corners + [(rng.randrange(2 * p), rng.randrange(6 * p)) for _ in range(20000)]:
+            r = _general_multiply(a, w, c)
+            assert 0 < r < 4 * p
+            worst = max(worst, r)
+        assert 2 * worst < 8 * p                                   # d1 = c0 c1' + c1 c0' enters inv_from8
+    # the compile-time guards beside GPQ_SPLIT_CMAX (modarith.hpp) say the same in closed form
+    cmax = SPLIT_CMAX
+    assert 7 * (1 << 29) * cmax < 1 << 60 and 12 * cmax < 1 << 32 and 12 * cmax * cmax < 1 << 60
+
+
 @pytest.mark.parametrize("c", [4849665, 113508353, WIDE_CMAX - 1])
 def test_wide_split_stage_ranges_close(c):
     """ct_bfly_wide: stage A (no subtraction) takes x, y < 6p to x' < 8p, y' <= 8p - c - 2; stage B (subtract 4p) takes

@@ -20,7 +20,7 @@ def shard_host(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("shard") / "shard_host")
     lib_dir = os.path.join(ROOT, "gpqhe_amd")
     subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "shard_host.c"),
-                           "-L", lib_dir, "-lgpqhe_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+                           "-L", lib_dir, "-lgpqhe_hip", "-pthread", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", out])
     return out
 
 
@@ -42,7 +42,11 @@ def test_batch_sharded_over_a_device_list_from_plain_c(shard_host, oracle_ctx, l
         lines = res.stdout.strip().split("\n")
         assert lines[0].split()[:3] == ["devices", "visible", lines[0].split()[2]] and lines[0].endswith("shards %d" % len(devs.split(",")))
         got = {}
+        placed = [ln for ln in lines[1:] if ln.startswith("shard ")]       # one worker thread per shard, each reporting its placement
+        assert len(placed) == len(devs.split(",")) and all("worker confined to" in ln for ln in placed)
         for ln in lines[1:]:
+            if ln.startswith("shard "):
+                continue
             f = ln.split()
             assert f[0] == "ct" and f[2] == "dev" and f[3] == "0"
             got[int(f[1])] = f[4:]
@@ -71,7 +75,8 @@ def test_eight_shards_with_their_own_contexts_on_one_device(shard_host, oracle_c
     assert res.returncode == 0, res.stderr
     lines = res.stdout.strip().split("\n")
     assert lines[0].endswith("shards 8")
-    got = {int(f[1]): f[4:] for f in (ln.split() for ln in lines[1:])}
+    assert sum(ln.startswith("shard ") for ln in lines) == 8          # eight worker threads, each placed before its first device call
+    got = {int(f[1]): f[4:] for f in (ln.split() for ln in lines[1:] if ln.startswith("ct "))}
     assert sorted(got) == list(range(batch))
     for k in range(batch):
         assert got[k] == expect[k % period], k
