@@ -1,4 +1,4 @@
-"""The configuration of the one unexplained record, `gpurun_out/r4_soak_rns_long.txt` (round 4, 18:57):
+"""The configuration of the one unexplained record, `profiles/r04/v16_soak_rns_long_the_one_record.txt` (round 4, 18:57):
 
     MISMATCH ntt ciphertext 2 {'logn': 16, 'dim': 1, 'batch': 3, 'chunk': 3, 'limb_block': 0, 'classes': (1, 2), 'nt_policy': 1,
                                'seeds': [843779584, 892266427, 40055201, 69458351, 222764240, 954993035, 482770568]}

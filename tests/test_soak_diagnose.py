@@ -1,6 +1,6 @@
 """The mismatch handler of tools/soak.py, fed every case it has to tell apart (CPU; torch CPU tensors stand for the device's).
 
-The one open parity record (gpurun_out/r4_soak_rns_long.txt, HISTORY.md R5.1 / R6.1) was one line: it could not separate "the kernels wrote wrong
+The one open parity record (profiles/r04/v16_soak_rns_long_the_one_record.txt, HISTORY.md R5.1 / R6.1) was one line: it could not separate "the kernels wrote wrong
 words" from "the input was already wrong on the device" from "the copy back was wrong" from "the checker was wrong".  A recurrence now prints the
 observation that splits them; this test is the proof that the handler draws the right conclusion from each combination."""
 import importlib.util
