@@ -11,7 +11,10 @@ line-by-line restatement of:
   mpi_rdiv         src/types.c:115-128     floor(a/m), plus one when the remainder > floor(m/2)
   poly_rns2mpi     src/poly.c:109-120      reconstruct, centre mod P, centre mod q
   poly_mul         src/poly.c:84-107       (the RNS limb loop itself is supplied by the caller)
-Pinned by the phat_invmp values SURVEY.md 8c took from tests/polymul.c output.
+Pinned by the phat_invmp values SURVEY.md 8c took from tests/polymul.c output, by the polymul KAT and the tests/crt.c walk, and
+(round 6) against libgcrypt ITSELF: tests/test_libgcrypt_pin.py runs mpi_smod, mpi_rdiv, rns_decompose and poly_rns2mpi line by line on
+the image's libgcrypt.so.20 -- every sign for mpi_smod, non-negative dividends for mpi_rdiv (libgcrypt 1.9.4 loses the quotient's sign on
+negative ones; its remainder and |quotient| still agree with this file), CRT at 30 / 45 limbs.
 Pure Python: small cases only.
 """
 
