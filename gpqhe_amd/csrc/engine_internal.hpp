@@ -199,7 +199,7 @@ void gpq_bridge_release(gpq_ctx *c);
 
 // ---------------------------------------------------------------------------
 // Two launch groups in flight (gpq_set_overlap).  A call over more than one launch group hands every other group to the context's PEER -- a
-// second context over the same primes (own tables, scratch, flag words: no mutable state is shared) on a second stream -- by calling the same
+// second context over the same primes (the parent's read-only tables by pointer; own scratch and flag words: no mutable state is shared) on a second stream -- by calling the same
 // entry point on it for that group's slice of the batch.  Launch tails of one lane fill with the other's work, and the bridge kernels of one
 // group (HBM-bound) meet transforms of the other (issue-bound): +3.5 ... +4 % whole he_mul at the headline shape, +12 % at the reference's
 // default shape (profiles/r04/v13_two_lanes_ab.txt).  The caller's stream still orders the call as a whole: the peer's stream waits for an
