@@ -696,6 +696,7 @@ def parse_args(argv=None):
     ap.add_argument("--quick", action="store_true", help="of the secondary legs keep only the clock / power sample, the VALU floor and the copy yardstick (tests)")
     ap.add_argument("--lanes", choices=("auto", "1", "2"), default="auto", help="RNS-core steps: gpq_set_overlap of the context (auto = the library's default; 1 for kernel traces "
                     "and PMC passes, whose durations should be those of kernels with nothing running beside them)")
+    ap.add_argument("--host-pipeline-sub", type=int, default=2, help="with_host_scatter: ciphertexts per sub-batch of the pipelined (three-stream) variant; 0 = skip it")
     ap.add_argument("--no-affinity", action="store_true", help="leave the process's CPU mask alone (default: bind to the CPUs of the GPU's NUMA node before the first HIP call)")
     ap.add_argument("--no-check", action="store_true", help="skip the restated-reference check of the whole-function legs (about 40 s of CPU after the timed legs)")
     ap.add_argument("--streams", type=int, default=1, help="2: tensor stage and key-switch stage on separate HIP streams")
@@ -968,7 +969,7 @@ def main(argv=None):
         if world == 1 and not args.no_ntt and not args.quick:
             # The PCIe-inclusive rate of the same core on this one GPU (never `value`): the shard uploaded from page-locked host memory -- first-touched on
             # the GPU's own NUMA node, see `affinity` -- and the five output slabs downloaded, inside the timed region (at N > 1 every rank does this)
-            out["with_host_scatter"] = host_scatter_step(torch, ctx, (a0, a1, b0, b1), x, (e0, e1), (wsA, wsB), min(B, 16), 1, barrier, repeats=3)
+            out["with_host_scatter"] = host_scatter_step(torch, ctx, (a0, a1, b0, b1), x, (e0, e1), (wsA, wsB), min(B, 16), 1, barrier, repeats=3, pipeline_sub=args.host_pipeline_sub)
         if world == 1 and not args.no_ntt and args.quick:
             # the quick line still carries both halves of the metric: one NTT leg (the headline ring) and the whole function, timed briefly
             head = ntt_rate(torch, gpqhe_amd, 16, DIM_A, B, iters=8)
@@ -1068,7 +1069,7 @@ def main(argv=None):
         dist.destroy_process_group()
 
 
-def host_scatter_step(torch, ctx, ins, x, evk, wss, Bs, world, barrier, progress=None, repeats=1):
+def host_scatter_step(torch, ctx, ins, x, evk, wss, Bs, world, barrier, progress=None, repeats=1, pipeline_sub=0):
     """One step over Bs ciphertexts per rank with every rank sourcing ITS OWN shard from page-locked host memory and returning its five
     output slabs there, transfers inside the timed region: SURVEY.md 8e's alternative to the root-GPU scatter (which one 153 GB/s xGMI
     link per peer bounds) -- all GPUs load over their own PCIe links in parallel, no GPU-to-GPU traffic at all.  Needs no process group
@@ -1105,10 +1106,50 @@ def host_scatter_step(torch, ctx, ins, x, evk, wss, Bs, world, barrier, progress
     ctx.he_mul_tensor(ref[0], ref[1], ref[2], a0[: Bs * per_a], a1[: Bs * per_a], b0[: Bs * per_a], b1[: Bs * per_a], DIM_A, wss[0])
     ctx.he_keyswitch(ref[3], ref[4], x[: Bs * per_b], evk[0], evk[1], DIM_B, wss[1])
     torch.cuda.synchronize()
-    same = bool(all(torch.equal(h, r.cpu()) for h, r in zip(host_out, ref)))
+    ref_host = [r.cpu() for r in ref]
+    same = bool(all(torch.equal(h, r) for h, r in zip(host_out, ref_host)))
+    # The same as a three-stage PIPELINE over sub-batches -- upload of sub-batch k+1, compute of k and download of k-1 on three streams tied by events: the
+    # link is full duplex, so uploads and downloads overlap each other and the compute ("overlap copies with compute on separate HIP streams").
+    piped = None
+    if pipeline_sub and Bs % pipeline_sub == 0 and Bs // pipeline_sub >= 2:
+        progress["stage"] = "host scatter: pipelined passes"
+        nsub = Bs // pipeline_sub
+        s_up, s_cmp, s_dn = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+        for t in o:
+            t.zero_()
+        for h in host_out:
+            h.zero_()
+        ptimes = []
+        for rep in range(repeats):
+            barrier()
+            t1 = time.perf_counter()
+            for k in range(nsub):
+                ia, ib = slice(k * pipeline_sub * per_a, (k + 1) * pipeline_sub * per_a), slice(k * pipeline_sub * per_b, (k + 1) * pipeline_sub * per_b)
+                with torch.cuda.stream(s_up):
+                    for j in range(4):
+                        dev_in[j][ia].copy_(host_in[j][ia], non_blocking=True)
+                    dev_in[4][ib].copy_(host_in[4][ib], non_blocking=True)
+                    up = torch.cuda.Event(); up.record()
+                with torch.cuda.stream(s_cmp):
+                    s_cmp.wait_event(up)
+                    ctx.he_mul_tensor(o[0][ia], o[1][ia], o[2][ia], dev_in[0][ia], dev_in[1][ia], dev_in[2][ia], dev_in[3][ia], DIM_A, wss[0])
+                    ctx.he_keyswitch(o[3][ib], o[4][ib], dev_in[4][ib], evk[0], evk[1], DIM_B, wss[1])
+                    done = torch.cuda.Event(); done.record()
+                with torch.cuda.stream(s_dn):
+                    s_dn.wait_event(done)
+                    for j in range(3):
+                        host_out[j][ia].copy_(o[j][ia], non_blocking=True)
+                    for j in (3, 4):
+                        host_out[j][ib].copy_(o[j][ib], non_blocking=True)
+            barrier()                                           # (torch.cuda.synchronize(): all three streams)
+            dtp = time.perf_counter() - t1
+            ptimes.append(max_over_ranks(dtp) if world > 1 else dtp)
+        dtp = min(ptimes)
+        piped = {"sub_batch": pipeline_sub, "equals_resident_run": bool(all(torch.equal(h, r) for h, r in zip(host_out, ref_host))), "he_mul_per_s": round(Bs * world / dtp, 1), "ms": round(dtp * 1e3, 2), "GBps_per_gpu_both_directions": round(moved / dtp / 1e9, 1),
+                 "ms_every_pass": [round(t * 1e3, 2) for t in ptimes]}
     progress["stage"] = "host scatter: done"
     return {"batch_per_gpu": Bs, "he_mul_per_s": round(Bs * world / dt, 1), "ms": round(dt * 1e3, 2), "bytes_per_gpu_over_pcie": moved,
-            "GBps_per_gpu": round(moved / dt / 1e9, 1), "equals_resident_run": same, "ms_every_pass": [round(t * 1e3, 2) for t in times],
+            "GBps_per_gpu": round(moved / dt / 1e9, 1), "equals_resident_run": same, "ms_every_pass": [round(t * 1e3, 2) for t in times], "pipelined": piped,
             "how": "every rank uploads its own shard from page-locked host memory and downloads its five output slabs, inside the timed region (SURVEY.md 8e)"}
 
 
