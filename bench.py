@@ -1050,7 +1050,8 @@ def main(argv=None):
                 progress["stage"] = "stalled on purpose (--sg-stall-rank)"
                 threading.Event().wait()
             # SURVEY.md 8e's alternative first: every rank sources its own shard from page-locked host memory (PCIe, all GPUs in parallel)
-            hs = host_scatter_step(torch, ctx, (a0, a1, b0, b1), x, (e0, e1), (wsA, wsB), min(total_batch // world, 16), world, barrier, progress)
+            hs = host_scatter_step(torch, ctx, (a0, a1, b0, b1), x, (e0, e1), (wsA, wsB), min(total_batch // world, 16), world, barrier, progress,
+                                   repeats=2, pipeline_sub=args.host_pipeline_sub)
             sg = scatter_gather_step(torch, dist, ctx, (a0, a1, b0, b1), x, (e0, e1), (wsA, wsB), min(total_batch // world, 16), world, rank, barrier, progress)
         except Exception as exc:           # noqa: BLE001
             # the peers may be inside a transfer with this rank: no barrier any more (it could never complete); their own watchdogs
