@@ -44,6 +44,7 @@ SIGNATURES = {
     "gpq_download": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "gpq_copy": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "gpq_stream_sync": (C.c_int, [vp]),
+    "gpq_stream_wait": (C.c_int, [vp, vp]),
     "gpq_device_count": (C.c_int, []),
     "gpq_bind_thread_to_device": (C.c_int, [C.c_int]),
     "gpq_device_local_cpus": (C.c_int, [C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]),

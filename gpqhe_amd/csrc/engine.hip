@@ -405,6 +405,19 @@ extern "C" int gpq_copy(void *dst, const void *src, size_t bytes, void *stream) 
   return GPQ_OK;
 }
 extern "C" int gpq_stream_sync(void *stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return GPQ_OK; }
+// Ordering between two streams without stopping the host: work queued on `waiter` after this call starts only when everything queued on `on` up to
+// this call has finished.  What a host needs to run uploads, the two stages and downloads of successive sub-batches on three streams (the link is full
+// duplex: bench.py's `with_host_scatter.pipelined`, tests/c/shard_host.c `pipe`).  The event lives until the wait has been consumed (destroying a
+// recorded event only releases it once it completes).
+extern "C" int gpq_stream_wait(void *waiter, void *on) {
+  hipEvent_t e;
+  HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipError_t rc = hipEventRecord(e, (hipStream_t)on);
+  if (rc == hipSuccess) rc = hipStreamWaitEvent((hipStream_t)waiter, e, 0);
+  (void)hipEventDestroy(e);
+  if (rc != hipSuccess) return gpq_fail(GPQ_ERR_HIP, "gpq_stream_wait: %s", hipGetErrorString(rc));
+  return GPQ_OK;
+}
 
 // Several devices from one C program (independent ciphertexts, one shard per GPU): the calling thread's current
 // device decides where gpq_malloc allocates and where a new stream lives; a context is bound to the device it was created on.

@@ -87,6 +87,10 @@ int gpq_upload(void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int gpq_download(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int gpq_copy(void *dst_dev, const void *src_dev, size_t bytes, void *stream);      /* device to device, same device */
 int gpq_stream_sync(void *stream);
+/* Stream-to-stream ordering without blocking the host: work queued on `waiter` AFTER this call starts only when everything queued on `on` BEFORE it
+ * has finished.  With it a plain-C host pipelines sub-batches over three streams -- gpq_upload of k+1 | the stages of k | gpq_download of k-1 -- and the
+ * full-duplex link carries uploads and downloads at once (PCIe-inclusive he_mul/s 302 -> 470 on one MI355X; tests/c/shard_host.c `pipe`). */
+int gpq_stream_wait(void *waiter, void *on);
 /* Several devices from one C program: gpq_malloc and gpq_stream_create act on the calling thread's current device
  * (gpq_set_device); a context belongs to the device given to gpq_ctx_create and is used with streams and buffers of that
  * device.  Independent ciphertexts shard over devices without any exchange (tests/c/shard_host.c). */

@@ -3,7 +3,7 @@
  * ("one ciphertext per GPU", no exchange inside a transform; src/he-mult.c:116-138 and :58-66 carry no
  * cross-ciphertext state).  Only the C ABI of include/gpqhe_hip.h is used -- no HIP headers, no torch:
  *
- *   shard_host <logn> <dimA> <dimB> <batch> <dev,dev,...> [period]
+ *   shard_host <logn> <dimA> <dimB> <batch> <dev,dev,...> [period [pipe]]
  *
  * Shard s (block partition of the batch, the first batch % shards shards take one more) lives on device <dev_s>: its own
  * WORKER THREAD, context, stream, buffers.  A worker's first action is gpq_bind_thread_to_device(device): it confines itself to the
@@ -14,7 +14,9 @@
  * Inputs: ciphertext k uses gen(1000 + 4k .. 1003 + 4k, dimA) and gen(2000 + k, dimB), one key gen(3000 / 3001, dimB) --
  * the synthetic batch of SURVEY.md 8d.  Prints, per ciphertext, the FNV-1a-64 digests of d0, d1, d2, c0, c1; the pytest
  * wrapper compares them with the oracle's.  With a `period` P > 0 ciphertext k carries the inputs of ciphertext k mod P (BASELINE
- * configs[3]'s batch of 512 with P oracle evaluations instead of 512: every ciphertext must print the digests of k mod P).
+ * configs[3]'s batch of 512 with P oracle evaluations instead of 512: every ciphertext must print the digests of k mod P).  With `pipe` S > 0
+ * every shard runs its ciphertexts as sub-batches of S pipelined over three streams (stages of k on one stream while the outputs of k - 1 leave on
+ * another), ordered by gpq_stream_wait alone.
  */
 #include <pthread.h>
 #include <stdio.h>
@@ -52,6 +54,7 @@ static void gen(uint64_t *out, uint64_t seed, unsigned dim, size_t n, const uint
 struct shard {
   int index, device; unsigned lo, hi;
   unsigned logn, dimA, dimB, period;
+  unsigned pipe;             /* > 0: sub-batches of `pipe` ciphertexts pipelined over three streams (upload | stages | download), gpq_stream_wait between them */
   int bound_cpus;            /* gpq_bind_thread_to_device: CPUs of the GPU's NUMA node this worker is confined to (0 = left where it was) */
   gpq_ctx *ctx; void *stream;
   uint64_t *d_in[4], *d_x, *d_e[2], *d_out[5], *d_wsA, *d_wsB;
@@ -109,10 +112,36 @@ static void *run_shard(void *arg)
     CHECK(gpq_upload(h->d_e[i], host, perB * 8, h->stream));
     CHECK(gpq_stream_sync(h->stream));
   }
-  CHECK(gpq_he_mul_tensor(h->ctx, h->d_out[0], h->d_out[1], h->d_out[2], h->d_in[0], h->d_in[1], h->d_in[2], h->d_in[3], dimA, cnt, h->d_wsA, h->stream));
-  CHECK(gpq_keyswitch(h->ctx, h->d_out[3], h->d_out[4], h->d_x, h->d_e[0], h->d_e[1], dimB, cnt, h->d_wsB, h->stream));
-  for (int i = 0; i < 5; i++) CHECK(gpq_download(h->h_out[i], h->d_out[i], cnt * (i < 3 ? perA : perB) * 8, h->stream));
-  CHECK(gpq_stream_sync(h->stream));
+  if (!h->pipe) {
+    CHECK(gpq_he_mul_tensor(h->ctx, h->d_out[0], h->d_out[1], h->d_out[2], h->d_in[0], h->d_in[1], h->d_in[2], h->d_in[3], dimA, cnt, h->d_wsA, h->stream));
+    CHECK(gpq_keyswitch(h->ctx, h->d_out[3], h->d_out[4], h->d_x, h->d_e[0], h->d_e[1], dimB, cnt, h->d_wsB, h->stream));
+    for (int i = 0; i < 5; i++) CHECK(gpq_download(h->h_out[i], h->d_out[i], cnt * (i < 3 ? perA : perB) * 8, h->stream));
+    CHECK(gpq_stream_sync(h->stream));
+  } else {
+    /* The pipelined form: the inputs are on the device already (uploaded above on h->stream = the "upload" stream; a real host would stream them
+     * from page-locked memory sub-batch by sub-batch exactly like the downloads below).  Sub-batch k runs its two stages on the compute stream once
+     * the upload stream has delivered, and its five output pieces leave on the download stream once the stages are done, while sub-batch k + 1
+     * computes: three streams, ordered by gpq_stream_wait only -- the host never blocks until the end.  One context, ONE compute stream. */
+    void *cmp, *dn;
+    CHECK(gpq_stream_create(&cmp));
+    CHECK(gpq_stream_create(&dn));
+    for (unsigned k0 = 0; k0 < cnt; k0 += h->pipe) {
+      const unsigned m = cnt - k0 < h->pipe ? cnt - k0 : h->pipe;
+      CHECK(gpq_stream_wait(cmp, h->stream));               /* (uploads of this sub-batch: here all of them were queued before the loop) */
+      CHECK(gpq_he_mul_tensor(h->ctx, h->d_out[0] + k0 * perA, h->d_out[1] + k0 * perA, h->d_out[2] + k0 * perA, h->d_in[0] + k0 * perA, h->d_in[1] + k0 * perA,
+                              h->d_in[2] + k0 * perA, h->d_in[3] + k0 * perA, dimA, m, h->d_wsA, cmp));
+      CHECK(gpq_keyswitch(h->ctx, h->d_out[3] + k0 * perB, h->d_out[4] + k0 * perB, h->d_x + k0 * perB, h->d_e[0], h->d_e[1], dimB, m, h->d_wsB, cmp));
+      CHECK(gpq_stream_wait(dn, cmp));
+      for (int i = 0; i < 5; i++) {
+        const size_t per = i < 3 ? perA : perB;
+        CHECK(gpq_download(h->h_out[i] + k0 * per, h->d_out[i] + k0 * per, m * per * 8, dn));
+      }
+    }
+    CHECK(gpq_stream_sync(dn));
+    CHECK(gpq_stream_sync(cmp));
+    CHECK(gpq_stream_destroy(cmp));
+    CHECK(gpq_stream_destroy(dn));
+  }
   free(primes); free(host);
   h->done = 1;
   return NULL;
@@ -127,12 +156,13 @@ int main(int argc, char **argv)
   for (char *tok = strtok(argv[5], ","); tok && shards < 64; tok = strtok(NULL, ",")) devs[shards++] = atoi(tok);
   if (!shards || batch < (unsigned)shards || dimA > dimB) return 2;
   const unsigned period = argc > 6 ? (unsigned)atoi(argv[6]) : 0;
+  const unsigned pipe = argc > 7 ? (unsigned)atoi(argv[7]) : 0;
   printf("devices visible %d, shards %d\n", gpq_device_count(), shards);
   for (int s = 0; s < shards; s++)
     if (devs[s] < 0 || devs[s] >= gpq_device_count()) { fprintf(stderr, "device %d is not there\n", devs[s]); return 1; }
 
-  struct shard *sh = calloc((size_t)shards, sizeof *sh);
-  pthread_t *th = calloc((size_t)shards, sizeof *th);
+  struct shard *sh = calloc((size_t)(unsigned)shards, sizeof *sh);
+  pthread_t *th = calloc((size_t)(unsigned)shards, sizeof *th);
   const unsigned base = batch / shards, extra = batch % shards;
   /* every shard's worker starts before any is waited for: the devices (and their PCIe links, and the sockets that generate the inputs) work concurrently */
   for (int s = 0; s < shards; s++) {
@@ -140,7 +170,7 @@ int main(int argc, char **argv)
     h->index = s; h->device = devs[s];
     h->lo = s * base + ((unsigned)s < extra ? (unsigned)s : extra);
     h->hi = h->lo + base + ((unsigned)s < extra ? 1 : 0);
-    h->logn = logn; h->dimA = dimA; h->dimB = dimB; h->period = period;
+    h->logn = logn; h->dimA = dimA; h->dimB = dimB; h->period = period; h->pipe = pipe;
     if (pthread_create(&th[s], NULL, run_shard, h) != 0) { fprintf(stderr, "pthread_create failed\n"); return 1; }
   }
   int rc = 0;

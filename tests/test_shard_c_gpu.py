@@ -36,8 +36,8 @@ def test_batch_sharded_over_a_device_list_from_plain_c(shard_host, oracle_ctx, l
         d = o.he_mul_tensor(*ins, dim_a)
         c = o.keyswitch(o.gen(2000 + k, dim_b), ev[0], ev[1], dim_b)
         expect[k] = [fnv(v) for v in list(d) + list(c)]
-    for devs in ("0", "0,0,0"):
-        res = subprocess.run([shard_host, str(logn), str(dim_a), str(dim_b), str(batch), devs], capture_output=True, text=True, timeout=500)
+    for devs, extra in (("0", []), ("0,0,0", []), ("0", ["0", "2"]), ("0,0,0", ["0", "2"])):     # plain, and pipelined in sub-batches of 2 (gpq_stream_wait)
+        res = subprocess.run([shard_host, str(logn), str(dim_a), str(dim_b), str(batch), devs] + extra, capture_output=True, text=True, timeout=500)
         assert res.returncode == 0, res.stderr
         lines = res.stdout.strip().split("\n")
         assert lines[0].split()[:3] == ["devices", "visible", lines[0].split()[2]] and lines[0].endswith("shards %d" % len(devs.split(",")))
@@ -52,7 +52,7 @@ def test_batch_sharded_over_a_device_list_from_plain_c(shard_host, oracle_ctx, l
             got[int(f[1])] = f[4:]
         assert sorted(got) == list(range(batch))
         for k in range(batch):
-            assert got[k] == expect[k], (devs, k)
+            assert got[k] == expect[k], (devs, extra, k)
     if logn == 16:
         assert expect[0] == ["99655f317c50d5c1", "e7658c5a00ed9eac", "12600b1bac18b63e", "466a17f24e0654d2", "578cf3337a189ad0"]   # SURVEY.md 8c, k = 0
 
