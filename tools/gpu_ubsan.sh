@@ -17,7 +17,7 @@ gcc -O1 -std=gnu11 -I include tests/c/mpi_host.c -L $D -lgpqhe_hip -lgpqhe_hip_c
 gcc -O1 -std=gnu11 -I include tests/c/dropin_host.c -L $D -lgpqhe_hip -Wl,-rpath,$D -Wl,-rpath,/opt/rocm/lib -Wl,--unresolved-symbols=ignore-in-shared-libs -o $D/dropin_host || exit 1
 gcc -O1 -std=gnu11 -I include tests/c/shard_host.c -L $D -lgpqhe_hip -pthread -Wl,-rpath,$D -Wl,-rpath,/opt/rocm/lib -Wl,--unresolved-symbols=ignore-in-shared-libs -o $D/shard_host || exit 1
 for cmd in "mpi_host polymul" "mpi_host polymulodd" "mpi_host crt" "mpi_host polymulmono 13" "mpi_host keygen 7 120" "mpi_host ctxcheck 7 61 1073741824" \
-           "mpi_host ctxcheck 16 850 1125899906842624" "mpi_host hemultime 16 850" "dropin_host 13 3 1" "dropin_host 16 2 5" "shard_host 13 3 4 7 0,0,0"; do
+           "mpi_host ctxcheck 16 850 1125899906842624" "mpi_host hemultime 16 850" "dropin_host 13 3 1" "dropin_host 16 2 5" "shard_host 13 3 4 7 0,0,0" "shard_host 13 3 4 7 0,0,0 0 2"; do
   echo "== $cmd" >> gpurun_out/ubsan.txt
   LD_PRELOAD=$RT UBSAN_OPTIONS=print_stacktrace=1 timeout -k 10 300 $D/$cmd 2>&1 | tail -3 | cut -c1-200 >> gpurun_out/ubsan.txt || echo "FAILED: $cmd" | tee -a gpurun_out/ubsan.txt
 done
