@@ -622,11 +622,28 @@ int crt_decompose_stream(gpq_ctx *c, gpq_bridge_basis *bA, uint64_t *out, const 
   const size_t slab_bytes = ((size_t)polys * dimA << c->logn) * 8;
   if (slab_bytes >= 0xfffff000ull) return GPQ_OK;
   CrtDecomposeArgs a{slab, slab_bytes, out, (const v4i *)tr->d_bfrag, tr->d_kc, tr->d_pm, (const v4i *)td->d_bfrag, td->d_pk, c->d_redo, c->d_wave_any,
-                     dimA, dimB, td->NT, c->logn, logq, W, groups, c->debug_force_redo, (c->lazy_decompose && c->logn > 12) ? 1u : 0u};
+                     dimA, dimB, td->NT, c->logn, logq, W, groups, dimB, c->debug_force_redo, (c->lazy_decompose && c->logn > 12) ? 1u : 0u};
   {
     ProfScope prof(c, GPQ_K_CRT_DECOMPOSE, s);
+#if defined(GPQ_CRT_SPLIT) && GPQ_CRT_SPLIT
+    // A/B build (HISTORY.md R6.5): the output limbs over TWO launches -- the first td->NT / 2 row tiles, then the rest -- each
+    // repeating the CRT of d2hat (second read of the slab, second product); constants, flags and per-wave words are the same in both.
+    const unsigned nt1 = (td->NT + 1) / 2, l1 = 4 * nt1 < dimB ? 4 * nt1 : dimB;
+    CrtDecomposeArgs a1 = a, a2 = a;
+    a1.NTD = nt1; a1.dimB = l1;
+    a2.NTD = td->NT - nt1; a2.dimB = dimB - l1;
+    a2.out = out + ((size_t)l1 << c->logn); a2.dfrag = a.dfrag + (size_t)nt1 * KSD * 64; a2.pk = a.pk + (size_t)3 * l1;
+    const size_t lds1 = (size_t)KS * NT * 1024 + (size_t)a1.NTD * KSD * 1024 + (size_t)65 * WL * 8, lds2 = (size_t)KS * NT * 1024 + (size_t)a2.NTD * KSD * 1024 + (size_t)65 * WL * 8;
+    if (WL == 7) rc = launch_crt_decompose_t<7, 4, 2, 4>(a1, lds1, blocks, s);
+    else rc = launch_crt_decompose_t<14, 8, 4, 4>(a1, lds1, blocks, s);
+    if (!rc && a2.NTD) {
+      if (WL == 7) rc = launch_crt_decompose_t<7, 4, 2, 4>(a2, lds2, blocks, s);
+      else rc = launch_crt_decompose_t<14, 8, 4, 4>(a2, lds2, blocks, s);
+    }
+#else
     if (WL == 7) rc = launch_crt_decompose_t<7, 4, 2, 4>(a, lds, blocks, s);
     else rc = launch_crt_decompose_t<14, 8, 4, 4>(a, lds, blocks, s);
+#endif
     if (rc) return rc;
   }
   // the coefficients in the CRT's window: exact CRT into the scratch words, integer-VALU decompose of those

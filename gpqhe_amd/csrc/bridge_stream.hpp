@@ -317,6 +317,7 @@ struct CrtDecomposeArgs {
   unsigned char *redo;       // [polys][n]
   unsigned *wave_any;        // [waves of the launch]
   unsigned dimA, dimB, NTD, logn, logq, W, total_groups;
+  unsigned dimS;             // limbs per polynomial of `out` (its stride); = dimB unless a launch writes a sub-range of the limbs (A/B builds: GPQ_CRT_SPLIT)
   unsigned force;            // tests: also flag every coefficient whose index is a multiple of it (the exact kernels must then give the same words)
   unsigned lazy;             // residues out in (0, 3p) for the forward transform that follows (decompose_tile_finish)
 };
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(512) void bridge_crt_decompose(CrtDecomposeArgs a) 
       X[0][s] = v4i{(int)p0l[0], (int)p0h[0], (int)p1l[0], (int)p1h[0]};
       X[1][s] = v4i{(int)p0l[1], (int)p0h[1], (int)p1l[1], (int)p1h[1]};
     }
-    const BufRsrc rs_out = window_rsrc(a.out + ((size_t)poly * a.dimB << a.logn) + coef0);       // limb 0 of the polynomial at the group's first coefficient
+    const BufRsrc rs_out = window_rsrc(a.out + ((size_t)poly * a.dimS << a.logn) + coef0);       // limb 0 of the polynomial at the group's first coefficient
     const unsigned out_off = (h << sh) + lane16;           // + limb j (uniform): lane half h stores limb j + h for coefficients 2r, 2r+1
     decompose_tiles<KSD>(dl, a.pk, a.NTD, X, rs_out, out_off, sh, h, a.dimB, a.lazy != 0);
   }
